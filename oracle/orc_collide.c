@@ -1,0 +1,338 @@
+/*
+ * oracle/orc_collide.c -- broadphase pair finding, narrowphase colliders and
+ * the reference's contact policy.  TEST INFRASTRUCTURE (see orc.h).
+ *
+ *   dSpaceCollide(space,NULL,NearCallback)   main.c:212
+ *   NearCallback                              main.c:674-693
+ *   dCollide(o1,o2,8,&c[0].geom,sizeof(dContact))  main.c:678
+ *
+ * Colliders restate ODE's [ODE-recall]: dCollideBoxPlane (box.cpp),
+ * dCollideSpherePlane / dCollideSphereSphere / dCollideSphereBox (sphere.cpp).
+ * Box-box (dBoxBox) lives in orc_boxbox.c.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "orc_internal.h"
+
+int orc_collide_box_box(const real *p1, const real *R1, const real *side1,
+                        const real *p2, const real *R2, const real *side2,
+                        int maxc, orc_contactgeom *out);
+
+/* ---- dCollideBoxPlane ---------------------------------------------------- */
+static int collide_box_plane(const real *pos, const real *Rm, const real *side,
+                             const real *pl, int maxc, orc_contactgeom *c)
+{
+    const real *n = pl;
+    /* project side lengths along the normal */
+    real Q1 = orc_dot3_14(n, Rm + 0);
+    real Q2 = orc_dot3_14(n, Rm + 1);
+    real Q3 = orc_dot3_14(n, Rm + 2);
+    real A[3] = { side[0] * Q1, side[1] * Q2, side[2] * Q3 };
+    real B[3] = { orc_fabs(A[0]), orc_fabs(A[1]), orc_fabs(A[2]) };
+
+    real depth = pl[3] + R(0.5) * (B[0] + B[1] + B[2]) - orc_dot3(n, pos);
+    if (depth < 0) return 0;
+
+    if (maxc < 1) maxc = 1;
+    if (maxc > 4) maxc = 4;
+
+    /* deepest corner */
+    real p[3] = { pos[0], pos[1], pos[2] };
+    for (int i = 0; i < 3; i++) {
+        real hs = R(0.5) * side[i];
+        if (A[i] > 0) {
+            p[0] -= hs * Rm[0 + i]; p[1] -= hs * Rm[4 + i]; p[2] -= hs * Rm[8 + i];
+        } else {
+            p[0] += hs * Rm[0 + i]; p[1] += hs * Rm[4 + i]; p[2] += hs * Rm[8 + i];
+        }
+    }
+    c[0].pos[0] = p[0]; c[0].pos[1] = p[1]; c[0].pos[2] = p[2];
+    c[0].depth = depth;
+    int ret = 1;
+
+    if (maxc > 1) {
+        /* second and third contacts: walk from p along the two sides with the
+           smallest projected length */
+        int s1, s2;
+        if (B[0] < B[1]) {
+            if (B[2] < B[0]) { s1 = 2; s2 = (B[0] < B[1]) ? 0 : 1; }
+            else             { s1 = 0; s2 = (B[1] < B[2]) ? 1 : 2; }
+        } else {
+            if (B[2] < B[1]) { s1 = 2; s2 = (B[0] < B[1]) ? 0 : 1; }
+            else             { s1 = 1; s2 = (B[0] < B[2]) ? 0 : 2; }
+        }
+        int order[2] = { s1, s2 };
+        for (int k = 0; k < 2 && ret < maxc && ret < 3; k++) {
+            int s = order[k];
+            if (depth - B[s] < 0) break;
+            real sg = (A[s] > 0) ? R(1.0) : R(-1.0);
+            c[ret].pos[0] = p[0] + sg * side[s] * Rm[0 + s];
+            c[ret].pos[1] = p[1] + sg * side[s] * Rm[4 + s];
+            c[ret].pos[2] = p[2] + sg * side[s] * Rm[8 + s];
+            c[ret].depth = depth - B[s];
+            ret++;
+        }
+        if (maxc == 4 && ret == 3) {
+            /* fourth corner of the resting face */
+            real d4 = c[1].depth + c[2].depth - depth;
+            if (d4 > 0) {
+                c[3].pos[0] = c[1].pos[0] + c[2].pos[0] - p[0];
+                c[3].pos[1] = c[1].pos[1] + c[2].pos[1] - p[1];
+                c[3].pos[2] = c[1].pos[2] + c[2].pos[2] - p[2];
+                c[3].depth = d4;
+                ret++;
+            }
+        }
+    }
+    for (int i = 0; i < ret; i++) {
+        c[i].normal[0] = n[0]; c[i].normal[1] = n[1]; c[i].normal[2] = n[2];
+    }
+    return ret;
+}
+
+/* ---- dCollideSpherePlane -------------------------------------------------- */
+static int collide_sphere_plane(const real *pos, real radius, const real *pl, orc_contactgeom *c)
+{
+    real k = orc_dot3(pos, pl);
+    real depth = pl[3] - k + radius;
+    if (depth >= 0) {
+        for (int i = 0; i < 3; i++) {
+            c->normal[i] = pl[i];
+            c->pos[i] = pos[i] - pl[i] * radius;
+        }
+        c->depth = depth;
+        return 1;
+    }
+    return 0;
+}
+
+/* ---- dCollideSphereSphere -> dCollideSpheres ------------------------------ */
+static int collide_sphere_sphere(const real *p1, real r1, const real *p2, real r2, orc_contactgeom *c)
+{
+    real dx = p1[0] - p2[0], dy = p1[1] - p2[1], dz = p1[2] - p2[2];
+    real d = orc_sqrt(dx * dx + dy * dy + dz * dz);
+    if (d > (r1 + r2)) return 0;
+    if (d <= 0) {
+        c->pos[0] = p1[0]; c->pos[1] = p1[1]; c->pos[2] = p1[2];
+        c->normal[0] = 1; c->normal[1] = 0; c->normal[2] = 0;
+        c->depth = r1 + r2;
+    } else {
+        real d1 = R(1.0) / d;
+        c->normal[0] = dx * d1; c->normal[1] = dy * d1; c->normal[2] = dz * d1;
+        real k = R(0.5) * (r2 - r1 - d);
+        c->pos[0] = p1[0] + c->normal[0] * k;
+        c->pos[1] = p1[1] + c->normal[1] * k;
+        c->pos[2] = p1[2] + c->normal[2] * k;
+        c->depth = r1 + r2 - d;
+    }
+    return 1;
+}
+
+/* _dSafeNormalize3 */
+static void safe_normalize3(real *a)
+{
+    real aa0 = orc_fabs(a[0]), aa1 = orc_fabs(a[1]), aa2 = orc_fabs(a[2]), m;
+    if (aa1 > aa0) m = (aa2 > aa1) ? aa2 : aa1;
+    else if (aa2 > aa0) m = aa2;
+    else {
+        if (aa0 <= 0) { a[0] = 1; a[1] = 0; a[2] = 0; return; }
+        m = aa0;
+    }
+    a[0] /= m; a[1] /= m; a[2] /= m;
+    real l = R(1.0) / orc_sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    a[0] *= l; a[1] *= l; a[2] *= l;
+}
+
+/* ---- dCollideSphereBox ---------------------------------------------------- */
+static int collide_sphere_box(const real *sp, real radius, const real *bp, const real *bR,
+                              const real *side, orc_contactgeom *c)
+{
+    real l[3], t[3], p[3], q[3], r[3];
+    int onborder = 0;
+    p[0] = sp[0] - bp[0]; p[1] = sp[1] - bp[1]; p[2] = sp[2] - bp[2];
+    for (int i = 0; i < 3; i++) {
+        l[i] = side[i] * R(0.5);
+        t[i] = orc_dot3_14(p, bR + i);
+        if (t[i] < -l[i]) { t[i] = -l[i]; onborder = 1; }
+        if (t[i] > l[i])  { t[i] = l[i];  onborder = 1; }
+    }
+    if (!onborder) {
+        /* centre inside the box: push out through the closest face */
+        real min_distance = l[0] - orc_fabs(t[0]);
+        int mini = 0;
+        for (int i = 1; i < 3; i++) {
+            real fd = l[i] - orc_fabs(t[i]);
+            if (fd < min_distance) { min_distance = fd; mini = i; }
+        }
+        c->pos[0] = sp[0]; c->pos[1] = sp[1]; c->pos[2] = sp[2];
+        real tmp[3] = { 0, 0, 0 };
+        tmp[mini] = (t[mini] > 0) ? R(1.0) : R(-1.0);
+        orc_mul0_331(c->normal, bR, tmp);
+        c->depth = min_distance + radius;
+        return 1;
+    }
+    orc_mul0_331(q, bR, t);
+    r[0] = p[0] - q[0]; r[1] = p[1] - q[1]; r[2] = p[2] - q[2];
+    real depth = radius - orc_sqrt(orc_dot3(r, r));
+    if (depth < 0) return 0;
+    c->pos[0] = q[0] + bp[0]; c->pos[1] = q[1] + bp[1]; c->pos[2] = q[2] + bp[2];
+    c->normal[0] = r[0]; c->normal[1] = r[1]; c->normal[2] = r[2];
+    safe_normalize3(c->normal);
+    c->depth = depth;
+    return 1;
+}
+
+/* ---- dCollide dispatch (main.c:678) --------------------------------------- */
+static int collide_ordered(orc_world *w, const orc_geom *a, const orc_geom *b, int maxc,
+                           orc_contactgeom *out, int *handled)
+{
+    *handled = 1;
+    const real *pa = orc_geom_pos(w, a), *Ra = orc_geom_R(w, a);
+    const real *pb = orc_geom_pos(w, b), *Rb = orc_geom_R(w, b);
+    if (a->type == ORC_GEOM_BOX && b->type == ORC_GEOM_PLANE)
+        return collide_box_plane(pa, Ra, a->side, b->plane, maxc, out);
+    if (a->type == ORC_GEOM_SPHERE && b->type == ORC_GEOM_PLANE)
+        return collide_sphere_plane(pa, a->side[0], b->plane, out);
+    if (a->type == ORC_GEOM_SPHERE && b->type == ORC_GEOM_SPHERE)
+        return collide_sphere_sphere(pa, a->side[0], pb, b->side[0], out);
+    if (a->type == ORC_GEOM_SPHERE && b->type == ORC_GEOM_BOX)
+        return collide_sphere_box(pa, a->side[0], pb, Rb, b->side, out);
+    if (a->type == ORC_GEOM_BOX && b->type == ORC_GEOM_BOX)
+        return orc_collide_box_box(pa, Ra, a->side, pb, Rb, b->side, maxc, out);
+    *handled = 0;
+    return 0;
+}
+
+int orc_collide(orc_world *w, int g1, int g2, int maxc, orc_contactgeom *out)
+{
+    /* [ODE-recall] dCollide: no self / same-body contacts; if only the
+       reversed class pair has a collider, call it swapped and flip normals */
+    if (g1 == g2) return 0;
+    const orc_geom *a = &w->geoms[g1], *b = &w->geoms[g2];
+    if (a->body >= 0 && a->body == b->body) return 0;
+    int handled, n;
+    n = collide_ordered(w, a, b, maxc, out, &handled);
+    if (handled) {
+        for (int i = 0; i < n; i++) { out[i].g1 = g1; out[i].g2 = g2; }
+        return n;
+    }
+    n = collide_ordered(w, b, a, maxc, out, &handled);
+    if (!handled) return 0;   /* plane-plane: no collider */
+    for (int i = 0; i < n; i++) {
+        out[i].normal[0] = -out[i].normal[0];
+        out[i].normal[1] = -out[i].normal[1];
+        out[i].normal[2] = -out[i].normal[2];
+        out[i].g1 = g1; out[i].g2 = g2;
+    }
+    return n;
+}
+
+/* ---- NearCallback (main.c:674-693) ---------------------------------------- */
+static void joint_push(orc_world *w, const orc_contactgeom *cg, int b1, int b2)
+{
+    if (w->nj == w->cap_j) {
+        w->cap_j = w->cap_j ? 2 * w->cap_j : 256;
+        w->joints = (orc_joint *)realloc(w->joints, (size_t)w->cap_j * sizeof(orc_joint));
+    }
+    orc_joint *j = &w->joints[w->nj++];
+    j->geom = *cg;
+    j->mode = w->surf_mode;               /* main.c:684 */
+    j->bounce = w->surf_bounce;           /* main.c:685 */
+    j->bounce_vel = w->surf_bounce_vel;   /* main.c:686 */
+    j->mu = w->surf_mu;                   /* main.c:687 */
+    /* [ODE-recall] dJointAttach: if body1 is null and body2 is not, swap and
+       set dJOINT_REVERSE */
+    j->reverse = 0;
+    if (b1 < 0 && b2 >= 0) { b1 = b2; b2 = -1; j->reverse = 1; }
+    j->b1 = b1; j->b2 = b2;
+    j->tag = 0;
+}
+
+static void near_callback(orc_world *w, int o1, int o2)
+{
+    orc_contactgeom cg[16];
+    int maxc = w->max_contacts > 16 ? 16 : w->max_contacts;
+    int nc = orc_collide(w, o1, o2, maxc, cg);          /* main.c:678 */
+    if (nc <= 0) return;
+    int b1 = w->geoms[o1].body, b2 = w->geoms[o2].body; /* main.c:691 dGeomGetBody */
+    if (b1 < 0 && b2 < 0) return;   /* static-static joints are ignored by the stepper (SURVEY a-5) */
+    for (int i = 0; i < nc; i++) joint_push(w, &cg[i], b1, b2);
+}
+
+/* ---- broadphase ------------------------------------------------------------ */
+typedef struct { real lo[3], hi[3]; int g; } aabb_t;
+
+static int cmp_aabb(const void *a, const void *b)
+{
+    real x = ((const aabb_t *)a)->lo[0], y = ((const aabb_t *)b)->lo[0];
+    if (x < y) return -1;
+    if (x > y) return 1;
+    int ga = ((const aabb_t *)a)->g, gb = ((const aabb_t *)b)->g;
+    return (ga > gb) - (ga < gb);
+}
+
+static int cmp_pair(const void *a, const void *b)
+{
+    const int *p = (const int *)a, *q = (const int *)b;
+    if (p[0] != q[0]) return (p[0] > q[0]) - (p[0] < q[0]);
+    return (p[1] > q[1]) - (p[1] < q[1]);
+}
+
+static int pair_passes(const orc_geom *a, const orc_geom *b)
+{
+    /* [ODE-recall] collideAABBs: same non-null body -> skip; category/collide test */
+    if (a->body >= 0 && a->body == b->body) return 0;
+    if (!((a->cat & b->col) || (b->cat & a->col))) return 0;
+    return 1;
+}
+
+void orc_collide_all(orc_world *w)
+{
+    w->nj = 0;
+    int ng = w->ng;
+    aabb_t *bb = (aabb_t *)malloc((size_t)(ng ? ng : 1) * sizeof(aabb_t));
+    int nbb = 0;
+    int *pairs = NULL; size_t np = 0, cap = 0;
+#define PUSH_PAIR(A, B) do { if (np == cap) { cap = cap ? 2 * cap : 1024; \
+        pairs = (int *)realloc(pairs, 2 * cap * sizeof(int)); } \
+        pairs[2 * np] = (A) < (B) ? (A) : (B); pairs[2 * np + 1] = (A) < (B) ? (B) : (A); np++; } while (0)
+
+    /* finite AABBs: box = centre +- sum_j |R_ij| side_j / 2; sphere = centre +- r */
+    for (int g = 0; g < ng; g++) {
+        const orc_geom *ge = &w->geoms[g];
+        if (ge->type == ORC_GEOM_PLANE) continue;
+        const real *p = orc_geom_pos(w, ge), *Rm = orc_geom_R(w, ge);
+        aabb_t *a = &bb[nbb++];
+        a->g = g;
+        for (int i = 0; i < 3; i++) {
+            real r = (ge->type == ORC_GEOM_SPHERE)
+                         ? ge->side[0]
+                         : R(0.5) * (orc_fabs(Rm[4 * i] * ge->side[0]) +
+                                     orc_fabs(Rm[4 * i + 1] * ge->side[1]) +
+                                     orc_fabs(Rm[4 * i + 2] * ge->side[2]));
+            a->lo[i] = p[i] - r; a->hi[i] = p[i] + r;
+        }
+    }
+    /* planes are unbounded: test against every non-plane geom */
+    for (int g = 0; g < ng; g++) {
+        if (w->geoms[g].type != ORC_GEOM_PLANE) continue;
+        for (int k = 0; k < nbb; k++)
+            if (pair_passes(&w->geoms[g], &w->geoms[bb[k].g])) PUSH_PAIR(g, bb[k].g);
+    }
+    /* sweep along x over the finite AABBs */
+    qsort(bb, (size_t)nbb, sizeof(aabb_t), cmp_aabb);
+    for (int i = 0; i < nbb; i++) {
+        for (int j = i + 1; j < nbb && bb[j].lo[0] <= bb[i].hi[0]; j++) {
+            if (bb[j].lo[1] > bb[i].hi[1] || bb[i].lo[1] > bb[j].hi[1]) continue;
+            if (bb[j].lo[2] > bb[i].hi[2] || bb[i].lo[2] > bb[j].hi[2]) continue;
+            if (pair_passes(&w->geoms[bb[i].g], &w->geoms[bb[j].g])) PUSH_PAIR(bb[i].g, bb[j].g);
+        }
+    }
+    /* canonical order: ascending (g1,g2), g1 < g2 */
+    qsort(pairs, np, 2 * sizeof(int), cmp_pair);
+    for (size_t k = 0; k < np; k++) near_callback(w, pairs[2 * k], pairs[2 * k + 1]);
+    free(pairs);
+    free(bb);
+#undef PUSH_PAIR
+}

@@ -1,0 +1,177 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle_f{32,64}.so).
+
+TEST INFRASTRUCTURE ONLY (see oracle/orc.h): imported by tests/, by
+__graft_entry__.smoke() and by bench.py's cpu_baseline leg -- never by the
+product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+GEOM_SPHERE, GEOM_BOX, GEOM_PLANE = 0, 1, 2
+CONTACT_BOUNCE = 0x004
+ORDER_FIXED, ORDER_ODE = 0, 1
+GYRO_OFF, GYRO_EXPLICIT, GYRO_IMPLICIT = 0, 1, 2
+
+
+def build():
+    """Compile the oracle's C restatement (gcc, a few seconds)."""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+class _ContactGeom64(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("normal", C.c_double * 3),
+                ("depth", C.c_double), ("g1", C.c_int), ("g2", C.c_int)]
+
+
+class _ContactGeom32(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("normal", C.c_float * 3),
+                ("depth", C.c_float), ("g1", C.c_int), ("g2", C.c_int)]
+
+
+class Oracle:
+    """One precision of the oracle library."""
+
+    def __init__(self, dtype):
+        self.dtype = np.dtype(dtype)
+        name = {4: "liboracle_f32.so", 8: "liboracle_f64.so"}[self.dtype.itemsize]
+        path = os.path.join(_HERE, name)
+        if not os.path.exists(path):
+            build()
+        self.lib = lib = C.CDLL(path)
+        self.real = real = C.c_float if self.dtype.itemsize == 4 else C.c_double
+        self.ContactGeom = _ContactGeom32 if self.dtype.itemsize == 4 else _ContactGeom64
+        P = C.c_void_p
+        RP = C.POINTER(real)
+
+        def sig(fn, res, *args):
+            f = getattr(lib, fn)
+            f.restype = res
+            f.argtypes = list(args)
+
+        sig("orc_world_create", P)
+        sig("orc_world_destroy", None, P)
+        sig("orc_world_set_gravity", None, P, real, real, real)
+        sig("orc_world_set_erp", None, P, real)
+        sig("orc_world_set_cfm", None, P, real)
+        sig("orc_world_set_quickstep", None, P, C.c_int, real)
+        sig("orc_world_set_row_order", None, P, C.c_int)
+        sig("orc_world_set_gyro_mode", None, P, C.c_int)
+        sig("orc_world_set_surface", None, P, C.c_int, real, real, real)
+        sig("orc_world_set_max_contacts", None, P, C.c_int)
+        sig("orc_rand_seed", None, C.c_uint32)
+        sig("orc_body_create", C.c_int, P)
+        sig("orc_body_set_position", None, P, C.c_int, real, real, real)
+        sig("orc_body_set_rotation", None, P, C.c_int, RP)
+        sig("orc_body_set_quaternion", None, P, C.c_int, RP)
+        sig("orc_body_set_linear_vel", None, P, C.c_int, real, real, real)
+        sig("orc_body_set_angular_vel", None, P, C.c_int, real, real, real)
+        sig("orc_body_set_mass", None, P, C.c_int, real, RP)
+        sig("orc_body_add_force", None, P, C.c_int, real, real, real)
+        sig("orc_body_add_torque", None, P, C.c_int, real, real, real)
+        for g in ("position", "quaternion", "linear_vel", "angular_vel", "rotation"):
+            sig("orc_body_get_" + g, RP, P, C.c_int)
+        sig("orc_geom_create_box", C.c_int, P, real, real, real)
+        sig("orc_geom_create_sphere", C.c_int, P, real)
+        sig("orc_geom_create_plane", C.c_int, P, real, real, real, real)
+        sig("orc_geom_set_body", None, P, C.c_int, C.c_int)
+        sig("orc_geom_set_position", None, P, C.c_int, real, real, real)
+        sig("orc_geom_set_rotation", None, P, C.c_int, RP)
+        sig("orc_geom_set_category_bits", None, P, C.c_int, C.c_uint32)
+        sig("orc_geom_set_collide_bits", None, P, C.c_int, C.c_uint32)
+        sig("orc_collide", C.c_int, P, C.c_int, C.c_int, C.c_int, C.POINTER(self.ContactGeom))
+        sig("orc_world_tick", None, P, real)
+        sig("orc_world_last_contact_count", C.c_int, P)
+        sig("orc_world_last_sor_residual", C.c_double, P)
+        sig("orc_world_body_count", C.c_int, P)
+        sig("orc_world_add_boxes", None, P, C.c_int, P, P, P, P, P, P, P)
+        sig("orc_world_add_spheres", None, P, C.c_int, P, P, P, P, P, P, P)
+        sig("orc_world_get_state", None, P, P, P, P, P)
+        sig("orc_world_run", C.c_double, P, real, C.c_int)
+        sig("orc_pack_transform", None, RP, RP, RP)
+        sig("orc_ref_rand_seed", None, C.c_uint32)
+        sig("orc_ref_rand_next", C.c_uint32)
+        sig("orc_ref_rand_int", C.c_int32, C.c_int32, C.c_int32)
+        sig("orc_ref_rand_double", C.c_double, C.c_double, C.c_double)
+        sig("orc_real_size", C.c_int)
+        assert lib.orc_real_size() == self.dtype.itemsize
+
+    def arr(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        return a, a.ctypes.data_as(C.POINTER(self.real))
+
+    def world(self, **kw):
+        return World(self, **kw)
+
+
+class World:
+    """Thin object wrapper around orc_world."""
+
+    def __init__(self, orc, gravity=(0.0, -9.8, 0.0)):
+        self.o = orc
+        self.lib = orc.lib
+        self.w = self.lib.orc_world_create()
+        self.lib.orc_world_set_gravity(self.w, *gravity)   # main.c:96
+        self._keep = []
+
+    def close(self):
+        if self.w:
+            self.lib.orc_world_destroy(self.w)
+            self.w = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _p(self, a):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=self.o.dtype)
+        self._keep.append(a)
+        return a.ctypes.data
+
+    # bulk ------------------------------------------------------------------
+    def add_boxes(self, pos, quat, lvel, avel, mass, idiag, sides):
+        n = len(pos)
+        self.lib.orc_world_add_boxes(self.w, n, self._p(pos), self._p(quat), self._p(lvel),
+                                     self._p(avel), self._p(mass), self._p(idiag), self._p(sides))
+        self._keep.clear()
+
+    def add_spheres(self, pos, quat, lvel, avel, mass, idiag, radius):
+        n = len(pos)
+        self.lib.orc_world_add_spheres(self.w, n, self._p(pos), self._p(quat), self._p(lvel),
+                                       self._p(avel), self._p(mass), self._p(idiag), self._p(radius))
+        self._keep.clear()
+
+    def add_plane(self, a, b, c, d):
+        return self.lib.orc_geom_create_plane(self.w, a, b, c, d)
+
+    def state(self):
+        n = self.lib.orc_world_body_count(self.w)
+        dt = self.o.dtype
+        pos = np.empty((n, 3), dt)
+        quat = np.empty((n, 4), dt)
+        lvel = np.empty((n, 3), dt)
+        avel = np.empty((n, 3), dt)
+        self.lib.orc_world_get_state(self.w, pos.ctypes.data, quat.ctypes.data,
+                                     lvel.ctypes.data, avel.ctypes.data)
+        return pos, quat, lvel, avel
+
+    def run(self, h, steps):
+        """steps ticks of main.c:211-215; returns seconds spent in the loop."""
+        return self.lib.orc_world_run(self.w, h, steps)
+
+    def tick(self, h):
+        self.lib.orc_world_tick(self.w, h)
+
+    def n_contacts(self):
+        return self.lib.orc_world_last_contact_count(self.w)
+
+    def sor_residual(self):
+        return self.lib.orc_world_last_sor_residual(self.w)

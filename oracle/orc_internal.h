@@ -1,0 +1,66 @@
+/* oracle/orc_internal.h -- private structs of the CPU oracle (TEST INFRASTRUCTURE, see orc.h) */
+#ifndef ORC_INTERNAL_H
+#define ORC_INTERNAL_H
+
+#include "orc.h"
+#include "orc_math.h"
+
+enum { ORC_BODY_KINEMATIC = 1, ORC_BODY_NOGRAVITY = 2 };
+
+typedef struct {
+    real pos[4];
+    real q[4];
+    real R[12];
+    real lvel[4], avel[4];
+    real facc[4], tacc[4];
+    real mass, invMass;
+    real I[12], invI[12];     /* body frame */
+    int flags;
+    int tag;
+} orc_body;
+
+typedef struct {
+    int type;
+    int body;                 /* -1 = static geom (dGeomGetBody == 0, main.c:691) */
+    real side[3];             /* box: full side lengths; sphere: side[0] = radius */
+    real plane[4];
+    real pos[4];              /* used when body < 0 */
+    real R[12];
+    uint32_t cat, col;
+} orc_geom;
+
+typedef struct {
+    orc_contactgeom geom;
+    int mode;
+    real mu, bounce, bounce_vel;
+    int b1, b2;               /* b1 >= 0 always; b2 may be -1 */
+    int reverse;              /* dJOINT_REVERSE: bodies were swapped at attach */
+    int tag;
+} orc_joint;
+
+struct orc_world {
+    real gravity[4];
+    real erp, cfm, sor_w;
+    int iters;
+    int row_order, gyro_mode;
+    int surf_mode; real surf_mu, surf_bounce, surf_bounce_vel;
+    int max_contacts;
+
+    orc_body *bodies; int nb, cap_b;
+    orc_geom *geoms;  int ng, cap_g;
+    orc_joint *joints; int nj, cap_j;
+
+    int last_contacts;
+    double last_residual;
+};
+
+/* geometry pose, whether body-attached or static */
+const real *orc_geom_pos(const orc_world *w, const orc_geom *g);
+const real *orc_geom_R(const orc_world *w, const orc_geom *g);
+
+void orc_collide_all(orc_world *w);           /* dSpaceCollide + NearCallback */
+void orc_quickstep(orc_world *w, real h);     /* dWorldQuickStep */
+uint32_t orc_ode_rand(void);
+int orc_ode_rand_int(int n);
+
+#endif

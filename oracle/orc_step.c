@@ -1,0 +1,405 @@
+/*
+ * oracle/orc_step.c -- dWorldQuickStep restated (TEST INFRASTRUCTURE, see orc.h).
+ *
+ * Reference call site: dWorldStep(world, physicsTime) at main.c:213, stepped
+ * with QuickStep semantics as BASELINE.json's configs name.
+ * Everything below is [ODE-recall] of ODE 0.13-0.16:
+ *   util.cpp   dxProcessIslands  -> islands()
+ *   quickstep.cpp dxQuickStepIsland stages 0-6 -> step_island()
+ *   quickstep.cpp SOR_LCP        -> sor_lcp()
+ *   contact.cpp dxJointContact::getInfo1/getInfo2 -> contact_rows()
+ *   util.cpp   dxStepBody        -> step_body()
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "orc_internal.h"
+
+typedef struct {
+    /* per island, sized on demand */
+    int *ibody, *ijoint, *stack;
+    real *invI, *J, *iMJ, *rhs, *cfm, *lo, *hi, *lambda, *Ad, *fc, *tmp1, *c;
+    int *jb, *findex, *order, *local;
+    size_t cap_b, cap_m;
+    /* adjacency */
+    int *adj_off, *adj, *adj_fill;
+    size_t cap_adj_b, cap_adj;
+} scratch_t;
+
+static scratch_t S;
+
+static void need_bodies(size_t nb)
+{
+    if (nb <= S.cap_b) return;
+    S.cap_b = nb * 2;
+    S.invI = (real *)realloc(S.invI, S.cap_b * 12 * sizeof(real));
+    S.fc = (real *)realloc(S.fc, S.cap_b * 6 * sizeof(real));
+    S.tmp1 = (real *)realloc(S.tmp1, S.cap_b * 6 * sizeof(real));
+}
+
+static void need_rows(size_t m)
+{
+    if (m <= S.cap_m) return;
+    S.cap_m = m * 2;
+    S.J = (real *)realloc(S.J, S.cap_m * 12 * sizeof(real));
+    S.iMJ = (real *)realloc(S.iMJ, S.cap_m * 12 * sizeof(real));
+    S.rhs = (real *)realloc(S.rhs, S.cap_m * sizeof(real));
+    S.c = (real *)realloc(S.c, S.cap_m * sizeof(real));
+    S.cfm = (real *)realloc(S.cfm, S.cap_m * sizeof(real));
+    S.lo = (real *)realloc(S.lo, S.cap_m * sizeof(real));
+    S.hi = (real *)realloc(S.hi, S.cap_m * sizeof(real));
+    S.lambda = (real *)realloc(S.lambda, S.cap_m * sizeof(real));
+    S.Ad = (real *)realloc(S.Ad, S.cap_m * sizeof(real));
+    S.jb = (int *)realloc(S.jb, S.cap_m * 2 * sizeof(int));
+    S.findex = (int *)realloc(S.findex, S.cap_m * sizeof(int));
+    S.order = (int *)realloc(S.order, S.cap_m * sizeof(int));
+}
+
+/* dxStepBody: x += h v; q += h * 1/2 (0,w) q; normalise; R = R(q) */
+static void step_body(orc_body *b, real h)
+{
+    for (int j = 0; j < 3; j++) b->pos[j] += h * b->lvel[j];
+    real dq[4];
+    orc_w_to_dq(b->avel, b->q, dq);
+    for (int j = 0; j < 4; j++) b->q[j] += h * dq[j];
+    orc_normalize4(b->q);
+    orc_q_to_R(b->q, b->R);
+}
+
+/* gyroscopic torque into tacc */
+static void gyro_torque(const orc_world *w, orc_body *b, real h)
+{
+    real tmp[12], I[12];
+    orc_mul2_333(tmp, b->I, b->R);      /* I_b R^T   */
+    orc_mul0_333(I, b->R, tmp);         /* R I_b R^T */
+    if (w->gyro_mode == ORC_GYRO_EXPLICIT) {
+        real L[3], c[3];
+        orc_mul0_331(L, I, b->avel);
+        orc_cross3(c, b->avel, L);
+        b->tacc[0] -= c[0]; b->tacc[1] -= c[1]; b->tacc[2] -= c[2];
+        return;
+    }
+    /* implicit (Lacoursiere): Itild = I - h [L]x ; tau = (I Itild^-1 - 1) L / h */
+    real L[3];
+    orc_mul0_331(L, I, b->avel);
+    real It[12];
+    memset(It, 0, sizeof(It));
+    /* dSetCrossMatrixMinus(It, L, 4) */
+    It[1] = L[2];  It[2] = -L[1];
+    It[4] = -L[2]; It[6] = L[0];
+    It[8] = L[1];  It[9] = -L[0];
+    for (int i = 0; i < 12; i++) It[i] = It[i] * h + I[i];
+    real hinv = R(1.0) / h;
+    L[0] *= hinv; L[1] *= hinv; L[2] *= hinv;
+    real itInv[12];
+    if (orc_invert3(itInv, It)) {
+        orc_mul0_333(It, I, itInv);
+        It[0] -= 1; It[5] -= 1; It[10] -= 1;
+        real tau[3];
+        orc_mul0_331(tau, It, L);
+        b->tacc[0] += tau[0]; b->tacc[1] += tau[1]; b->tacc[2] += tau[2];
+    }
+}
+
+/* dxJointContact::getInfo1: rows for this contact */
+static int contact_m(const orc_joint *j)
+{
+    real mu = j->mu < 0 ? 0 : j->mu;
+    return (mu > 0) ? 3 : 1;
+}
+
+/* dxJointContact::getInfo2: fills m rows starting at row r */
+static void contact_rows(const orc_world *w, const orc_joint *j, int lb1, int lb2,
+                         int r, real fps)
+{
+    const orc_body *B1 = &w->bodies[j->b1];
+    const orc_body *B2 = j->b2 >= 0 ? &w->bodies[j->b2] : NULL;
+    int m = contact_m(j);
+    real normal[3], c1[3], c2[3] = { 0, 0, 0 };
+    for (int k = 0; k < 3; k++) {
+        normal[k] = j->reverse ? -j->geom.normal[k] : j->geom.normal[k];
+        c1[k] = j->geom.pos[k] - B1->pos[k];
+        if (B2) c2[k] = j->geom.pos[k] - B2->pos[k];
+    }
+    real *J = S.J + 12 * (size_t)r;
+    memset(J, 0, (size_t)m * 12 * sizeof(real));
+    for (int k = 0; k < m; k++) {
+        S.jb[2 * (r + k)] = lb1; S.jb[2 * (r + k) + 1] = lb2;
+        S.c[r + k] = 0; S.cfm[r + k] = w->cfm;
+        S.findex[r + k] = -1;
+    }
+    /* normal row */
+    J[0] = normal[0]; J[1] = normal[1]; J[2] = normal[2];
+    orc_cross3(J + 3, c1, normal);
+    if (B2) {
+        J[6] = -normal[0]; J[7] = -normal[1]; J[8] = -normal[2];
+        orc_cross3(J + 9, c2, normal);
+        J[9] = -J[9]; J[10] = -J[10]; J[11] = -J[11];
+    }
+    real k_erp = fps * w->erp;
+    real depth = j->geom.depth;          /* min_depth = 0 */
+    if (depth < 0) depth = 0;
+    real pushout = k_erp * depth;
+    S.c[r] = pushout;                    /* max_vel = infinity */
+    if (j->mode & ORC_CONTACT_BOUNCE) {
+        real outgoing = orc_dot3(J, B1->lvel) + orc_dot3(J + 3, B1->avel);
+        if (B2) outgoing += orc_dot3(J + 6, B2->lvel) + orc_dot3(J + 9, B2->avel);
+        if (j->bounce_vel >= 0 && (-outgoing) > j->bounce_vel) {
+            real newc = -j->bounce * outgoing;
+            if (newc > S.c[r]) S.c[r] = newc;
+        }
+    }
+    S.lo[r] = 0; S.hi[r] = ORC_INF;
+    if (m >= 2) {
+        real t1[3], t2[3];
+        orc_plane_space(normal, t1, t2);
+        real *J1 = J + 12, *J2 = J + 24;
+        J1[0] = t1[0]; J1[1] = t1[1]; J1[2] = t1[2];
+        orc_cross3(J1 + 3, c1, t1);
+        if (B2) {
+            J1[6] = -t1[0]; J1[7] = -t1[1]; J1[8] = -t1[2];
+            orc_cross3(J1 + 9, c2, t1);
+            J1[9] = -J1[9]; J1[10] = -J1[10]; J1[11] = -J1[11];
+        }
+        S.lo[r + 1] = -j->mu; S.hi[r + 1] = j->mu;
+        J2[0] = t2[0]; J2[1] = t2[1]; J2[2] = t2[2];
+        orc_cross3(J2 + 3, c1, t2);
+        if (B2) {
+            J2[6] = -t2[0]; J2[7] = -t2[1]; J2[8] = -t2[2];
+            orc_cross3(J2 + 9, c2, t2);
+            J2[9] = -J2[9]; J2[10] = -J2[10]; J2[11] = -J2[11];
+        }
+        S.lo[r + 2] = -j->mu; S.hi[r + 2] = j->mu;
+    }
+}
+
+/* SOR_LCP */
+static double sor_lcp(const orc_world *w, int m, int nb, const int *ibody)
+{
+    real *J = S.J, *iMJ = S.iMJ, *b = S.rhs, *lambda = S.lambda, *Ad = S.Ad, *fc = S.fc;
+    const int *jb = S.jb;
+    double resid = 0;
+    /* iMJ = inv(M) J^T */
+    for (int i = 0; i < m; i++) {
+        real *ip = iMJ + 12 * (size_t)i; const real *jp = J + 12 * (size_t)i;
+        int b1 = jb[2 * i], b2 = jb[2 * i + 1];
+        real k = w->bodies[ibody[b1]].flags & ORC_BODY_KINEMATIC ? 0 : w->bodies[ibody[b1]].invMass;
+        for (int j = 0; j < 3; j++) ip[j] = k * jp[j];
+        orc_mul0_331(ip + 3, S.invI + 12 * (size_t)b1, jp + 3);
+        if (b2 >= 0) {
+            k = w->bodies[ibody[b2]].flags & ORC_BODY_KINEMATIC ? 0 : w->bodies[ibody[b2]].invMass;
+            for (int j = 0; j < 3; j++) ip[6 + j] = k * jp[6 + j];
+            orc_mul0_331(ip + 9, S.invI + 12 * (size_t)b2, jp + 9);
+        } else {
+            for (int j = 6; j < 12; j++) ip[j] = 0;
+        }
+    }
+    memset(lambda, 0, (size_t)m * sizeof(real));
+    memset(fc, 0, (size_t)nb * 6 * sizeof(real));
+    /* Ad = w / (diag(J iMJ) + cfm) */
+    for (int i = 0; i < m; i++) {
+        const real *ip = iMJ + 12 * (size_t)i, *jp = J + 12 * (size_t)i;
+        real sum = 0;
+        for (int j = 0; j < 6; j++) sum += ip[j] * jp[j];
+        if (jb[2 * i + 1] >= 0)
+            for (int j = 6; j < 12; j++) sum += ip[j] * jp[j];
+        Ad[i] = w->sor_w / (sum + S.cfm[i]);
+    }
+    /* scale J and b by Ad; Ad *= cfm */
+    for (int i = 0; i < m; i++) {
+        real *jp = J + 12 * (size_t)i;
+        for (int j = 0; j < 12; j++) jp[j] *= Ad[i];
+        b[i] *= Ad[i];
+        Ad[i] *= S.cfm[i];
+    }
+    /* rows with findex < 0 first (all of them here) */
+    {
+        int f = 0, k = 1;
+        for (int i = 0; i < m; i++) {
+            if (S.findex[i] < 0) S.order[f++] = i;
+            else S.order[m - k++] = i;
+        }
+    }
+    for (int it = 0; it < w->iters; it++) {
+        if (w->row_order == ORC_ORDER_ODE && (it & 7) == 0) {
+            for (int i = 1; i < m; i++) {
+                int sw = orc_ode_rand_int(i + 1);
+                int t = S.order[i]; S.order[i] = S.order[sw]; S.order[sw] = t;
+            }
+        }
+        int last = (it == w->iters - 1);
+        for (int i = 0; i < m; i++) {
+            int idx = S.order[i];
+            int b1 = jb[2 * idx], b2 = jb[2 * idx + 1];
+            real *fc1 = fc + 6 * (size_t)b1;
+            real *fc2 = b2 >= 0 ? fc + 6 * (size_t)b2 : NULL;
+            real old_lambda = lambda[idx];
+            real delta = b[idx] - old_lambda * Ad[idx];
+            const real *jp = J + 12 * (size_t)idx;
+            delta -= fc1[0] * jp[0] + fc1[1] * jp[1] + fc1[2] * jp[2] +
+                     fc1[3] * jp[3] + fc1[4] * jp[4] + fc1[5] * jp[5];
+            if (fc2)
+                delta -= fc2[0] * jp[6] + fc2[1] * jp[7] + fc2[2] * jp[8] +
+                         fc2[3] * jp[9] + fc2[4] * jp[10] + fc2[5] * jp[11];
+            real lo_act, hi_act;
+            if (S.findex[idx] >= 0) {
+                hi_act = orc_fabs(S.hi[idx] * lambda[S.findex[idx]]);
+                lo_act = -hi_act;
+            } else { hi_act = S.hi[idx]; lo_act = S.lo[idx]; }
+            real new_lambda = old_lambda + delta;
+            if (new_lambda < lo_act) { delta = lo_act - old_lambda; lambda[idx] = lo_act; }
+            else if (new_lambda > hi_act) { delta = hi_act - old_lambda; lambda[idx] = hi_act; }
+            else lambda[idx] = new_lambda;
+            const real *ip = iMJ + 12 * (size_t)idx;
+            for (int k = 0; k < 6; k++) fc1[k] += delta * ip[k];
+            if (fc2) for (int k = 0; k < 6; k++) fc2[k] += delta * ip[6 + k];
+            if (last) resid += (double)orc_fabs(delta);
+        }
+    }
+    return resid;
+}
+
+static void step_island(orc_world *w, const int *ibody, int nb, const int *ijoint, int nj, real h)
+{
+    real stepsize1 = R(1.0) / h;
+    need_bodies((size_t)nb);
+    /* stage 0: gravity, world-frame inverse inertia, gyroscopic torque */
+    for (int i = 0; i < nb; i++) {
+        orc_body *b = &w->bodies[ibody[i]];
+        if (!(b->flags & (ORC_BODY_NOGRAVITY | ORC_BODY_KINEMATIC)))
+            for (int j = 0; j < 3; j++) b->facc[j] += b->mass * w->gravity[j];
+        real tmp[12];
+        if (b->flags & ORC_BODY_KINEMATIC) {
+            memset(S.invI + 12 * (size_t)i, 0, 12 * sizeof(real));
+        } else {
+            orc_mul2_333(tmp, b->invI, b->R);
+            orc_mul0_333(S.invI + 12 * (size_t)i, b->R, tmp);
+            if (w->gyro_mode != ORC_GYRO_OFF) gyro_torque(w, b, h);
+        }
+    }
+    /* rows */
+    int m = 0;
+    for (int k = 0; k < nj; k++) m += contact_m(&w->joints[ijoint[k]]);
+    if (m > 0) {
+        need_rows((size_t)m);
+        int r = 0;
+        for (int k = 0; k < nj; k++) {
+            const orc_joint *j = &w->joints[ijoint[k]];
+            int lb1 = S.local[j->b1];
+            int lb2 = j->b2 >= 0 ? S.local[j->b2] : -1;
+            contact_rows(w, j, lb1, lb2, r, stepsize1);
+            r += contact_m(j);
+        }
+        /* rhs = c/h - J (v/h + invM fe) */
+        for (int i = 0; i < nb; i++) {
+            const orc_body *b = &w->bodies[ibody[i]];
+            real im = (b->flags & ORC_BODY_KINEMATIC) ? 0 : b->invMass;
+            real *t = S.tmp1 + 6 * (size_t)i;
+            for (int j = 0; j < 3; j++) t[j] = b->facc[j] * im + b->lvel[j] * stepsize1;
+            orc_mul0_331(t + 3, S.invI + 12 * (size_t)i, b->tacc);
+            for (int j = 0; j < 3; j++) t[3 + j] += b->avel[j] * stepsize1;
+        }
+        for (int i = 0; i < m; i++) {
+            const real *jp = S.J + 12 * (size_t)i;
+            int b1 = S.jb[2 * i], b2 = S.jb[2 * i + 1];
+            real sum = 0;
+            const real *in = S.tmp1 + 6 * (size_t)b1;
+            for (int j = 0; j < 6; j++) sum += jp[j] * in[j];
+            if (b2 >= 0) {
+                in = S.tmp1 + 6 * (size_t)b2;
+                for (int j = 0; j < 6; j++) sum += jp[6 + j] * in[j];
+            }
+            S.rhs[i] = S.c[i] * stepsize1 - sum;
+            S.cfm[i] *= stepsize1;
+        }
+        w->last_residual += sor_lcp(w, m, nb, ibody);
+        /* v += h * cforce */
+        for (int i = 0; i < nb; i++) {
+            orc_body *b = &w->bodies[ibody[i]];
+            const real *cf = S.fc + 6 * (size_t)i;
+            for (int j = 0; j < 3; j++) b->lvel[j] += h * cf[j];
+            for (int j = 0; j < 3; j++) b->avel[j] += h * cf[3 + j];
+        }
+    }
+    /* v += h invM fe; integrate; clear accumulators */
+    for (int i = 0; i < nb; i++) {
+        orc_body *b = &w->bodies[ibody[i]];
+        if (!(b->flags & ORC_BODY_KINEMATIC)) {
+            real im = b->invMass;
+            for (int j = 0; j < 3; j++) b->lvel[j] += h * im * b->facc[j];
+            for (int j = 0; j < 3; j++) b->tacc[j] *= h;
+            orc_muladd0_331(b->avel, S.invI + 12 * (size_t)i, b->tacc);
+        }
+    }
+    for (int i = 0; i < nb; i++) {
+        orc_body *b = &w->bodies[ibody[i]];
+        step_body(b, h);
+        b->facc[0] = b->facc[1] = b->facc[2] = 0;
+        b->tacc[0] = b->tacc[1] = b->tacc[2] = 0;
+    }
+}
+
+/* dxProcessIslands: DFS over joints between bodies */
+void orc_quickstep(orc_world *w, real h)
+{
+    int nb = w->nb, nj = w->nj;
+    w->last_residual = 0;
+    if (nb == 0) return;
+    /* adjacency: joints per body, in creation order */
+    if ((size_t)nb + 1 > S.cap_adj_b) {
+        S.cap_adj_b = (size_t)nb + 1;
+        S.adj_off = (int *)realloc(S.adj_off, S.cap_adj_b * sizeof(int));
+        S.adj_fill = (int *)realloc(S.adj_fill, S.cap_adj_b * sizeof(int));
+        S.ibody = (int *)realloc(S.ibody, S.cap_adj_b * sizeof(int));
+        S.stack = (int *)realloc(S.stack, S.cap_adj_b * sizeof(int));
+        S.local = (int *)realloc(S.local, S.cap_adj_b * sizeof(int));
+    }
+    if ((size_t)2 * nj + 1 > S.cap_adj) {
+        S.cap_adj = (size_t)2 * nj + 1;
+        S.adj = (int *)realloc(S.adj, S.cap_adj * sizeof(int));
+        S.ijoint = (int *)realloc(S.ijoint, S.cap_adj * sizeof(int));
+    }
+    memset(S.adj_off, 0, ((size_t)nb + 1) * sizeof(int));
+    for (int j = 0; j < nj; j++) {
+        S.adj_off[w->joints[j].b1 + 1]++;
+        if (w->joints[j].b2 >= 0) S.adj_off[w->joints[j].b2 + 1]++;
+        w->joints[j].tag = 0;
+    }
+    for (int i = 0; i < nb; i++) S.adj_off[i + 1] += S.adj_off[i];
+    memcpy(S.adj_fill, S.adj_off, (size_t)nb * sizeof(int));
+    for (int j = 0; j < nj; j++) {
+        S.adj[S.adj_fill[w->joints[j].b1]++] = j;
+        if (w->joints[j].b2 >= 0) S.adj[S.adj_fill[w->joints[j].b2]++] = j;
+    }
+    for (int i = 0; i < nb; i++) w->bodies[i].tag = 0;
+
+    int ode = (w->row_order == ORC_ORDER_ODE);
+    for (int s = 0; s < nb; s++) {
+        /* ODE's body list is head-inserted: newest body first */
+        int bb = ode ? nb - 1 - s : s;
+        if (w->bodies[bb].tag) continue;
+        w->bodies[bb].tag = 1;
+        int bcount = 0, jcount = 0, sp = 0;
+        int b = bb;
+        for (;;) {
+            S.local[b] = bcount;
+            S.ibody[bcount++] = b;
+            int lo = S.adj_off[b], hi = S.adj_off[b + 1];
+            for (int t = 0; t < hi - lo; t++) {
+                /* per-body joint list is head-inserted too in ODE */
+                int j = ode ? S.adj[hi - 1 - t] : S.adj[lo + t];
+                orc_joint *jt = &w->joints[j];
+                if (jt->tag) continue;
+                jt->tag = 1;
+                S.ijoint[jcount++] = j;
+                int other = (jt->b1 == b) ? jt->b2 : jt->b1;
+                if (other >= 0 && !w->bodies[other].tag) {
+                    w->bodies[other].tag = 1;
+                    S.stack[sp++] = other;
+                }
+            }
+            if (sp == 0) break;
+            b = S.stack[--sp];
+        }
+        step_island(w, S.ibody, bcount, S.ijoint, jcount, h);
+    }
+}

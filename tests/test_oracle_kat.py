@@ -1,0 +1,297 @@
+"""Analytic known-answer tests that pin the CPU oracle.
+
+The reference ships no tests and ODE is not vendored (parity unpinned), so the
+oracle is pinned by closed forms that follow from the integrator / contact
+definitions, plus the golden values of the one compilable reference slice
+(src/rand.c, tests/golden/rand_golden.json).
+"""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc_ctypes as oc
+
+H = 1.0 / 60.0
+G = -9.8
+
+
+def _one_box(orc, pos=(0, 10, 0), quat=(1, 0, 0, 0), lvel=(0, 0, 0), avel=(0, 0, 0),
+             mass=None, idiag=None, sides=(1, 1, 1), gravity=(0, G, 0)):
+    w = orc.world(gravity=gravity)
+    w.add_boxes([pos], [quat], [lvel], [avel],
+                None if mass is None else [mass],
+                None if idiag is None else [idiag], [sides])
+    return w
+
+
+# ---------------------------------------------------------------- golden: rand.c
+def test_rand_golden(orc64):
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rand_golden.json")))
+    lib = orc64.lib
+    for case in g["next"]:
+        lib.orc_ref_rand_seed(case["seed"])
+        assert [lib.orc_ref_rand_next() for _ in case["values"]] == case["values"]
+    lib.orc_ref_rand_seed(g["mixed"]["seed"])
+    for call in g["mixed"]["calls"]:
+        if call["fn"] == "double":
+            assert lib.orc_ref_rand_double(call["min"], call["max"]) == call["value"]
+        else:
+            assert lib.orc_ref_rand_int(call["min"], call["max"]) == call["value"]
+
+
+# ---------------------------------------------------------------- KAT-1 free fall
+@pytest.mark.parametrize("prec", ["float64", "float32"])
+def test_kat1_free_fall_symplectic_euler(prec):
+    orc = oc.Oracle(prec)
+    w = _one_box(orc, pos=(1.0, 100.0, -2.0))
+    n = 60
+    w.run(H, n)
+    pos, quat, lvel, avel = w.state()
+    # velocity first, then position with the NEW velocity
+    v = n * H * G
+    dy = G * H * H * n * (n + 1) / 2.0
+    assert abs(dy - (-4.981666666666667)) < 1e-12
+    tol = 1e-12 if prec == "float64" else 2e-6
+    assert abs(lvel[0, 1] - v) <= tol * abs(v)
+    assert abs(pos[0, 1] - (100.0 + dy)) <= tol * 100.0
+    assert pos[0, 0] == 1.0 and pos[0, 2] == -2.0
+    assert np.all(quat[0] == np.array([1, 0, 0, 0], quat.dtype))
+
+
+def test_kat1_initial_velocity(orc64):
+    w = _one_box(orc64, pos=(0, 0, 0), lvel=(3.0, 5.0, -1.0))
+    n = 17
+    w.run(H, n)
+    pos, _, lvel, _ = w.state()
+    assert abs(lvel[0, 1] - (5.0 + n * H * G)) < 1e-12
+    assert abs(pos[0, 1] - (n * H * 5.0 + G * H * H * n * (n + 1) / 2.0)) < 1e-12
+    assert abs(pos[0, 0] - 3.0 * n * H) < 1e-12
+    assert abs(pos[0, 2] + 1.0 * n * H) < 1e-12
+
+
+# ---------------------------------------------------------------- KAT-2 quaternion update
+@pytest.mark.parametrize("axis", [(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 2, -2)])
+def test_kat2_spin_angle_is_2atan(orc64, axis):
+    a = np.array(axis, float)
+    a /= np.linalg.norm(a)
+    wmag = 3.0
+    w = _one_box(orc64, avel=tuple(wmag * a), gravity=(0, 0, 0))
+    n = 25
+    w.run(H, n)
+    _, quat, _, avel = w.state()
+    theta = 2.0 * n * math.atan(wmag * H / 2.0)     # NOT n*|w|*h
+    expect = np.concatenate([[math.cos(theta / 2)], math.sin(theta / 2) * a])
+    assert np.allclose(quat[0], expect, atol=1e-13)
+    assert abs(np.linalg.norm(quat[0]) - 1.0) < 1e-15
+    # isotropic default inertia: the gyroscopic torque vanishes to rounding
+    assert np.allclose(avel[0], wmag * a, rtol=0, atol=1e-13)
+
+
+def test_kat2_quaternion_order_wxyz(orc64):
+    # 90 deg about z given as (w,x,y,z) -> R maps x to y
+    s = math.sqrt(0.5)
+    w = _one_box(orc64, quat=(s, 0, 0, s), gravity=(0, 0, 0))
+    Rm = np.ctypeslib.as_array(orc64.lib.orc_body_get_rotation(w.w, 0), shape=(12,)).reshape(3, 4)
+    assert np.allclose(Rm[:, :3] @ np.array([1.0, 0, 0]), [0, 1, 0], atol=1e-15)
+    assert np.all(Rm[:, 3] == 0)
+
+
+# ---------------------------------------------------------------- KAT-3 gyroscopic term
+def _cross_mat(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+
+def test_kat3_gyro_explicit(orc64):
+    I = np.array([1.0, 2.0, 3.5])
+    w0 = np.array([0.7, -1.1, 0.4])
+    w = _one_box(orc64, avel=tuple(w0), mass=2.0, idiag=tuple(I), gravity=(0, 0, 0))
+    orc64.lib.orc_world_set_gyro_mode(w.w, oc.GYRO_EXPLICIT)
+    w.run(H, 1)
+    _, _, _, avel = w.state()
+    expect = w0 + H * (-np.cross(w0, I * w0)) / I
+    assert np.allclose(avel[0], expect, rtol=0, atol=1e-14)
+
+
+def test_kat3_gyro_implicit_lacoursiere(orc64):
+    I = np.array([1.0, 2.0, 3.5])
+    w0 = np.array([0.7, -1.1, 0.4])
+    w = _one_box(orc64, avel=tuple(w0), mass=2.0, idiag=tuple(I), gravity=(0, 0, 0))
+    w.run(H, 1)     # default mode = implicit
+    _, _, _, avel = w.state()
+    L = I * w0
+    expect = np.linalg.solve(np.diag(I) - H * _cross_mat(L), L)   # (I - h[L]x) w' = L
+    assert np.allclose(avel[0], expect, rtol=0, atol=1e-13)
+    # and it differs from the explicit form at O(h^2)
+    assert np.linalg.norm(expect - (w0 + H * (-np.cross(w0, I * w0)) / I)) > 1e-6
+
+
+def test_kat3_rotated_body_uses_world_inertia(orc64):
+    # rotate the body 90 deg about z: world inertia swaps Ixx and Iyy
+    s = math.sqrt(0.5)
+    I = np.array([1.0, 2.0, 3.5])
+    w0 = np.array([0.7, -1.1, 0.4])
+    w = _one_box(orc64, quat=(s, 0, 0, s), avel=tuple(w0), mass=1.0, idiag=tuple(I),
+                 gravity=(0, 0, 0))
+    orc64.lib.orc_world_set_gyro_mode(w.w, oc.GYRO_EXPLICIT)
+    w.run(H, 1)
+    _, _, _, avel = w.state()
+    Iw = np.array([2.0, 1.0, 3.5])
+    expect = w0 + H * (-np.cross(w0, Iw * w0)) / Iw
+    assert np.allclose(avel[0], expect, rtol=0, atol=1e-13)
+
+
+# ---------------------------------------------------------------- KAT-4 contact row rhs / bounce
+def _sphere_on_plane(orc, depth, vy, radius=0.5, gravity=(0, 0, 0)):
+    w = orc.world(gravity=gravity)
+    w.add_plane(0, 1, 0, 0)
+    w.add_spheres([(0.0, radius - depth, 0.0)], None, [(0.0, vy, 0.0)], None, None, None, [radius])
+    return w
+
+
+def test_kat4_resting_penetration_pushout(orc64):
+    d = 0.01
+    w = _sphere_on_plane(orc64, d, 0.0)
+    w.tick(H)
+    assert w.n_contacts() == 1
+    _, _, lvel, avel = w.state()
+    # bias dominates: post-step normal velocity = erp*d/h (CFM 1e-10 negligible)
+    assert abs(lvel[0, 1] - 0.2 * d / H) < 1e-8
+    assert np.allclose(lvel[0, [0, 2]], 0, atol=1e-14) and np.allclose(avel[0], 0, atol=1e-14)
+    assert w.sor_residual() < 1e-8        # |1-1.3|^19 * 1.3 * lambda: geometric contraction on a 1-row problem
+
+
+def test_kat4_bounce_rule(orc64):
+    d = 0.001
+    # incoming 2 m/s > bounce_vel 0.1: outgoing = max(erp*d/h, 0.2*2) = 0.4   (main.c:684-686)
+    w = _sphere_on_plane(orc64, d, -2.0)
+    w.tick(H)
+    _, _, lvel, _ = w.state()
+    # exact row equation: (1 + cfm/h) * lambda = (c + 2)/h with c = 0.2*2, v' = -2 + h*lambda
+    assert abs(lvel[0, 1] - (-2.0 + 2.4 / (1.0 + 1e-10 / H))) < 1e-10
+    assert abs(lvel[0, 1] - 0.4) < 1e-7
+    # incoming 0.05 m/s < bounce_vel: no bounce, only the ERP push-out
+    w = _sphere_on_plane(orc64, d, -0.05)
+    w.tick(H)
+    _, _, lvel, _ = w.state()
+    assert abs(lvel[0, 1] - 0.2 * d / H) < 1e-8
+
+
+def test_kat4_gravity_is_cancelled_by_contact(orc64):
+    d = 0.0
+    w = _sphere_on_plane(orc64, d, 0.0, gravity=(0, G, 0))
+    w.tick(H)
+    _, _, lvel, _ = w.state()
+    assert abs(lvel[0, 1]) < 1e-8          # v' = erp*0/h = 0, gravity absorbed by lambda
+
+
+def test_kat4_separated_no_contact(orc64):
+    w = _sphere_on_plane(orc64, -0.25, 0.0, gravity=(0, G, 0))
+    w.tick(H)
+    assert w.n_contacts() == 0
+    _, _, lvel, _ = w.state()
+    assert abs(lvel[0, 1] - H * G) < 1e-15
+
+
+# ---------------------------------------------------------------- KAT-5 box-plane contact set
+def _box_plane_contacts(orc, pos, quat, sides, maxc=8):
+    w = orc.world()
+    pl = w.add_plane(0, 1, 0, 0)
+    w.add_boxes([pos], [quat], None, None, None, None, [sides])
+    cg = (orc.ContactGeom * 16)()
+    n = orc.lib.orc_collide(w.w, 1, pl, maxc, cg)
+    return [(np.array(cg[i].pos[:]), np.array(cg[i].normal[:]), cg[i].depth) for i in range(n)]
+
+
+def test_kat5_axis_aligned_box_four_corners(orc64):
+    c = _box_plane_contacts(orc64, (0.0, 0.45, 0.0), (1, 0, 0, 0), (1.0, 1.0, 2.0))
+    assert len(c) == 4
+    for p, n, d in c:
+        assert np.all(n == [0, 1, 0])
+        assert abs(d - 0.05) < 1e-15
+        assert abs(p[1] + 0.05) < 1e-15          # the box corner, below the plane
+        assert abs(abs(p[0]) - 0.5) < 1e-15 and abs(abs(p[2]) - 1.0) < 1e-15
+    assert len({(round(p[0], 6), round(p[2], 6)) for p, _, _ in c}) == 4
+
+
+def test_kat5_tilted_box_edge_contact(orc64):
+    # 45 deg about z: the lowest feature is an edge along z -> two equally deep contacts
+    a = math.pi / 4
+    q = (math.cos(a / 2), 0, 0, math.sin(a / 2))
+    half_diag = math.sqrt(0.5)
+    c = _box_plane_contacts(orc64, (0.0, half_diag - 0.02, 0.0), q, (1.0, 1.0, 1.0))
+    assert len(c) == 2
+    assert abs(c[0][2] - 0.02) < 1e-12 and abs(c[1][2] - 0.02) < 1e-12
+    assert abs(c[0][0][2] - c[1][0][2]) == pytest.approx(1.0, abs=1e-12)   # one side apart along z
+    assert c[0][2] >= c[1][2]                                               # deepest first
+
+
+def test_kat5_corner_contact_and_limits(orc64):
+    # generic tilt: one corner deepest, depths non-increasing from the first
+    q = np.array([0.9, 0.3, 0.2, 0.1])
+    q /= np.linalg.norm(q)
+    c = _box_plane_contacts(orc64, (0.0, 0.6, 0.0), tuple(q), (1.0, 0.8, 0.6))
+    assert 1 <= len(c) <= 4
+    assert all(c[0][2] >= ci[2] for ci in c[1:])
+    # depth of each contact = -(n . p) for the plane y = 0
+    for p, n, d in c:
+        assert abs(d + p[1]) < 1e-12
+    # maxc = 1 keeps only the deepest
+    c1 = _box_plane_contacts(orc64, (0.0, 0.6, 0.0), tuple(q), (1.0, 0.8, 0.6), maxc=1)
+    assert len(c1) == 1 and c1[0][2] == c[0][2]
+    # above the plane: nothing
+    assert _box_plane_contacts(orc64, (0.0, 5.0, 0.0), tuple(q), (1.0, 0.8, 0.6)) == []
+
+
+def test_reversed_pair_flips_normal(orc64):
+    w = orc64.world()
+    pl = w.add_plane(0, 1, 0, 0)
+    w.add_spheres([(0.0, 0.4, 0.0)], None, None, None, None, None, [0.5])
+    cg = (orc64.ContactGeom * 4)()
+    assert orc64.lib.orc_collide(w.w, 1, pl, 8, cg) == 1
+    assert cg[0].normal[1] == 1.0 and (cg[0].g1, cg[0].g2) == (1, pl)
+    assert orc64.lib.orc_collide(w.w, pl, 1, 8, cg) == 1
+    assert cg[0].normal[1] == -1.0 and (cg[0].g1, cg[0].g2) == (pl, 1)
+
+
+# ---------------------------------------------------------------- resting box, settles
+def test_box_settles_on_plane(orc64):
+    w = orc64.world()
+    w.add_plane(0, 1, 0, 0)
+    w.add_boxes([(0.0, 1.0, 0.0)], None, None, None, None, None, [(1.0, 0.5, 0.8)])
+    w.run(H, 600)
+    pos, quat, lvel, avel = w.state()
+    assert w.n_contacts() == 4
+    assert abs(pos[0, 1] - 0.25) < 2e-3            # resting height = half side (small ERP sag)
+    assert np.linalg.norm(lvel[0]) < 1e-3 and np.linalg.norm(avel[0]) < 1e-3
+    assert abs(np.linalg.norm(quat[0]) - 1.0) < 1e-14
+
+
+# ---------------------------------------------------------------- pose packing
+def test_pack_transform_matches_reference_layout(orc64):
+    # GetTransformMat, main.c:602-622
+    R = np.arange(12, dtype=float) + 1.0
+    p = np.array([7.0, 8.0, 9.0])
+    out = np.zeros(16)
+    RP = C.POINTER(C.c_double)
+    orc64.lib.orc_pack_transform(out.ctypes.data_as(RP), p.ctypes.data_as(RP), R.ctypes.data_as(RP))
+    expect = [R[0], R[4], R[8], 0, R[1], R[5], R[9], 0, R[2], R[6], R[10], 0, 7, 8, 9, 1]
+    assert list(out) == expect
+
+
+# ---------------------------------------------------------------- row-order modes agree on 1-body islands to solver tolerance
+def test_ode_row_order_mode_close_to_fixed(orc64):
+    def run(mode):
+        w = orc64.world()
+        orc64.lib.orc_world_set_row_order(w.w, mode)
+        orc64.lib.orc_rand_seed(0)
+        w.add_plane(0, 1, 0, 0)
+        w.add_boxes([(0.0, 0.6, 0.0)], [(0.99, 0.1, 0.05, 0.02)], None, None, None, None,
+                    [(1.0, 0.5, 0.8)])
+        w.run(H, 240)
+        return w.state()
+    a, b = run(oc.ORDER_FIXED), run(oc.ORDER_ODE)
+    assert np.allclose(a[0], b[0], atol=5e-3)
