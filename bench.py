@@ -1,0 +1,167 @@
+"""bench.py -- body-steps/s of the rigid-body step hot path on MI355X.
+
+One "step" = one tick (collide -> QuickStep -> clear contacts, main.c:211-215)
+over the whole batch of synthetic bodies.  At N=1 the workload is BASELINE.json
+configs[1]: 1 048 576 free-falling boxes, no contacts, dt = 1/60.  With N>1
+every rank owns one such slab of disjoint islands (weak scaling) and exchanges
+the state of its slab-boundary bodies with an RCCL all-gather every step.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description),
+including `roofline` (HBM, algorithmic bytes / measured kernel time) and
+`cpu_baseline` (the CPU oracle timed on the host cores, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = 1.0 / 60.0
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+BYTES_PER_BODY_STEP = {"free": 30, "plane": 33}   # reals; SURVEY.md 8(d)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3], help="BASELINE.json configs[] index + 1")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--side", type=int, default=0, help="grid side (bodies = side^2 per GPU); 0 = config default")
+    ap.add_argument("--exchange", default="boundary", choices=["boundary", "none"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(pkg, scene, dtype, kind, budget_s):
+    """Time the CPU oracle (oracle/, the checker) on a bounded sample of the same workload."""
+    from oracle.orc_ctypes import Oracle
+    orc = Oracle(dtype)
+    ow = orc.world()
+    if scene.plane is not None:
+        ow.add_plane(*scene.plane)
+    ow.add_boxes(scene.pos, scene.quat, scene.lvel, scene.avel, scene.mass[:, 0], scene.inertia, scene.sides)
+    t = ow.run(H, 2)                                   # probe
+    steps = int(max(2, min(2000, budget_s / max(t / 2, 1e-9))))
+    t = ow.run(H, steps)
+    return {"value": scene.n * steps / t, "unit": "body-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{scene.n} bodies x {steps} steps of the same scene ({kind}), oracle/ C restatement "
+                      f"-O2 single thread, {t:.1f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    pkg = load_package()
+
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(1)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    dtype = "float32" if a.dtype == "f32" else "float64"
+    rsize = np.dtype(dtype).itemsize
+    if a.config == 2:
+        side = a.side or 1024
+        kind = "free"
+        workload = f"configs[1]: {side * side} free-falling boxes per GPU, no contacts, dt=1/60"
+        # every rank draws its own slab with its own seed; slabs are disjoint islands (configs[3] layout)
+        scene = pkg.scenes.box_grid(side, side, seed=1 + rank, spin=True, plane=False).astype(dtype)
+    else:
+        side = a.side or 512
+        kind = "plane"
+        workload = f"configs[2]: {side * side} boxes on the ground plane per GPU, 20 SOR iterations, dt=1/60"
+        scene = pkg.scenes.box_grid(side, side, seed=1 + rank, y_range=(1.0, 3.0), spin=False, plane=True).astype(dtype)
+
+    w = pkg.BatchWorld(scene.n, dtype=dtype, device=local_rank)
+    w.load_scene(scene)
+    stream = torch.cuda.current_stream()
+    w.set_stream(stream.cuda_stream)        # kernels run on torch's current stream: its events see them
+
+    exchange = None
+    if world > 1 and a.exchange == "boundary":
+        exchange = pkg.shard.BoundaryExchange(w, scene, side, rank, world)
+
+    def run(nsteps):
+        if exchange is None:
+            w.step(H, nsteps)
+        else:
+            for _ in range(nsteps):
+                w.step(H, 1)
+                exchange.step()
+
+    if a.config == 3:
+        run(120)                            # let the boxes land: timed steps are all in contact
+    run(a.warmup)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    run(a.steps)
+    e1.record(stream)
+    fence()
+    dt = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    total_bodies = scene.n * world
+    value = total_bodies * a.steps / dt
+    kernel_s = dev_ms * 1e-3 / a.steps                       # average launch duration, HIP events on the launch stream
+    alg_bytes = BYTES_PER_BODY_STEP[kind] * rsize * scene.n  # per launch (one GPU)
+    achieved = alg_bytes / kernel_s / 1e9
+    out = {
+        "metric": "body-steps/sec at 1M rigid bodies, dt=1/60",
+        "value": value, "unit": "body-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": workload, "bodies_per_gpu": scene.n, "bodies_total": total_bodies, "dt": "1/60",
+                   "parallelism": f"islands sharded over {world} GPU(s), exchange={a.exchange if world > 1 else 'n/a'}",
+                   "integrator": "QuickStep semantics: gravity + implicit gyroscopic torque + semi-implicit Euler + "
+                                 "quaternion renormalise" + ("; box-plane contacts, 20 SOR sweeps" if kind == "plane" else "")},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "integrate_free" if kind == "free" else "step_plane",
+                     "kernel_us": kernel_s * 1e6,
+                     "algorithmic_bytes_per_body_step": BYTES_PER_BODY_STEP[kind] * rsize},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(pkg, scene, dtype, kind, a.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    w.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

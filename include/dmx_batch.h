@@ -1,0 +1,118 @@
+/*
+ * include/dmx_batch.h -- batch extension of the ODE-compatible C ABI.
+ *
+ * The reference drives ODE one geom pair at a time through a host callback
+ * (dSpaceCollide -> NearCallback -> dCollide -> dJointCreateContact,
+ * /root/reference/src/main.c:212, 674-693) and one body at a time through
+ * dBodyCreate/dBodySet* (main.c:695-733) and dBodyGet* (main.c:221-237).
+ * That shape cannot feed 10^6 bodies to a GPU, so the scenes of
+ * BASELINE.json are driven through this batch form of the SAME calls: each
+ * entry point below names the reference call (file:line) whose per-object
+ * loop it replaces.  Plain C, plain pointers and sizes, no framework types.
+ *
+ * All state lives in HBM as structure-of-arrays; `real` is float (DMX_F32,
+ * ODE dSINGLE) or double (DMX_F64, ODE dDOUBLE) per batch.  Host arrays are
+ * array-of-structs, row-major n x k, in the batch's precision.
+ *
+ * Every function returns 0 on success and a negative DMX_E* code on failure
+ * (and prints the HIP error to stderr); nothing falls back to the CPU.
+ */
+#ifndef DMX_BATCH_H
+#define DMX_BATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dmxBatch *dmxBatchID;
+
+enum { DMX_F32 = 0, DMX_F64 = 1 };
+
+enum {
+    DMX_OK = 0,
+    DMX_ENODEVICE = -1,   /* no usable HIP device */
+    DMX_EHIP = -2,        /* a HIP call failed */
+    DMX_EINVAL = -3,      /* bad argument */
+    DMX_ENOMEM = -4
+};
+
+/* per-body fields (k = components per body) */
+enum {
+    DMX_POS = 0,      /* k=3  dBodySetPosition / dBodyGetPosition   main.c:708, 229 */
+    DMX_QUAT = 1,     /* k=4  (w,x,y,z); dBodySetRotation's R as q  main.c:709, 230 */
+    DMX_LVEL = 2,     /* k=3  linear velocity  (0 at creation)      main.c:703      */
+    DMX_AVEL = 3,     /* k=3  angular velocity (0 at creation)      main.c:703      */
+    DMX_MASS = 4,     /* k=1  dBodySetMass mass  (default 1)             */
+    DMX_INERTIA = 5,  /* k=3  body-frame principal inertia (default 1,1,1)          */
+    DMX_SIDES = 6,    /* k=3  dCreateBox side lengths / (r,-,-) for a sphere  main.c:717,720 */
+    DMX_FORCE = 7,    /* k=3  dBodyAddForce accumulator, cleared each step    main.c:532 */
+    DMX_TORQUE = 8,   /* k=3  dBodyAddTorque accumulator                                  */
+    DMX_NFIELDS = 9
+};
+
+/* geometry class per body (uint8 array) */
+enum { DMX_GEOM_NONE = 0, DMX_GEOM_SPHERE = 1, DMX_GEOM_BOX = 2 };   /* BodyType, inc/body.h:14-18 */
+
+enum { DMX_GYRO_OFF = 0, DMX_GYRO_EXPLICIT = 1, DMX_GYRO_IMPLICIT = 2 };
+
+/* dContactBounce etc: surface mode bits accepted by dmxBatchSetSurface */
+enum { DMX_CONTACT_BOUNCE = 0x004 };
+
+/* ---- lifecycle: dInitODE/dWorldCreate/dHashSpaceCreate/dJointGroupCreate (main.c:94-98) */
+int dmxDeviceCount(void);                 /* >=1 or DMX_ENODEVICE; never touches a CPU path */
+int dmxBatchCreate(dmxBatchID *out, int64_t n_bodies, int precision, int device);
+int dmxBatchDestroy(dmxBatchID b);        /* dWorldDestroy / dCloseODE  main.c:258-268 */
+int64_t dmxBatchBodyCount(dmxBatchID b);
+int dmxBatchPrecision(dmxBatchID b);
+
+/* ---- world parameters */
+int dmxBatchSetGravity(dmxBatchID b, double gx, double gy, double gz);      /* dWorldSetGravity main.c:96 */
+int dmxBatchSetERP(dmxBatchID b, double erp);                                /* dWorldSetERP  (default 0.2) */
+int dmxBatchSetCFM(dmxBatchID b, double cfm);                                /* dWorldSetCFM  (default 1e-5f / 1e-10) */
+int dmxBatchSetQuickStep(dmxBatchID b, int iterations, double sor_w);        /* dWorldSetQuickStepNumIterations / W */
+int dmxBatchSetGyroMode(dmxBatchID b, int mode);                             /* dBodySetGyroscopicMode + form */
+/* NearCallback's per-contact surface, applied to every generated contact (main.c:684-687) */
+int dmxBatchSetSurface(dmxBatchID b, int mode, double mu, double bounce, double bounce_vel);
+int dmxBatchSetMaxContacts(dmxBatchID b, int max_contacts);                  /* dCollide flags (main.c:675,678) */
+/* dCreatePlane(space,a,b,c,d): the one static half-space bodies collide with; enable=0 removes it */
+int dmxBatchSetPlane(dmxBatchID b, double a, double bb, double c, double d, int enable);
+
+/* ---- body data: replaces the AddBody loop (main.c:695-733) and the read-back loop (main.c:221-237) */
+int dmxBatchUpload(dmxBatchID b, int field, const void *host_aos, int64_t first, int64_t count);
+int dmxBatchDownload(dmxBatchID b, int field, void *host_aos, int64_t first, int64_t count);
+int dmxBatchUploadGeomType(dmxBatchID b, const uint8_t *types, int64_t first, int64_t count);
+/* device-resident SoA component c of a field (stride between components = dmxBatchStride) */
+void *dmxBatchDevicePtr(dmxBatchID b, int field, int component);
+int64_t dmxBatchStride(dmxBatchID b);
+
+/* ---- stepping: the tick loop of main.c:211-215 (collide -> step -> clear contacts), nsteps times.
+ * Asynchronous on the batch's stream.  QuickStep semantics. */
+int dmxBatchStep(dmxBatchID b, double h, int nsteps);
+int dmxBatchSynchronize(dmxBatchID b);
+/* run on a caller-owned hipStream_t (e.g. the framework's current stream); NULL restores the batch's own */
+int dmxBatchSetStream(dmxBatchID b, void *hip_stream);
+/* step nsteps times bracketed by HIP events on the batch's stream; *ms = elapsed device milliseconds */
+int dmxBatchStepTimed(dmxBatchID b, double h, int nsteps, float *ms);
+
+/* ---- diagnostics of the last step */
+int dmxBatchLastContactCount(dmxBatchID b, int64_t *n);       /* contact joints created in the last tick */
+int dmxBatchLastResidual(dmxBatchID b, double *r);            /* sum |delta lambda| of the last SOR sweep */
+
+/* ---- pose read-back for the 60 Hz snapshot (main.c:221-240): GetTransformMat (main.c:602-622) on
+ * device; out_dev/out_host receive count x 16 reals, column-major 4x4 per body */
+int dmxBatchPackTransforms(dmxBatchID b, void *out_dev, int64_t first, int64_t count);
+int dmxBatchDownloadTransforms(dmxBatchID b, void *out_host, int64_t first, int64_t count);
+
+/* ---- boundary-body exchange for island sharding across GPUs: gather pos+quat+lvel+avel
+ * (13 reals) of the listed bodies into a contiguous device buffer (count x 13, AoS) and back */
+int dmxBatchGatherBodies(dmxBatchID b, const int32_t *idx_dev, int64_t count, void *out_dev);
+int dmxBatchScatterBodies(dmxBatchID b, const int32_t *idx_dev, int64_t count, const void *in_dev);
+
+const char *dmxVersion(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,152 @@
+"""BatchWorld: Python view of one dmxBatch (include/dmx_batch.h).
+
+Mirrors the reference's physics-facing calls in batch form: world setup
+(main.c:94-98), AddBody (main.c:695-733), the tick loop (main.c:211-215) and
+the pose read-back (main.c:221-237), all through the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+DMX_F32, DMX_F64 = 0, 1
+POS, QUAT, LVEL, AVEL, MASS, INERTIA, SIDES, FORCE, TORQUE = range(9)
+_K = {POS: 3, QUAT: 4, LVEL: 3, AVEL: 3, MASS: 1, INERTIA: 3, SIDES: 3, FORCE: 3, TORQUE: 3}
+GEOM_NONE, GEOM_SPHERE, GEOM_BOX = 0, 1, 2
+GYRO_OFF, GYRO_EXPLICIT, GYRO_IMPLICIT = 0, 1, 2
+CONTACT_BOUNCE = 0x004
+
+
+class DmxError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise DmxError(f"{what} failed with code {rc}")
+
+
+class BatchWorld:
+    def __init__(self, n_bodies, dtype="float32", device=0, gravity=(0.0, -9.8, 0.0)):
+        self.lib = _lib.load()
+        self.dtype = np.dtype(dtype)
+        prec = {4: DMX_F32, 8: DMX_F64}[self.dtype.itemsize]
+        self.n = int(n_bodies)
+        h = C.c_void_p()
+        _check(self.lib.dmxBatchCreate(C.byref(h), self.n, prec, device), "dmxBatchCreate")
+        self.h = h
+        self.set_gravity(*gravity)       # dWorldSetGravity(world, 0, -9.8, 0)  main.c:96
+
+    # -- lifecycle -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dmxBatchDestroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- parameters ------------------------------------------------------------
+    def set_gravity(self, x, y, z):
+        _check(self.lib.dmxBatchSetGravity(self.h, x, y, z), "dmxBatchSetGravity")
+
+    def set_erp(self, erp):
+        _check(self.lib.dmxBatchSetERP(self.h, erp), "dmxBatchSetERP")
+
+    def set_cfm(self, cfm):
+        _check(self.lib.dmxBatchSetCFM(self.h, cfm), "dmxBatchSetCFM")
+
+    def set_quickstep(self, iters, sor_w=1.3):
+        _check(self.lib.dmxBatchSetQuickStep(self.h, iters, sor_w), "dmxBatchSetQuickStep")
+
+    def set_gyro_mode(self, mode):
+        _check(self.lib.dmxBatchSetGyroMode(self.h, mode), "dmxBatchSetGyroMode")
+
+    def set_surface(self, mode=CONTACT_BOUNCE, mu=float("inf"), bounce=0.2, bounce_vel=0.1):
+        _check(self.lib.dmxBatchSetSurface(self.h, mode, mu, bounce, bounce_vel), "dmxBatchSetSurface")
+
+    def set_max_contacts(self, n):
+        _check(self.lib.dmxBatchSetMaxContacts(self.h, n), "dmxBatchSetMaxContacts")
+
+    def set_plane(self, a, b, c, d, enable=True):
+        _check(self.lib.dmxBatchSetPlane(self.h, a, b, c, d, int(enable)), "dmxBatchSetPlane")
+
+    # -- data ----------------------------------------------------------------------
+    def upload(self, field, arr, first=0):
+        a = np.ascontiguousarray(arr, dtype=self.dtype).reshape(-1, _K[field])
+        _check(self.lib.dmxBatchUpload(self.h, field, a.ctypes.data, first, a.shape[0]), "dmxBatchUpload")
+
+    def download(self, field, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.empty((count, _K[field]), self.dtype)
+        _check(self.lib.dmxBatchDownload(self.h, field, out.ctypes.data, first, count), "dmxBatchDownload")
+        return out
+
+    def upload_geom_type(self, types, first=0):
+        t = np.ascontiguousarray(types, dtype=np.uint8)
+        _check(self.lib.dmxBatchUploadGeomType(self.h, t.ctypes.data, first, t.shape[0]), "dmxBatchUploadGeomType")
+
+    def load_scene(self, scene):
+        """Upload a scenes.Scene (the batch form of the AddBody loop, main.c:695-733)."""
+        self.upload(POS, scene.pos)
+        self.upload(QUAT, scene.quat)
+        self.upload(LVEL, scene.lvel)
+        self.upload(AVEL, scene.avel)
+        self.upload(MASS, scene.mass)
+        self.upload(INERTIA, scene.inertia)
+        self.upload(SIDES, scene.sides)
+        self.upload_geom_type(scene.gtype)
+        if scene.plane is not None:
+            self.set_plane(*scene.plane, enable=True)
+
+    def state(self):
+        return (self.download(POS), self.download(QUAT), self.download(LVEL), self.download(AVEL))
+
+    def device_ptr(self, field, comp):
+        return self.lib.dmxBatchDevicePtr(self.h, field, comp)
+
+    @property
+    def stride(self):
+        return self.lib.dmxBatchStride(self.h)
+
+    # -- stepping ----------------------------------------------------------------------
+    def step(self, h, nsteps=1):
+        _check(self.lib.dmxBatchStep(self.h, h, nsteps), "dmxBatchStep")
+
+    def step_timed(self, h, nsteps):
+        ms = C.c_float()
+        _check(self.lib.dmxBatchStepTimed(self.h, h, nsteps, C.byref(ms)), "dmxBatchStepTimed")
+        return ms.value
+
+    def synchronize(self):
+        _check(self.lib.dmxBatchSynchronize(self.h), "dmxBatchSynchronize")
+
+    def set_stream(self, stream_handle):
+        _check(self.lib.dmxBatchSetStream(self.h, stream_handle), "dmxBatchSetStream")
+
+    def last_contact_count(self):
+        n = C.c_int64()
+        _check(self.lib.dmxBatchLastContactCount(self.h, C.byref(n)), "dmxBatchLastContactCount")
+        return n.value
+
+    def last_residual(self):
+        r = C.c_double()
+        _check(self.lib.dmxBatchLastResidual(self.h, C.byref(r)), "dmxBatchLastResidual")
+        return r.value
+
+    def transforms(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.empty((count, 16), self.dtype)
+        _check(self.lib.dmxBatchDownloadTransforms(self.h, out.ctypes.data, first, count),
+               "dmxBatchDownloadTransforms")
+        return out

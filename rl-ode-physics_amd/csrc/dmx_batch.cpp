@@ -1,0 +1,415 @@
+// dmx_batch.cpp -- the batch C ABI declared in include/dmx_batch.h.
+//
+// Host side only: owns the HBM slab, the stream and the world parameters, and
+// enqueues the kernels of dmx_kernels.hip.  There is no CPU execution path:
+// without a HIP device every entry point fails with DMX_ENODEVICE.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "../../include/dmx_batch.h"
+#include "dmx_internal.hpp"
+
+using namespace dmx;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "libode_mi355: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), \
+                    __FILE__, __LINE__);                                                           \
+            return DMX_EHIP;                                                                       \
+        }                                                                                          \
+    } while (0)
+
+struct dmxBatch {
+    int64_t n = 0, stride = 0;
+    int precision = DMX_F32;
+    int device = 0;
+    size_t rsize = 4;
+    void *slab = nullptr;            // C_COUNT x stride reals
+    uint8_t *gtype = nullptr;        // stride bytes
+    StepDiag *diag = nullptr;        // device
+    StepDiag *diag_host = nullptr;   // pinned
+    void *stage = nullptr;           // device staging for AoS <-> SoA
+    size_t stage_bytes = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // world parameters (defaults: dWorldCreate [ODE], gravity unset = 0)
+    double g[3] = { 0, 0, 0 };
+    double erp = 0.2, cfm = 1e-5, sor_w = 1.3;
+    int iters = 20;
+    int gyro = DMX_GYRO_IMPLICIT;
+    int plane_on = 0;
+    double plane[4] = { 0, 1, 0, 0 };
+    int surf_mode = DMX_CONTACT_BOUNCE;                 // main.c:684
+    double mu = __builtin_huge_val(), bounce = 0.2, bounce_vel = 0.1;   // main.c:685-687
+    int max_contacts = 8;                               // main.c:675
+    bool ext_pending = false;
+    bool stepped_with_plane = false;
+};
+
+static const int k_field_comp0[DMX_NFIELDS] = { C_POS, C_QUAT, C_LVEL, C_AVEL, C_MASS, C_INERTIA, C_SIDES, C_FORCE, C_TORQUE };
+static const int k_field_k[DMX_NFIELDS] = { 3, 4, 3, 3, 1, 3, 3, 3, 3 };
+
+extern "C" const char *dmxVersion(void) { return "libode_mi355 0.1 (gfx950)"; }
+
+extern "C" int dmxDeviceCount(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return DMX_ENODEVICE;
+    return n;
+}
+
+static int ensure_stage(dmxBatch *b, size_t bytes)
+{
+    if (bytes <= b->stage_bytes) return DMX_OK;
+    if (b->stage) HIP_TRY(hipFree(b->stage));
+    b->stage = nullptr; b->stage_bytes = 0;
+    HIP_TRY(hipMalloc(&b->stage, bytes));
+    b->stage_bytes = bytes;
+    return DMX_OK;
+}
+
+template <class T> static int fill_defaults(dmxBatch *b)
+{
+    // every slot, pad included: mass 1, inertia 1 (dBodyCreate default), q = identity
+    std::vector<T> host((size_t)b->stride);
+    T *S = (T *)b->slab;
+    HIP_TRY(hipMemsetAsync(b->slab, 0, (size_t)C_COUNT * b->stride * sizeof(T), b->stream));
+    for (auto &x : host) x = T(1);
+    const int ones[] = { C_QUAT, C_MASS, C_INERTIA, C_INERTIA + 1, C_INERTIA + 2 };
+    for (int c : ones)
+        HIP_TRY(hipMemcpyAsync(S + (size_t)c * b->stride, host.data(), (size_t)b->stride * sizeof(T),
+                               hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemsetAsync(b->gtype, 0, (size_t)b->stride, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int device)
+{
+    if (!out || n <= 0 || (precision != DMX_F32 && precision != DMX_F64)) return DMX_EINVAL;
+    *out = nullptr;
+    int ndev = dmxDeviceCount();
+    if (ndev < 0) {
+        fprintf(stderr, "libode_mi355: no HIP device available; this library has no CPU path\n");
+        return DMX_ENODEVICE;
+    }
+    if (device < 0 || device >= ndev) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(device));
+    dmxBatch *b = new (std::nothrow) dmxBatch();
+    if (!b) return DMX_ENOMEM;
+    b->n = n;
+    b->stride = (n + 255) / 256 * 256;
+    b->precision = precision;
+    b->device = device;
+    b->rsize = precision == DMX_F32 ? 4 : 8;
+    b->cfm = precision == DMX_F32 ? 1e-5 : 1e-10;      // dWorldCreate default per precision [ODE]
+    int rc = DMX_OK;
+    do {
+        if (hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = DMX_EHIP; break; }
+        b->stream = b->own_stream;
+        if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { rc = DMX_EHIP; break; }
+        if (hipMalloc(&b->slab, (size_t)C_COUNT * b->stride * b->rsize) != hipSuccess) { rc = DMX_ENOMEM; break; }
+        if (hipMalloc((void **)&b->gtype, (size_t)b->stride) != hipSuccess) { rc = DMX_ENOMEM; break; }
+        if (hipMalloc((void **)&b->diag, sizeof(StepDiag)) != hipSuccess) { rc = DMX_ENOMEM; break; }
+        if (hipHostMalloc((void **)&b->diag_host, sizeof(StepDiag)) != hipSuccess) { rc = DMX_ENOMEM; break; }
+        if (hipMemset(b->diag, 0, sizeof(StepDiag)) != hipSuccess) { rc = DMX_EHIP; break; }
+        rc = precision == DMX_F32 ? fill_defaults<float>(b) : fill_defaults<double>(b);
+    } while (0);
+    if (rc != DMX_OK) {
+        fprintf(stderr, "libode_mi355: dmxBatchCreate failed (%d): %s\n", rc, hipGetErrorString(hipGetLastError()));
+        dmxBatchDestroy(b);
+        return rc;
+    }
+    *out = b;
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchDestroy(dmxBatchID b)
+{
+    if (!b) return DMX_EINVAL;
+    (void)hipSetDevice(b->device);
+    if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
+    if (b->slab) (void)hipFree(b->slab);
+    if (b->gtype) (void)hipFree(b->gtype);
+    if (b->diag) (void)hipFree(b->diag);
+    if (b->diag_host) (void)hipHostFree(b->diag_host);
+    if (b->stage) (void)hipFree(b->stage);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
+    delete b;
+    return DMX_OK;
+}
+
+extern "C" int64_t dmxBatchBodyCount(dmxBatchID b) { return b ? b->n : DMX_EINVAL; }
+extern "C" int dmxBatchPrecision(dmxBatchID b) { return b ? b->precision : DMX_EINVAL; }
+extern "C" int64_t dmxBatchStride(dmxBatchID b) { return b ? b->stride : DMX_EINVAL; }
+
+extern "C" int dmxBatchSetGravity(dmxBatchID b, double x, double y, double z)
+{ if (!b) return DMX_EINVAL; b->g[0] = x; b->g[1] = y; b->g[2] = z; return DMX_OK; }
+extern "C" int dmxBatchSetERP(dmxBatchID b, double erp) { if (!b) return DMX_EINVAL; b->erp = erp; return DMX_OK; }
+extern "C" int dmxBatchSetCFM(dmxBatchID b, double cfm) { if (!b) return DMX_EINVAL; b->cfm = cfm; return DMX_OK; }
+extern "C" int dmxBatchSetQuickStep(dmxBatchID b, int iters, double w)
+{ if (!b || iters < 0) return DMX_EINVAL; b->iters = iters; b->sor_w = w; return DMX_OK; }
+extern "C" int dmxBatchSetGyroMode(dmxBatchID b, int mode)
+{ if (!b || mode < 0 || mode > 2) return DMX_EINVAL; b->gyro = mode; return DMX_OK; }
+extern "C" int dmxBatchSetSurface(dmxBatchID b, int mode, double mu, double bounce, double bounce_vel)
+{
+    if (!b) return DMX_EINVAL;
+    b->surf_mode = mode; b->mu = mu < 0 ? 0 : mu; b->bounce = bounce; b->bounce_vel = bounce_vel;
+    return DMX_OK;
+}
+extern "C" int dmxBatchSetMaxContacts(dmxBatchID b, int m)
+{ if (!b || m < 1) return DMX_EINVAL; b->max_contacts = m; return DMX_OK; }
+
+template <class T> static void normalize_plane(const double in[4], T out[4])
+{
+    // dCreatePlane normalises (a,b,c,d) by |(a,b,c)| in the library's precision
+    T a = (T)in[0], bb = (T)in[1], c = (T)in[2], d = (T)in[3];
+    T l = a * a + bb * bb + c * c;
+    if (l > 0) { l = T(1) / tsqrt<T>(l); a *= l; bb *= l; c *= l; d *= l; }
+    else { a = 1; bb = 0; c = 0; d = 0; }
+    out[0] = a; out[1] = bb; out[2] = c; out[3] = d;
+}
+
+extern "C" int dmxBatchSetPlane(dmxBatchID b, double a, double bb, double c, double d, int enable)
+{
+    if (!b) return DMX_EINVAL;
+    b->plane[0] = a; b->plane[1] = bb; b->plane[2] = c; b->plane[3] = d;
+    b->plane_on = enable ? 1 : 0;
+    return DMX_OK;
+}
+
+// ---- upload / download -------------------------------------------------------------------------
+template <class T>
+static int upload_t(dmxBatch *b, int field, const void *host, int64_t first, int64_t count)
+{
+    const int k = k_field_k[field];
+    const size_t bytes = (size_t)count * k * sizeof(T);
+    int rc = ensure_stage(b, bytes);
+    if (rc != DMX_OK) return rc;
+    const T *src = (const T *)host;
+    std::vector<T> tmp;
+    if (field == DMX_QUAT) {
+        // dBodySetQuaternion: store the normalised quaternion
+        tmp.assign(src, src + (size_t)count * 4);
+        for (int64_t i = 0; i < count; i++) {
+            Q4<T> q = { tmp[4 * i], tmp[4 * i + 1], tmp[4 * i + 2], tmp[4 * i + 3] };
+            normalize(q);
+            tmp[4 * i] = q.w; tmp[4 * i + 1] = q.x; tmp[4 * i + 2] = q.y; tmp[4 * i + 3] = q.z;
+        }
+        src = tmp.data();
+    }
+    HIP_TRY(hipMemcpyAsync(b->stage, src, bytes, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(launch_aos_to_soa<T>((T *)b->slab, b->stride, k_field_comp0[field], k, first, count,
+                                 (const T *)b->stage, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));   // host buffer (and tmp) may be released on return
+    if (field == DMX_FORCE || field == DMX_TORQUE) b->ext_pending = true;
+    return DMX_OK;
+}
+
+template <class T>
+static int download_t(dmxBatch *b, int field, void *host, int64_t first, int64_t count)
+{
+    const int k = k_field_k[field];
+    const size_t bytes = (size_t)count * k * sizeof(T);
+    int rc = ensure_stage(b, bytes);
+    if (rc != DMX_OK) return rc;
+    HIP_TRY(launch_soa_to_aos<T>((const T *)b->slab, b->stride, k_field_comp0[field], k, first, count,
+                                 (T *)b->stage, b->stream));
+    HIP_TRY(hipMemcpyAsync(host, b->stage, bytes, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return DMX_OK;
+}
+
+static bool range_ok(dmxBatch *b, int field, const void *p, int64_t first, int64_t count)
+{
+    return b && p && field >= 0 && field < DMX_NFIELDS && first >= 0 && count >= 0 && first + count <= b->n;
+}
+
+extern "C" int dmxBatchUpload(dmxBatchID b, int field, const void *host, int64_t first, int64_t count)
+{
+    if (!range_ok(b, field, host, first, count)) return DMX_EINVAL;
+    if (count == 0) return DMX_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    return b->precision == DMX_F32 ? upload_t<float>(b, field, host, first, count)
+                                   : upload_t<double>(b, field, host, first, count);
+}
+
+extern "C" int dmxBatchDownload(dmxBatchID b, int field, void *host, int64_t first, int64_t count)
+{
+    if (!range_ok(b, field, host, first, count)) return DMX_EINVAL;
+    if (count == 0) return DMX_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    return b->precision == DMX_F32 ? download_t<float>(b, field, host, first, count)
+                                   : download_t<double>(b, field, host, first, count);
+}
+
+extern "C" int dmxBatchUploadGeomType(dmxBatchID b, const uint8_t *types, int64_t first, int64_t count)
+{
+    if (!b || !types || first < 0 || count < 0 || first + count > b->n) return DMX_EINVAL;
+    if (count == 0) return DMX_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpyAsync(b->gtype + first, types, (size_t)count, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return DMX_OK;
+}
+
+extern "C" void *dmxBatchDevicePtr(dmxBatchID b, int field, int component)
+{
+    if (!b || field < 0 || field >= DMX_NFIELDS || component < 0 || component >= k_field_k[field]) return nullptr;
+    return (char *)b->slab + (size_t)(k_field_comp0[field] + component) * b->stride * b->rsize;
+}
+
+// ---- stepping ----------------------------------------------------------------------------------
+template <class T> static StepParams<T> make_params(dmxBatch *b, double h)
+{
+    StepParams<T> P;
+    P.g = { (T)b->g[0], (T)b->g[1], (T)b->g[2] };
+    P.h = (T)h;
+    P.erp = (T)b->erp; P.cfm = (T)b->cfm; P.sor_w = (T)b->sor_w;
+    P.iters = b->iters;
+    P.gyro = b->gyro;
+    P.plane_on = b->plane_on;
+    T pl[4];
+    normalize_plane<T>(b->plane, pl);
+    P.pn = { pl[0], pl[1], pl[2] }; P.pd = pl[3];
+    P.surf_mode = b->surf_mode;
+    P.mu = (T)b->mu; P.bounce = (T)b->bounce; P.bounce_vel = (T)b->bounce_vel;
+    P.max_contacts = b->max_contacts;
+    return P;
+}
+
+template <class T> static int step_t(dmxBatch *b, double h, int nsteps)
+{
+    const StepParams<T> P = make_params<T>(b, h);
+    for (int s = 0; s < nsteps; s++) {
+        if (b->plane_on) HIP_TRY(hipMemsetAsync(b->diag, 0, sizeof(StepDiag), b->stream));
+        HIP_TRY(launch_step<T>((T *)b->slab, b->gtype, b->stride, b->n, P, b->ext_pending, b->diag, b->stream));
+        b->ext_pending = false;   // the step cleared the accumulators
+    }
+    b->stepped_with_plane = b->plane_on != 0;
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchStep(dmxBatchID b, double h, int nsteps)
+{
+    if (!b || !(h > 0) || nsteps < 0) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    return b->precision == DMX_F32 ? step_t<float>(b, h, nsteps) : step_t<double>(b, h, nsteps);
+}
+
+extern "C" int dmxBatchSynchronize(dmxBatchID b)
+{
+    if (!b) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchSetStream(dmxBatchID b, void *hip_stream)
+{
+    if (!b) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    b->stream = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchStepTimed(dmxBatchID b, double h, int nsteps, float *ms)
+{
+    if (!b || !ms) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipEventRecord(b->ev0, b->stream));
+    int rc = dmxBatchStep(b, h, nsteps);
+    if (rc != DMX_OK) return rc;
+    HIP_TRY(hipEventRecord(b->ev1, b->stream));
+    HIP_TRY(hipEventSynchronize(b->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, b->ev0, b->ev1));
+    return DMX_OK;
+}
+
+static int fetch_diag(dmxBatch *b)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpyAsync(b->diag_host, b->diag, sizeof(StepDiag), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchLastContactCount(dmxBatchID b, int64_t *n)
+{
+    if (!b || !n) return DMX_EINVAL;
+    if (!b->stepped_with_plane) { *n = 0; return DMX_OK; }
+    int rc = fetch_diag(b);
+    if (rc != DMX_OK) return rc;
+    *n = (int64_t)b->diag_host->contacts;
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchLastResidual(dmxBatchID b, double *r)
+{
+    if (!b || !r) return DMX_EINVAL;
+    if (!b->stepped_with_plane) { *r = 0; return DMX_OK; }
+    int rc = fetch_diag(b);
+    if (rc != DMX_OK) return rc;
+    *r = b->diag_host->residual;
+    return DMX_OK;
+}
+
+// ---- pose snapshot -----------------------------------------------------------------------------
+extern "C" int dmxBatchPackTransforms(dmxBatchID b, void *out_dev, int64_t first, int64_t count)
+{
+    if (!b || !out_dev || first < 0 || count < 0 || first + count > b->n) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->precision == DMX_F32)
+        HIP_TRY(launch_pack_transforms<float>((const float *)b->slab, b->stride, first, count, (float *)out_dev, b->stream));
+    else
+        HIP_TRY(launch_pack_transforms<double>((const double *)b->slab, b->stride, first, count, (double *)out_dev, b->stream));
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchDownloadTransforms(dmxBatchID b, void *out_host, int64_t first, int64_t count)
+{
+    if (!b || !out_host || first < 0 || count < 0 || first + count > b->n) return DMX_EINVAL;
+    if (count == 0) return DMX_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t bytes = (size_t)count * 16 * b->rsize;
+    int rc = ensure_stage(b, bytes);
+    if (rc != DMX_OK) return rc;
+    rc = dmxBatchPackTransforms(b, b->stage, first, count);
+    if (rc != DMX_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out_host, b->stage, bytes, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return DMX_OK;
+}
+
+// ---- boundary exchange -------------------------------------------------------------------------
+extern "C" int dmxBatchGatherBodies(dmxBatchID b, const int32_t *idx_dev, int64_t count, void *out_dev)
+{
+    if (!b || count < 0 || (count > 0 && (!idx_dev || !out_dev))) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->precision == DMX_F32)
+        HIP_TRY(launch_gather<float>((const float *)b->slab, b->stride, idx_dev, count, (float *)out_dev, b->stream));
+    else
+        HIP_TRY(launch_gather<double>((const double *)b->slab, b->stride, idx_dev, count, (double *)out_dev, b->stream));
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchScatterBodies(dmxBatchID b, const int32_t *idx_dev, int64_t count, const void *in_dev)
+{
+    if (!b || count < 0 || (count > 0 && (!idx_dev || !in_dev))) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->precision == DMX_F32)
+        HIP_TRY(launch_scatter<float>((float *)b->slab, b->stride, idx_dev, count, (const float *)in_dev, b->stream));
+    else
+        HIP_TRY(launch_scatter<double>((double *)b->slab, b->stride, idx_dev, count, (const double *)in_dev, b->stream));
+    return DMX_OK;
+}

@@ -1,0 +1,61 @@
+// dmx_internal.hpp -- layout constants and launch interface shared by the kernels
+// (dmx_kernels.hip), the batch C ABI (dmx_batch.cpp) and the ODE-compatible API (ode_compat.cpp).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dmx_math.hpp"
+
+namespace dmx {
+
+// SoA component indices inside the body slab (component c of body i at S[c*stride + i])
+enum : int {
+    C_POS = 0,       // 3
+    C_QUAT = 3,      // 4  (w,x,y,z)
+    C_LVEL = 7,      // 3
+    C_AVEL = 10,     // 3
+    C_MASS = 13,     // 1   -- everything below is read-only during a step
+    C_INERTIA = 14,  // 3
+    C_SIDES = 17,    // 3
+    C_FORCE = 20,    // 3   -- external accumulators, cleared by the step
+    C_TORQUE = 23,   // 3
+    C_COUNT = 26
+};
+
+enum : int { GEOM_NONE = 0, GEOM_SPHERE = 1, GEOM_BOX = 2 };
+enum : int { SURF_BOUNCE = 0x004 };
+
+template <class T> struct StepParams {
+    V3<T> g;            // gravity
+    T h;                // step size
+    T erp, cfm, sor_w;  // world ERP, CFM, SOR over-relaxation
+    int iters;          // QuickStep iterations
+    int gyro;           // 0 off, 1 explicit, 2 implicit
+    int plane_on;       // ground half-space present
+    V3<T> pn; T pd;     // plane n.x = d
+    int surf_mode; T mu, bounce, bounce_vel;   // contact surface (NearCallback, main.c:684-687)
+    int max_contacts;
+};
+
+struct StepDiag {
+    unsigned long long contacts;
+    double residual;
+};
+
+template <class T>
+hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, const StepParams<T> &P, bool ext,
+                       StepDiag *diag, hipStream_t st);
+template <class T>
+hipError_t launch_pack_transforms(const T *S, int64_t stride, int64_t first, int64_t count, T *out, hipStream_t st);
+template <class T>
+hipError_t launch_gather(const T *S, int64_t stride, const int32_t *idx, int64_t count, T *out, hipStream_t st);
+template <class T>
+hipError_t launch_scatter(T *S, int64_t stride, const int32_t *idx, int64_t count, const T *in, hipStream_t st);
+template <class T>
+hipError_t launch_aos_to_soa(T *S, int64_t stride, int comp0, int k, int64_t first, int64_t count, const T *aos,
+                             hipStream_t st);
+template <class T>
+hipError_t launch_soa_to_aos(const T *S, int64_t stride, int comp0, int k, int64_t first, int64_t count, T *aos,
+                             hipStream_t st);
+
+}  // namespace dmx

@@ -1,0 +1,522 @@
+// dmx_kernels.hip -- gfx950 kernels of the rigid-body step hot path.
+//
+// Replaces, per tick, the three ODE calls of the reference's physics loop
+// (/root/reference/src/main.c:211-215): dSpaceCollide + NearCallback
+// (main.c:674-693), dWorldStep stepped with QuickStep semantics, and
+// dJointGroupEmpty -- for scenes whose dynamics islands are single bodies
+// (free bodies, and bodies in contact with the static ground plane only).
+//
+// Data layout: one slab `S` of `real`, structure-of-arrays, component c of
+// body i at S[c * stride + i]; stride is the body count rounded up to 256 so
+// every component array is 1 KiB aligned and pad bodies are valid, inert
+// memory (mass 1, unit quaternion).  Loads are 16 B per lane
+// (global_load_dwordx4): V = 4 bodies per lane in f32, 2 in f64.
+//
+// No MFMA: there is no dense contraction on this path.  integrate_free is
+// HBM-bound (30 reals per body-step); step_plane is VALU/latency bound
+// (20 SOR sweeps over <= 12 rows held in registers).
+#include <hip/hip_runtime.h>
+#include "dmx_internal.hpp"
+#include "dmx_math.hpp"
+
+namespace dmx {
+
+template <class T, int V> struct alignas(sizeof(T) * V) Pack { T v[V]; };
+
+template <class T, int V>
+__device__ __forceinline__ Pack<T, V> ldv(const T *__restrict__ base, int64_t stride, int comp, int64_t i)
+{
+    return *reinterpret_cast<const Pack<T, V> *>(base + comp * stride + i);
+}
+template <class T, int V>
+__device__ __forceinline__ void stv(T *__restrict__ base, int64_t stride, int comp, int64_t i, const Pack<T, V> &p)
+{
+    *reinterpret_cast<Pack<T, V> *>(base + comp * stride + i) = p;
+}
+
+// One body: external force/torque -> new velocities (no constraints) -> new pose.
+//   facc = fext + m g ; tacc = text + gyro
+//   v += (h/m) facc ; w += Iw^-1 (h tacc)
+//   x += h v ; q += h/2 (0,w) q ; q /= |q|
+template <class T>
+__device__ __forceinline__ void free_body_step(V3<T> &x, Q4<T> &q, V3<T> &v, V3<T> &w,
+                                               T mass, const V3<T> &Ib, V3<T> facc, V3<T> tacc,
+                                               const V3<T> &g, T h, int gyro)
+{
+    const M3<T> R = quat_to_R(q);
+    const T invMass = T(1) / mass;
+    const V3<T> invIb = { T(1) / Ib.x, T(1) / Ib.y, T(1) / Ib.z };
+    facc.x += mass * g.x; facc.y += mass * g.y; facc.z += mass * g.z;
+    const M3<T> invIw = rotate_diag(R, invIb);
+    if (gyro != 0) {
+        const M3<T> Iw = rotate_diag(R, Ib);
+        add_gyro_torque(tacc, Iw, w, h, gyro);
+    }
+    const T hm = h * invMass;
+    v.x += hm * facc.x; v.y += hm * facc.y; v.z += hm * facc.z;
+    tacc.x *= h; tacc.y *= h; tacc.z *= h;
+    const V3<T> dw = mulv(invIw, tacc);
+    w.x += dw.x; w.y += dw.y; w.z += dw.z;
+    x.x += h * v.x; x.y += h * v.y; x.z += h * v.z;
+    integrate_quat(q, w, h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// integrate_free: contact-free tick (BASELINE config 2/4).  Algorithmic traffic per body-step:
+// read 13 state + 4 constant reals, write 13 state reals = 30 reals (120 B f32 / 240 B f64).
+// ---------------------------------------------------------------------------------------------
+template <class T, int V, bool EXT>
+__global__ __launch_bounds__(256) void integrate_free(T *__restrict__ S, int64_t stride, int64_t nvec,
+                                                      StepParams<T> P)
+{
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nvec;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t * V;
+        Pack<T, V> c[C_SIDES];
+#pragma unroll
+        for (int k = 0; k < C_SIDES; k++) c[k] = ldv<T, V>(S, stride, k, i);
+        Pack<T, V> f[6];
+        if (EXT) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) f[k] = ldv<T, V>(S, stride, C_FORCE + k, i);
+        }
+#pragma unroll
+        for (int b = 0; b < V; b++) {
+            V3<T> x = { c[C_POS].v[b], c[C_POS + 1].v[b], c[C_POS + 2].v[b] };
+            Q4<T> q = { c[C_QUAT].v[b], c[C_QUAT + 1].v[b], c[C_QUAT + 2].v[b], c[C_QUAT + 3].v[b] };
+            V3<T> v = { c[C_LVEL].v[b], c[C_LVEL + 1].v[b], c[C_LVEL + 2].v[b] };
+            V3<T> w = { c[C_AVEL].v[b], c[C_AVEL + 1].v[b], c[C_AVEL + 2].v[b] };
+            const V3<T> Ib = { c[C_INERTIA].v[b], c[C_INERTIA + 1].v[b], c[C_INERTIA + 2].v[b] };
+            V3<T> facc = { T(0), T(0), T(0) }, tacc = { T(0), T(0), T(0) };
+            if (EXT) {
+                facc = { f[0].v[b], f[1].v[b], f[2].v[b] };
+                tacc = { f[3].v[b], f[4].v[b], f[5].v[b] };
+            }
+            free_body_step(x, q, v, w, c[C_MASS].v[b], Ib, facc, tacc, P.g, P.h, P.gyro);
+            c[C_POS].v[b] = x.x; c[C_POS + 1].v[b] = x.y; c[C_POS + 2].v[b] = x.z;
+            c[C_QUAT].v[b] = q.w; c[C_QUAT + 1].v[b] = q.x; c[C_QUAT + 2].v[b] = q.y; c[C_QUAT + 3].v[b] = q.z;
+            c[C_LVEL].v[b] = v.x; c[C_LVEL + 1].v[b] = v.y; c[C_LVEL + 2].v[b] = v.z;
+            c[C_AVEL].v[b] = w.x; c[C_AVEL + 1].v[b] = w.y; c[C_AVEL + 2].v[b] = w.z;
+        }
+#pragma unroll
+        for (int k = 0; k < C_MASS; k++) stv<T, V>(S, stride, k, i, c[k]);
+        if (EXT) {
+            Pack<T, V> z;
+#pragma unroll
+            for (int b = 0; b < V; b++) z.v[b] = T(0);
+#pragma unroll
+            for (int k = 0; k < 6; k++) stv<T, V>(S, stride, C_FORCE + k, i, z);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Narrowphase against the ground half-space n.x = d: box (<= 4 contacts, deepest corner first,
+// then along the two sides with the smallest projection, then the fourth corner of a resting face)
+// and sphere (1 contact).  Contact normal is the plane normal.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ int box_plane(const V3<T> &pos, const M3<T> &R, const T side[3], const V3<T> &n, T d,
+                                         int maxc, V3<T> cp[4], T cd[4])
+{
+    const T Q1 = n.x * R.m[0][0] + n.y * R.m[1][0] + n.z * R.m[2][0];
+    const T Q2 = n.x * R.m[0][1] + n.y * R.m[1][1] + n.z * R.m[2][1];
+    const T Q3 = n.x * R.m[0][2] + n.y * R.m[1][2] + n.z * R.m[2][2];
+    const T A[3] = { side[0] * Q1, side[1] * Q2, side[2] * Q3 };
+    const T B[3] = { tabs(A[0]), tabs(A[1]), tabs(A[2]) };
+    const T depth = d + T(0.5) * (B[0] + B[1] + B[2]) - (n.x * pos.x + n.y * pos.y + n.z * pos.z);
+    if (depth < 0) return 0;
+    if (maxc < 1) maxc = 1;
+    if (maxc > 4) maxc = 4;
+    V3<T> p = pos;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const T hs = T(0.5) * side[i];
+        if (A[i] > 0) { p.x -= hs * R.m[0][i]; p.y -= hs * R.m[1][i]; p.z -= hs * R.m[2][i]; }
+        else          { p.x += hs * R.m[0][i]; p.y += hs * R.m[1][i]; p.z += hs * R.m[2][i]; }
+    }
+    cp[0] = p; cd[0] = depth;
+    int ret = 1;
+    if (maxc > 1) {
+        int s1, s2;
+        if (B[0] < B[1]) {
+            if (B[2] < B[0]) { s1 = 2; s2 = 0; }
+            else             { s1 = 0; s2 = (B[1] < B[2]) ? 1 : 2; }
+        } else {
+            if (B[2] < B[1]) { s1 = 2; s2 = 1; }
+            else             { s1 = 1; s2 = (B[0] < B[2]) ? 0 : 2; }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int s = k == 0 ? s1 : s2;
+            // select column s without dynamic register indexing
+            const T Bs = s == 0 ? B[0] : (s == 1 ? B[1] : B[2]);
+            const T As = s == 0 ? A[0] : (s == 1 ? A[1] : A[2]);
+            const T ss = s == 0 ? side[0] : (s == 1 ? side[1] : side[2]);
+            const T r0 = s == 0 ? R.m[0][0] : (s == 1 ? R.m[0][1] : R.m[0][2]);
+            const T r1 = s == 0 ? R.m[1][0] : (s == 1 ? R.m[1][1] : R.m[1][2]);
+            const T r2 = s == 0 ? R.m[2][0] : (s == 1 ? R.m[2][1] : R.m[2][2]);
+            if (ret == k + 1 && ret < maxc) {
+                if (!(depth - Bs < 0)) {
+                    const T sg = (As > 0) ? T(1) : T(-1);
+                    cp[k + 1] = { p.x + sg * ss * r0, p.y + sg * ss * r1, p.z + sg * ss * r2 };
+                    cd[k + 1] = depth - Bs;
+                    ret = k + 2;
+                }
+            }
+        }
+        if (maxc == 4 && ret == 3) {
+            const T d4 = cd[1] + cd[2] - depth;
+            if (d4 > 0) {
+                cp[3] = { cp[1].x + cp[2].x - p.x, cp[1].y + cp[2].y - p.y, cp[1].z + cp[2].z - p.z };
+                cd[3] = d4;
+                ret = 4;
+            }
+        }
+    }
+    return ret;
+}
+
+template <class T>
+__device__ __forceinline__ int sphere_plane(const V3<T> &pos, T radius, const V3<T> &n, T d, V3<T> cp[4], T cd[4])
+{
+    const T k = pos.x * n.x + pos.y * n.y + pos.z * n.z;
+    const T depth = d - k + radius;
+    if (depth >= 0) {
+        cp[0] = { pos.x - n.x * radius, pos.y - n.y * radius, pos.z - n.z * radius };
+        cd[0] = depth;
+        return 1;
+    }
+    return 0;
+}
+
+template <class T> __device__ __forceinline__ T wave_sum(T x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// step_plane: fused tick for single-body islands resting on / falling onto the ground plane
+// (BASELINE config 1/3): narrowphase -> contact rows (normal + 2 friction per contact) ->
+// SOR-PGS sweeps -> velocity update -> integrate.  One lane per body; rows live in registers.
+// Algorithmic traffic per body-step: 13 + 4 + 3 (sides) read, 13 written = 33 reals.
+// ---------------------------------------------------------------------------------------------
+constexpr int MAXC = 4;          // box-plane yields at most 4 contacts
+constexpr int MAXR = 3 * MAXC;   // rows per body
+
+template <class T, bool EXT>
+__global__ __launch_bounds__(256) void step_plane(T *__restrict__ S, const uint8_t *__restrict__ gtype,
+                                                  int64_t stride, int64_t n, StepParams<T> P,
+                                                  StepDiag *__restrict__ diag)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int my_contacts = 0;
+    double my_resid = 0.0;
+    if (i < n) {
+        V3<T> x = { S[(C_POS + 0) * stride + i], S[(C_POS + 1) * stride + i], S[(C_POS + 2) * stride + i] };
+        Q4<T> q = { S[(C_QUAT + 0) * stride + i], S[(C_QUAT + 1) * stride + i],
+                    S[(C_QUAT + 2) * stride + i], S[(C_QUAT + 3) * stride + i] };
+        V3<T> v = { S[(C_LVEL + 0) * stride + i], S[(C_LVEL + 1) * stride + i], S[(C_LVEL + 2) * stride + i] };
+        V3<T> w = { S[(C_AVEL + 0) * stride + i], S[(C_AVEL + 1) * stride + i], S[(C_AVEL + 2) * stride + i] };
+        const T mass = S[C_MASS * stride + i];
+        const V3<T> Ib = { S[(C_INERTIA + 0) * stride + i], S[(C_INERTIA + 1) * stride + i],
+                           S[(C_INERTIA + 2) * stride + i] };
+        const T side[3] = { S[(C_SIDES + 0) * stride + i], S[(C_SIDES + 1) * stride + i],
+                            S[(C_SIDES + 2) * stride + i] };
+        const int gt = gtype[i];
+        V3<T> facc = { T(0), T(0), T(0) }, tacc = { T(0), T(0), T(0) };
+        if (EXT) {
+            facc = { S[(C_FORCE + 0) * stride + i], S[(C_FORCE + 1) * stride + i], S[(C_FORCE + 2) * stride + i] };
+            tacc = { S[(C_TORQUE + 0) * stride + i], S[(C_TORQUE + 1) * stride + i], S[(C_TORQUE + 2) * stride + i] };
+        }
+
+        const T h = P.h;
+        const M3<T> R = quat_to_R(q);
+        const T invMass = T(1) / mass;
+        const V3<T> invIb = { T(1) / Ib.x, T(1) / Ib.y, T(1) / Ib.z };
+        facc.x += mass * P.g.x; facc.y += mass * P.g.y; facc.z += mass * P.g.z;
+        const M3<T> invIw = rotate_diag(R, invIb);
+        if (P.gyro != 0) {
+            const M3<T> Iw = rotate_diag(R, Ib);
+            add_gyro_torque(tacc, Iw, w, h, P.gyro);
+        }
+
+        // ---- narrowphase (dCollide) --------------------------------------------------------
+        V3<T> cp[MAXC];
+        T cd[MAXC];
+        int nc = 0;
+        if (P.plane_on) {
+            if (gt == GEOM_BOX) nc = box_plane(x, R, side, P.pn, P.pd, P.max_contacts, cp, cd);
+            else if (gt == GEOM_SPHERE) nc = sphere_plane(x, side[0], P.pn, P.pd, cp, cd);
+        }
+        my_contacts = nc;
+
+        if (nc > 0) {
+            // ---- rows: contact k contributes [n | c x n], [t1 | c x t1], [t2 | c x t2] ----
+            const int rpc = P.mu > 0 ? 3 : 1;
+            const T hinv = T(1) / h;
+            V3<T> dir[3];
+            dir[0] = P.pn;
+            plane_space(P.pn, dir[1], dir[2]);
+            // v/h + M^-1 f
+            const V3<T> tl = { facc.x * invMass + v.x * hinv, facc.y * invMass + v.y * hinv,
+                               facc.z * invMass + v.z * hinv };
+            V3<T> ta = mulv(invIw, tacc);
+            ta.x += w.x * hinv; ta.y += w.y * hinv; ta.z += w.z * hinv;
+            const V3<T> iml[3] = { { invMass * dir[0].x, invMass * dir[0].y, invMass * dir[0].z },
+                                   { invMass * dir[1].x, invMass * dir[1].y, invMass * dir[1].z },
+                                   { invMass * dir[2].x, invMass * dir[2].y, invMass * dir[2].z } };
+            const T cfm = P.cfm * hinv;
+
+            T Ad[MAXR], rhs[MAXR], adcfm[MAXR], lam[MAXR], lo[MAXR], hi[MAXR];
+            V3<T> Ja[MAXR], iMa[MAXR];
+#pragma unroll
+            for (int k = 0; k < MAXC; k++) {
+                if (k < nc) {
+                    const V3<T> c1 = { cp[k].x - x.x, cp[k].y - x.y, cp[k].z - x.z };
+#pragma unroll
+                    for (int dnum = 0; dnum < 3; dnum++) {
+                        const int r = 3 * k + dnum;
+                        if (dnum < rpc) {
+                            const V3<T> ja = cross(c1, dir[dnum]);
+                            T c = T(0);
+                            if (dnum == 0) {
+                                T depth = cd[k];
+                                if (depth < 0) depth = 0;
+                                c = (hinv * P.erp) * depth;
+                                if (P.surf_mode & SURF_BOUNCE) {
+                                    const T outgoing = dot(dir[0], v) + dot(ja, w);
+                                    if (P.bounce_vel >= 0 && (-outgoing) > P.bounce_vel) {
+                                        const T newc = -P.bounce * outgoing;
+                                        if (newc > c) c = newc;
+                                    }
+                                }
+                                lo[r] = 0; hi[r] = Limits<T>::inf();
+                            } else {
+                                lo[r] = -P.mu; hi[r] = P.mu;
+                            }
+                            T sum = T(0);
+                            sum += dir[dnum].x * tl.x; sum += dir[dnum].y * tl.y; sum += dir[dnum].z * tl.z;
+                            sum += ja.x * ta.x; sum += ja.y * ta.y; sum += ja.z * ta.z;
+                            const T b = c * hinv - sum;
+                            const V3<T> ima = mulv(invIw, ja);
+                            T s2 = T(0);
+                            s2 += iml[dnum].x * dir[dnum].x; s2 += iml[dnum].y * dir[dnum].y;
+                            s2 += iml[dnum].z * dir[dnum].z;
+                            s2 += ima.x * ja.x; s2 += ima.y * ja.y; s2 += ima.z * ja.z;
+                            const T ad = P.sor_w / (s2 + cfm);
+                            Ad[r] = ad;
+                            Ja[r] = { ja.x * ad, ja.y * ad, ja.z * ad };
+                            iMa[r] = ima;
+                            rhs[r] = b * ad;
+                            adcfm[r] = ad * cfm;
+                            lam[r] = T(0);
+                        }
+                    }
+                }
+            }
+
+            // ---- SOR-PGS: lambda = 0 start, rows in creation order --------------------------
+            V3<T> fl = { T(0), T(0), T(0) }, fa = { T(0), T(0), T(0) };
+            for (int it = 0; it < P.iters; it++) {
+                const bool last = (it == P.iters - 1);
+#pragma unroll
+                for (int k = 0; k < MAXC; k++) {
+                    if (k < nc) {
+#pragma unroll
+                        for (int dnum = 0; dnum < 3; dnum++) {
+                            const int r = 3 * k + dnum;
+                            if (dnum < rpc) {
+                                const T old = lam[r];
+                                T delta = rhs[r] - old * adcfm[r];
+                                const T ad = Ad[r];
+                                delta -= fl.x * (dir[dnum].x * ad) + fl.y * (dir[dnum].y * ad) +
+                                         fl.z * (dir[dnum].z * ad) + fa.x * Ja[r].x + fa.y * Ja[r].y +
+                                         fa.z * Ja[r].z;
+                                const T nl = old + delta;
+                                if (nl < lo[r]) { delta = lo[r] - old; lam[r] = lo[r]; }
+                                else if (nl > hi[r]) { delta = hi[r] - old; lam[r] = hi[r]; }
+                                else lam[r] = nl;
+                                fl.x += delta * iml[dnum].x; fl.y += delta * iml[dnum].y; fl.z += delta * iml[dnum].z;
+                                fa.x += delta * iMa[r].x; fa.y += delta * iMa[r].y; fa.z += delta * iMa[r].z;
+                                if (last) my_resid += (double)tabs(delta);
+                            }
+                        }
+                    }
+                }
+            }
+            // v += h * (M^-1 J^T lambda)
+            v.x += h * fl.x; v.y += h * fl.y; v.z += h * fl.z;
+            w.x += h * fa.x; w.y += h * fa.y; w.z += h * fa.z;
+        }
+
+        // ---- v += h M^-1 f_ext ; integrate ----------------------------------------------------
+        const T hm = h * invMass;
+        v.x += hm * facc.x; v.y += hm * facc.y; v.z += hm * facc.z;
+        tacc.x *= h; tacc.y *= h; tacc.z *= h;
+        const V3<T> dw = mulv(invIw, tacc);
+        w.x += dw.x; w.y += dw.y; w.z += dw.z;
+        x.x += h * v.x; x.y += h * v.y; x.z += h * v.z;
+        integrate_quat(q, w, h);
+
+        S[(C_POS + 0) * stride + i] = x.x; S[(C_POS + 1) * stride + i] = x.y; S[(C_POS + 2) * stride + i] = x.z;
+        S[(C_QUAT + 0) * stride + i] = q.w; S[(C_QUAT + 1) * stride + i] = q.x;
+        S[(C_QUAT + 2) * stride + i] = q.y; S[(C_QUAT + 3) * stride + i] = q.z;
+        S[(C_LVEL + 0) * stride + i] = v.x; S[(C_LVEL + 1) * stride + i] = v.y; S[(C_LVEL + 2) * stride + i] = v.z;
+        S[(C_AVEL + 0) * stride + i] = w.x; S[(C_AVEL + 1) * stride + i] = w.y; S[(C_AVEL + 2) * stride + i] = w.z;
+        if (EXT) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) S[(C_FORCE + k) * stride + i] = T(0);
+        }
+    }
+    // ---- diagnostics: wavefront reduction, one atomic per wave -----------------------------------
+    const int wc = wave_sum<int>(my_contacts);
+    const double wr = wave_sum<double>(my_resid);
+    if ((threadIdx.x & 63) == 0 && (wc != 0)) {
+        atomicAdd(&diag->contacts, (unsigned long long)wc);
+        atomicAdd(&diag->residual, wr);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack_transforms: GetTransformMat (main.c:602-622) per body: column-major 4x4 from pos + R(q).
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void pack_transforms(const T *__restrict__ S, int64_t stride, int64_t first,
+                                                       int64_t count, T *__restrict__ out)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int64_t i = first + t;
+    const Q4<T> q = { S[(C_QUAT + 0) * stride + i], S[(C_QUAT + 1) * stride + i],
+                      S[(C_QUAT + 2) * stride + i], S[(C_QUAT + 3) * stride + i] };
+    const M3<T> R = quat_to_R(q);
+    T *o = out + 16 * t;
+    o[0] = R.m[0][0]; o[1] = R.m[1][0]; o[2] = R.m[2][0]; o[3] = T(0);
+    o[4] = R.m[0][1]; o[5] = R.m[1][1]; o[6] = R.m[2][1]; o[7] = T(0);
+    o[8] = R.m[0][2]; o[9] = R.m[1][2]; o[10] = R.m[2][2]; o[11] = T(0);
+    o[12] = S[(C_POS + 0) * stride + i]; o[13] = S[(C_POS + 1) * stride + i];
+    o[14] = S[(C_POS + 2) * stride + i]; o[15] = T(1);
+}
+
+// gather / scatter the 13 state reals of listed bodies (boundary exchange between GPUs)
+template <class T>
+__global__ __launch_bounds__(256) void gather_bodies(const T *__restrict__ S, int64_t stride,
+                                                     const int32_t *__restrict__ idx, int64_t count,
+                                                     T *__restrict__ out)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= count * C_MASS) return;
+    const int64_t b = t / C_MASS;
+    const int c = (int)(t - b * C_MASS);
+    out[t] = S[c * stride + idx[b]];
+}
+template <class T>
+__global__ __launch_bounds__(256) void scatter_bodies(T *__restrict__ S, int64_t stride,
+                                                      const int32_t *__restrict__ idx, int64_t count,
+                                                      const T *__restrict__ in)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= count * C_MASS) return;
+    const int64_t b = t / C_MASS;
+    const int c = (int)(t - b * C_MASS);
+    S[c * stride + idx[b]] = in[t];
+}
+
+// AoS (n x k) <-> SoA component arrays, used by upload/download through a staging buffer
+template <class T>
+__global__ __launch_bounds__(256) void aos_to_soa(T *__restrict__ S, int64_t stride, int comp0, int k,
+                                                  int64_t first, int64_t count, const T *__restrict__ aos)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= count * k) return;
+    const int64_t b = t / k;
+    const int c = (int)(t - b * k);
+    S[(comp0 + c) * stride + first + b] = aos[t];
+}
+template <class T>
+__global__ __launch_bounds__(256) void soa_to_aos(const T *__restrict__ S, int64_t stride, int comp0, int k,
+                                                  int64_t first, int64_t count, T *__restrict__ aos)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= count * k) return;
+    const int64_t b = t / k;
+    const int c = (int)(t - b * k);
+    aos[t] = S[(comp0 + c) * stride + first + b];
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline unsigned blocks_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+template <class T>
+hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, const StepParams<T> &P, bool ext,
+                       StepDiag *diag, hipStream_t st)
+{
+    if (!P.plane_on) {
+        constexpr int V = 16 / sizeof(T);
+        const int64_t nvec = (n + V - 1) / V;     // pad bodies up to `stride` are valid memory
+        const unsigned grid = blocks_for(nvec, 256);
+        if (ext) hipLaunchKernelGGL((integrate_free<T, V, true>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P);
+        else     hipLaunchKernelGGL((integrate_free<T, V, false>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P);
+    } else {
+        const unsigned grid = blocks_for(n, 256);
+        if (ext) hipLaunchKernelGGL((step_plane<T, true>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag);
+        else     hipLaunchKernelGGL((step_plane<T, false>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag);
+    }
+    return hipGetLastError();
+}
+
+template <class T>
+hipError_t launch_pack_transforms(const T *S, int64_t stride, int64_t first, int64_t count, T *out, hipStream_t st)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL((pack_transforms<T>), dim3(blocks_for(count, 256)), dim3(256), 0, st, S, stride, first, count, out);
+    return hipGetLastError();
+}
+template <class T>
+hipError_t launch_gather(const T *S, int64_t stride, const int32_t *idx, int64_t count, T *out, hipStream_t st)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL((gather_bodies<T>), dim3(blocks_for(count * C_MASS, 256)), dim3(256), 0, st, S, stride, idx, count, out);
+    return hipGetLastError();
+}
+template <class T>
+hipError_t launch_scatter(T *S, int64_t stride, const int32_t *idx, int64_t count, const T *in, hipStream_t st)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL((scatter_bodies<T>), dim3(blocks_for(count * C_MASS, 256)), dim3(256), 0, st, S, stride, idx, count, in);
+    return hipGetLastError();
+}
+template <class T>
+hipError_t launch_aos_to_soa(T *S, int64_t stride, int comp0, int k, int64_t first, int64_t count, const T *aos,
+                             hipStream_t st)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL((aos_to_soa<T>), dim3(blocks_for(count * k, 256)), dim3(256), 0, st, S, stride, comp0, k, first, count, aos);
+    return hipGetLastError();
+}
+template <class T>
+hipError_t launch_soa_to_aos(const T *S, int64_t stride, int comp0, int k, int64_t first, int64_t count, T *aos,
+                             hipStream_t st)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL((soa_to_aos<T>), dim3(blocks_for(count * k, 256)), dim3(256), 0, st, S, stride, comp0, k, first, count, aos);
+    return hipGetLastError();
+}
+
+#define DMX_INSTANTIATE(T)                                                                                         \
+    template hipError_t launch_step<T>(T *, const uint8_t *, int64_t, int64_t, const StepParams<T> &, bool,        \
+                                       StepDiag *, hipStream_t);                                                   \
+    template hipError_t launch_pack_transforms<T>(const T *, int64_t, int64_t, int64_t, T *, hipStream_t);         \
+    template hipError_t launch_gather<T>(const T *, int64_t, const int32_t *, int64_t, T *, hipStream_t);          \
+    template hipError_t launch_scatter<T>(T *, int64_t, const int32_t *, int64_t, const T *, hipStream_t);         \
+    template hipError_t launch_aos_to_soa<T>(T *, int64_t, int, int, int64_t, int64_t, const T *, hipStream_t);    \
+    template hipError_t launch_soa_to_aos<T>(const T *, int64_t, int, int, int64_t, int64_t, T *, hipStream_t);
+DMX_INSTANTIATE(float)
+DMX_INSTANTIATE(double)
+
+}  // namespace dmx

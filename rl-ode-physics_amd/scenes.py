@@ -1,0 +1,101 @@
+"""Synthetic scenes of BASELINE.json's configs, drawn with the reference's PRNG
+and spawn distributions (main.c:504-509: y in [20,50], box sides in [0.2,1.0])
+on a grid with 2.5 m pitch so that boxes (diagonal <= 1.74 m) never touch one
+another and every dynamics island is a single body.
+
+Each body consumes 7 draws, in this order: side x, side y, side z, height y,
+omega x, omega y, omega z.
+"""
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .rand import Rand
+
+GEOM_SPHERE, GEOM_BOX = 1, 2
+PITCH = 2.5
+DRAWS_PER_BODY = 7
+
+
+@dataclass
+class Scene:
+    pos: np.ndarray       # n x 3
+    quat: np.ndarray      # n x 4 (w,x,y,z)
+    lvel: np.ndarray      # n x 3
+    avel: np.ndarray      # n x 3
+    mass: np.ndarray      # n x 1
+    inertia: np.ndarray   # n x 3 (body-frame principal moments)
+    sides: np.ndarray     # n x 3 (box side lengths; sphere: radius in column 0)
+    gtype: np.ndarray     # n uint8
+    plane: Optional[Tuple[float, float, float, float]]
+
+    @property
+    def n(self):
+        return self.pos.shape[0]
+
+    def astype(self, dtype):
+        f = lambda a: np.ascontiguousarray(a, dtype=dtype)
+        return Scene(f(self.pos), f(self.quat), f(self.lvel), f(self.avel), f(self.mass),
+                     f(self.inertia), f(self.sides), self.gtype, self.plane)
+
+    def slice(self, lo, hi):
+        return Scene(self.pos[lo:hi], self.quat[lo:hi], self.lvel[lo:hi], self.avel[lo:hi],
+                     self.mass[lo:hi], self.inertia[lo:hi], self.sides[lo:hi], self.gtype[lo:hi], self.plane)
+
+
+def box_grid(nx, nz, *, seed=1, y_range=(20.0, 50.0), spin=True, box_mass=False, plane=True,
+             slabs=1, slab_gap=0.0):
+    """nx x nz boxes; x = column, z = row (row-major body order).
+
+    spin     -- omega_0 components drawn from Rand_Double(-1,1); otherwise 0
+    box_mass -- dMassSetBox(density 1) instead of the reference's default m=1, I=identity
+    slabs    -- split the rows into `slabs` equal groups, consecutive groups pushed apart along z by
+                slab_gap metres (BASELINE config 4: disjoint islands, one slab per GPU)
+    """
+    n = nx * nz
+    r = Rand(seed)
+    d = r.next(n * DRAWS_PER_BODY).astype(np.float64).reshape(n, DRAWS_PER_BODY) / float(0xFFFFFFFF)
+    sides = 0.2 + d[:, 0:3] * (1.0 - 0.2)
+    y = y_range[0] + d[:, 3] * (y_range[1] - y_range[0])
+    omega = (-1.0 + d[:, 4:7] * 2.0) if spin else np.zeros((n, 3))
+    col = np.tile(np.arange(nx, dtype=np.float64), nz)
+    row = np.repeat(np.arange(nz, dtype=np.float64), nx)
+    x = (col - (nx - 1) / 2.0) * PITCH
+    z = (row - (nz - 1) / 2.0) * PITCH
+    if slabs > 1:
+        rows_per = nz // slabs
+        z = z + np.floor(row / rows_per) * slab_gap
+    pos = np.stack([x, y, z], axis=1)
+    quat = np.zeros((n, 4))
+    quat[:, 0] = 1.0
+    if box_mass:
+        m = sides[:, 0] * sides[:, 1] * sides[:, 2]
+        s2 = sides * sides
+        inertia = (m / 12.0)[:, None] * np.stack([s2[:, 1] + s2[:, 2], s2[:, 0] + s2[:, 2], s2[:, 0] + s2[:, 1]], 1)
+        mass = m[:, None]
+    else:
+        mass = np.ones((n, 1))
+        inertia = np.ones((n, 3))
+    return Scene(pos, quat, np.zeros((n, 3)), omega, mass, inertia, sides,
+                 np.full(n, GEOM_BOX, np.uint8), (0.0, 1.0, 0.0, 0.0) if plane else None)
+
+
+def config1(box_mass=False, spin=False):
+    """1 024 free-falling boxes over a ground plane (BASELINE configs[0])."""
+    return box_grid(32, 32, seed=1, spin=spin or box_mass, box_mass=box_mass, plane=True)
+
+
+def config2(n_side=1024, box_mass=False):
+    """1 048 576 free-falling boxes, no contacts (BASELINE configs[1])."""
+    return box_grid(n_side, n_side, seed=1, spin=True, box_mass=box_mass, plane=False)
+
+
+def config3(n_side=512):
+    """262 144 boxes dropping onto the ground plane from y in [1,3] (BASELINE configs[2])."""
+    return box_grid(n_side, n_side, seed=1, y_range=(1.0, 3.0), spin=False, plane=True)
+
+
+def config4(n_side=1024, slabs=8):
+    """configs[1]'s scene split into `slabs` disjoint slabs >= 10 m apart (BASELINE configs[3])."""
+    return box_grid(n_side, n_side, seed=1, spin=True, plane=False, slabs=slabs, slab_gap=10.0)

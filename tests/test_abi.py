@@ -1,0 +1,51 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol that
+include/*.h declares (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from __graft_entry__ import load_package, ROOT
+
+pkg = load_package()
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dmx[A-Z]\w*|d[A-Z]\w*)\s*\(", src)))
+
+
+def test_library_loads_and_exports_batch_abi():
+    lib = pkg._lib.load()
+    names = _declared("dmx_batch.h")
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/dmx_batch.h but not exported"
+    assert sorted(pkg._lib.BATCH_SYMBOLS) == names
+    assert b"gfx950" in lib.dmxVersion()
+
+
+def test_no_cpu_fallback_without_device():
+    """On a box without a GPU the product refuses to run instead of falling back."""
+    lib = pkg._lib.load()
+    if lib.dmxDeviceCount() > 0:
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    assert lib.dmxBatchCreate(C.byref(h), 16, 0, 0) == -1      # DMX_ENODEVICE
+    assert not h.value
+    with pytest.raises(pkg.batch.DmxError):
+        pkg.BatchWorld(16)
+
+
+def test_product_does_not_reference_oracle():
+    """The shipped library and package never link / import anything under oracle/."""
+    import subprocess
+    out = subprocess.run(["ldd", pkg._lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rl-ode-physics_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "orc_" not in txt and "liboracle" not in txt, os.path.join(dirpath, f)

@@ -1,0 +1,273 @@
+"""GPU parity: the HIP path (through the C ABI) vs the CPU oracle on the same
+seeded inputs, plus size-independent properties at BASELINE.json's full sizes.
+
+Tolerance: north_star asks for 1e-5 relative on positions / quaternions after
+N steps.  The library is built without FMA contraction and mirrors the step's
+evaluation order, so on single-body islands the result is expected to be
+bit-identical to the oracle in both precisions; the tests assert exact
+equality where that holds and the 1e-5 bound everywhere.
+"""
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+
+pkg = load_package()
+pytestmark = pytest.mark.gpu
+
+H = 1.0 / 60.0
+REL_TOL = 1e-5          # BASELINE.json north_star
+
+
+def _oracle_run(orc, scene, steps, gyro=None, spheres=False, setup=None):
+    ow = orc.world()
+    if gyro is not None:
+        orc.lib.orc_world_set_gyro_mode(ow.w, gyro)
+    if setup:
+        setup(orc, ow)
+    if scene.plane is not None:
+        ow.add_plane(*scene.plane)
+    if spheres:
+        ow.add_spheres(scene.pos, scene.quat, scene.lvel, scene.avel, scene.mass[:, 0], scene.inertia,
+                       scene.sides[:, 0])
+    else:
+        ow.add_boxes(scene.pos, scene.quat, scene.lvel, scene.avel, scene.mass[:, 0], scene.inertia, scene.sides)
+    ow.run(H, steps)
+    return ow
+
+
+def _gpu_run(scene, dtype, steps, gyro=None, setup=None):
+    w = pkg.BatchWorld(scene.n, dtype=dtype)
+    if gyro is not None:
+        w.set_gyro_mode(gyro)
+    if setup:
+        setup(w)
+    w.load_scene(scene)
+    w.step(H, steps)
+    w.synchronize()
+    return w
+
+
+def _rel_err(a, b):
+    scale = np.maximum(np.abs(b), 1.0)
+    return float(np.max(np.abs(a - b) / scale))
+
+
+def _compare(got, ref, exact=True):
+    for name, a, b in zip(("pos", "quat", "lvel", "avel"), got, ref):
+        assert np.all(np.isfinite(a)), name
+        assert _rel_err(a, b) <= REL_TOL, f"{name}: rel err {_rel_err(a, b)}"
+        if exact:
+            assert np.array_equal(a, b), f"{name}: not bit-identical, max abs diff {np.max(np.abs(a - b))}"
+
+
+def _orc(dtype):
+    from oracle.orc_ctypes import Oracle
+    return Oracle(dtype)
+
+
+# ----------------------------------------------------------------- free flight (configs[1] shape)
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("box_mass", [False, True])
+def test_free_flight_matches_oracle(dtype, box_mass):
+    scene = pkg.scenes.box_grid(64, 64, seed=1, spin=True, box_mass=box_mass, plane=False).astype(dtype)
+    w = _gpu_run(scene, dtype, 600)
+    ow = _oracle_run(_orc(dtype), scene, 600)
+    _compare(w.state(), ow.state())
+    assert w.last_contact_count() == 0
+
+
+@pytest.mark.parametrize("gyro", [0, 1, 2])
+def test_gyro_modes_match_oracle(gyro):
+    scene = pkg.scenes.box_grid(32, 16, seed=5, spin=True, box_mass=True, plane=False).astype("float64")
+    scene.avel[:] *= 4.0
+    w = _gpu_run(scene, "float64", 240, gyro=gyro)
+    ow = _oracle_run(_orc("float64"), scene, 240, gyro=gyro)
+    _compare(w.state(), ow.state())
+
+
+@pytest.mark.parametrize("n", [1, 3, 255, 256, 257, 1000])
+def test_ragged_sizes(n):
+    full = pkg.scenes.box_grid(40, 25, seed=3, spin=True, box_mass=True, plane=False)
+    scene = full.slice(0, n).astype("float32")
+    w = _gpu_run(scene, "float32", 50)
+    ow = _oracle_run(_orc("float32"), scene, 50)
+    _compare(w.state(), ow.state())
+
+
+# ----------------------------------------------------------------- contact path (configs[0] / configs[2])
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_config1_boxes_on_plane_matches_oracle(dtype):
+    """BASELINE configs[0]: 1 024 boxes over the ground plane, 600 QuickSteps at dt = 1/60."""
+    scene = pkg.scenes.config1().astype(dtype)
+    w = _gpu_run(scene, dtype, 600)
+    ow = _oracle_run(_orc(dtype), scene, 600)
+    _compare(w.state(), ow.state())
+    assert w.last_contact_count() == ow.n_contacts() > 0
+    assert abs(w.last_residual() - ow.sor_residual()) <= 1e-6 * max(1.0, ow.sor_residual())
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_tumbling_boxes_land_and_settle(dtype):
+    """Spinning boxes with dMassSetBox inertia: edge/corner landings, 1-4 contacts, bounce rule."""
+    scene = pkg.scenes.box_grid(32, 32, seed=11, y_range=(0.8, 4.0), spin=True, box_mass=True).astype(dtype)
+    scene.avel[:] *= 3.0
+    w = _gpu_run(scene, dtype, 400)
+    ow = _oracle_run(_orc(dtype), scene, 400)
+    _compare(w.state(), ow.state())
+    assert w.last_contact_count() == ow.n_contacts()
+
+
+def test_config3_shape_reduced():
+    """configs[2] at 64x64: drop from y in [1,3], all in contact after ~60 steps."""
+    scene = pkg.scenes.config3(64).astype("float32")
+    w = _gpu_run(scene, "float32", 180)
+    ow = _oracle_run(_orc("float32"), scene, 180)
+    _compare(w.state(), ow.state())
+    assert w.last_contact_count() == ow.n_contacts() == 4 * scene.n
+
+
+def test_spheres_on_plane():
+    scene = pkg.scenes.box_grid(24, 24, seed=2, y_range=(0.3, 2.0), spin=True).astype("float64")
+    scene.sides[:, 0] = 0.1 + 0.3 * (scene.sides[:, 0] - 0.2) / 0.8      # radius in [0.1, 0.4]  main.c:516
+    scene.gtype[:] = pkg.scenes.GEOM_SPHERE
+    w = _gpu_run(scene, "float64", 240)
+    ow = _oracle_run(_orc("float64"), scene, 240, spheres=True)
+    _compare(w.state(), ow.state())
+    assert w.last_contact_count() == ow.n_contacts() > 0
+
+
+def test_solver_parameters_are_honoured():
+    scene = pkg.scenes.box_grid(16, 16, seed=4, y_range=(0.6, 1.2), spin=False).astype("float64")
+
+    def gs(w):
+        w.set_erp(0.35); w.set_cfm(1e-6); w.set_quickstep(7, 1.1); w.set_surface(mu=0.0, bounce=0.5, bounce_vel=0.3)
+
+    def os_(orc, ow):
+        lib = orc.lib
+        lib.orc_world_set_erp(ow.w, 0.35); lib.orc_world_set_cfm(ow.w, 1e-6)
+        lib.orc_world_set_quickstep(ow.w, 7, 1.1)
+        lib.orc_world_set_surface(ow.w, 0x004, 0.0, 0.5, 0.3)
+    w = _gpu_run(scene, "float64", 120, setup=gs)
+    ow = _oracle_run(_orc("float64"), scene, 120, setup=os_)
+    _compare(w.state(), ow.state())
+
+
+def test_tilted_plane():
+    scene = pkg.scenes.box_grid(16, 16, seed=6, y_range=(3.0, 5.0), spin=True, box_mass=True).astype("float64")
+    scene.plane = (0.1, 1.0, -0.2, -0.5)
+    w = _gpu_run(scene, "float64", 200)
+    ow = _oracle_run(_orc("float64"), scene, 200)
+    _compare(w.state(), ow.state())
+
+
+# ----------------------------------------------------------------- pose snapshot (GetTransformMat)
+def test_pack_transforms_matches_reference_layout():
+    import ctypes as C
+    scene = pkg.scenes.box_grid(20, 10, seed=9, spin=True, plane=False).astype("float64")
+    w = _gpu_run(scene, "float64", 30)
+    T = w.transforms()
+    orc = _orc("float64")
+    ow = _oracle_run(orc, scene, 30)
+    RP = C.POINTER(C.c_double)
+    out = np.zeros(16)
+    for i in (0, 1, 57, 199):
+        orc.lib.orc_pack_transform(out.ctypes.data_as(RP), orc.lib.orc_body_get_position(ow.w, i),
+                                   orc.lib.orc_body_get_rotation(ow.w, i))
+        assert np.array_equal(T[i], out)
+    part = w.transforms(first=50, count=7)
+    assert np.array_equal(part, T[50:57])
+
+
+# ----------------------------------------------------------------- upload / download, gather / scatter
+def test_upload_download_roundtrip_and_partial_ranges():
+    n = 777
+    rng = np.random.default_rng(0)
+    w = pkg.BatchWorld(n, dtype="float32")
+    B = pkg.batch
+    a = rng.standard_normal((n, 3)).astype(np.float32)
+    w.upload(B.POS, a)
+    assert np.array_equal(w.download(B.POS), a)
+    w.upload(B.LVEL, a[100:200] * 2, first=300)
+    got = w.download(B.LVEL)
+    assert np.array_equal(got[300:400], a[100:200] * 2) and not got[:300].any() and not got[400:].any()
+    assert np.array_equal(w.download(B.LVEL, first=350, count=10), a[150:160] * 2)
+    # defaults of untouched fields: m = 1, I = identity, q = identity (dBodyCreate)
+    assert np.all(w.download(B.MASS) == 1) and np.all(w.download(B.INERTIA) == 1)
+    assert np.array_equal(w.download(B.QUAT), np.tile([1, 0, 0, 0], (n, 1)).astype(np.float32))
+    # quaternions are normalised on upload (dBodySetQuaternion)
+    q = rng.standard_normal((n, 4)).astype(np.float32)
+    w.upload(B.QUAT, q)
+    assert np.allclose(np.linalg.norm(w.download(B.QUAT), axis=1), 1.0, atol=1e-6)
+
+
+def test_external_force_is_applied_once_and_cleared():
+    B = pkg.batch
+    w = pkg.BatchWorld(300, dtype="float64", gravity=(0, 0, 0))
+    f = np.zeros((300, 3)); f[:, 0] = 6.0
+    w.upload(B.FORCE, f)
+    w.step(H, 1)
+    v = w.download(B.LVEL)
+    assert np.allclose(v[:, 0], 6.0 * H) and not w.download(B.FORCE).any()
+    w.step(H, 3)
+    assert np.allclose(w.download(B.LVEL)[:, 0], 6.0 * H)      # no further acceleration
+
+
+def test_gather_scatter_bodies_roundtrip():
+    import torch
+    B = pkg.batch
+    scene = pkg.scenes.box_grid(32, 8, seed=3, spin=True, plane=False).astype("float32")
+    w = pkg.BatchWorld(scene.n, dtype="float32"); w.load_scene(scene); w.step(H, 5)
+    idx = torch.tensor([0, 31, 32, 255, 100], dtype=torch.int32, device="cuda")
+    buf = torch.empty((5, 13), dtype=torch.float32, device="cuda")
+    assert w.lib.dmxBatchGatherBodies(w.h, idx.data_ptr(), 5, buf.data_ptr()) == 0
+    w.synchronize()
+    pos, quat, lvel, avel = w.state()
+    ref = np.concatenate([pos, quat, lvel, avel], axis=1)[[0, 31, 32, 255, 100]]
+    assert np.array_equal(buf.cpu().numpy(), ref)
+    w2 = pkg.BatchWorld(scene.n, dtype="float32")
+    assert w2.lib.dmxBatchScatterBodies(w2.h, idx.data_ptr(), 5, buf.data_ptr()) == 0
+    w2.synchronize()
+    assert np.array_equal(w2.download(B.POS)[[0, 31, 32, 255, 100]], ref[:, :3])
+
+
+# ----------------------------------------------------------------- full-size properties (configs[1], configs[2])
+def test_config2_full_size_properties():
+    """1 048 576 free bodies: closed-form free fall, conserved horizontal motion, unit quaternions,
+    and bit-parity with the oracle on a strided sample of bodies."""
+    scene = pkg.scenes.config2().astype("float32")
+    steps = 120
+    w = _gpu_run(scene, "float32", steps)
+    pos, quat, lvel, avel = w.state()
+    assert np.all(np.abs(np.linalg.norm(quat.astype(np.float64), axis=1) - 1.0) < 2e-6)
+    assert np.array_equal(pos[:, 0], scene.pos[:, 0]) and np.array_equal(pos[:, 2], scene.pos[:, 2])
+    g, n = -9.8, steps
+    assert np.allclose(lvel[:, 1], n * H * g, rtol=1e-5)
+    y = scene.pos[:, 1].astype(np.float64) + g * H * H * n * (n + 1) / 2
+    assert np.max(np.abs(pos[:, 1] - y) / np.abs(y)) < 1e-5
+    # isotropic inertia: |omega| is conserved
+    assert np.allclose(np.linalg.norm(avel, axis=1), np.linalg.norm(scene.avel, axis=1), rtol=1e-4)
+    sel = np.arange(0, scene.n, 257)
+    sub = pkg.scenes.Scene(scene.pos[sel], scene.quat[sel], scene.lvel[sel], scene.avel[sel], scene.mass[sel],
+                           scene.inertia[sel], scene.sides[sel], scene.gtype[sel], None)
+    ow = _oracle_run(_orc("float32"), sub, steps)
+    for a, b in zip((pos, quat, lvel, avel), ow.state()):
+        assert np.array_equal(a[sel], b)
+
+
+def test_config3_full_size_properties():
+    """262 144 boxes onto the plane: everything lands, rests with 4 contacts, no penetration runaway."""
+    scene = pkg.scenes.config3().astype("float32")
+    w = _gpu_run(scene, "float32", 240)
+    pos, quat, lvel, avel = w.state()
+    assert w.last_contact_count() == 4 * scene.n
+    assert np.all(np.abs(np.linalg.norm(quat.astype(np.float64), axis=1) - 1.0) < 2e-6)
+    rest = scene.sides[:, 1] / 2
+    assert np.max(np.abs(pos[:, 1] - rest)) < 5e-3          # resting height = half the vertical side
+    assert np.max(np.abs(lvel)) < 5e-2 and np.max(np.abs(avel)) < 5e-2
+    sel = np.arange(0, scene.n, 521)
+    sub = pkg.scenes.Scene(scene.pos[sel], scene.quat[sel], scene.lvel[sel], scene.avel[sel], scene.mass[sel],
+                           scene.inertia[sel], scene.sides[sel], scene.gtype[sel], scene.plane)
+    ow = _oracle_run(_orc("float32"), sub, 240)
+    for a, b in zip((pos, quat, lvel, avel), ow.state()):
+        assert np.array_equal(a[sel], b)
