@@ -95,8 +95,10 @@ def main():
 
     w = pkg.BatchWorld(scene.n, dtype=dtype, device=local_rank)
     w.load_scene(scene)
-    stream = torch.cuda.current_stream()
-    w.set_stream(stream.cuda_stream)        # kernels run on torch's current stream: its events see them
+    stream = torch.cuda.Stream()            # a real (non-null) stream: the batch launches on it and the
+    torch.cuda.set_stream(stream)           # timing events below are recorded on it, so they bracket the kernels
+    assert stream.cuda_stream != 0
+    w.set_stream(stream.cuda_stream)
 
     exchange = None
     if world > 1 and a.exchange == "boundary":

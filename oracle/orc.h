@@ -116,6 +116,8 @@ int orc_collide(orc_world *w, int g1, int g2, int max_contacts, orc_contactgeom 
  * (main.c:211-215 with QuickStep substituted for dWorldStep) */
 void orc_world_tick(orc_world *w, real h);
 int  orc_world_last_contact_count(orc_world *w);
+/* geom pairs with finite AABBs (i.e. not involving a plane) that passed the broadphase in the last tick */
+int  orc_world_last_body_pairs(orc_world *w);
 /* diagnostic: sum over rows of |delta lambda| in the last SOR sweep of the last tick */
 double orc_world_last_sor_residual(orc_world *w);
 

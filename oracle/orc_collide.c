@@ -290,6 +290,7 @@ static int pair_passes(const orc_geom *a, const orc_geom *b)
 void orc_collide_all(orc_world *w)
 {
     w->nj = 0;
+    w->last_body_pairs = 0;
     int ng = w->ng;
     aabb_t *bb = (aabb_t *)malloc((size_t)(ng ? ng : 1) * sizeof(aabb_t));
     int nbb = 0;
@@ -326,7 +327,7 @@ void orc_collide_all(orc_world *w)
         for (int j = i + 1; j < nbb && bb[j].lo[0] <= bb[i].hi[0]; j++) {
             if (bb[j].lo[1] > bb[i].hi[1] || bb[i].lo[1] > bb[j].hi[1]) continue;
             if (bb[j].lo[2] > bb[i].hi[2] || bb[i].lo[2] > bb[j].hi[2]) continue;
-            if (pair_passes(&w->geoms[bb[i].g], &w->geoms[bb[j].g])) PUSH_PAIR(bb[i].g, bb[j].g);
+            if (pair_passes(&w->geoms[bb[i].g], &w->geoms[bb[j].g])) { PUSH_PAIR(bb[i].g, bb[j].g); w->last_body_pairs++; }
         }
     }
     /* canonical order: ascending (g1,g2), g1 < g2 */

@@ -86,6 +86,7 @@ class Oracle:
         sig("orc_collide", C.c_int, P, C.c_int, C.c_int, C.c_int, C.POINTER(self.ContactGeom))
         sig("orc_world_tick", None, P, real)
         sig("orc_world_last_contact_count", C.c_int, P)
+        sig("orc_world_last_body_pairs", C.c_int, P)
         sig("orc_world_last_sor_residual", C.c_double, P)
         sig("orc_world_body_count", C.c_int, P)
         sig("orc_world_add_boxes", None, P, C.c_int, P, P, P, P, P, P, P)
@@ -172,6 +173,9 @@ class World:
 
     def n_contacts(self):
         return self.lib.orc_world_last_contact_count(self.w)
+
+    def n_body_pairs(self):
+        return self.lib.orc_world_last_body_pairs(self.w)
 
     def sor_residual(self):
         return self.lib.orc_world_last_sor_residual(self.w)

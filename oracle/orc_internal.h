@@ -51,6 +51,7 @@ struct orc_world {
     orc_joint *joints; int nj, cap_j;
 
     int last_contacts;
+    int last_body_pairs;      /* finite-AABB pairs that reached the near callback in the last tick */
     double last_residual;
 };
 

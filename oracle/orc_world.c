@@ -199,6 +199,7 @@ void orc_world_tick(orc_world *w, real h)
 }
 
 int orc_world_last_contact_count(orc_world *w) { return w->last_contacts; }
+int orc_world_last_body_pairs(orc_world *w) { return w->last_body_pairs; }
 double orc_world_last_sor_residual(orc_world *w) { return w->last_residual; }
 
 /* ---- bulk helpers ------------------------------------------------------- */
