@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--side", type=int, default=0, help="grid side (bodies = side^2 per GPU); 0 = config default")
     ap.add_argument("--exchange", default="boundary", choices=["boundary", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gyro", type=int, default=2, choices=[0, 1, 2], help="0 off, 1 explicit, 2 implicit (ODE default)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -95,6 +96,7 @@ def main():
 
     w = pkg.BatchWorld(scene.n, dtype=dtype, device=local_rank)
     w.load_scene(scene)
+    w.set_gyro_mode(a.gyro)
     stream = torch.cuda.Stream()            # a real (non-null) stream: the batch launches on it and the
     torch.cuda.set_stream(stream)           # timing events below are recorded on it, so they bracket the kernels
     assert stream.cuda_stream != 0

@@ -338,6 +338,12 @@ static void step_island(orc_world *w, const int *ibody, int nb, const int *ijoin
     }
 }
 
+static int cmp_int(const void *a, const void *b)
+{
+    int x = *(const int *)a, y = *(const int *)b;
+    return (x > y) - (x < y);
+}
+
 /* dxProcessIslands: DFS over joints between bodies */
 void orc_quickstep(orc_world *w, real h)
 {
@@ -399,6 +405,12 @@ void orc_quickstep(orc_world *w, real h)
             }
             if (sp == 0) break;
             b = S.stack[--sp];
+        }
+        if (!ode) {
+            /* ORC_ORDER_FIXED: bodies by index, joints (hence rows) in creation order */
+            qsort(S.ibody, (size_t)bcount, sizeof(int), cmp_int);
+            qsort(S.ijoint, (size_t)jcount, sizeof(int), cmp_int);
+            for (int k = 0; k < bcount; k++) S.local[S.ibody[k]] = k;
         }
         step_island(w, S.ibody, bcount, S.ijoint, jcount, h);
     }

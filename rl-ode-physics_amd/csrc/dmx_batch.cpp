@@ -49,6 +49,7 @@ struct dmxBatch {
     double mu = __builtin_huge_val(), bounce = 0.2, bounce_vel = 0.1;   // main.c:685-687
     int max_contacts = 8;                               // main.c:675
     bool ext_pending = false;
+    int vec = 0;                     // DMX_VEC launch-tuning override (bodies per lane), 0 = 16 B per lane
     bool stepped_with_plane = false;
 };
 
@@ -110,6 +111,7 @@ extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int dev
     b->device = device;
     b->rsize = precision == DMX_F32 ? 4 : 8;
     b->cfm = precision == DMX_F32 ? 1e-5 : 1e-10;      // dWorldCreate default per precision [ODE]
+    if (const char *v = getenv("DMX_VEC")) b->vec = atoi(v);
     int rc = DMX_OK;
     do {
         if (hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = DMX_EHIP; break; }
@@ -284,6 +286,7 @@ template <class T> static StepParams<T> make_params(dmxBatch *b, double h)
     P.surf_mode = b->surf_mode;
     P.mu = (T)b->mu; P.bounce = (T)b->bounce; P.bounce_vel = (T)b->bounce_vel;
     P.max_contacts = b->max_contacts;
+    P.vec = b->vec;
     return P;
 }
 

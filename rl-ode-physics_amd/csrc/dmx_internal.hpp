@@ -35,6 +35,7 @@ template <class T> struct StepParams {
     V3<T> pn; T pd;     // plane n.x = d
     int surf_mode; T mu, bounce, bounce_vel;   // contact surface (NearCallback, main.c:684-687)
     int max_contacts;
+    int vec;            // launch tuning: bodies per lane in integrate_free (0 = 16 B per lane)
 };
 
 struct StepDiag {

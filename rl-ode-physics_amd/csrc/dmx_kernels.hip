@@ -457,11 +457,19 @@ hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, co
                        StepDiag *diag, hipStream_t st)
 {
     if (!P.plane_on) {
-        constexpr int V = 16 / sizeof(T);
+        constexpr int VMAX = 16 / sizeof(T);
+        const int V = (P.vec == 1 || P.vec == 2 || P.vec == VMAX) ? P.vec : VMAX;
         const int64_t nvec = (n + V - 1) / V;     // pad bodies up to `stride` are valid memory
         const unsigned grid = blocks_for(nvec, 256);
-        if (ext) hipLaunchKernelGGL((integrate_free<T, V, true>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P);
-        else     hipLaunchKernelGGL((integrate_free<T, V, false>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P);
+#define DMX_LAUNCH_FREE(VV)                                                                                      \
+    do {                                                                                                         \
+        if (ext) hipLaunchKernelGGL((integrate_free<T, VV, true>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P);  \
+        else     hipLaunchKernelGGL((integrate_free<T, VV, false>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P); \
+    } while (0)
+        if (V == 1) DMX_LAUNCH_FREE(1);
+        else if (V == 2) DMX_LAUNCH_FREE(2);
+        else DMX_LAUNCH_FREE(VMAX);
+#undef DMX_LAUNCH_FREE
     } else {
         const unsigned grid = blocks_for(n, 256);
         if (ext) hipLaunchKernelGGL((step_plane<T, true>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag);
