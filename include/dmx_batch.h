@@ -49,7 +49,9 @@ enum {
     DMX_SIDES = 6,    /* k=3  dCreateBox side lengths / (r,-,-) for a sphere  main.c:717,720 */
     DMX_FORCE = 7,    /* k=3  dBodyAddForce accumulator, cleared each step    main.c:532 */
     DMX_TORQUE = 8,   /* k=3  dBodyAddTorque accumulator                                  */
-    DMX_NFIELDS = 9
+    DMX_QUAT_RAW = 9, /* k=4  like DMX_QUAT but stored as given (DMX_QUAT normalises on upload,
+                              as dBodySetQuaternion does); for state that came from the device */
+    DMX_NFIELDS = 10
 };
 
 /* geometry class per body (uint8 array) */
@@ -95,6 +97,23 @@ int dmxBatchSynchronize(dmxBatchID b);
 int dmxBatchSetStream(dmxBatchID b, void *hip_stream);
 /* step nsteps times bracketed by HIP events on the batch's stream; *ms = elapsed device milliseconds */
 int dmxBatchStepTimed(dmxBatchID b, double h, int nsteps, float *ms);
+
+/* ---- explicit contact joints: the callback form of the tick.  The reference's near callback makes one
+ * dJointCreateContact + dJointAttach per contact (main.c:683-692) and then calls dWorldStep (main.c:213);
+ * this entry takes the whole tick's contact joints at once, groups them into dynamics islands, and steps
+ * every live body (bodies without joints integrate freely).  body2 = -1 (or body1 = -1) means static
+ * geometry (dGeomGetBody == 0, main.c:691); the normal points into body1 as dCollide returns it. */
+typedef struct dmxContactJoint {
+    double pos[3], normal[3], depth;      /* dContactGeom */
+    int32_t body1, body2;                 /* body slots, -1 = none */
+    int32_t mode;                         /* dContactBounce | dContactSoftERP | dContactSoftCFM */
+    double mu, bounce, bounce_vel, soft_erp, soft_cfm;   /* dSurfaceParameters (main.c:684-687) */
+} dmxContactJoint;
+int dmxBatchStepJoints(dmxBatchID b, double h, int64_t n_joints, const dmxContactJoint *joints);
+
+/* per-body flags for the island path: dBodyDestroy'ed slots, dBodySetKinematic (main.c:712), gravity / gyro modes */
+enum { DMX_BODY_ALIVE = 1, DMX_BODY_KINEMATIC = 2, DMX_BODY_NOGRAVITY = 4, DMX_BODY_NOGYRO = 8 };
+int dmxBatchUploadBodyFlags(dmxBatchID b, const uint8_t *flags, int64_t first, int64_t count);
 
 /* ---- diagnostics of the last step */
 int dmxBatchLastContactCount(dmxBatchID b, int64_t *n);       /* contact joints created in the last tick */

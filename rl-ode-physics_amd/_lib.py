@@ -18,6 +18,7 @@ BATCH_SYMBOLS = [
     "dmxBatchDevicePtr", "dmxBatchStride", "dmxBatchStep", "dmxBatchSynchronize", "dmxBatchSetStream",
     "dmxBatchStepTimed", "dmxBatchLastContactCount", "dmxBatchLastResidual", "dmxBatchPackTransforms",
     "dmxBatchDownloadTransforms", "dmxBatchGatherBodies", "dmxBatchScatterBodies",
+    "dmxBatchStepJoints", "dmxBatchUploadBodyFlags",
 ]
 
 _lib = None
@@ -75,5 +76,7 @@ def load():
     sig("dmxBatchDownloadTransforms", I, P, P, L, L)
     sig("dmxBatchGatherBodies", I, P, P, L, P)
     sig("dmxBatchScatterBodies", I, P, P, L, P)
+    sig("dmxBatchStepJoints", I, P, D, L, P)
+    sig("dmxBatchUploadBodyFlags", I, P, P, L, L)
     _lib = lib
     return lib

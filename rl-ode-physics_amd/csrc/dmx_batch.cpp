@@ -10,51 +10,10 @@
 #include <new>
 #include <vector>
 
-#include "../../include/dmx_batch.h"
-#include "dmx_internal.hpp"
+#include "dmx_batch_priv.hpp"
 
-using namespace dmx;
-
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess) {                                                                    \
-            fprintf(stderr, "libode_mi355: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), \
-                    __FILE__, __LINE__);                                                           \
-            return DMX_EHIP;                                                                       \
-        }                                                                                          \
-    } while (0)
-
-struct dmxBatch {
-    int64_t n = 0, stride = 0;
-    int precision = DMX_F32;
-    int device = 0;
-    size_t rsize = 4;
-    void *slab = nullptr;            // C_COUNT x stride reals
-    uint8_t *gtype = nullptr;        // stride bytes
-    StepDiag *diag = nullptr;        // device
-    StepDiag *diag_host = nullptr;   // pinned
-    void *stage = nullptr;           // device staging for AoS <-> SoA
-    size_t stage_bytes = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // world parameters (defaults: dWorldCreate [ODE], gravity unset = 0)
-    double g[3] = { 0, 0, 0 };
-    double erp = 0.2, cfm = 1e-5, sor_w = 1.3;
-    int iters = 20;
-    int gyro = DMX_GYRO_IMPLICIT;
-    int plane_on = 0;
-    double plane[4] = { 0, 1, 0, 0 };
-    int surf_mode = DMX_CONTACT_BOUNCE;                 // main.c:684
-    double mu = __builtin_huge_val(), bounce = 0.2, bounce_vel = 0.1;   // main.c:685-687
-    int max_contacts = 8;                               // main.c:675
-    bool ext_pending = false;
-    int vec = 0;                     // DMX_VEC launch-tuning override (bodies per lane), 0 = 16 B per lane
-    bool stepped_with_plane = false;
-};
-
-static const int k_field_comp0[DMX_NFIELDS] = { C_POS, C_QUAT, C_LVEL, C_AVEL, C_MASS, C_INERTIA, C_SIDES, C_FORCE, C_TORQUE };
-static const int k_field_k[DMX_NFIELDS] = { 3, 4, 3, 3, 1, 3, 3, 3, 3 };
+static const int k_field_comp0[DMX_NFIELDS] = { C_POS, C_QUAT, C_LVEL, C_AVEL, C_MASS, C_INERTIA, C_SIDES, C_FORCE, C_TORQUE, C_QUAT };
+static const int k_field_k[DMX_NFIELDS] = { 3, 4, 3, 3, 1, 3, 3, 3, 3, 4 };
 
 extern "C" const char *dmxVersion(void) { return "libode_mi355 0.1 (gfx950)"; }
 
@@ -119,6 +78,10 @@ extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int dev
         if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { rc = DMX_EHIP; break; }
         if (hipMalloc(&b->slab, (size_t)C_COUNT * b->stride * b->rsize) != hipSuccess) { rc = DMX_ENOMEM; break; }
         if (hipMalloc((void **)&b->gtype, (size_t)b->stride) != hipSuccess) { rc = DMX_ENOMEM; break; }
+        if (hipMalloc((void **)&b->bflags, (size_t)b->stride) != hipSuccess) { rc = DMX_ENOMEM; break; }
+        b->h_bflags.assign((size_t)b->stride, 0);
+        for (int64_t i = 0; i < n; i++) b->h_bflags[(size_t)i] = BF_ALIVE;
+        if (hipMemcpy(b->bflags, b->h_bflags.data(), (size_t)b->stride, hipMemcpyHostToDevice) != hipSuccess) { rc = DMX_EHIP; break; }
         if (hipMalloc((void **)&b->diag, sizeof(StepDiag)) != hipSuccess) { rc = DMX_ENOMEM; break; }
         if (hipHostMalloc((void **)&b->diag_host, sizeof(StepDiag)) != hipSuccess) { rc = DMX_ENOMEM; break; }
         if (hipMemset(b->diag, 0, sizeof(StepDiag)) != hipSuccess) { rc = DMX_EHIP; break; }
@@ -140,6 +103,11 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
     if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
     if (b->slab) (void)hipFree(b->slab);
     if (b->gtype) (void)hipFree(b->gtype);
+    if (b->bflags) (void)hipFree(b->bflags);
+    for (dmxBatch::DevBuf *d : { &b->jd_int, &b->jd_real, &b->jd_rows, &b->jd_rowjb, &b->jd_bscr, &b->jd_local })
+        if (d->p) (void)hipFree(d->p);
+    if (b->jh_int) (void)hipHostFree(b->jh_int);
+    if (b->jh_real) (void)hipHostFree(b->jh_real);
     if (b->diag) (void)hipFree(b->diag);
     if (b->diag_host) (void)hipHostFree(b->diag_host);
     if (b->stage) (void)hipFree(b->stage);
@@ -170,16 +138,6 @@ extern "C" int dmxBatchSetSurface(dmxBatchID b, int mode, double mu, double boun
 }
 extern "C" int dmxBatchSetMaxContacts(dmxBatchID b, int m)
 { if (!b || m < 1) return DMX_EINVAL; b->max_contacts = m; return DMX_OK; }
-
-template <class T> static void normalize_plane(const double in[4], T out[4])
-{
-    // dCreatePlane normalises (a,b,c,d) by |(a,b,c)| in the library's precision
-    T a = (T)in[0], bb = (T)in[1], c = (T)in[2], d = (T)in[3];
-    T l = a * a + bb * bb + c * c;
-    if (l > 0) { l = T(1) / tsqrt<T>(l); a *= l; bb *= l; c *= l; d *= l; }
-    else { a = 1; bb = 0; c = 0; d = 0; }
-    out[0] = a; out[1] = bb; out[2] = c; out[3] = d;
-}
 
 extern "C" int dmxBatchSetPlane(dmxBatchID b, double a, double bb, double c, double d, int enable)
 {
@@ -264,6 +222,28 @@ extern "C" int dmxBatchUploadGeomType(dmxBatchID b, const uint8_t *types, int64_
     return DMX_OK;
 }
 
+extern "C" int dmxBatchUploadBodyFlags(dmxBatchID b, const uint8_t *flags, int64_t first, int64_t count)
+{
+    if (!b || !flags || first < 0 || count < 0 || first + count > b->n) return DMX_EINVAL;
+    if (count == 0) return DMX_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    for (int64_t i = 0; i < count; i++) b->h_bflags[(size_t)(first + i)] = flags[i];
+    HIP_TRY(hipMemcpyAsync(b->bflags + first, b->h_bflags.data() + first, (size_t)count, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return DMX_OK;
+}
+
+int dmx_ensure_dev(dmxBatch::DevBuf &d, size_t bytes)
+{
+    if (bytes <= d.bytes) return DMX_OK;
+    if (d.p) HIP_TRY(hipFree(d.p));
+    d.p = nullptr; d.bytes = 0;
+    size_t want = bytes + bytes / 2 + 256;
+    HIP_TRY(hipMalloc(&d.p, want));
+    d.bytes = want;
+    return DMX_OK;
+}
+
 extern "C" void *dmxBatchDevicePtr(dmxBatchID b, int field, int component)
 {
     if (!b || field < 0 || field >= DMX_NFIELDS || component < 0 || component >= k_field_k[field]) return nullptr;
@@ -271,28 +251,9 @@ extern "C" void *dmxBatchDevicePtr(dmxBatchID b, int field, int component)
 }
 
 // ---- stepping ----------------------------------------------------------------------------------
-template <class T> static StepParams<T> make_params(dmxBatch *b, double h)
-{
-    StepParams<T> P;
-    P.g = { (T)b->g[0], (T)b->g[1], (T)b->g[2] };
-    P.h = (T)h;
-    P.erp = (T)b->erp; P.cfm = (T)b->cfm; P.sor_w = (T)b->sor_w;
-    P.iters = b->iters;
-    P.gyro = b->gyro;
-    P.plane_on = b->plane_on;
-    T pl[4];
-    normalize_plane<T>(b->plane, pl);
-    P.pn = { pl[0], pl[1], pl[2] }; P.pd = pl[3];
-    P.surf_mode = b->surf_mode;
-    P.mu = (T)b->mu; P.bounce = (T)b->bounce; P.bounce_vel = (T)b->bounce_vel;
-    P.max_contacts = b->max_contacts;
-    P.vec = b->vec;
-    return P;
-}
-
 template <class T> static int step_t(dmxBatch *b, double h, int nsteps)
 {
-    const StepParams<T> P = make_params<T>(b, h);
+    const StepParams<T> P = dmx_make_params<T>(b, h);
     for (int s = 0; s < nsteps; s++) {
         if (b->plane_on) HIP_TRY(hipMemsetAsync(b->diag, 0, sizeof(StepDiag), b->stream));
         HIP_TRY(launch_step<T>((T *)b->slab, b->gtype, b->stride, b->n, P, b->ext_pending, b->diag, b->stream));

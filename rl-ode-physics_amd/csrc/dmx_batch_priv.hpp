@@ -1,0 +1,92 @@
+// dmx_batch_priv.hpp -- the batch object behind dmxBatchID, shared by the C-ABI translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include <vector>
+
+#include "../../include/dmx_batch.h"
+#include "dmx_internal.hpp"
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "libode_mi355: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), \
+                    __FILE__, __LINE__);                                                           \
+            return DMX_EHIP;                                                                       \
+        }                                                                                          \
+    } while (0)
+
+using namespace dmx;
+
+struct dmxBatch {
+    int64_t n = 0, stride = 0;
+    int precision = DMX_F32;
+    int device = 0;
+    size_t rsize = 4;
+    void *slab = nullptr;            // C_COUNT x stride reals
+    uint8_t *gtype = nullptr;        // stride bytes
+    StepDiag *diag = nullptr;        // device
+    StepDiag *diag_host = nullptr;   // pinned
+    void *stage = nullptr;           // device staging for AoS <-> SoA
+    size_t stage_bytes = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // world parameters (defaults: dWorldCreate [ODE], gravity unset = 0)
+    double g[3] = { 0, 0, 0 };
+    double erp = 0.2, cfm = 1e-5, sor_w = 1.3;
+    int iters = 20;
+    int gyro = DMX_GYRO_IMPLICIT;
+    int plane_on = 0;
+    double plane[4] = { 0, 1, 0, 0 };
+    int surf_mode = DMX_CONTACT_BOUNCE;                 // main.c:684
+    double mu = __builtin_huge_val(), bounce = 0.2, bounce_vel = 0.1;   // main.c:685-687
+    int max_contacts = 8;                               // main.c:675
+    bool ext_pending = false;
+    int vec = 0;                     // DMX_VEC launch-tuning override (bodies per lane), 0 = 16 B per lane
+    bool stepped_with_plane = false;
+    // general island path (explicit contact joints)
+    uint8_t *bflags = nullptr;                 // device, per-slot BF_* flags
+    std::vector<uint8_t> h_bflags;             // host mirror
+    struct DevBuf { void *p = nullptr; size_t bytes = 0; };
+    DevBuf jd_int, jd_real, jd_rows, jd_rowjb, jd_bscr, jd_local;   // device staging / scratch
+    void *jh_int = nullptr, *jh_real = nullptr;                      // pinned host staging
+    size_t jh_int_bytes = 0, jh_real_bytes = 0;
+};
+
+int dmx_ensure_dev(dmxBatch::DevBuf &d, size_t bytes);
+
+
+template <class T> inline void dmx_normalize_plane(const double in[4], T out[4])
+{
+    // dCreatePlane normalises (a,b,c,d) by |(a,b,c)| in the library's precision
+    T a = (T)in[0], bb = (T)in[1], c = (T)in[2], d = (T)in[3];
+    T l = a * a + bb * bb + c * c;
+    if (l > 0) { l = T(1) / tsqrt<T>(l); a *= l; bb *= l; c *= l; d *= l; }
+    else { a = 1; bb = 0; c = 0; d = 0; }
+    out[0] = a; out[1] = bb; out[2] = c; out[3] = d;
+}
+
+
+template <class T> inline StepParams<T> dmx_make_params(dmxBatch *b, double h)
+{
+    StepParams<T> P;
+    P.g = { (T)b->g[0], (T)b->g[1], (T)b->g[2] };
+    P.h = (T)h;
+    P.erp = (T)b->erp; P.cfm = (T)b->cfm; P.sor_w = (T)b->sor_w;
+    P.iters = b->iters;
+    P.gyro = b->gyro;
+    P.plane_on = b->plane_on;
+    T pl[4];
+    dmx_normalize_plane<T>(b->plane, pl);
+    P.pn = { pl[0], pl[1], pl[2] }; P.pd = pl[3];
+    P.surf_mode = b->surf_mode;
+    P.mu = (T)b->mu; P.bounce = (T)b->bounce; P.bounce_vel = (T)b->bounce_vel;
+    P.max_contacts = b->max_contacts;
+    P.vec = b->vec;
+    return P;
+}
+

@@ -1,0 +1,412 @@
+// dmx_collide.hpp -- narrowphase colliders (dCollide, /root/reference/src/main.c:678) for the geometry
+// classes the reference creates (main.c:717 sphere, 720/743 box) plus the ground half-space of the
+// BASELINE scenes.  __host__ __device__ templates: the device kernels call them per body / per pair,
+// and the host side of the ODE-compatible API calls the same code from inside the user's near callback.
+// Contact normals point into the first geometry ("body 1"), as the contact-joint rows expect.
+#pragma once
+
+#include "dmx_math.hpp"
+
+namespace dmx {
+
+template <class T> struct ContactPoint {
+    V3<T> pos;
+    V3<T> normal;
+    T depth;
+};
+
+template <class T> DMX_HD V3<T> colv(const M3<T> &R, int j) { return { R.m[0][j], R.m[1][j], R.m[2][j] }; }
+template <class T> DMX_HD T pick(const T v[3], int s) { return s == 0 ? v[0] : (s == 1 ? v[1] : v[2]); }
+
+// ---- box vs half-space n.x = d: <= 4 contacts, deepest corner first, then along the two sides with the
+// smallest projection on n, then the fourth corner of a resting face --------------------------------------
+template <class T>
+DMX_HD int box_plane(const V3<T> &pos, const M3<T> &R, const T side[3], const V3<T> &n, T d, int maxc,
+                     V3<T> cp[4], T cd[4])
+{
+    const T Q1 = n.x * R.m[0][0] + n.y * R.m[1][0] + n.z * R.m[2][0];
+    const T Q2 = n.x * R.m[0][1] + n.y * R.m[1][1] + n.z * R.m[2][1];
+    const T Q3 = n.x * R.m[0][2] + n.y * R.m[1][2] + n.z * R.m[2][2];
+    const T A[3] = { side[0] * Q1, side[1] * Q2, side[2] * Q3 };
+    const T B[3] = { tabs(A[0]), tabs(A[1]), tabs(A[2]) };
+    const T depth = d + T(0.5) * (B[0] + B[1] + B[2]) - (n.x * pos.x + n.y * pos.y + n.z * pos.z);
+    if (depth < 0) return 0;
+    if (maxc < 1) maxc = 1;
+    if (maxc > 4) maxc = 4;
+    V3<T> p = pos;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const T hs = T(0.5) * side[i];
+        if (A[i] > 0) { p.x -= hs * R.m[0][i]; p.y -= hs * R.m[1][i]; p.z -= hs * R.m[2][i]; }
+        else          { p.x += hs * R.m[0][i]; p.y += hs * R.m[1][i]; p.z += hs * R.m[2][i]; }
+    }
+    cp[0] = p; cd[0] = depth;
+    int ret = 1;
+    if (maxc > 1) {
+        int s1, s2;
+        if (B[0] < B[1]) {
+            if (B[2] < B[0]) { s1 = 2; s2 = 0; }
+            else             { s1 = 0; s2 = (B[1] < B[2]) ? 1 : 2; }
+        } else {
+            if (B[2] < B[1]) { s1 = 2; s2 = 1; }
+            else             { s1 = 1; s2 = (B[0] < B[2]) ? 0 : 2; }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int s = k == 0 ? s1 : s2;
+            // select column s without dynamic register indexing
+            const T Bs = pick(B, s), As = pick(A, s), ss = pick(side, s);
+            const T r0 = s == 0 ? R.m[0][0] : (s == 1 ? R.m[0][1] : R.m[0][2]);
+            const T r1 = s == 0 ? R.m[1][0] : (s == 1 ? R.m[1][1] : R.m[1][2]);
+            const T r2 = s == 0 ? R.m[2][0] : (s == 1 ? R.m[2][1] : R.m[2][2]);
+            if (ret == k + 1 && ret < maxc) {
+                if (!(depth - Bs < 0)) {
+                    const T sg = (As > 0) ? T(1) : T(-1);
+                    cp[k + 1] = { p.x + sg * ss * r0, p.y + sg * ss * r1, p.z + sg * ss * r2 };
+                    cd[k + 1] = depth - Bs;
+                    ret = k + 2;
+                }
+            }
+        }
+        if (maxc == 4 && ret == 3) {
+            const T d4 = cd[1] + cd[2] - depth;
+            if (d4 > 0) {
+                cp[3] = { cp[1].x + cp[2].x - p.x, cp[1].y + cp[2].y - p.y, cp[1].z + cp[2].z - p.z };
+                cd[3] = d4;
+                ret = 4;
+            }
+        }
+    }
+    return ret;
+}
+
+template <class T>
+DMX_HD int sphere_plane(const V3<T> &pos, T radius, const V3<T> &n, T d, V3<T> cp[4], T cd[4])
+{
+    const T k = pos.x * n.x + pos.y * n.y + pos.z * n.z;
+    const T depth = d - k + radius;
+    if (depth >= 0) {
+        cp[0] = { pos.x - n.x * radius, pos.y - n.y * radius, pos.z - n.z * radius };
+        cd[0] = depth;
+        return 1;
+    }
+    return 0;
+}
+
+// ---- sphere vs sphere ------------------------------------------------------------------------------------
+template <class T>
+DMX_HD int sphere_sphere(const V3<T> &p1, T r1, const V3<T> &p2, T r2, ContactPoint<T> *c)
+{
+    const T dx = p1.x - p2.x, dy = p1.y - p2.y, dz = p1.z - p2.z;
+    const T d = tsqrt<T>(dx * dx + dy * dy + dz * dz);
+    if (d > (r1 + r2)) return 0;
+    if (d <= 0) {
+        c->pos = p1;
+        c->normal = { T(1), T(0), T(0) };
+        c->depth = r1 + r2;
+    } else {
+        const T d1 = T(1) / d;
+        c->normal = { dx * d1, dy * d1, dz * d1 };
+        const T k = T(0.5) * (r2 - r1 - d);
+        c->pos = { p1.x + c->normal.x * k, p1.y + c->normal.y * k, p1.z + c->normal.z * k };
+        c->depth = r1 + r2 - d;
+    }
+    return 1;
+}
+
+template <class T> DMX_HD void safe_normalize3(V3<T> &a)
+{
+    const T aa0 = tabs(a.x), aa1 = tabs(a.y), aa2 = tabs(a.z);
+    T m;
+    if (aa1 > aa0) m = (aa2 > aa1) ? aa2 : aa1;
+    else if (aa2 > aa0) m = aa2;
+    else {
+        if (aa0 <= 0) { a = { T(1), T(0), T(0) }; return; }
+        m = aa0;
+    }
+    a.x /= m; a.y /= m; a.z /= m;
+    const T l = T(1) / tsqrt<T>(a.x * a.x + a.y * a.y + a.z * a.z);
+    a.x *= l; a.y *= l; a.z *= l;
+}
+
+// ---- sphere (geom 1) vs box (geom 2) -----------------------------------------------------------------------
+template <class T>
+DMX_HD int sphere_box(const V3<T> &sp, T radius, const V3<T> &bp, const M3<T> &bR, const T side[3],
+                      ContactPoint<T> *c)
+{
+    T l[3], t[3];
+    bool onborder = false;
+    const V3<T> p = { sp.x - bp.x, sp.y - bp.y, sp.z - bp.z };
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        l[i] = side[i] * T(0.5);
+        t[i] = dot(p, colv(bR, i));
+        if (t[i] < -l[i]) { t[i] = -l[i]; onborder = true; }
+        if (t[i] > l[i])  { t[i] = l[i];  onborder = true; }
+    }
+    if (!onborder) {
+        // centre inside the box: push out through the closest face
+        T min_distance = l[0] - tabs(t[0]);
+        int mini = 0;
+#pragma unroll
+        for (int i = 1; i < 3; i++) {
+            const T fd = l[i] - tabs(t[i]);
+            if (fd < min_distance) { min_distance = fd; mini = i; }
+        }
+        c->pos = sp;
+        V3<T> tmp = { T(0), T(0), T(0) };
+        const T sg = (pick(t, mini) > 0) ? T(1) : T(-1);
+        if (mini == 0) tmp.x = sg; else if (mini == 1) tmp.y = sg; else tmp.z = sg;
+        c->normal = mulv(bR, tmp);
+        c->depth = min_distance + radius;
+        return 1;
+    }
+    const V3<T> tv = { t[0], t[1], t[2] };
+    const V3<T> q = mulv(bR, tv);
+    V3<T> r = { p.x - q.x, p.y - q.y, p.z - q.z };
+    const T depth = radius - tsqrt<T>(dot(r, r));
+    if (depth < 0) return 0;
+    c->pos = { q.x + bp.x, q.y + bp.y, q.z + bp.z };
+    safe_normalize3(r);
+    c->normal = r;
+    c->depth = depth;
+    return 1;
+}
+
+// ---- box vs box: 15-axis separating-axis test, then edge-edge closest points or reference-face /
+// incident-face clipping (<= 8 contacts) --------------------------------------------------------------------
+namespace detail {
+
+template <class T>
+DMX_HD void line_closest_approach(const V3<T> &pa, const V3<T> &ua, const V3<T> &pb, const V3<T> &ub, T &alpha, T &beta)
+{
+    const V3<T> p = { pb.x - pa.x, pb.y - pa.y, pb.z - pa.z };
+    const T uaub = dot(ua, ub);
+    const T q1 = dot(ua, p);
+    const T q2 = -dot(ub, p);
+    T d = 1 - uaub * uaub;
+    if (d <= T(0.0001)) { alpha = 0; beta = 0; }
+    else {
+        d = T(1) / d;
+        alpha = (q1 + uaub * q2) * d;
+        beta = (uaub * q1 + q2) * d;
+    }
+}
+
+// clip the quad p[8] (4 xy pairs) against |x| <= h[0], |y| <= h[1]; result in ret[16], returns point count
+template <class T> DMX_HD int intersect_rect_quad(const T h[2], const T p[8], T ret[16])
+{
+    T bufA[16], bufB[16];
+    for (int i = 0; i < 8; i++) bufA[i] = p[i];
+    T *q = bufA, *r = bufB;
+    int nq = 4, nr = 0;
+    bool full = false;
+    for (int dir = 0; dir <= 1 && !full; dir++) {
+        for (int sign = -1; sign <= 1 && !full; sign += 2) {
+            nr = 0;
+            for (int i = 0; i < nq && !full; i++) {
+                const T *pq = q + 2 * i;
+                const T *nextq = (i + 1 < nq) ? pq + 2 : q;
+                const bool in0 = sign * pq[dir] < h[dir];
+                const bool in1 = sign * nextq[dir] < h[dir];
+                if (in0) {
+                    r[2 * nr] = pq[0]; r[2 * nr + 1] = pq[1];
+                    nr++;
+                    if (nr & 8) { full = true; break; }
+                }
+                if (in0 != in1) {
+                    r[2 * nr + (1 - dir)] = pq[1 - dir] + (nextq[1 - dir] - pq[1 - dir]) / (nextq[dir] - pq[dir]) *
+                                                             (sign * h[dir] - pq[dir]);
+                    r[2 * nr + dir] = sign * h[dir];
+                    nr++;
+                    if (nr & 8) { full = true; break; }
+                }
+            }
+            T *t = q; q = r; r = t;
+            nq = nr;
+        }
+    }
+    for (int i = 0; i < 2 * nr; i++) ret[i] = q[i];
+    return nr;
+}
+
+}  // namespace detail
+
+// Returns the contact count; contacts' normal = -(box1 -> box2 separating axis).  maxc >= 8 returns every
+// clipped point (the reference asks for 8, main.c:675); smaller maxc keeps the first maxc in clip order after
+// the deepest one (angular culling of surplus points is not implemented on this path).
+template <class T>
+DMX_HD int box_box(const V3<T> &p1, const M3<T> &R1, const T side1[3], const V3<T> &p2, const M3<T> &R2,
+                   const T side2[3], int maxc_in, ContactPoint<T> *out)
+{
+    const T fudge_factor = T(1.05);
+    const V3<T> p = { p2.x - p1.x, p2.y - p1.y, p2.z - p1.z };
+    const T pp[3] = { dot(colv(R1, 0), p), dot(colv(R1, 1), p), dot(colv(R1, 2), p) };
+    T A[3], B[3], Rr[3][3], Q[3][3];
+    for (int i = 0; i < 3; i++) { A[i] = side1[i] * T(0.5); B[i] = side2[i] * T(0.5); }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { Rr[i][j] = dot(colv(R1, i), colv(R2, j)); Q[i][j] = tabs(Rr[i][j]); }
+
+    T s = -Limits<T>::inf(), s2, l, e;
+    bool invert_normal = false;
+    int code = 0;
+    int normalR_box = 0, normalR_col = 0;     // code <= 6: normal is column normalR_col of R{normalR_box}
+    V3<T> normalC = { T(0), T(0), T(0) };
+
+#define DMX_TST1(expr1, expr2, box, colj, cc)                                            \
+    e = (expr1); s2 = tabs(e) - (expr2);                                                 \
+    if (s2 > 0) return 0;                                                                \
+    if (s2 > s) { s = s2; normalR_box = (box); normalR_col = (colj); invert_normal = (e < 0); code = (cc); }
+
+    DMX_TST1(pp[0], (A[0] + B[0] * Q[0][0] + B[1] * Q[0][1] + B[2] * Q[0][2]), 1, 0, 1);
+    DMX_TST1(pp[1], (A[1] + B[0] * Q[1][0] + B[1] * Q[1][1] + B[2] * Q[1][2]), 1, 1, 2);
+    DMX_TST1(pp[2], (A[2] + B[0] * Q[2][0] + B[1] * Q[2][1] + B[2] * Q[2][2]), 1, 2, 3);
+    DMX_TST1(dot(colv(R2, 0), p), (A[0] * Q[0][0] + A[1] * Q[1][0] + A[2] * Q[2][0] + B[0]), 2, 0, 4);
+    DMX_TST1(dot(colv(R2, 1), p), (A[0] * Q[0][1] + A[1] * Q[1][1] + A[2] * Q[2][1] + B[1]), 2, 1, 5);
+    DMX_TST1(dot(colv(R2, 2), p), (A[0] * Q[0][2] + A[1] * Q[1][2] + A[2] * Q[2][2] + B[2]), 2, 2, 6);
+#undef DMX_TST1
+
+#define DMX_TST2(expr1, expr2, n1, n2, n3, cc)                                           \
+    e = (expr1); s2 = tabs(e) - (expr2);                                                 \
+    if (s2 > 0) return 0;                                                                \
+    l = tsqrt<T>((n1) * (n1) + (n2) * (n2) + (n3) * (n3));                               \
+    if (l > 0) {                                                                         \
+        s2 /= l;                                                                         \
+        if (s2 * fudge_factor > s) {                                                     \
+            s = s2; normalR_box = 0;                                                     \
+            normalC = { (n1) / l, (n2) / l, (n3) / l };                                  \
+            invert_normal = (e < 0); code = (cc);                                        \
+        }                                                                                \
+    }
+    // edge axes u_i x v_j
+    DMX_TST2(pp[2] * Rr[1][0] - pp[1] * Rr[2][0], (A[1] * Q[2][0] + A[2] * Q[1][0] + B[1] * Q[0][2] + B[2] * Q[0][1]), T(0), -Rr[2][0], Rr[1][0], 7);
+    DMX_TST2(pp[2] * Rr[1][1] - pp[1] * Rr[2][1], (A[1] * Q[2][1] + A[2] * Q[1][1] + B[0] * Q[0][2] + B[2] * Q[0][0]), T(0), -Rr[2][1], Rr[1][1], 8);
+    DMX_TST2(pp[2] * Rr[1][2] - pp[1] * Rr[2][2], (A[1] * Q[2][2] + A[2] * Q[1][2] + B[0] * Q[0][1] + B[1] * Q[0][0]), T(0), -Rr[2][2], Rr[1][2], 9);
+    DMX_TST2(pp[0] * Rr[2][0] - pp[2] * Rr[0][0], (A[0] * Q[2][0] + A[2] * Q[0][0] + B[1] * Q[1][2] + B[2] * Q[1][1]), Rr[2][0], T(0), -Rr[0][0], 10);
+    DMX_TST2(pp[0] * Rr[2][1] - pp[2] * Rr[0][1], (A[0] * Q[2][1] + A[2] * Q[0][1] + B[0] * Q[1][2] + B[2] * Q[1][0]), Rr[2][1], T(0), -Rr[0][1], 11);
+    DMX_TST2(pp[0] * Rr[2][2] - pp[2] * Rr[0][2], (A[0] * Q[2][2] + A[2] * Q[0][2] + B[0] * Q[1][1] + B[1] * Q[1][0]), Rr[2][2], T(0), -Rr[0][2], 12);
+    DMX_TST2(pp[1] * Rr[0][0] - pp[0] * Rr[1][0], (A[0] * Q[1][0] + A[1] * Q[0][0] + B[1] * Q[2][2] + B[2] * Q[2][1]), -Rr[1][0], Rr[0][0], T(0), 13);
+    DMX_TST2(pp[1] * Rr[0][1] - pp[0] * Rr[1][1], (A[0] * Q[1][1] + A[1] * Q[0][1] + B[0] * Q[2][2] + B[2] * Q[2][0]), -Rr[1][1], Rr[0][1], T(0), 14);
+    DMX_TST2(pp[1] * Rr[0][2] - pp[0] * Rr[1][2], (A[0] * Q[1][2] + A[1] * Q[0][2] + B[0] * Q[2][1] + B[1] * Q[2][0]), -Rr[1][2], Rr[0][2], T(0), 15);
+#undef DMX_TST2
+
+    if (!code) return 0;
+
+    V3<T> normal;
+    if (normalR_box == 1) normal = colv(R1, normalR_col);
+    else if (normalR_box == 2) normal = colv(R2, normalR_col);
+    else normal = mulv(R1, normalC);
+    if (invert_normal) normal = { -normal.x, -normal.y, -normal.z };
+    const T depth = -s;
+    const V3<T> cn = { -normal.x, -normal.y, -normal.z };      // contact normal: into box 1
+
+    if (code > 6) {
+        V3<T> pa = p1, pb = p2;
+        for (int j = 0; j < 3; j++) {
+            const V3<T> cj = colv(R1, j);
+            const T sign = (dot(normal, cj) > 0) ? T(1) : T(-1);
+            pa.x += sign * A[j] * cj.x; pa.y += sign * A[j] * cj.y; pa.z += sign * A[j] * cj.z;
+        }
+        for (int j = 0; j < 3; j++) {
+            const V3<T> cj = colv(R2, j);
+            const T sign = (dot(normal, cj) > 0) ? T(-1) : T(1);
+            pb.x += sign * B[j] * cj.x; pb.y += sign * B[j] * cj.y; pb.z += sign * B[j] * cj.z;
+        }
+        const V3<T> ua = colv(R1, (code - 7) / 3), ub = colv(R2, (code - 7) % 3);
+        T alpha, beta;
+        detail::line_closest_approach(pa, ua, pb, ub, alpha, beta);
+        pa.x += ua.x * alpha; pa.y += ua.y * alpha; pa.z += ua.z * alpha;
+        pb.x += ub.x * beta; pb.y += ub.y * beta; pb.z += ub.z * beta;
+        out[0].pos = { T(0.5) * (pa.x + pb.x), T(0.5) * (pa.y + pb.y), T(0.5) * (pa.z + pb.z) };
+        out[0].depth = depth;
+        out[0].normal = cn;
+        return 1;
+    }
+
+    // face contact: 'a' = box owning the reference face, 'b' = incident box
+    const bool ref1 = code <= 3;
+    const M3<T> &Ra = ref1 ? R1 : R2, &Rb = ref1 ? R2 : R1;
+    const V3<T> &pa = ref1 ? p1 : p2, &pb = ref1 ? p2 : p1;
+    const T *Sa = ref1 ? A : B, *Sb = ref1 ? B : A;
+    const V3<T> normal2 = ref1 ? normal : V3<T>{ -normal.x, -normal.y, -normal.z };
+    const T nr[3] = { dot(colv(Rb, 0), normal2), dot(colv(Rb, 1), normal2), dot(colv(Rb, 2), normal2) };
+    const T anr[3] = { tabs(nr[0]), tabs(nr[1]), tabs(nr[2]) };
+    int lanr, a1, a2;
+    if (anr[1] > anr[0]) {
+        if (anr[1] > anr[2]) { a1 = 0; lanr = 1; a2 = 2; }
+        else { a1 = 0; a2 = 1; lanr = 2; }
+    } else {
+        if (anr[0] > anr[2]) { lanr = 0; a1 = 1; a2 = 2; }
+        else { a1 = 0; a2 = 1; lanr = 2; }
+    }
+    const V3<T> bl = colv(Rb, lanr);
+    V3<T> center;
+    if (nr[lanr] < 0)
+        center = { pb.x - pa.x + Sb[lanr] * bl.x, pb.y - pa.y + Sb[lanr] * bl.y, pb.z - pa.z + Sb[lanr] * bl.z };
+    else
+        center = { pb.x - pa.x - Sb[lanr] * bl.x, pb.y - pa.y - Sb[lanr] * bl.y, pb.z - pa.z - Sb[lanr] * bl.z };
+    const int codeN = ref1 ? code - 1 : code - 4;
+    const int code1 = codeN == 0 ? 1 : 0;
+    const int code2 = codeN == 2 ? 1 : 2;
+
+    const V3<T> ra1 = colv(Ra, code1), ra2 = colv(Ra, code2), rb1 = colv(Rb, a1), rb2 = colv(Rb, a2);
+    const T c1 = dot(center, ra1), c2 = dot(center, ra2);
+    T m11 = dot(ra1, rb1), m12 = dot(ra1, rb2), m21 = dot(ra2, rb1), m22 = dot(ra2, rb2);
+    T quad[8];
+    {
+        const T k1 = m11 * Sb[a1], k2 = m21 * Sb[a1], k3 = m12 * Sb[a2], k4 = m22 * Sb[a2];
+        quad[0] = c1 - k1 - k3; quad[1] = c2 - k2 - k4;
+        quad[2] = c1 - k1 + k3; quad[3] = c2 - k2 + k4;
+        quad[4] = c1 + k1 + k3; quad[5] = c2 + k2 + k4;
+        quad[6] = c1 + k1 - k3; quad[7] = c2 + k2 - k4;
+    }
+    const T rect[2] = { Sa[code1], Sa[code2] };
+    T ret[16];
+    const int n = detail::intersect_rect_quad(rect, quad, ret);
+    if (n < 1) return 0;
+
+    V3<T> point[8];
+    T dep[8];
+    const T det1 = T(1) / (m11 * m22 - m12 * m21);
+    m11 *= det1; m12 *= det1; m21 *= det1; m22 *= det1;
+    int cnum = 0;
+    for (int j = 0; j < n; j++) {
+        const T k1 = m22 * (ret[j * 2] - c1) - m12 * (ret[j * 2 + 1] - c2);
+        const T k2 = -m21 * (ret[j * 2] - c1) + m11 * (ret[j * 2 + 1] - c2);
+        point[cnum] = { center.x + k1 * rb1.x + k2 * rb2.x, center.y + k1 * rb1.y + k2 * rb2.y,
+                        center.z + k1 * rb1.z + k2 * rb2.z };
+        dep[cnum] = Sa[codeN] - dot(normal2, point[cnum]);
+        if (dep[cnum] >= 0) cnum++;
+    }
+    if (cnum < 1) return 0;
+
+    int maxc = maxc_in;
+    if (maxc > cnum) maxc = cnum;
+    if (maxc < 1) maxc = 1;
+    if (cnum <= maxc) {
+        for (int j = 0; j < cnum; j++) {
+            out[j].pos = { point[j].x + pa.x, point[j].y + pa.y, point[j].z + pa.z };
+            if (!ref1) {
+                out[j].pos.x -= normal.x * dep[j]; out[j].pos.y -= normal.y * dep[j]; out[j].pos.z -= normal.z * dep[j];
+            }
+            out[j].depth = dep[j];
+            out[j].normal = cn;
+        }
+        return cnum;
+    }
+    // fewer contacts wanted than found: deepest first, then clip order
+    int i1 = 0;
+    T maxdepth = dep[0];
+    for (int i = 1; i < cnum; i++) if (dep[i] > maxdepth) { maxdepth = dep[i]; i1 = i; }
+    int w = 0;
+    out[w].pos = { point[i1].x + pa.x, point[i1].y + pa.y, point[i1].z + pa.z };
+    out[w].depth = dep[i1]; out[w].normal = cn; w++;
+    for (int j = 0; j < cnum && w < maxc; j++) {
+        if (j == i1) continue;
+        out[w].pos = { point[j].x + pa.x, point[j].y + pa.y, point[j].z + pa.z };
+        out[w].depth = dep[j]; out[w].normal = cn; w++;
+    }
+    return w;
+}
+
+}  // namespace dmx

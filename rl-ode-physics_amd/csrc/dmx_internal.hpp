@@ -23,7 +23,27 @@ enum : int {
 };
 
 enum : int { GEOM_NONE = 0, GEOM_SPHERE = 1, GEOM_BOX = 2 };
-enum : int { SURF_BOUNCE = 0x004 };
+enum : int { SURF_BOUNCE = 0x004, SURF_SOFT_ERP = 0x008, SURF_SOFT_CFM = 0x010 };
+// per-slot body flags (uint8 array)
+enum : int { BF_ALIVE = 1, BF_KINEMATIC = 2, BF_NOGRAVITY = 4, BF_NOGYRO = 8 };
+
+// Contact joints grouped by dynamics island, as the general island step consumes them.  Islands list
+// their bodies (slot indices, ascending) and their contacts (creation order); body 1 of a contact is
+// always a dynamic slot, body 2 is a slot or -1 (static geometry), the normal points into body 1.
+template <class T> struct IslandSet {
+    int n_islands;
+    const int *body_off;   // [n_islands+1] into bodies
+    const int *bodies;
+    const int *con_off;    // [n_islands+1] into the contact arrays
+    const int *row_off;    // [n_islands+1] into rows (3 rows reserved per contact)
+    const T *cpos, *cnormal, *cdepth;             // 3, 3, 1 per contact
+    const int *cb1, *cb2, *cmode;
+    const T *cmu, *cbounce, *cbounce_vel, *csoft_erp, *csoft_cfm;
+    T *rows;               // scratch: 29 reals per row
+    int *rowjb;            // scratch: 2 ints per row
+    T *bscr;               // scratch: 28 reals per island body
+    int *local;            // scratch: per slot, index of the body inside its island
+};
 
 template <class T> struct StepParams {
     V3<T> g;            // gravity
@@ -46,6 +66,9 @@ struct StepDiag {
 template <class T>
 hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, const StepParams<T> &P, bool ext,
                        StepDiag *diag, hipStream_t st);
+template <class T>
+hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
+                          StepDiag *diag, hipStream_t st);
 template <class T>
 hipError_t launch_pack_transforms(const T *S, int64_t stride, int64_t first, int64_t count, T *out, hipStream_t st);
 template <class T>

@@ -1,0 +1,145 @@
+// dmx_joints.cpp -- dmxBatchStepJoints: one tick driven by an explicit list of contact joints (the form the
+// reference's near callback produces, /root/reference/src/main.c:683-692, followed by dWorldStep, main.c:213).
+//
+// Host work is bookkeeping only: group bodies into dynamics islands (union-find over joints that connect two
+// dynamic bodies; static geometry does not link islands), order islands / bodies / joints canonically
+// (islands by lowest slot, bodies ascending, joints in creation order), copy the arrays to the device and
+// launch solve_islands.  All arithmetic of the step runs on the GPU.
+#include <string.h>
+#include <numeric>
+
+#include "dmx_batch_priv.hpp"
+
+namespace {
+
+struct UnionFind {
+    std::vector<int> p;
+    explicit UnionFind(size_t n) : p(n) { std::iota(p.begin(), p.end(), 0); }
+    int find(int x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
+    void unite(int a, int b) { a = find(a); b = find(b); if (a != b) { if (a < b) p[b] = a; else p[a] = b; } }
+};
+
+int ensure_pinned(void **p, size_t *have, size_t bytes)
+{
+    if (bytes <= *have) return DMX_OK;
+    if (*p) HIP_TRY(hipHostFree(*p));
+    *p = nullptr; *have = 0;
+    size_t want = bytes + bytes / 2 + 256;
+    HIP_TRY(hipHostMalloc(p, want));
+    *have = want;
+    return DMX_OK;
+}
+
+template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const dmxContactJoint *joints)
+{
+    const int n = (int)b->n;
+    // previous tick's async copies read the pinned staging buffers: drain before refilling
+    HIP_TRY(hipStreamSynchronize(b->stream));
+
+    // ---- canonical joints: body1 is a live dynamic slot, normal points into it -----------------------
+    struct CJ { int b1, b2; const dmxContactJoint *j; bool rev; };
+    std::vector<CJ> cj;
+    cj.reserve((size_t)nj_in);
+    auto live = [&](int s) { return s >= 0 && s < n && (b->h_bflags[(size_t)s] & BF_ALIVE); };
+    for (int64_t k = 0; k < nj_in; k++) {
+        const dmxContactJoint &j = joints[k];
+        int b1 = live(j.body1) ? j.body1 : -1, b2 = live(j.body2) ? j.body2 : -1;
+        bool rev = false;
+        if (b1 < 0 && b2 >= 0) { b1 = b2; b2 = -1; rev = true; }   // dJointAttach(c, 0, body): swap + reverse
+        if (b1 < 0) continue;                                       // static-static: the stepper ignores it
+        if (b1 == b2) continue;
+        cj.push_back({ b1, b2, &j, rev });
+    }
+    const int nc = (int)cj.size();
+
+    // ---- islands ----------------------------------------------------------------------------------------
+    UnionFind uf((size_t)n);
+    for (const CJ &c : cj) if (c.b2 >= 0) uf.unite(c.b1, c.b2);
+    std::vector<int> island_of((size_t)n, -1);
+    int ni = 0, nlive = 0;
+    for (int s = 0; s < n; s++) {
+        if (!(b->h_bflags[(size_t)s] & BF_ALIVE)) continue;
+        nlive++;
+        const int r = uf.find(s);             // roots are the lowest slot of their component
+        if (r == s) island_of[(size_t)s] = ni++;
+    }
+    for (int s = 0; s < n; s++)
+        if ((b->h_bflags[(size_t)s] & BF_ALIVE) && island_of[(size_t)s] < 0) island_of[(size_t)s] = island_of[(size_t)uf.find(s)];
+
+    // int staging: body_off[ni+1] bodies[nlive] con_off[ni+1] row_off[ni+1] cb1[nc] cb2[nc] cmode[nc]
+    const size_t n_int = (size_t)3 * (ni + 1) + (size_t)nlive + (size_t)3 * nc;
+    // real staging: cpos[3nc] cnormal[3nc] cdepth cmu cbounce cbounce_vel csoft_erp csoft_cfm [nc each]
+    const size_t n_real = (size_t)12 * nc;
+    int rc;
+    if ((rc = ensure_pinned(&b->jh_int, &b->jh_int_bytes, n_int * sizeof(int) + 64)) != DMX_OK) return rc;
+    if ((rc = ensure_pinned(&b->jh_real, &b->jh_real_bytes, n_real * sizeof(T) + 64)) != DMX_OK) return rc;
+    int *hi = (int *)b->jh_int;
+    T *hr = (T *)b->jh_real;
+    int *body_off = hi, *bodies = body_off + (ni + 1), *con_off = bodies + nlive, *row_off = con_off + (ni + 1);
+    int *cb1 = row_off + (ni + 1), *cb2 = cb1 + nc, *cmode = cb2 + nc;
+    T *cpos = hr, *cnormal = cpos + 3 * (size_t)nc, *cdepth = cnormal + 3 * (size_t)nc, *cmu = cdepth + nc,
+      *cbounce = cmu + nc, *cbv = cbounce + nc, *cserp = cbv + nc, *cscfm = cserp + nc;
+
+    // counting sort of bodies and joints by island (stable: ascending slots / creation order)
+    memset(body_off, 0, (size_t)(ni + 1) * sizeof(int));
+    memset(con_off, 0, (size_t)(ni + 1) * sizeof(int));
+    for (int s = 0; s < n; s++) if (island_of[(size_t)s] >= 0) body_off[island_of[(size_t)s] + 1]++;
+    for (const CJ &c : cj) con_off[island_of[(size_t)c.b1] + 1]++;
+    for (int i = 0; i < ni; i++) { body_off[i + 1] += body_off[i]; con_off[i + 1] += con_off[i]; }
+    for (int i = 0; i <= ni; i++) row_off[i] = 3 * con_off[i];
+    {
+        std::vector<int> fill(body_off, body_off + ni);
+        for (int s = 0; s < n; s++) if (island_of[(size_t)s] >= 0) bodies[fill[(size_t)island_of[(size_t)s]]++] = s;
+        std::vector<int> cfill(con_off, con_off + ni);
+        for (const CJ &c : cj) {
+            const int d = cfill[(size_t)island_of[(size_t)c.b1]]++;
+            const dmxContactJoint &j = *c.j;
+            cb1[d] = c.b1; cb2[d] = c.b2; cmode[d] = j.mode;
+            for (int k = 0; k < 3; k++) {
+                cpos[3 * (size_t)d + k] = (T)j.pos[k];
+                const T nk = (T)j.normal[k];
+                cnormal[3 * (size_t)d + k] = c.rev ? -nk : nk;
+            }
+            cdepth[d] = (T)j.depth; cmu[d] = (T)j.mu; cbounce[d] = (T)j.bounce; cbv[d] = (T)j.bounce_vel;
+            cserp[d] = (T)j.soft_erp; cscfm[d] = (T)j.soft_cfm;
+        }
+    }
+
+    // ---- device buffers -----------------------------------------------------------------------------------
+    const size_t nrows = (size_t)3 * nc;
+    if ((rc = dmx_ensure_dev(b->jd_int, n_int * sizeof(int) + 64)) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->jd_real, n_real * sizeof(T) + 64)) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->jd_rows, (nrows + 1) * 29 * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->jd_rowjb, (nrows + 1) * 2 * sizeof(int))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->jd_bscr, ((size_t)nlive + 1) * 28 * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->jd_local, (size_t)b->stride * sizeof(int))) != DMX_OK) return rc;
+    if (n_int) HIP_TRY(hipMemcpyAsync(b->jd_int.p, hi, n_int * sizeof(int), hipMemcpyHostToDevice, b->stream));
+    if (n_real) HIP_TRY(hipMemcpyAsync(b->jd_real.p, hr, n_real * sizeof(T), hipMemcpyHostToDevice, b->stream));
+
+    IslandSet<T> I;
+    int *di = (int *)b->jd_int.p;
+    T *dr = (T *)b->jd_real.p;
+    I.n_islands = ni;
+    I.body_off = di; I.bodies = di + (ni + 1); I.con_off = I.bodies + nlive; I.row_off = I.con_off + (ni + 1);
+    I.cb1 = I.row_off + (ni + 1); I.cb2 = I.cb1 + nc; I.cmode = I.cb2 + nc;
+    I.cpos = dr; I.cnormal = dr + 3 * (size_t)nc; I.cdepth = I.cnormal + 3 * (size_t)nc; I.cmu = I.cdepth + nc;
+    I.cbounce = I.cmu + nc; I.cbounce_vel = I.cbounce + nc; I.csoft_erp = I.cbounce_vel + nc; I.csoft_cfm = I.csoft_erp + nc;
+    I.rows = (T *)b->jd_rows.p; I.rowjb = (int *)b->jd_rowjb.p; I.bscr = (T *)b->jd_bscr.p; I.local = (int *)b->jd_local.p;
+
+    StepParams<T> P = dmx_make_params<T>(b, h);
+    HIP_TRY(hipMemsetAsync(b->diag, 0, sizeof(StepDiag), b->stream));
+    HIP_TRY(launch_islands<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag, b->stream));
+    b->ext_pending = false;
+    b->stepped_with_plane = true;     // diagnostics are valid
+    return DMX_OK;
+}
+
+}  // namespace
+
+extern "C" int dmxBatchStepJoints(dmxBatchID b, double h, int64_t n_joints, const dmxContactJoint *joints)
+{
+    if (!b || !(h > 0) || n_joints < 0 || (n_joints > 0 && !joints)) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    return b->precision == DMX_F32 ? step_joints_t<float>(b, h, n_joints, joints)
+                                   : step_joints_t<double>(b, h, n_joints, joints);
+}

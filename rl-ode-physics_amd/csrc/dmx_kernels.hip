@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include "dmx_internal.hpp"
 #include "dmx_math.hpp"
+#include "dmx_collide.hpp"
 
 namespace dmx {
 
@@ -108,86 +109,6 @@ __global__ __launch_bounds__(256) void integrate_free(T *__restrict__ S, int64_t
             for (int k = 0; k < 6; k++) stv<T, V>(S, stride, C_FORCE + k, i, z);
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Narrowphase against the ground half-space n.x = d: box (<= 4 contacts, deepest corner first,
-// then along the two sides with the smallest projection, then the fourth corner of a resting face)
-// and sphere (1 contact).  Contact normal is the plane normal.
-// ---------------------------------------------------------------------------------------------
-template <class T>
-__device__ __forceinline__ int box_plane(const V3<T> &pos, const M3<T> &R, const T side[3], const V3<T> &n, T d,
-                                         int maxc, V3<T> cp[4], T cd[4])
-{
-    const T Q1 = n.x * R.m[0][0] + n.y * R.m[1][0] + n.z * R.m[2][0];
-    const T Q2 = n.x * R.m[0][1] + n.y * R.m[1][1] + n.z * R.m[2][1];
-    const T Q3 = n.x * R.m[0][2] + n.y * R.m[1][2] + n.z * R.m[2][2];
-    const T A[3] = { side[0] * Q1, side[1] * Q2, side[2] * Q3 };
-    const T B[3] = { tabs(A[0]), tabs(A[1]), tabs(A[2]) };
-    const T depth = d + T(0.5) * (B[0] + B[1] + B[2]) - (n.x * pos.x + n.y * pos.y + n.z * pos.z);
-    if (depth < 0) return 0;
-    if (maxc < 1) maxc = 1;
-    if (maxc > 4) maxc = 4;
-    V3<T> p = pos;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const T hs = T(0.5) * side[i];
-        if (A[i] > 0) { p.x -= hs * R.m[0][i]; p.y -= hs * R.m[1][i]; p.z -= hs * R.m[2][i]; }
-        else          { p.x += hs * R.m[0][i]; p.y += hs * R.m[1][i]; p.z += hs * R.m[2][i]; }
-    }
-    cp[0] = p; cd[0] = depth;
-    int ret = 1;
-    if (maxc > 1) {
-        int s1, s2;
-        if (B[0] < B[1]) {
-            if (B[2] < B[0]) { s1 = 2; s2 = 0; }
-            else             { s1 = 0; s2 = (B[1] < B[2]) ? 1 : 2; }
-        } else {
-            if (B[2] < B[1]) { s1 = 2; s2 = 1; }
-            else             { s1 = 1; s2 = (B[0] < B[2]) ? 0 : 2; }
-        }
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int s = k == 0 ? s1 : s2;
-            // select column s without dynamic register indexing
-            const T Bs = s == 0 ? B[0] : (s == 1 ? B[1] : B[2]);
-            const T As = s == 0 ? A[0] : (s == 1 ? A[1] : A[2]);
-            const T ss = s == 0 ? side[0] : (s == 1 ? side[1] : side[2]);
-            const T r0 = s == 0 ? R.m[0][0] : (s == 1 ? R.m[0][1] : R.m[0][2]);
-            const T r1 = s == 0 ? R.m[1][0] : (s == 1 ? R.m[1][1] : R.m[1][2]);
-            const T r2 = s == 0 ? R.m[2][0] : (s == 1 ? R.m[2][1] : R.m[2][2]);
-            if (ret == k + 1 && ret < maxc) {
-                if (!(depth - Bs < 0)) {
-                    const T sg = (As > 0) ? T(1) : T(-1);
-                    cp[k + 1] = { p.x + sg * ss * r0, p.y + sg * ss * r1, p.z + sg * ss * r2 };
-                    cd[k + 1] = depth - Bs;
-                    ret = k + 2;
-                }
-            }
-        }
-        if (maxc == 4 && ret == 3) {
-            const T d4 = cd[1] + cd[2] - depth;
-            if (d4 > 0) {
-                cp[3] = { cp[1].x + cp[2].x - p.x, cp[1].y + cp[2].y - p.y, cp[1].z + cp[2].z - p.z };
-                cd[3] = d4;
-                ret = 4;
-            }
-        }
-    }
-    return ret;
-}
-
-template <class T>
-__device__ __forceinline__ int sphere_plane(const V3<T> &pos, T radius, const V3<T> &n, T d, V3<T> cp[4], T cd[4])
-{
-    const T k = pos.x * n.x + pos.y * n.y + pos.z * n.z;
-    const T depth = d - k + radius;
-    if (depth >= 0) {
-        cp[0] = { pos.x - n.x * radius, pos.y - n.y * radius, pos.z - n.z * radius };
-        cd[0] = depth;
-        return 1;
-    }
-    return 0;
 }
 
 template <class T> __device__ __forceinline__ T wave_sum(T x)

@@ -99,3 +99,48 @@ def config3(n_side=512):
 def config4(n_side=1024, slabs=8):
     """configs[1]'s scene split into `slabs` disjoint slabs >= 10 m apart (BASELINE configs[3])."""
     return box_grid(n_side, n_side, seed=1, spin=True, plane=False, slabs=slabs, slab_gap=10.0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The reference's own scene: static map boxes (StartServer, main.c:115-121) and the key-M spawner
+# (main.c:502-521).  Used by the ODE-API tests, which drive these numbers through the C harness.
+# ---------------------------------------------------------------------------------------------------------
+def _rot_z(angle):
+    """3x4 row-major rotation about z, as GetTransformMatV (main.c:624-651) yields for rot = (0,0,angle)."""
+    import math
+    c, s = math.cos(angle), math.sin(angle)
+    return [c, -s, 0.0, 0.0, s, c, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0]
+
+
+def reference_map():
+    """(size, pos, R[12]) of the floor and the three walls the reference creates (main.c:115-121)."""
+    ident = _rot_z(0.0)
+    return [
+        ((100.0, 1.0, 100.0), (0.0, 0.0, 0.0), ident),
+        ((0.5, 8.0, 12.0), (4.0, 3.0, 0.0), _rot_z(-0.5)),
+        ((12.0, 8.0, 0.5), (0.0, 3.0, 6.0), ident),
+        ((12.0, 8.0, 0.5), (0.0, 3.0, -6.0), ident),
+    ]
+
+
+def reference_spawn(n, seed=1, y_range=(20.0, 50.0)):
+    """n bodies as the key-M spawner draws them (main.c:504-519): position x,z in [-4,4], y in y_range,
+    then Rand_Int(0,2) == 0 -> box with three sides in [0.2,1.0], else sphere with radius in [0.1,0.4];
+    each body also consumes the three Rand_Int draws of its Rand_Color.  Returns a list of
+    (type, (sx,sy,sz), (x,y,z)) with type 2 = box, 1 = sphere (BodyType, inc/body.h:14-18)."""
+    r = Rand(seed)
+    out = []
+    for _ in range(n):
+        x = r.double(-4.0, 4.0)
+        y = r.double(*y_range)
+        z = r.double(-4.0, 4.0)
+        if r.int(0, 2) == 0:
+            size = (r.double(0.2, 1.0), r.double(0.2, 1.0), r.double(0.2, 1.0))
+            kind = GEOM_BOX
+        else:
+            size = (r.double(0.1, 0.4), 0.0, 0.0)
+            kind = GEOM_SPHERE
+        for _c in range(3):
+            r.int(30, 190)          # Rand_Color(30, 190)
+        out.append((kind, size, (x, y, z)))
+    return out

@@ -1,0 +1,129 @@
+/*
+ * ode_tick_harness.c -- a headless stand-in for the physics half of the reference's StartServer()
+ * (/root/reference/src/main.c:59-270), written against include/ode/ode.h only.  It makes the same
+ * ODE calls in the same order as the reference does -- world setup (main.c:94-98), static map boxes
+ * (AddBodyMap, main.c:735-761, including its double dGeomSetCategoryBits), dynamic bodies (AddBody,
+ * main.c:695-733), the tick loop (main.c:211-215) with the reference's contact policy (NearCallback,
+ * main.c:674-693) and the pose read-back (main.c:221-237 + GetTransformMat, main.c:602-622) -- with
+ * raylib / ENet / the window loop left out.  The scene comes from stdin so tests can feed the CPU
+ * oracle the same numbers.
+ *
+ * stdin:  dt steps use_plane
+ *         n_static  then per static box : sx sy sz  px py pz  R[12]
+ *         n_body    then per body       : type(1 sphere, 2 box) sx sy sz  px py pz  R[12]
+ * stdout: per body 16 numbers (column-major 4x4 transform), %.17g
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <ode/ode.h>
+
+#define MAX_CONTACTS 8              /* main.c:675 */
+enum { CMASK_MAP = 1, CMASK_OBJ = 2, CMASK_ALL = ~0 };   /* inc/body.h:8-12 */
+
+static dWorldID world;
+static dSpaceID space;
+static dJointGroupID contactGroup;
+
+static void near_callback(void *data, dGeomID o1, dGeomID o2)
+{
+    dContact contacts[MAX_CONTACTS];
+    int i, nc;
+    (void)data;
+    nc = dCollide(o1, o2, MAX_CONTACTS, &contacts[0].geom, sizeof(dContact));
+    if (nc <= 0) return;
+    for (i = 0; i < nc; i++) {
+        dJointID c;
+        contacts[i].surface.mode = dContactBounce;
+        contacts[i].surface.bounce = 0.2;
+        contacts[i].surface.bounce_vel = 0.1;
+        contacts[i].surface.mu = dInfinity;
+        c = dJointCreateContact(world, contactGroup, &contacts[i]);
+        dJointAttach(c, dGeomGetBody(o1), dGeomGetBody(o2));
+    }
+}
+
+static void pack_transform(dReal res[16], const dReal *pos, const dReal *rot)
+{
+    res[0] = rot[0]; res[1] = rot[4]; res[2] = rot[8];  res[3] = 0;
+    res[4] = rot[1]; res[5] = rot[5]; res[6] = rot[9];  res[7] = 0;
+    res[8] = rot[2]; res[9] = rot[6]; res[10] = rot[10]; res[11] = 0;
+    res[12] = pos[0]; res[13] = pos[1]; res[14] = pos[2]; res[15] = 1;
+}
+
+static double rd(void)
+{
+    double v;
+    if (scanf("%lf", &v) != 1) { fprintf(stderr, "harness: bad scene input\n"); exit(2); }
+    return v;
+}
+
+int main(void)
+{
+    int steps, use_plane, n_static, n_body, i, k, s;
+    double dt;
+    dBodyID *bodies;
+    dGeomID *geoms;
+
+    dt = rd(); steps = (int)rd(); use_plane = (int)rd();
+
+    dInitODE();
+    world = dWorldCreate();
+    dWorldSetGravity(world, 0.0, -9.8, 0.0);
+    space = dHashSpaceCreate(0);
+    contactGroup = dJointGroupCreate(0);
+    if (use_plane) dCreatePlane(space, 0, 1, 0, 0);
+
+    n_static = (int)rd();
+    for (i = 0; i < n_static; i++) {
+        dReal sx = (dReal)rd(), sy = (dReal)rd(), sz = (dReal)rd();
+        dReal px = (dReal)rd(), py = (dReal)rd(), pz = (dReal)rd();
+        dMatrix3 rm;
+        dGeomID g;
+        for (k = 0; k < 12; k++) rm[k] = (dReal)rd();
+        g = dCreateBox(space, sx, sy, sz);
+        dGeomSetPosition(g, px, py, pz);
+        dGeomSetRotation(g, rm);
+        dGeomSetCategoryBits(g, CMASK_MAP);
+        dGeomSetCategoryBits(g, CMASK_ALL & ~CMASK_MAP);      /* sic: main.c:751-752 */
+    }
+
+    n_body = (int)rd();
+    bodies = (dBodyID *)calloc((size_t)n_body + 1, sizeof(dBodyID));
+    geoms = (dGeomID *)calloc((size_t)n_body + 1, sizeof(dGeomID));
+    for (i = 0; i < n_body; i++) {
+        int type = (int)rd();
+        dReal sx = (dReal)rd(), sy = (dReal)rd(), sz = (dReal)rd();
+        dReal px = (dReal)rd(), py = (dReal)rd(), pz = (dReal)rd();
+        dMatrix3 rm;
+        for (k = 0; k < 12; k++) rm[k] = (dReal)rd();
+        bodies[i] = dBodyCreate(world);
+        dBodySetPosition(bodies[i], px, py, pz);
+        dBodySetRotation(bodies[i], rm);
+        geoms[i] = (type == 1) ? dCreateSphere(space, sx) : dCreateBox(space, sx, sy, sz);
+        dGeomSetCategoryBits(geoms[i], CMASK_OBJ);
+        dGeomSetCollideBits(geoms[i], CMASK_OBJ | CMASK_MAP);
+        dGeomSetBody(geoms[i], bodies[i]);
+    }
+
+    for (s = 0; s < steps; s++) {
+        dSpaceCollide(space, NULL, near_callback);
+        dWorldStep(world, (dReal)dt);
+        dJointGroupEmpty(contactGroup);
+    }
+
+    for (i = 0; i < n_body; i++) {
+        dReal t[16];
+        pack_transform(t, dBodyGetPosition(bodies[i]), dBodyGetRotation(bodies[i]));
+        for (k = 0; k < 16; k++) printf("%.17g%c", (double)t[k], k == 15 ? '\n' : ' ');
+    }
+
+    for (i = 0; i < n_body; i++) {
+        dBodyDestroy(bodies[i]);
+        dGeomDestroy(geoms[i]);
+    }
+    dJointGroupDestroy(contactGroup);
+    dWorldDestroy(world);
+    dCloseODE();
+    free(bodies); free(geoms);
+    return 0;
+}

@@ -1,0 +1,165 @@
+"""The ODE C API boundary (include/ode/ode.h): a C program that makes the reference's own sequence of
+ODE calls (tests/harness/ode_tick_harness.c) compiles against the shim headers, links against
+libode_mi355*.so, and -- on the GPU box -- reproduces the CPU oracle's poses on the reference's scene."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package, ROOT
+
+pkg = load_package()
+PKG = os.path.join(ROOT, "rl-ode-physics_amd")
+HARNESS = os.path.join(ROOT, "tests", "harness", "ode_tick_harness.c")
+
+
+def _build_harness(tmp, single):
+    exe = os.path.join(tmp, "harness_s" if single else "harness_d")
+    cmd = ["gcc", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), HARNESS, "-o", exe,
+           "-L" + PKG, "-lode_mi355_single" if single else "-lode_mi355", "-Wl,-rpath," + PKG, "-lm"]
+    if single:
+        cmd.insert(1, "-DdSINGLE")
+    subprocess.run(cmd, check=True)
+    return exe
+
+
+def _scene_text(dt, steps, use_plane, statics, bodies):
+    ident = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0]
+    lines = [f"{dt!r} {steps} {int(use_plane)}", str(len(statics))]
+    for size, pos, R in statics:
+        lines.append(" ".join(repr(float(v)) for v in (*size, *pos, *R)))
+    lines.append(str(len(bodies)))
+    for kind, size, pos in bodies:
+        lines.append(f"{kind} " + " ".join(repr(float(v)) for v in (*size, *pos, *ident)))
+    return "\n".join(lines) + "\n"
+
+
+def _oracle_poses(dtype, dt, steps, use_plane, statics, bodies):
+    from oracle.orc_ctypes import Oracle
+    import ctypes as C
+    orc = Oracle(dtype)
+    lib = orc.lib
+    ow = orc.world()
+    if use_plane:
+        ow.add_plane(0, 1, 0, 0)
+    for size, pos, R in statics:
+        g = lib.orc_geom_create_box(ow.w, *size)
+        lib.orc_geom_set_position(ow.w, g, *pos)
+        _, rp = orc.arr(R)
+        lib.orc_geom_set_rotation(ow.w, g, rp)
+        lib.orc_geom_set_category_bits(ow.w, g, 0xFFFFFFFE)      # the double SetCategoryBits of main.c:751-752
+    ident = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0]
+    for kind, size, pos in bodies:
+        b = lib.orc_body_create(ow.w)
+        lib.orc_body_set_position(ow.w, b, *pos)
+        _, rp = orc.arr(ident)
+        lib.orc_body_set_rotation(ow.w, b, rp)
+        g = lib.orc_geom_create_sphere(ow.w, size[0]) if kind == 1 else lib.orc_geom_create_box(ow.w, *size)
+        lib.orc_geom_set_category_bits(ow.w, g, 2)
+        lib.orc_geom_set_collide_bits(ow.w, g, 3)
+        lib.orc_geom_set_body(ow.w, g, b)
+    ow.run(dt, steps)
+    out = np.zeros((len(bodies), 16), orc.dtype)
+    RP = C.POINTER(orc.real)
+    for i in range(len(bodies)):
+        lib.orc_pack_transform(out[i].ctypes.data_as(RP), lib.orc_body_get_position(ow.w, i),
+                               lib.orc_body_get_rotation(ow.w, i))
+    return out, ow
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dmx[A-Z]\w*|d[A-Z]\w*)\s*\(", src)) - {"dNearCallback"})
+
+
+# the 33 symbols /root/reference/src/main.c references
+REFERENCE_SYMBOLS = """dInitODE dCloseODE dWorldCreate dWorldDestroy dWorldSetGravity dHashSpaceCreate dJointGroupCreate
+dJointGroupEmpty dJointGroupDestroy dBodyCreate dBodyDestroy dBodySetPosition dBodySetRotation dBodySetKinematic
+dBodyGetPosition dBodyGetRotation dBodyAddForce dCreateBox dCreateSphere dGeomDestroy dGeomSetBody dGeomGetBody
+dGeomSetPosition dGeomSetRotation dGeomGetPosition dGeomGetRotation dGeomSetCategoryBits dGeomSetCollideBits
+dSpaceCollide dCollide dJointCreateContact dJointAttach dWorldStep""".split()
+
+
+@pytest.mark.parametrize("libname", ["libode_mi355.so", "libode_mi355_single.so"])
+def test_ode_symbols_exported(libname):
+    import ctypes as C
+    pkg._lib.load()
+    lib = C.CDLL(os.path.join(PKG, libname))
+    names = _declared("ode/ode.h")
+    assert len(REFERENCE_SYMBOLS) == 33 and set(REFERENCE_SYMBOLS) <= set(names)
+    for n in names + ["dWorldQuickStep", "dCreatePlane", "dBodySetMass", "dMassSetBox"]:
+        assert hasattr(lib, n), f"{n} declared in include/ode/ode.h but not exported by {libname}"
+    for n in _declared("dmx_batch.h"):
+        assert hasattr(lib, n)
+
+
+@pytest.mark.parametrize("single", [False, True])
+def test_reference_call_sequence_compiles_and_links(tmp_path, single):
+    exe = _build_harness(str(tmp_path), single)
+    out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert ("libode_mi355_single.so" if single else "libode_mi355.so") in out
+
+
+def test_reference_spawner_draws():
+    b = pkg.scenes.reference_spawn(200, seed=1)
+    kinds = [k for k, _, _ in b]
+    assert 60 < kinds.count(2) < 140                      # Rand_Int(0,2) == 0 -> box, about half
+    for kind, size, pos in b:
+        assert -4 <= pos[0] <= 4 and 20 <= pos[1] <= 50 and -4 <= pos[2] <= 4      # main.c:504
+        if kind == 2:
+            assert all(0.2 <= s <= 1.0 for s in size)     # main.c:508
+        else:
+            assert 0.1 <= size[0] <= 0.4                  # main.c:516
+    m = pkg.scenes.reference_map()
+    assert m[0][0] == (100.0, 1.0, 100.0) and len(m) == 4
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _run_harness(exe, text):
+    p = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return np.array([[float(v) for v in line.split()] for line in p.stdout.strip().splitlines()])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("single", [False, True])
+def test_reference_scene_through_ode_api_matches_oracle(tmp_path, single):
+    """The reference's map (floor + 3 walls, static boxes) and 48 spawned boxes/spheres dropped from
+    y in [1.5, 9]: box-box, sphere-box, sphere-sphere contacts and multi-body islands, dWorldStep at
+    1/120 s (main.c:208, 213), 360 ticks."""
+    dtype = "float32" if single else "float64"
+    statics = pkg.scenes.reference_map()
+    bodies = pkg.scenes.reference_spawn(48, seed=7, y_range=(1.5, 9.0))
+    dt, steps = 1.0 / 120.0, 360
+    exe = _build_harness(str(tmp_path), single)
+    got = _run_harness(exe, _scene_text(dt, steps, False, statics, bodies))
+    ref, ow = _oracle_poses(dtype, dt, steps, False, statics, bodies)
+    assert ow.n_contacts() > 48 and ow.n_body_pairs() > 0       # resting on the floor and on each other
+    assert got.shape == ref.shape
+    assert np.all(np.isfinite(got))
+    assert np.array_equal(got.astype(ref.dtype), ref), np.abs(got - ref).max()
+
+
+@pytest.mark.gpu
+def test_plane_scene_through_ode_api_matches_oracle(tmp_path):
+    bodies = pkg.scenes.reference_spawn(64, seed=3, y_range=(0.8, 6.0))
+    dt, steps = 1.0 / 60.0, 300
+    exe = _build_harness(str(tmp_path), False)
+    got = _run_harness(exe, _scene_text(dt, steps, True, [], bodies))
+    ref, ow = _oracle_poses("float64", dt, steps, True, [], bodies)
+    assert np.array_equal(got, ref), np.abs(got - ref).max()
+
+
+@pytest.mark.gpu
+def test_growth_beyond_512_bodies(tmp_path):
+    """More bodies than MAX_BODIES (inc/body.h:6): the world's device batch doubles transparently."""
+    bodies = pkg.scenes.reference_spawn(700, seed=5, y_range=(2.0, 400.0))
+    dt, steps = 1.0 / 60.0, 20
+    exe = _build_harness(str(tmp_path), False)
+    got = _run_harness(exe, _scene_text(dt, steps, True, [], bodies))
+    ref, _ = _oracle_poses("float64", dt, steps, True, [], bodies)
+    assert np.array_equal(got, ref)
