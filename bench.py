@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--side", type=int, default=0, help="grid side (bodies = side^2 per GPU); 0 = config default")
     ap.add_argument("--exchange", default="boundary", choices=["boundary", "none"])
+    ap.add_argument("--graph-steps", type=int, default=10, help="ticks per captured HIP graph when exchanging (0 = eager)")
+    ap.add_argument("--force-exchange", action="store_true", help="run the exchange path even with one rank (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gyro", type=int, default=2, choices=[0, 1, 2], help="0 off, 1 explicit, 2 implicit (ODE default)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -76,9 +78,11 @@ def main():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.force_exchange
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     dtype = "float32" if a.dtype == "f32" else "float64"
     rsize = np.dtype(dtype).itemsize
@@ -94,32 +98,38 @@ def main():
         workload = f"configs[2]: {side * side} boxes on the ground plane per GPU, 20 SOR iterations, dt=1/60"
         scene = pkg.scenes.box_grid(side, side, seed=1 + rank, y_range=(1.0, 3.0), spin=False, plane=True).astype(dtype)
 
-    w = pkg.BatchWorld(scene.n, dtype=dtype, device=local_rank)
+    layout = pkg.shard.SlabLayout(side, side)
+    exchanging = use_dist and a.exchange == "boundary"
+    w = pkg.BatchWorld(layout.n_total if exchanging else scene.n, dtype=dtype, device=local_rank)
     w.load_scene(scene)
+    if exchanging:
+        w.set_active_count(scene.n)         # the slots behind are ghosts of the neighbours' boundary rows
     w.set_gyro_mode(a.gyro)
     stream = torch.cuda.Stream()            # a real (non-null) stream: the batch launches on it and the
     torch.cuda.set_stream(stream)           # timing events below are recorded on it, so they bracket the kernels
     assert stream.cuda_stream != 0
     w.set_stream(stream.cuda_stream)
 
-    exchange = None
-    if world > 1 and a.exchange == "boundary":
-        exchange = pkg.shard.BoundaryExchange(w, scene, side, rank, world)
+    stepper = pkg.shard.ShardedStepper(w, layout, rank, world,
+                                       exchange=a.exchange if exchanging else "none", device=torch.device("cuda", local_rank))
+    if a.force_exchange and world == 1 and exchanging:
+        # one-rank group: the collective degenerates to a copy, every other step of the path is exercised
+        stepper.exchange = pkg.shard.BoundaryExchange(pkg.shard.DeviceOps(w, torch.device("cuda", local_rank)), layout, 0, 1)
 
     def run(nsteps):
-        if exchange is None:
-            w.step(H, nsteps)
-        else:
-            for _ in range(nsteps):
-                w.step(H, 1)
-                exchange.step()
+        stepper.run(H, nsteps)
 
     if a.config == 3:
         run(120)                            # let the boxes land: timed steps are all in contact
     run(a.warmup)
+    graphed = False
+    if stepper.exchange is not None and a.graph_steps > 0:
+        torch.cuda.synchronize()
+        graphed = stepper.capture(H, a.graph_steps, stream)
+        run(a.graph_steps)                  # one replay outside the timed region
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -149,7 +159,10 @@ def main():
         "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": workload, "bodies_per_gpu": scene.n, "bodies_total": total_bodies, "dt": "1/60",
-                   "parallelism": f"islands sharded over {world} GPU(s), exchange={a.exchange if world > 1 else 'n/a'}",
+                   "parallelism": f"islands sharded over {world} GPU(s), one slab per rank; "
+                                  + (f"boundary rows all-gathered over RCCL every tick, overlapped with the interior"
+                                     f"{', HIP-graph replay' if graphed else ''}" if stepper.exchange is not None
+                                     else "no exchange (one rank)" if world == 1 else "no exchange"),
                    "integrator": "QuickStep semantics: gravity + implicit gyroscopic torque + semi-implicit Euler + "
                                  "quaternion renormalise" + ("; box-plane contacts, 20 SOR sweeps" if kind == "plane" else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -163,7 +176,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     w.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -93,8 +93,15 @@ int64_t dmxBatchStride(dmxBatchID b);
  * Asynchronous on the batch's stream.  QuickStep semantics. */
 int dmxBatchStep(dmxBatchID b, double h, int nsteps);
 int dmxBatchSynchronize(dmxBatchID b);
+/* Island sharding across GPUs: slots [0, n_active) are this rank's own bodies and are stepped;
+ * slots [n_active, n) hold read-only ghost copies of neighbouring ranks' boundary bodies.  n_active must be
+ * a multiple of 4 (or n).  dmxBatchStepRange steps one tick over [first, first+count) only, so boundary
+ * rows can be stepped (and sent) before the interior; first/count must be multiples of 16 B / sizeof(real). */
+int dmxBatchSetActiveCount(dmxBatchID b, int64_t n_active);
+int dmxBatchStepRange(dmxBatchID b, double h, int64_t first, int64_t count, int reset_diag);
 /* run on a caller-owned hipStream_t (e.g. the framework's current stream); NULL restores the batch's own */
 int dmxBatchSetStream(dmxBatchID b, void *hip_stream);
+int dmxBatchGetStream(dmxBatchID b, void **hip_stream);
 /* step nsteps times bracketed by HIP events on the batch's stream; *ms = elapsed device milliseconds */
 int dmxBatchStepTimed(dmxBatchID b, double h, int nsteps, float *ms);
 

@@ -18,7 +18,8 @@ BATCH_SYMBOLS = [
     "dmxBatchDevicePtr", "dmxBatchStride", "dmxBatchStep", "dmxBatchSynchronize", "dmxBatchSetStream",
     "dmxBatchStepTimed", "dmxBatchLastContactCount", "dmxBatchLastResidual", "dmxBatchPackTransforms",
     "dmxBatchDownloadTransforms", "dmxBatchGatherBodies", "dmxBatchScatterBodies",
-    "dmxBatchStepJoints", "dmxBatchUploadBodyFlags",
+    "dmxBatchStepJoints", "dmxBatchUploadBodyFlags", "dmxBatchSetActiveCount", "dmxBatchStepRange",
+    "dmxBatchGetStream",
 ]
 
 _lib = None
@@ -78,5 +79,8 @@ def load():
     sig("dmxBatchScatterBodies", I, P, P, L, P)
     sig("dmxBatchStepJoints", I, P, D, L, P)
     sig("dmxBatchUploadBodyFlags", I, P, P, L, L)
+    sig("dmxBatchSetActiveCount", I, P, L)
+    sig("dmxBatchStepRange", I, P, D, L, L, I)
+    sig("dmxBatchGetStream", I, P, C.POINTER(P))
     _lib = lib
     return lib

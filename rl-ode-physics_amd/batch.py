@@ -123,6 +123,18 @@ class BatchWorld:
     def step(self, h, nsteps=1):
         _check(self.lib.dmxBatchStep(self.h, h, nsteps), "dmxBatchStep")
 
+    def set_active_count(self, n_active):
+        _check(self.lib.dmxBatchSetActiveCount(self.h, n_active), "dmxBatchSetActiveCount")
+
+    def step_range(self, h, first, count, reset_diag=False):
+        _check(self.lib.dmxBatchStepRange(self.h, h, first, count, int(reset_diag)), "dmxBatchStepRange")
+
+    def gather_bodies(self, idx_ptr, count, out_ptr):
+        _check(self.lib.dmxBatchGatherBodies(self.h, idx_ptr, count, out_ptr), "dmxBatchGatherBodies")
+
+    def scatter_bodies(self, idx_ptr, count, in_ptr):
+        _check(self.lib.dmxBatchScatterBodies(self.h, idx_ptr, count, in_ptr), "dmxBatchScatterBodies")
+
     def step_timed(self, h, nsteps):
         ms = C.c_float()
         _check(self.lib.dmxBatchStepTimed(self.h, h, nsteps, C.byref(ms)), "dmxBatchStepTimed")

@@ -65,6 +65,7 @@ extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int dev
     dmxBatch *b = new (std::nothrow) dmxBatch();
     if (!b) return DMX_ENOMEM;
     b->n = n;
+    b->n_active = n;
     b->stride = (n + 255) / 256 * 256;
     b->precision = precision;
     b->device = device;
@@ -251,13 +252,13 @@ extern "C" void *dmxBatchDevicePtr(dmxBatchID b, int field, int component)
 }
 
 // ---- stepping ----------------------------------------------------------------------------------
-template <class T> static int step_t(dmxBatch *b, double h, int nsteps)
+template <class T> static int step_t(dmxBatch *b, double h, int nsteps, int64_t first, int64_t count, bool reset_diag)
 {
     const StepParams<T> P = dmx_make_params<T>(b, h);
     for (int s = 0; s < nsteps; s++) {
-        if (b->plane_on) HIP_TRY(hipMemsetAsync(b->diag, 0, sizeof(StepDiag), b->stream));
-        HIP_TRY(launch_step<T>((T *)b->slab, b->gtype, b->stride, b->n, P, b->ext_pending, b->diag, b->stream));
-        b->ext_pending = false;   // the step cleared the accumulators
+        if (b->plane_on && reset_diag) HIP_TRY(hipMemsetAsync(b->diag, 0, sizeof(StepDiag), b->stream));
+        HIP_TRY(launch_step<T>((T *)b->slab + first, b->gtype + first, b->stride, count, P, b->ext_pending, b->diag,
+                               b->stream));
     }
     b->stepped_with_plane = b->plane_on != 0;
     return DMX_OK;
@@ -267,7 +268,30 @@ extern "C" int dmxBatchStep(dmxBatchID b, double h, int nsteps)
 {
     if (!b || !(h > 0) || nsteps < 0) return DMX_EINVAL;
     HIP_TRY(hipSetDevice(b->device));
-    return b->precision == DMX_F32 ? step_t<float>(b, h, nsteps) : step_t<double>(b, h, nsteps);
+    int rc = b->precision == DMX_F32 ? step_t<float>(b, h, nsteps, 0, b->n_active, true)
+                                     : step_t<double>(b, h, nsteps, 0, b->n_active, true);
+    b->ext_pending = false;   // the step cleared the accumulators
+    return rc;
+}
+
+extern "C" int dmxBatchSetActiveCount(dmxBatchID b, int64_t n_active)
+{
+    if (!b || n_active < 0 || n_active > b->n) return DMX_EINVAL;
+    if (n_active != b->n && n_active % 4 != 0) return DMX_EINVAL;   // the last 16 B pack must not reach into ghost slots
+    b->n_active = n_active;
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchStepRange(dmxBatchID b, double h, int64_t first, int64_t count, int reset_diag)
+{
+    if (!b || !(h > 0) || first < 0 || count < 0 || first + count > b->n_active) return DMX_EINVAL;
+    // lanes own 16 B packs of consecutive bodies: ranges must start on a pack and end on one (or at the end)
+    const int64_t pack = 16 / (int64_t)b->rsize;
+    if (first % pack != 0 || (count % pack != 0 && first + count != b->n_active)) return DMX_EINVAL;
+    if (count == 0) return DMX_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    return b->precision == DMX_F32 ? step_t<float>(b, h, 1, first, count, reset_diag != 0)
+                                   : step_t<double>(b, h, 1, first, count, reset_diag != 0);
 }
 
 extern "C" int dmxBatchSynchronize(dmxBatchID b)
@@ -284,6 +308,13 @@ extern "C" int dmxBatchSetStream(dmxBatchID b, void *hip_stream)
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
     b->stream = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchGetStream(dmxBatchID b, void **hip_stream)
+{
+    if (!b || !hip_stream) return DMX_EINVAL;
+    *hip_stream = (void *)b->stream;
     return DMX_OK;
 }
 

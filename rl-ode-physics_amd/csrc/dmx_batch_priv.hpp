@@ -24,6 +24,7 @@ using namespace dmx;
 
 struct dmxBatch {
     int64_t n = 0, stride = 0;
+    int64_t n_active = 0;            // bodies [0, n_active) are stepped; the rest are ghost slots
     int precision = DMX_F32;
     int device = 0;
     size_t rsize = 4;
