@@ -72,6 +72,7 @@ extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int dev
     b->rsize = precision == DMX_F32 ? 4 : 8;
     b->cfm = precision == DMX_F32 ? 1e-5 : 1e-10;      // dWorldCreate default per precision [ODE]
     if (const char *v = getenv("DMX_VEC")) b->vec = atoi(v);
+    if (const char *v = getenv("DMX_PLANE_VARIANT")) b->variant = atoi(v);
     int rc = DMX_OK;
     do {
         if (hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = DMX_EHIP; break; }
@@ -83,9 +84,14 @@ extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int dev
         b->h_bflags.assign((size_t)b->stride, 0);
         for (int64_t i = 0; i < n; i++) b->h_bflags[(size_t)i] = BF_ALIVE;
         if (hipMemcpy(b->bflags, b->h_bflags.data(), (size_t)b->stride, hipMemcpyHostToDevice) != hipSuccess) { rc = DMX_EHIP; break; }
-        if (hipMalloc((void **)&b->diag, sizeof(StepDiag)) != hipSuccess) { rc = DMX_ENOMEM; break; }
-        if (hipHostMalloc((void **)&b->diag_host, sizeof(StepDiag)) != hipSuccess) { rc = DMX_ENOMEM; break; }
-        if (hipMemset(b->diag, 0, sizeof(StepDiag)) != hipSuccess) { rc = DMX_EHIP; break; }
+        // one diagnostics slot per wave of the fused step (plain stores, summed on the host when asked),
+        // plus one atomically accumulated slot for the island path
+        b->n_diag = (size_t)(b->stride / 64) + 1;
+        if (hipMalloc((void **)&b->diag, b->n_diag * sizeof(StepDiag)) != hipSuccess) { rc = DMX_ENOMEM; break; }
+        if (hipMalloc((void **)&b->diag_isl, sizeof(StepDiag)) != hipSuccess) { rc = DMX_ENOMEM; break; }
+        if (hipHostMalloc((void **)&b->diag_host, b->n_diag * sizeof(StepDiag)) != hipSuccess) { rc = DMX_ENOMEM; break; }
+        if (hipMemset(b->diag, 0, b->n_diag * sizeof(StepDiag)) != hipSuccess) { rc = DMX_EHIP; break; }
+        if (hipMemset(b->diag_isl, 0, sizeof(StepDiag)) != hipSuccess) { rc = DMX_EHIP; break; }
         rc = precision == DMX_F32 ? fill_defaults<float>(b) : fill_defaults<double>(b);
     } while (0);
     if (rc != DMX_OK) {
@@ -110,6 +116,7 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
     if (b->jh_int) (void)hipHostFree(b->jh_int);
     if (b->jh_real) (void)hipHostFree(b->jh_real);
     if (b->diag) (void)hipFree(b->diag);
+    if (b->diag_isl) (void)hipFree(b->diag_isl);
     if (b->diag_host) (void)hipHostFree(b->diag_host);
     if (b->stage) (void)hipFree(b->stage);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -256,11 +263,12 @@ template <class T> static int step_t(dmxBatch *b, double h, int nsteps, int64_t 
 {
     const StepParams<T> P = dmx_make_params<T>(b, h);
     for (int s = 0; s < nsteps; s++) {
-        if (b->plane_on && reset_diag) HIP_TRY(hipMemsetAsync(b->diag, 0, sizeof(StepDiag), b->stream));
-        HIP_TRY(launch_step<T>((T *)b->slab + first, b->gtype + first, b->stride, count, P, b->ext_pending, b->diag,
-                               b->stream));
+        (void)reset_diag;   // every wave overwrites its own slot each tick: nothing to clear
+        HIP_TRY(launch_step<T>((T *)b->slab + first, b->gtype + first, b->stride, count, P, b->ext_pending,
+                               b->diag + first / 64, b->stream));
     }
     b->stepped_with_plane = b->plane_on != 0;
+    b->last_islands = false;
     return DMX_OK;
 }
 
@@ -288,6 +296,7 @@ extern "C" int dmxBatchStepRange(dmxBatchID b, double h, int64_t first, int64_t 
     // lanes own 16 B packs of consecutive bodies: ranges must start on a pack and end on one (or at the end)
     const int64_t pack = 16 / (int64_t)b->rsize;
     if (first % pack != 0 || (count % pack != 0 && first + count != b->n_active)) return DMX_EINVAL;
+    if (first % 64 != 0) return DMX_EINVAL;      // ranges start on a wave so per-wave diagnostics slots stay disjoint
     if (count == 0) return DMX_OK;
     HIP_TRY(hipSetDevice(b->device));
     return b->precision == DMX_F32 ? step_t<float>(b, h, 1, first, count, reset_diag != 0)
@@ -331,11 +340,21 @@ extern "C" int dmxBatchStepTimed(dmxBatchID b, double h, int nsteps, float *ms)
     return DMX_OK;
 }
 
-static int fetch_diag(dmxBatch *b)
+static int fetch_diag(dmxBatch *b, unsigned long long *contacts, double *residual)
 {
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipMemcpyAsync(b->diag_host, b->diag, sizeof(StepDiag), hipMemcpyDeviceToHost, b->stream));
+    if (b->last_islands) {
+        HIP_TRY(hipMemcpyAsync(b->diag_host, b->diag_isl, sizeof(StepDiag), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        *contacts = b->diag_host[0].contacts; *residual = b->diag_host[0].residual;
+        return DMX_OK;
+    }
+    const size_t nw = (size_t)((b->n_active + 63) / 64);
+    HIP_TRY(hipMemcpyAsync(b->diag_host, b->diag, nw * sizeof(StepDiag), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
+    unsigned long long c = 0; double r = 0;
+    for (size_t i = 0; i < nw; i++) { c += b->diag_host[i].contacts; r += b->diag_host[i].residual; }
+    *contacts = c; *residual = r;
     return DMX_OK;
 }
 
@@ -343,19 +362,21 @@ extern "C" int dmxBatchLastContactCount(dmxBatchID b, int64_t *n)
 {
     if (!b || !n) return DMX_EINVAL;
     if (!b->stepped_with_plane) { *n = 0; return DMX_OK; }
-    int rc = fetch_diag(b);
+    unsigned long long c; double r;
+    int rc = fetch_diag(b, &c, &r);
     if (rc != DMX_OK) return rc;
-    *n = (int64_t)b->diag_host->contacts;
+    *n = (int64_t)c;
     return DMX_OK;
 }
 
-extern "C" int dmxBatchLastResidual(dmxBatchID b, double *r)
+extern "C" int dmxBatchLastResidual(dmxBatchID b, double *res)
 {
-    if (!b || !r) return DMX_EINVAL;
-    if (!b->stepped_with_plane) { *r = 0; return DMX_OK; }
-    int rc = fetch_diag(b);
+    if (!b || !res) return DMX_EINVAL;
+    if (!b->stepped_with_plane) { *res = 0; return DMX_OK; }
+    unsigned long long c; double r;
+    int rc = fetch_diag(b, &c, &r);
     if (rc != DMX_OK) return rc;
-    *r = b->diag_host->residual;
+    *res = r;
     return DMX_OK;
 }
 

@@ -30,7 +30,10 @@ struct dmxBatch {
     size_t rsize = 4;
     void *slab = nullptr;            // C_COUNT x stride reals
     uint8_t *gtype = nullptr;        // stride bytes
-    StepDiag *diag = nullptr;        // device
+    StepDiag *diag = nullptr;        // device, one slot per wave of the fused step
+    StepDiag *diag_isl = nullptr;    // device, island path (atomics)
+    size_t n_diag = 0;
+    bool last_islands = false;       // which diagnostics the last tick wrote
     StepDiag *diag_host = nullptr;   // pinned
     void *stage = nullptr;           // device staging for AoS <-> SoA
     size_t stage_bytes = 0;
@@ -47,6 +50,7 @@ struct dmxBatch {
     double mu = __builtin_huge_val(), bounce = 0.2, bounce_vel = 0.1;   // main.c:685-687
     int max_contacts = 8;                               // main.c:675
     bool ext_pending = false;
+    int variant = 0;                 // DMX_PLANE_VARIANT launch-tuning override for step_plane
     int vec = 0;                     // DMX_VEC launch-tuning override (bodies per lane), 0 = 16 B per lane
     bool stepped_with_plane = false;
     // general island path (explicit contact joints)
@@ -88,6 +92,7 @@ template <class T> inline StepParams<T> dmx_make_params(dmxBatch *b, double h)
     P.mu = (T)b->mu; P.bounce = (T)b->bounce; P.bounce_vel = (T)b->bounce_vel;
     P.max_contacts = b->max_contacts;
     P.vec = b->vec;
+    P.variant = b->variant;
     return P;
 }
 

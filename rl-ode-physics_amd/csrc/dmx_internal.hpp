@@ -56,6 +56,7 @@ template <class T> struct StepParams {
     int surf_mode; T mu, bounce, bounce_vel;   // contact surface (NearCallback, main.c:684-687)
     int max_contacts;
     int vec;            // launch tuning: bodies per lane in integrate_free (0 = 16 B per lane)
+    int variant;        // launch tuning: step_plane variant (0 = default)
 };
 
 struct StepDiag {

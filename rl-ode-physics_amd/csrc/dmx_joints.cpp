@@ -127,8 +127,9 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     I.rows = (T *)b->jd_rows.p; I.rowjb = (int *)b->jd_rowjb.p; I.bscr = (T *)b->jd_bscr.p; I.local = (int *)b->jd_local.p;
 
     StepParams<T> P = dmx_make_params<T>(b, h);
-    HIP_TRY(hipMemsetAsync(b->diag, 0, sizeof(StepDiag), b->stream));
-    HIP_TRY(launch_islands<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag, b->stream));
+    HIP_TRY(hipMemsetAsync(b->diag_isl, 0, sizeof(StepDiag), b->stream));
+    HIP_TRY(launch_islands<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, b->stream));
+    b->last_islands = true;
     b->ext_pending = false;
     b->stepped_with_plane = true;     // diagnostics are valid
     return DMX_OK;

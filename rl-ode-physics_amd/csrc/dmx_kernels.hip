@@ -127,8 +127,8 @@ template <class T> __device__ __forceinline__ T wave_sum(T x)
 constexpr int MAXC = 4;          // box-plane yields at most 4 contacts
 constexpr int MAXR = 3 * MAXC;   // rows per body
 
-template <class T, bool EXT>
-__global__ __launch_bounds__(256) void step_plane(T *__restrict__ S, const uint8_t *__restrict__ gtype,
+template <class T, bool EXT, int MINW>
+__global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const uint8_t *__restrict__ gtype,
                                                   int64_t stride, int64_t n, StepParams<T> P,
                                                   StepDiag *__restrict__ diag)
 {
@@ -191,8 +191,15 @@ __global__ __launch_bounds__(256) void step_plane(T *__restrict__ S, const uint8
                                    { invMass * dir[2].x, invMass * dir[2].y, invMass * dir[2].z } };
             const T cfm = P.cfm * hinv;
 
-            T Ad[MAXR], rhs[MAXR], adcfm[MAXR], lam[MAXR], lo[MAXR], hi[MAXR];
+            T Ad[MAXR], rhs[MAXR], adcfm[MAXR], lam[MAXR];
+            // row limits are implied by the row kind: normal rows [0, inf), friction rows [-mu, mu]
+            const T lo_f = -P.mu, hi_f = P.mu, hi_n = Limits<T>::inf();
             V3<T> Ja[MAXR], iMa[MAXR];
+#pragma unroll
+            for (int r = 0; r < MAXR; r++) {      // rows of absent contacts stay zero
+                Ad[r] = rhs[r] = adcfm[r] = lam[r] = T(0);
+                Ja[r] = { T(0), T(0), T(0) }; iMa[r] = { T(0), T(0), T(0) };
+            }
 #pragma unroll
             for (int k = 0; k < MAXC; k++) {
                 if (k < nc) {
@@ -214,9 +221,6 @@ __global__ __launch_bounds__(256) void step_plane(T *__restrict__ S, const uint8
                                         if (newc > c) c = newc;
                                     }
                                 }
-                                lo[r] = 0; hi[r] = Limits<T>::inf();
-                            } else {
-                                lo[r] = -P.mu; hi[r] = P.mu;
                             }
                             T sum = T(0);
                             sum += dir[dnum].x * tl.x; sum += dir[dnum].y * tl.y; sum += dir[dnum].z * tl.z;
@@ -240,12 +244,20 @@ __global__ __launch_bounds__(256) void step_plane(T *__restrict__ S, const uint8
             }
 
             // ---- SOR-PGS: lambda = 0 start, rows in creation order --------------------------
+            // Branch-free row update: the contact loop bound is the wave's maximum contact count (a scalar
+            // branch), lanes with fewer contacts carry zeroed rows and a zero delta; clamping is by select.
             V3<T> fl = { T(0), T(0), T(0) }, fa = { T(0), T(0), T(0) };
+            int ncu = 0;     // largest contact count among the wave's active lanes (wave-uniform by construction)
+#pragma unroll
+            for (int k = 0; k < MAXC; k++)
+                if (__ballot(nc > k) != 0ull) ncu = k + 1;
+            T rsum = T(0);
             for (int it = 0; it < P.iters; it++) {
-                const bool last = (it == P.iters - 1);
+                rsum = T(0);
 #pragma unroll
                 for (int k = 0; k < MAXC; k++) {
-                    if (k < nc) {
+                    if (k < ncu) {
+                        const bool act = k < nc;
 #pragma unroll
                         for (int dnum = 0; dnum < 3; dnum++) {
                             const int r = 3 * k + dnum;
@@ -257,17 +269,21 @@ __global__ __launch_bounds__(256) void step_plane(T *__restrict__ S, const uint8
                                          fl.z * (dir[dnum].z * ad) + fa.x * Ja[r].x + fa.y * Ja[r].y +
                                          fa.z * Ja[r].z;
                                 const T nl = old + delta;
-                                if (nl < lo[r]) { delta = lo[r] - old; lam[r] = lo[r]; }
-                                else if (nl > hi[r]) { delta = hi[r] - old; lam[r] = hi[r]; }
-                                else lam[r] = nl;
+                                const T lo = dnum == 0 ? T(0) : lo_f, hi = dnum == 0 ? hi_n : hi_f;
+                                const bool below = nl < lo, above = nl > hi;
+                                T nlam = below ? lo : (above ? hi : nl);
+                                delta = below ? lo - old : (above ? hi - old : delta);
+                                delta = act ? delta : T(0);
+                                lam[r] = act ? nlam : old;
                                 fl.x += delta * iml[dnum].x; fl.y += delta * iml[dnum].y; fl.z += delta * iml[dnum].z;
                                 fa.x += delta * iMa[r].x; fa.y += delta * iMa[r].y; fa.z += delta * iMa[r].z;
-                                if (last) my_resid += (double)tabs(delta);
+                                rsum += tabs(delta);
                             }
                         }
                     }
                 }
             }
+            my_resid = (double)rsum;      // |delta lambda| summed over the last sweep
             // v += h * (M^-1 J^T lambda)
             v.x += h * fl.x; v.y += h * fl.y; v.z += h * fl.z;
             w.x += h * fa.x; w.y += h * fa.y; w.z += h * fa.z;
@@ -292,12 +308,15 @@ __global__ __launch_bounds__(256) void step_plane(T *__restrict__ S, const uint8
             for (int k = 0; k < 6; k++) S[(C_FORCE + k) * stride + i] = T(0);
         }
     }
-    // ---- diagnostics: wavefront reduction, one atomic per wave -----------------------------------
+    // ---- diagnostics: wavefront reduction (__shfl_xor), one plain store per wave into the wave's own slot.
+    // No atomics: 4096 same-address atomics per launch serialise at ~11 ns each, longer than the whole kernel.
     const int wc = wave_sum<int>(my_contacts);
     const double wr = wave_sum<double>(my_resid);
-    if ((threadIdx.x & 63) == 0 && (wc != 0)) {
-        atomicAdd(&diag->contacts, (unsigned long long)wc);
-        atomicAdd(&diag->residual, wr);
+    if ((threadIdx.x & 63) == 0) {
+        StepDiag d;
+        d.contacts = (unsigned long long)wc;
+        d.residual = wr;
+        diag[(blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6] = d;
     }
 }
 
@@ -393,8 +412,18 @@ hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, co
 #undef DMX_LAUNCH_FREE
     } else {
         const unsigned grid = blocks_for(n, 256);
-        if (ext) hipLaunchKernelGGL((step_plane<T, true>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag);
-        else     hipLaunchKernelGGL((step_plane<T, false>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag);
+#define DMX_LAUNCH_PLANE(MW)                                                                                           \
+    do {                                                                                                                   \
+        if (ext) hipLaunchKernelGGL((step_plane<T, true, MW>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag);  \
+        else     hipLaunchKernelGGL((step_plane<T, false, MW>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag); \
+    } while (0)
+        switch (P.variant) {
+        case 1: DMX_LAUNCH_PLANE(1); break;
+        case 2: DMX_LAUNCH_PLANE(2); break;
+        default:
+            if (sizeof(T) == 4) DMX_LAUNCH_PLANE(2); else DMX_LAUNCH_PLANE(1);
+        }
+#undef DMX_LAUNCH_PLANE
     }
     return hipGetLastError();
 }

@@ -317,8 +317,8 @@ def test_config3_full_size_properties():
 @pytest.mark.parametrize("plane", [False, True])
 def test_boundary_first_range_stepping_equals_whole_step(plane):
     """The sharded tick (boundary rows, then interior, dmxBatchStepRange) is the same tick."""
-    scene = pkg.scenes.box_grid(32, 16, seed=8, y_range=(0.7, 3.0), spin=True, box_mass=True, plane=plane).astype("float32")
-    L = pkg.shard.SlabLayout(32, 16)
+    scene = pkg.scenes.box_grid(64, 8, seed=8, y_range=(0.7, 3.0), spin=True, box_mass=True, plane=plane).astype("float32")
+    L = pkg.shard.SlabLayout(64, 8)
     a = _gpu_run(scene, "float32", 60)
     b = pkg.BatchWorld(L.n_total, dtype="float32")       # with ghost slots behind the active bodies
     b.load_scene(scene)
@@ -334,9 +334,11 @@ def test_boundary_first_range_stepping_equals_whole_step(plane):
     assert a.last_contact_count() == b.last_contact_count()
     # ghost slots were never stepped: still the defaults of dBodyCreate
     assert not b.download(pkg.batch.POS, first=scene.n).any()
-    # ranges must respect the 16-byte packs
+    # ranges must start on a wave (64 bodies) and respect the 16-byte packs
     with pytest.raises(pkg.batch.DmxError):
         b.step_range(H, 2, 8)
+    with pytest.raises(pkg.batch.DmxError):
+        b.step_range(H, 64, 6)
 
 
 def test_slabs_of_config4_step_independently():
