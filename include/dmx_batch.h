@@ -35,7 +35,8 @@ enum {
     DMX_ENODEVICE = -1,   /* no usable HIP device */
     DMX_EHIP = -2,        /* a HIP call failed */
     DMX_EINVAL = -3,      /* bad argument */
-    DMX_ENOMEM = -4
+    DMX_ENOMEM = -4,
+    DMX_ECAPACITY = -5    /* a fixed-size device table overflowed (broadphase bucket / pair buffer) */
 };
 
 /* per-body fields (k = components per body) */
@@ -104,6 +105,16 @@ int dmxBatchSetStream(dmxBatchID b, void *hip_stream);
 int dmxBatchGetStream(dmxBatchID b, void **hip_stream);
 /* step nsteps times bracketed by HIP events on the batch's stream; *ms = elapsed device milliseconds */
 int dmxBatchStepTimed(dmxBatchID b, double h, int nsteps, float *ms);
+
+/* ---- body-body collisions inside dmxBatchStep (dSpaceCollide for body pairs, main.c:212).
+ * enable = 1 (default): every tick proves the body-pair set empty through per-body broadphase safe zones, or,
+ * when a body leaves its zone / bodies are crowded, runs the exact pair search + narrowphase + island solve
+ * for the bodies involved; results equal the sequential oracle's either way.  enable = 0: the caller asserts
+ * that bodies never touch one another (every island is a single body) and the check is skipped.
+ * stats: [0] ticks in fast mode, [1] ticks in exact mode, [2] safe-zone rebuilds, [3] ticks that had body
+ * pairs, [4] body pairs in the last tick, [5] crowded bodies at the last rebuild. */
+int dmxBatchSetBodyCollisions(dmxBatchID b, int enable);
+int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6]);
 
 /* ---- explicit contact joints: the callback form of the tick.  The reference's near callback makes one
  * dJointCreateContact + dJointAttach per contact (main.c:683-692) and then calls dWorldStep (main.c:213);

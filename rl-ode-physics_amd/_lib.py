@@ -19,7 +19,7 @@ BATCH_SYMBOLS = [
     "dmxBatchStepTimed", "dmxBatchLastContactCount", "dmxBatchLastResidual", "dmxBatchPackTransforms",
     "dmxBatchDownloadTransforms", "dmxBatchGatherBodies", "dmxBatchScatterBodies",
     "dmxBatchStepJoints", "dmxBatchUploadBodyFlags", "dmxBatchSetActiveCount", "dmxBatchStepRange",
-    "dmxBatchGetStream",
+    "dmxBatchGetStream", "dmxBatchSetBodyCollisions", "dmxBatchCollisionStats",
 ]
 
 _lib = None
@@ -82,5 +82,7 @@ def load():
     sig("dmxBatchSetActiveCount", I, P, L)
     sig("dmxBatchStepRange", I, P, D, L, L, I)
     sig("dmxBatchGetStream", I, P, C.POINTER(P))
+    sig("dmxBatchSetBodyCollisions", I, P, I)
+    sig("dmxBatchCollisionStats", I, P, C.POINTER(L))
     _lib = lib
     return lib

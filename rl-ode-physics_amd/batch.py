@@ -123,6 +123,14 @@ class BatchWorld:
     def step(self, h, nsteps=1):
         _check(self.lib.dmxBatchStep(self.h, h, nsteps), "dmxBatchStep")
 
+    def set_body_collisions(self, enable):
+        _check(self.lib.dmxBatchSetBodyCollisions(self.h, int(enable)), "dmxBatchSetBodyCollisions")
+
+    def collision_stats(self):
+        out = (C.c_int64 * 6)()
+        _check(self.lib.dmxBatchCollisionStats(self.h, out), "dmxBatchCollisionStats")
+        return dict(zip(("fast_ticks", "careful_ticks", "rebuilds", "pair_ticks", "last_pairs", "crowded"), out))
+
     def set_active_count(self, n_active):
         _check(self.lib.dmxBatchSetActiveCount(self.h, n_active), "dmxBatchSetActiveCount")
 

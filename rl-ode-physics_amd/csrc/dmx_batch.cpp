@@ -66,6 +66,8 @@ extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int dev
     if (!b) return DMX_ENOMEM;
     b->n = n;
     b->n_active = n;
+    b->h_sides.assign((size_t)3 * n, 0.0);
+    b->h_gtype.assign((size_t)n, 0);
     b->stride = (n + 255) / 256 * 256;
     b->precision = precision;
     b->device = device;
@@ -113,6 +115,9 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
     if (b->bflags) (void)hipFree(b->bflags);
     for (dmxBatch::DevBuf *d : { &b->jd_int, &b->jd_real, &b->jd_rows, &b->jd_rowjb, &b->jd_bscr, &b->jd_local })
         if (d->p) (void)hipFree(d->p);
+    for (dmxBatch::DevBuf *d : { &b->bp_count, &b->bp_items, &b->bp_flags, &b->bp_pairs, &b->bp_inpair, &b->bp_snapshot, &b->bp_idx, &b->bp_gather })
+        if (d->p) (void)hipFree(d->p);
+    if (b->bp_flags_host) (void)hipHostFree(b->bp_flags_host);
     if (b->jh_int) (void)hipHostFree(b->jh_int);
     if (b->jh_real) (void)hipHostFree(b->jh_real);
     if (b->diag) (void)hipFree(b->diag);
@@ -180,6 +185,12 @@ static int upload_t(dmxBatch *b, int field, const void *host, int64_t first, int
                                  (const T *)b->stage, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));   // host buffer (and tmp) may be released on return
     if (field == DMX_FORCE || field == DMX_TORQUE) b->ext_pending = true;
+    if (field == DMX_SIDES) {
+        const T *p = (const T *)host;
+        for (int64_t i = 0; i < count * 3; i++) b->h_sides[(size_t)(3 * first + i)] = (double)p[i];
+        b->bp_rmax = 0;
+    }
+    if (field == DMX_POS || field == DMX_SIDES) b->bp_valid = false;     // poses / extents changed under the safe zones
     return DMX_OK;
 }
 
@@ -226,6 +237,8 @@ extern "C" int dmxBatchUploadGeomType(dmxBatchID b, const uint8_t *types, int64_
     if (count == 0) return DMX_OK;
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemcpyAsync(b->gtype + first, types, (size_t)count, hipMemcpyHostToDevice, b->stream));
+    memcpy(b->h_gtype.data() + first, types, (size_t)count);
+    b->bp_rmax = 0; b->bp_valid = false;
     HIP_TRY(hipStreamSynchronize(b->stream));
     return DMX_OK;
 }
@@ -276,10 +289,28 @@ extern "C" int dmxBatchStep(dmxBatchID b, double h, int nsteps)
 {
     if (!b || !(h > 0) || nsteps < 0) return DMX_EINVAL;
     HIP_TRY(hipSetDevice(b->device));
+    if (b->bp_enabled) return dmx_step_collide(b, h, nsteps);
     int rc = b->precision == DMX_F32 ? step_t<float>(b, h, nsteps, 0, b->n_active, true)
                                      : step_t<double>(b, h, nsteps, 0, b->n_active, true);
     b->ext_pending = false;   // the step cleared the accumulators
+    b->last_mixed = false;
     return rc;
+}
+
+extern "C" int dmxBatchSetBodyCollisions(dmxBatchID b, int enable)
+{
+    if (!b) return DMX_EINVAL;
+    b->bp_enabled = enable ? 1 : 0;
+    b->bp_valid = false;
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6])
+{
+    if (!b || !out) return DMX_EINVAL;
+    out[0] = b->stat_fast_ticks; out[1] = b->stat_careful_ticks; out[2] = b->stat_rebuilds;
+    out[3] = b->stat_pair_ticks; out[4] = (int64_t)b->last_pairs; out[5] = (int64_t)b->bp_crowded;
+    return DMX_OK;
 }
 
 extern "C" int dmxBatchSetActiveCount(dmxBatchID b, int64_t n_active)
@@ -354,6 +385,11 @@ static int fetch_diag(dmxBatch *b, unsigned long long *contacts, double *residua
     HIP_TRY(hipStreamSynchronize(b->stream));
     unsigned long long c = 0; double r = 0;
     for (size_t i = 0; i < nw; i++) { c += b->diag_host[i].contacts; r += b->diag_host[i].residual; }
+    if (b->last_mixed) {      // bodies in pairs went through the island kernel: add its tally
+        HIP_TRY(hipMemcpyAsync(b->diag_host, b->diag_isl, sizeof(StepDiag), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        c += b->diag_host[0].contacts; r += b->diag_host[0].residual;
+    }
     *contacts = c; *residual = r;
     return DMX_OK;
 }
@@ -422,6 +458,7 @@ extern "C" int dmxBatchGatherBodies(dmxBatchID b, const int32_t *idx_dev, int64_
 extern "C" int dmxBatchScatterBodies(dmxBatchID b, const int32_t *idx_dev, int64_t count, const void *in_dev)
 {
     if (!b || count < 0 || (count > 0 && (!idx_dev || !in_dev))) return DMX_EINVAL;
+    b->bp_valid = false;
     HIP_TRY(hipSetDevice(b->device));
     if (b->precision == DMX_F32)
         HIP_TRY(launch_scatter<float>((float *)b->slab, b->stride, idx_dev, count, (const float *)in_dev, b->stream));

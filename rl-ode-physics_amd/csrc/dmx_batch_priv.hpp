@@ -59,10 +59,27 @@ struct dmxBatch {
     struct DevBuf { void *p = nullptr; size_t bytes = 0; };
     DevBuf jd_int, jd_real, jd_rows, jd_rowjb, jd_bscr, jd_local;   // device staging / scratch
     void *jh_int = nullptr, *jh_real = nullptr;                      // pinned host staging
+    // body-body broadphase (dmx_broadphase.hip / dmx_general.cpp)
+    int bp_enabled = 1;                        // dmxBatchSetBodyCollisions
+    bool bp_valid = false;                     // safe zones match the current constant data
+    uint32_t bp_crowded = 0;                   // bodies whose safe radius is <= 0 at the last build
+    double bp_rmax = 0;
+    uint32_t bp_mask = 0; int bp_cap = 8;
+    DevBuf bp_count, bp_items, bp_flags, bp_pairs, bp_inpair, bp_snapshot, bp_idx, bp_gather;
+    uint32_t *bp_flags_host = nullptr;         // pinned
+    int bp_max_pairs = 0;
+    std::vector<double> h_sides;               // host mirror of DMX_SIDES (exact values of the batch precision)
+    std::vector<uint8_t> h_gtype;
+    int64_t stat_fast_ticks = 0, stat_careful_ticks = 0, stat_rebuilds = 0, stat_pair_ticks = 0;
+    unsigned long long last_pairs = 0;
+    bool last_mixed = false;                   // last tick used fused + island kernels together
     size_t jh_int_bytes = 0, jh_real_bytes = 0;
 };
 
 int dmx_ensure_dev(dmxBatch::DevBuf &d, size_t bytes);
+int dmx_step_joints(dmxBatch *b, double h, int64_t n_joints, const dmxContactJoint *joints, const uint8_t *include);
+// body-body collision handling of the batch tick (dmx_general.cpp)
+int dmx_step_collide(dmxBatch *b, double h, int nsteps);
 
 
 template <class T> inline void dmx_normalize_plane(const double in[4], T out[4])

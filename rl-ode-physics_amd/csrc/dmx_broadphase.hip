@@ -1,0 +1,169 @@
+// dmx_broadphase.hip -- device side of dSpaceCollide for body-body pairs (/root/reference/src/main.c:212).
+//
+// ODE's hash space bins geom AABBs into cells and tests geoms of the same / adjacent cells.  Here bodies are
+// binned by the (x,z) column of their centre into a hashed table of fixed-capacity buckets; the cell size is
+// at least the largest bounding-sphere diameter, so two bodies whose AABBs overlap always sit in adjacent
+// columns (3x3 neighbourhood).  Two consumers:
+//   * bp_pairs     -- the exact pair search: every (i<j) whose AABBs overlap (what reaches NearCallback);
+//   * bp_safe_zone -- per body, half the horizontal gap to its nearest neighbour's bounding sphere.  While every
+//                     body stays inside its safe zone (a 3-real check fused into the step kernels) no two
+//                     bounding spheres can touch, so the pair set is provably empty without a search.
+// Integer / index work: coalesced loads of positions, hashed bucket atomics in L2, no MFMA, no LDS reuse to stage.
+#include <hip/hip_runtime.h>
+#include "dmx_internal.hpp"
+#include "dmx_math.hpp"
+
+namespace dmx {
+
+__device__ __forceinline__ uint32_t cell_hash(int ix, int iz, uint32_t mask)
+{
+    return ((uint32_t)ix * 73856093u ^ (uint32_t)iz * 19349663u) & mask;
+}
+
+template <class T> __device__ __forceinline__ T bound_radius(int gt, const T *S, int64_t stride, int64_t i)
+{
+    const T sx = S[(C_SIDES + 0) * stride + i];
+    if (gt == GEOM_SPHERE) return sx;
+    const T sy = S[(C_SIDES + 1) * stride + i], sz = S[(C_SIDES + 2) * stride + i];
+    return T(0.5) * tsqrt<T>(sx * sx + sy * sy + sz * sz);
+}
+
+// bodies [0,n) -> buckets of their (x,z) column
+template <class T>
+__global__ __launch_bounds__(256) void bp_insert(const T *__restrict__ S, const uint8_t *__restrict__ gtype,
+                                                 int64_t stride, int64_t n, GridParams<T> G)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n || gtype[i] == GEOM_NONE) return;
+    const int ix = (int)floor((double)(S[(C_POS + 0) * stride + i] * G.inv_cell));
+    const int iz = (int)floor((double)(S[(C_POS + 2) * stride + i] * G.inv_cell));
+    const uint32_t h = cell_hash(ix, iz, G.mask);
+    const uint32_t slot = atomicAdd(&G.count[h], 1u);
+    if (slot < (uint32_t)G.cap) G.items[(size_t)h * G.cap + slot] = (int32_t)i;
+    else atomicOr(&G.flags[BPF_OVERFLOW], 1u);
+}
+
+// per active body: build position (x,z) and safe radius = half the horizontal gap to the nearest bounding sphere
+template <class T>
+__global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uint8_t *__restrict__ gtype,
+                                                    int64_t stride, int64_t n_active, GridParams<T> G)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_active) return;
+    const int gt = gtype[i];
+    const T x = S[(C_POS + 0) * stride + i], z = S[(C_POS + 2) * stride + i];
+    T safe = Limits<T>::inf();
+    if (gt != GEOM_NONE) {
+        const T ri = bound_radius<T>(gt, S, stride, i);
+        const int ix = (int)floor((double)(x * G.inv_cell)), iz = (int)floor((double)(z * G.inv_cell));
+        // nothing outside the 3x3 block is closer than one cell: gap >= cell - r_i - r_max
+        T gap = G.cell - ri - G.r_max;
+        for (int dz = -1; dz <= 1; dz++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const uint32_t h = cell_hash(ix + dx, iz + dz, G.mask);
+                uint32_t cnt = G.count[h];
+                if (cnt > (uint32_t)G.cap) cnt = (uint32_t)G.cap;
+                for (uint32_t s = 0; s < cnt; s++) {
+                    const int64_t j = G.items[(size_t)h * G.cap + s];
+                    if (j == i) continue;
+                    const T ddx = S[(C_POS + 0) * stride + j] - x, ddz = S[(C_POS + 2) * stride + j] - z;
+                    const T g = tsqrt<T>(ddx * ddx + ddz * ddz) - ri - bound_radius<T>(gtype[j], S, stride, j);
+                    if (g < gap) gap = g;
+                }
+            }
+        safe = T(0.5) * gap;
+        if (!(safe > 0)) atomicAdd(&G.flags[BPF_CROWDED], 1u);
+    }
+    S[C_BPX * stride + i] = x;
+    S[C_BPZ * stride + i] = z;
+    S[C_BPSAFE * stride + i] = safe;
+}
+
+template <class T> __device__ __forceinline__ void body_aabb(const T *S, const uint8_t *gtype, int64_t stride,
+                                                             int64_t i, T lo[3], T hi[3])
+{
+    const T p[3] = { S[(C_POS + 0) * stride + i], S[(C_POS + 1) * stride + i], S[(C_POS + 2) * stride + i] };
+    T r[3];
+    if (gtype[i] == GEOM_SPHERE) {
+        r[0] = r[1] = r[2] = S[(C_SIDES + 0) * stride + i];
+    } else {
+        const Q4<T> q = { S[(C_QUAT + 0) * stride + i], S[(C_QUAT + 1) * stride + i],
+                          S[(C_QUAT + 2) * stride + i], S[(C_QUAT + 3) * stride + i] };
+        const M3<T> R = quat_to_R(q);
+        const T s[3] = { S[(C_SIDES + 0) * stride + i], S[(C_SIDES + 1) * stride + i], S[(C_SIDES + 2) * stride + i] };
+        for (int a = 0; a < 3; a++)
+            r[a] = T(0.5) * (tabs(R.m[a][0] * s[0]) + tabs(R.m[a][1] * s[1]) + tabs(R.m[a][2] * s[2]));
+    }
+    for (int a = 0; a < 3; a++) { lo[a] = p[a] - r[a]; hi[a] = p[a] + r[a]; }
+}
+
+// exact pair search: (i,j), i active, i<j or j a ghost slot, AABBs overlap
+template <class T>
+__global__ __launch_bounds__(256) void bp_pairs(const T *__restrict__ S, const uint8_t *__restrict__ gtype,
+                                                int64_t stride, int64_t n_active, GridParams<T> G,
+                                                int32_t *__restrict__ pairs, int max_pairs,
+                                                uint8_t *__restrict__ inpair)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_active || gtype[i] == GEOM_NONE) return;
+    T lo[3], hi[3];
+    body_aabb<T>(S, gtype, stride, i, lo, hi);
+    const int ix = (int)floor((double)(S[(C_POS + 0) * stride + i] * G.inv_cell));
+    const int iz = (int)floor((double)(S[(C_POS + 2) * stride + i] * G.inv_cell));
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dx = -1; dx <= 1; dx++) {
+            const uint32_t h = cell_hash(ix + dx, iz + dz, G.mask);
+            uint32_t cnt = G.count[h];
+            if (cnt > (uint32_t)G.cap) cnt = (uint32_t)G.cap;
+            for (uint32_t s = 0; s < cnt; s++) {
+                const int64_t j = G.items[(size_t)h * G.cap + s];
+                if (j <= i) continue;                       // each unordered pair once
+                // hashed buckets can mix columns: keep only true 3x3 neighbours so (i,j) is met in one cell only
+                const int jx = (int)floor((double)(S[(C_POS + 0) * stride + j] * G.inv_cell));
+                const int jz = (int)floor((double)(S[(C_POS + 2) * stride + j] * G.inv_cell));
+                if (jx != ix + dx || jz != iz + dz) continue;
+                T lo2[3], hi2[3];
+                body_aabb<T>(S, gtype, stride, j, lo2, hi2);
+                if (lo2[0] > hi[0] || lo[0] > hi2[0] || lo2[1] > hi[1] || lo[1] > hi2[1] || lo2[2] > hi[2] || lo[2] > hi2[2])
+                    continue;
+                const uint32_t k = atomicAdd(&G.flags[BPF_NPAIRS], 1u);
+                if (k < (uint32_t)max_pairs) { pairs[2 * k] = (int32_t)i; pairs[2 * k + 1] = (int32_t)j; }
+                inpair[i] = 1; inpair[j] = 1;
+            }
+        }
+}
+
+static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+template <class T>
+hipError_t launch_bp_insert(const T *S, const uint8_t *gtype, int64_t stride, int64_t n, const GridParams<T> &G, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL((bp_insert<T>), dim3(nblk(n)), dim3(256), 0, st, S, gtype, stride, n, G);
+    return hipGetLastError();
+}
+template <class T>
+hipError_t launch_bp_safe_zone(T *S, const uint8_t *gtype, int64_t stride, int64_t n_active, const GridParams<T> &G, hipStream_t st)
+{
+    if (n_active <= 0) return hipSuccess;
+    hipLaunchKernelGGL((bp_safe_zone<T>), dim3(nblk(n_active)), dim3(256), 0, st, S, gtype, stride, n_active, G);
+    return hipGetLastError();
+}
+template <class T>
+hipError_t launch_bp_pairs(const T *S, const uint8_t *gtype, int64_t stride, int64_t n_active, const GridParams<T> &G,
+                           int32_t *pairs, int max_pairs, uint8_t *inpair, hipStream_t st)
+{
+    if (n_active <= 0) return hipSuccess;
+    hipLaunchKernelGGL((bp_pairs<T>), dim3(nblk(n_active)), dim3(256), 0, st, S, gtype, stride, n_active, G, pairs, max_pairs, inpair);
+    return hipGetLastError();
+}
+
+#define DMX_BP_INST(T)                                                                                              \
+    template hipError_t launch_bp_insert<T>(const T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, hipStream_t); \
+    template hipError_t launch_bp_safe_zone<T>(T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, hipStream_t);    \
+    template hipError_t launch_bp_pairs<T>(const T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, int32_t *,     \
+                                           int, uint8_t *, hipStream_t);
+DMX_BP_INST(float)
+DMX_BP_INST(double)
+
+}  // namespace dmx

@@ -1,0 +1,283 @@
+// dmx_general.cpp -- the batch tick with body-body collision handling (dSpaceCollide for body pairs,
+// /root/reference/src/main.c:212, then dWorldStep over whatever islands result).
+//
+// Fast mode (the normal case for the BASELINE scenes): every body carries a broadphase safe zone -- half
+// the horizontal gap to its nearest neighbour's bounding sphere at build time.  While every body is inside
+// its zone no two bounding spheres can touch, so the tick's body-pair set is provably empty and the fused
+// single-body-island kernels are exact; the 3-real check rides inside those kernels.  Ticks are enqueued in
+// chunks with no host round trip; the violation flag is read once per chunk.
+//
+// Careful mode (a body left its zone, or bodies are crowded): the chunk is rolled back to its snapshot and
+// replayed tick by tick: exact device pair search (bp_insert + bp_pairs) -> pair count to the host -> for
+// bodies in pairs, host narrowphase (the same __host__ __device__ colliders) + island grouping, solved on
+// the device by solve_islands; every other body takes the fused kernel with those bodies masked out.
+// Both modes give the same bits as the sequential CPU oracle.
+#include <string.h>
+#include <algorithm>
+#include <cmath>
+
+#include "dmx_batch_priv.hpp"
+#include "dmx_collide.hpp"
+
+namespace {
+
+constexpr int kChunk = 32;          // ticks between violation-flag reads in fast mode
+constexpr int kBucketCap = 8;
+constexpr double kSkin = 1.25;      // cell = kSkin * largest bounding-sphere diameter
+
+template <class T> GridParams<T> grid_of(dmxBatch *b)
+{
+    GridParams<T> G;
+    G.r_max = (T)b->bp_rmax;
+    G.cell = (T)(2.0 * kSkin * b->bp_rmax);
+    G.inv_cell = T(1) / G.cell;
+    G.mask = b->bp_mask;
+    G.cap = b->bp_cap;
+    G.count = (uint32_t *)b->bp_count.p;
+    G.items = (int32_t *)b->bp_items.p;
+    G.flags = (uint32_t *)b->bp_flags.p;
+    return G;
+}
+
+int read_flags(dmxBatch *b)
+{
+    HIP_TRY(hipMemcpyAsync(b->bp_flags_host, b->bp_flags.p, BPF_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return DMX_OK;
+}
+
+int ensure_buffers(dmxBatch *b)
+{
+    if (b->bp_rmax <= 0) {
+        double r = 0;
+        for (int64_t i = 0; i < b->n; i++) {
+            const double *s = &b->h_sides[(size_t)3 * i];
+            const double ri = b->h_gtype[(size_t)i] == GEOM_SPHERE ? s[0]
+                            : b->h_gtype[(size_t)i] == GEOM_BOX ? 0.5 * std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]) : 0.0;
+            r = std::max(r, ri);
+        }
+        b->bp_rmax = r > 0 ? r : 1.0;
+    }
+    if (!b->bp_mask) {
+        uint32_t h = 1024;
+        while ((int64_t)h < 2 * b->n) h <<= 1;
+        b->bp_mask = h - 1;
+        b->bp_cap = kBucketCap;
+        b->bp_max_pairs = (int)std::min<int64_t>(4 * b->n + 1024, 1 << 24);
+    }
+    int rc;
+    const size_t tbl = (size_t)b->bp_mask + 1;
+    if ((rc = dmx_ensure_dev(b->bp_count, tbl * sizeof(uint32_t))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->bp_items, tbl * (size_t)b->bp_cap * sizeof(int32_t))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->bp_flags, 64)) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->bp_pairs, (size_t)b->bp_max_pairs * 2 * sizeof(int32_t))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->bp_inpair, (size_t)b->stride)) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->bp_snapshot, (size_t)C_MASS * b->stride * b->rsize)) != DMX_OK) return rc;
+    if (!b->bp_flags_host) HIP_TRY(hipHostMalloc((void **)&b->bp_flags_host, 64));
+    return DMX_OK;
+}
+
+template <class T> int fill_grid(dmxBatch *b)
+{
+    const GridParams<T> G = grid_of<T>(b);
+    HIP_TRY(hipMemsetAsync(b->bp_count.p, 0, ((size_t)b->bp_mask + 1) * sizeof(uint32_t), b->stream));
+    HIP_TRY(hipMemsetAsync(b->bp_flags.p, 0, BPF_COUNT * sizeof(uint32_t), b->stream));
+    HIP_TRY(launch_bp_insert<T>((const T *)b->slab, b->gtype, b->stride, b->n, G, b->stream));   // ghosts included
+    return DMX_OK;
+}
+
+// (re)build every body's safe zone from the current poses
+template <class T> int build_safe_zones(dmxBatch *b)
+{
+    int rc = ensure_buffers(b);
+    if (rc != DMX_OK) return rc;
+    if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
+    HIP_TRY(launch_bp_safe_zone<T>((T *)b->slab, b->gtype, b->stride, b->n_active, grid_of<T>(b), b->stream));
+    if ((rc = read_flags(b)) != DMX_OK) return rc;
+    if (b->bp_flags_host[BPF_OVERFLOW]) {
+        fprintf(stderr, "libode_mi355: broadphase bucket overflow (> %d bodies in one (x,z) column)\n", b->bp_cap);
+        return DMX_ECAPACITY;
+    }
+    b->bp_crowded = b->bp_flags_host[BPF_CROWDED];
+    b->bp_valid = true;
+    b->stat_rebuilds++;
+    return DMX_OK;
+}
+
+template <class T> int fused_tick(dmxBatch *b, double h, bool check, const uint8_t *skip)
+{
+    StepParams<T> P = dmx_make_params<T>(b, h);
+    P.bp_check = check ? 1 : 0;
+    P.bp_flags = (uint32_t *)b->bp_flags.p;
+    P.skip = skip;
+    HIP_TRY(launch_step<T>((T *)b->slab, b->gtype, b->stride, b->n_active, P, b->ext_pending, b->diag, b->stream));
+    b->ext_pending = false;
+    return DMX_OK;
+}
+
+// one exact tick: device pair search, then islands for bodies in pairs, fused kernel for the rest
+template <class T> int careful_tick(dmxBatch *b, double h)
+{
+    int rc;
+    if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
+    HIP_TRY(hipMemsetAsync(b->bp_inpair.p, 0, (size_t)b->stride, b->stream));
+    HIP_TRY(launch_bp_pairs<T>((const T *)b->slab, b->gtype, b->stride, b->n_active, grid_of<T>(b),
+                               (int32_t *)b->bp_pairs.p, b->bp_max_pairs, (uint8_t *)b->bp_inpair.p, b->stream));
+    if ((rc = read_flags(b)) != DMX_OK) return rc;
+    if (b->bp_flags_host[BPF_OVERFLOW]) {
+        fprintf(stderr, "libode_mi355: broadphase bucket overflow (> %d bodies in one (x,z) column)\n", b->bp_cap);
+        return DMX_ECAPACITY;
+    }
+    const uint32_t np = b->bp_flags_host[BPF_NPAIRS];
+    b->last_pairs = np;
+    b->stat_careful_ticks++;
+    if (np == 0) {
+        b->last_mixed = false;
+        return fused_tick<T>(b, h, false, nullptr);
+    }
+    if ((int64_t)np > b->bp_max_pairs) {
+        fprintf(stderr, "libode_mi355: %u body pairs exceed the pair buffer (%d)\n", np, b->bp_max_pairs);
+        return DMX_ECAPACITY;
+    }
+    b->stat_pair_ticks++;
+
+    // ---- pairs and the bodies in them, canonical order (ascending i, then j) ---------------------------
+    std::vector<int32_t> pr((size_t)2 * np);
+    HIP_TRY(hipMemcpyAsync(pr.data(), b->bp_pairs.p, pr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    std::vector<std::pair<int32_t, int32_t>> pairs(np);
+    for (uint32_t k = 0; k < np; k++) pairs[k] = { pr[2 * k], pr[2 * k + 1] };
+    std::sort(pairs.begin(), pairs.end());
+    std::vector<int32_t> inv;
+    inv.reserve((size_t)2 * np);
+    for (auto &p : pairs) { inv.push_back(p.first); inv.push_back(p.second); }
+    std::sort(inv.begin(), inv.end());
+    inv.erase(std::unique(inv.begin(), inv.end()), inv.end());
+    const int64_t ninv = (int64_t)inv.size();
+
+    // ---- their current state (13 reals each) to the host -------------------------------------------------
+    if ((rc = dmx_ensure_dev(b->bp_idx, (size_t)ninv * sizeof(int32_t))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->bp_gather, (size_t)ninv * C_MASS * sizeof(T))) != DMX_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(b->bp_idx.p, inv.data(), (size_t)ninv * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(launch_gather<T>((const T *)b->slab, b->stride, (const int32_t *)b->bp_idx.p, ninv, (T *)b->bp_gather.p, b->stream));
+    std::vector<T> st((size_t)ninv * C_MASS);
+    HIP_TRY(hipMemcpyAsync(st.data(), b->bp_gather.p, st.size() * sizeof(T), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+
+    struct Pose { V3<T> x; M3<T> R; T side[3]; int gt; };
+    std::vector<Pose> pose((size_t)ninv);
+    std::vector<uint8_t> include((size_t)b->n, 0);
+    for (int64_t k = 0; k < ninv; k++) {
+        const T *s = &st[(size_t)k * C_MASS];
+        Pose &p = pose[(size_t)k];
+        p.x = { s[0], s[1], s[2] };
+        p.R = quat_to_R(Q4<T>{ s[3], s[4], s[5], s[6] });
+        const int32_t id = inv[(size_t)k];
+        for (int a = 0; a < 3; a++) p.side[a] = (T)b->h_sides[(size_t)3 * id + a];
+        p.gt = b->h_gtype[(size_t)id];
+        include[(size_t)id] = 1;
+    }
+    auto pose_of = [&](int32_t id) -> const Pose & {
+        return pose[(size_t)(std::lower_bound(inv.begin(), inv.end(), id) - inv.begin())];
+    };
+
+    // ---- the tick's contact joints for those bodies, in creation order: ground-plane contacts by body,
+    //      then body pairs (what NearCallback would have created, main.c:674-693) --------------------------
+    std::vector<dmxContactJoint> joints;
+    auto push = [&](const V3<T> &pos, const V3<T> &nrm, T depth, int32_t b1, int32_t b2) {
+        dmxContactJoint j;
+        j.pos[0] = pos.x; j.pos[1] = pos.y; j.pos[2] = pos.z;
+        j.normal[0] = nrm.x; j.normal[1] = nrm.y; j.normal[2] = nrm.z;
+        j.depth = depth; j.body1 = b1; j.body2 = b2;
+        j.mode = b->surf_mode; j.mu = b->mu; j.bounce = b->bounce; j.bounce_vel = b->bounce_vel;
+        j.soft_erp = 0; j.soft_cfm = 0;
+        joints.push_back(j);
+    };
+    if (b->plane_on) {
+        T pl[4];
+        dmx_normalize_plane<T>(b->plane, pl);
+        const V3<T> pn = { pl[0], pl[1], pl[2] };
+        for (int64_t k = 0; k < ninv; k++) {
+            const Pose &p = pose[(size_t)k];
+            V3<T> cp[4]; T cd[4];
+            int nc = 0;
+            if (p.gt == GEOM_BOX) nc = box_plane(p.x, p.R, p.side, pn, pl[3], b->max_contacts, cp, cd);
+            else if (p.gt == GEOM_SPHERE) nc = sphere_plane(p.x, p.side[0], pn, pl[3], cp, cd);
+            for (int c = 0; c < nc; c++) push(cp[c], pn, cd[c], inv[(size_t)k], -1);
+        }
+    }
+    for (auto &pq : pairs) {
+        const Pose &A = pose_of(pq.first), &B = pose_of(pq.second);
+        ContactPoint<T> c[8];
+        int nc = 0;
+        bool flip = false;       // collider exists only for the swapped class order: swap, then negate the normal
+        if (A.gt == GEOM_BOX && B.gt == GEOM_BOX) nc = box_box(A.x, A.R, A.side, B.x, B.R, B.side, b->max_contacts, c);
+        else if (A.gt == GEOM_SPHERE && B.gt == GEOM_SPHERE) nc = sphere_sphere(A.x, A.side[0], B.x, B.side[0], c);
+        else if (A.gt == GEOM_SPHERE && B.gt == GEOM_BOX) nc = sphere_box(A.x, A.side[0], B.x, B.R, B.side, c);
+        else if (A.gt == GEOM_BOX && B.gt == GEOM_SPHERE) { nc = sphere_box(B.x, B.side[0], A.x, A.R, A.side, c); flip = true; }
+        if (nc > b->max_contacts) nc = b->max_contacts;
+        for (int k = 0; k < nc; k++) {
+            const V3<T> nrm = flip ? V3<T>{ -c[k].normal.x, -c[k].normal.y, -c[k].normal.z } : c[k].normal;
+            push(c[k].pos, nrm, c[k].depth, pq.first, pq.second);
+        }
+    }
+
+    // ---- islands of the bodies in pairs on the device; everyone else through the fused kernel -------------
+    if ((rc = dmx_step_joints(b, h, (int64_t)joints.size(), joints.data(), include.data())) != DMX_OK) return rc;
+    if ((rc = fused_tick<T>(b, h, false, (const uint8_t *)b->bp_inpair.p)) != DMX_OK) return rc;
+    b->last_islands = false;
+    b->last_mixed = true;
+    b->stepped_with_plane = true;
+    return DMX_OK;
+}
+
+template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
+{
+    int rc;
+    int remaining = nsteps;
+    while (remaining > 0) {
+        if (b->ext_pending) {
+            // freshly applied dBodyAddForce / AddTorque accumulators are consumed (and cleared) by exactly one tick:
+            // take that tick on the exact path so a rolled-back chunk can never lose them
+            if ((rc = ensure_buffers(b)) != DMX_OK) return rc;
+            if ((rc = careful_tick<T>(b, h)) != DMX_OK) return rc;
+            b->bp_valid = false;
+            remaining--;
+            continue;
+        }
+        if (!b->bp_valid && (rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
+        const int k = std::min(remaining, kChunk);
+        bool careful = b->bp_crowded > 0;
+        if (!careful) {
+            // fast chunk: snapshot, k fused ticks with the safe-zone check riding along, one flag read
+            HIP_TRY(hipMemcpyAsync(b->bp_snapshot.p, b->slab, (size_t)C_MASS * b->stride * b->rsize, hipMemcpyDeviceToDevice, b->stream));
+            for (int s = 0; s < k; s++)
+                if ((rc = fused_tick<T>(b, h, true, nullptr)) != DMX_OK) return rc;
+            if ((rc = read_flags(b)) != DMX_OK) return rc;
+            if (!b->bp_flags_host[BPF_VIOLATION]) {
+                b->stat_fast_ticks += k;
+                b->last_pairs = 0;
+                b->last_mixed = false;
+                remaining -= k;
+                continue;
+            }
+            // some body left its zone during the chunk: roll back and replay exactly
+            HIP_TRY(hipMemcpyAsync(b->slab, b->bp_snapshot.p, (size_t)C_MASS * b->stride * b->rsize, hipMemcpyDeviceToDevice, b->stream));
+            careful = true;
+        }
+        for (int s = 0; s < k; s++)
+            if ((rc = careful_tick<T>(b, h)) != DMX_OK) return rc;
+        b->bp_valid = false;           // poses moved: new safe zones before the next fast chunk
+        remaining -= k;
+    }
+    b->stepped_with_plane = b->plane_on != 0 || b->last_mixed;
+    b->last_islands = false;
+    return DMX_OK;
+}
+
+}  // namespace
+
+int dmx_step_collide(dmxBatch *b, double h, int nsteps)
+{
+    return b->precision == DMX_F32 ? step_collide_t<float>(b, h, nsteps) : step_collide_t<double>(b, h, nsteps);
+}

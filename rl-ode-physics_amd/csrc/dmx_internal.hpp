@@ -19,7 +19,10 @@ enum : int {
     C_SIDES = 17,    // 3
     C_FORCE = 20,    // 3   -- external accumulators, cleared by the step
     C_TORQUE = 23,   // 3
-    C_COUNT = 26
+    C_BPX = 26,      // broadphase safe zone: build position x, z and radius (see dmx_broadphase.hip)
+    C_BPZ = 27,
+    C_BPSAFE = 28,
+    C_COUNT = 29
 };
 
 enum : int { GEOM_NONE = 0, GEOM_SPHERE = 1, GEOM_BOX = 2 };
@@ -57,6 +60,20 @@ template <class T> struct StepParams {
     int max_contacts;
     int vec;            // launch tuning: bodies per lane in integrate_free (0 = 16 B per lane)
     int variant;        // launch tuning: step_plane variant (0 = default)
+    int bp_check;       // 1: test every body against its broadphase safe zone (pre-step position)
+    uint32_t *bp_flags; // device flags (BPF_*), written when a body has left its safe zone
+    const uint8_t *skip; // per-body: 1 = stepped by the island path this tick, leave untouched (may be null)
+};
+
+// hashed (x,z)-column grid of the body-body broadphase
+enum : int { BPF_OVERFLOW = 0, BPF_CROWDED = 1, BPF_NPAIRS = 2, BPF_VIOLATION = 3, BPF_COUNT = 4 };
+template <class T> struct GridParams {
+    T cell, inv_cell, r_max;
+    uint32_t mask;         // table size - 1 (power of two)
+    int cap;               // bodies per bucket
+    uint32_t *count;       // [mask+1]
+    int32_t *items;        // [(mask+1) * cap]
+    uint32_t *flags;       // [BPF_COUNT]
 };
 
 struct StepDiag {
@@ -70,6 +87,13 @@ hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, co
 template <class T>
 hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
                           StepDiag *diag, hipStream_t st);
+template <class T>
+hipError_t launch_bp_insert(const T *S, const uint8_t *gtype, int64_t stride, int64_t n, const GridParams<T> &G, hipStream_t st);
+template <class T>
+hipError_t launch_bp_safe_zone(T *S, const uint8_t *gtype, int64_t stride, int64_t n_active, const GridParams<T> &G, hipStream_t st);
+template <class T>
+hipError_t launch_bp_pairs(const T *S, const uint8_t *gtype, int64_t stride, int64_t n_active, const GridParams<T> &G,
+                           int32_t *pairs, int max_pairs, uint8_t *inpair, hipStream_t st);
 template <class T>
 hipError_t launch_pack_transforms(const T *S, int64_t stride, int64_t first, int64_t count, T *out, hipStream_t st);
 template <class T>

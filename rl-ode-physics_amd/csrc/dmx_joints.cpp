@@ -30,7 +30,8 @@ int ensure_pinned(void **p, size_t *have, size_t bytes)
     return DMX_OK;
 }
 
-template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const dmxContactJoint *joints)
+template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const dmxContactJoint *joints,
+                                     const uint8_t *include)
 {
     const int n = (int)b->n;
     // previous tick's async copies read the pinned staging buffers: drain before refilling
@@ -40,7 +41,8 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     struct CJ { int b1, b2; const dmxContactJoint *j; bool rev; };
     std::vector<CJ> cj;
     cj.reserve((size_t)nj_in);
-    auto live = [&](int s) { return s >= 0 && s < n && (b->h_bflags[(size_t)s] & BF_ALIVE); };
+    // `include` (optional) restricts the tick to a subset of bodies: the rest is stepped by the fused kernels
+    auto live = [&](int s) { return s >= 0 && s < n && (b->h_bflags[(size_t)s] & BF_ALIVE) && (!include || include[s]); };
     for (int64_t k = 0; k < nj_in; k++) {
         const dmxContactJoint &j = joints[k];
         int b1 = live(j.body1) ? j.body1 : -1, b2 = live(j.body2) ? j.body2 : -1;
@@ -58,13 +60,13 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     std::vector<int> island_of((size_t)n, -1);
     int ni = 0, nlive = 0;
     for (int s = 0; s < n; s++) {
-        if (!(b->h_bflags[(size_t)s] & BF_ALIVE)) continue;
+        if (!live(s)) continue;
         nlive++;
         const int r = uf.find(s);             // roots are the lowest slot of their component
         if (r == s) island_of[(size_t)s] = ni++;
     }
     for (int s = 0; s < n; s++)
-        if ((b->h_bflags[(size_t)s] & BF_ALIVE) && island_of[(size_t)s] < 0) island_of[(size_t)s] = island_of[(size_t)uf.find(s)];
+        if (live(s) && island_of[(size_t)s] < 0) island_of[(size_t)s] = island_of[(size_t)uf.find(s)];
 
     // int staging: body_off[ni+1] bodies[nlive] con_off[ni+1] row_off[ni+1] cb1[nc] cb2[nc] cmode[nc]
     const size_t n_int = (size_t)3 * (ni + 1) + (size_t)nlive + (size_t)3 * nc;
@@ -137,10 +139,15 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
 
 }  // namespace
 
+int dmx_step_joints(dmxBatch *b, double h, int64_t n_joints, const dmxContactJoint *joints, const uint8_t *include)
+{
+    return b->precision == DMX_F32 ? step_joints_t<float>(b, h, n_joints, joints, include)
+                                   : step_joints_t<double>(b, h, n_joints, joints, include);
+}
+
 extern "C" int dmxBatchStepJoints(dmxBatchID b, double h, int64_t n_joints, const dmxContactJoint *joints)
 {
     if (!b || !(h > 0) || n_joints < 0 || (n_joints > 0 && !joints)) return DMX_EINVAL;
     HIP_TRY(hipSetDevice(b->device));
-    return b->precision == DMX_F32 ? step_joints_t<float>(b, h, n_joints, joints)
-                                   : step_joints_t<double>(b, h, n_joints, joints);
+    return dmx_step_joints(b, h, n_joints, joints, nullptr);
 }

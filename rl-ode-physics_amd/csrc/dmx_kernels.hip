@@ -73,9 +73,22 @@ __global__ __launch_bounds__(256) void integrate_free(T *__restrict__ S, int64_t
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nvec;
          t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = t * V;
+        if (V == 1 && P.skip != nullptr && P.skip[i]) continue;      // this body belongs to the island path this tick
         Pack<T, V> c[C_SIDES];
 #pragma unroll
         for (int k = 0; k < C_SIDES; k++) c[k] = ldv<T, V>(S, stride, k, i);
+        if (P.bp_check) {
+            // dSpaceCollide for body-body pairs, by proof: a body inside its safe zone cannot touch any other
+            const Pack<T, V> bx = ldv<T, V>(S, stride, C_BPX, i), bz = ldv<T, V>(S, stride, C_BPZ, i),
+                             bs = ldv<T, V>(S, stride, C_BPSAFE, i);
+            bool out = false;
+#pragma unroll
+            for (int b = 0; b < V; b++) {
+                const T dx = c[C_POS].v[b] - bx.v[b], dz = c[C_POS + 2].v[b] - bz.v[b];
+                out |= !(dx * dx + dz * dz < bs.v[b] * bs.v[b]);
+            }
+            if (__ballot(out) != 0ull && out) atomicOr(&P.bp_flags[BPF_VIOLATION], 1u);
+        }
         Pack<T, V> f[6];
         if (EXT) {
 #pragma unroll
@@ -135,8 +148,12 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     int my_contacts = 0;
     double my_resid = 0.0;
-    if (i < n) {
+    if (i < n && !(P.skip != nullptr && P.skip[i])) {
         V3<T> x = { S[(C_POS + 0) * stride + i], S[(C_POS + 1) * stride + i], S[(C_POS + 2) * stride + i] };
+        if (P.bp_check) {
+            const T dx = x.x - S[C_BPX * stride + i], dz = x.z - S[C_BPZ * stride + i], sf = S[C_BPSAFE * stride + i];
+            if (!(dx * dx + dz * dz < sf * sf)) atomicOr(&P.bp_flags[BPF_VIOLATION], 1u);
+        }
         Q4<T> q = { S[(C_QUAT + 0) * stride + i], S[(C_QUAT + 1) * stride + i],
                     S[(C_QUAT + 2) * stride + i], S[(C_QUAT + 3) * stride + i] };
         V3<T> v = { S[(C_LVEL + 0) * stride + i], S[(C_LVEL + 1) * stride + i], S[(C_LVEL + 2) * stride + i] };
@@ -398,7 +415,7 @@ hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, co
 {
     if (!P.plane_on) {
         constexpr int VMAX = 16 / sizeof(T);
-        const int V = (P.vec == 1 || P.vec == 2 || P.vec == VMAX) ? P.vec : VMAX;
+        const int V = P.skip != nullptr ? 1 : (P.vec == 1 || P.vec == 2 || P.vec == VMAX) ? P.vec : VMAX;
         const int64_t nvec = (n + V - 1) / V;     // pad bodies up to `stride` are valid memory
         const unsigned grid = blocks_for(nvec, 256);
 #define DMX_LAUNCH_FREE(VV)                                                                                      \
