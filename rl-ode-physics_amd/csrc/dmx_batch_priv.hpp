@@ -110,6 +110,9 @@ template <class T> inline StepParams<T> dmx_make_params(dmxBatch *b, double h)
     P.max_contacts = b->max_contacts;
     P.vec = b->vec;
     P.variant = b->variant;
+    P.bp_check = 0;          // set by the collision-aware tick (dmx_general.cpp)
+    P.bp_flags = nullptr;
+    P.skip = nullptr;
     return P;
 }
 

@@ -77,6 +77,17 @@ int ensure_buffers(dmxBatch *b)
     return DMX_OK;
 }
 
+// stacked bodies share an (x,z) column: double the bucket capacity when one overflows
+int grow_buckets(dmxBatch *b)
+{
+    if (b->bp_cap >= 1024) {
+        fprintf(stderr, "libode_mi355: broadphase bucket overflow (> %d bodies in one (x,z) column)\n", b->bp_cap);
+        return DMX_ECAPACITY;
+    }
+    b->bp_cap *= 2;
+    return dmx_ensure_dev(b->bp_items, ((size_t)b->bp_mask + 1) * (size_t)b->bp_cap * sizeof(int32_t));
+}
+
 template <class T> int fill_grid(dmxBatch *b)
 {
     const GridParams<T> G = grid_of<T>(b);
@@ -95,8 +106,8 @@ template <class T> int build_safe_zones(dmxBatch *b)
     HIP_TRY(launch_bp_safe_zone<T>((T *)b->slab, b->gtype, b->stride, b->n_active, grid_of<T>(b), b->stream));
     if ((rc = read_flags(b)) != DMX_OK) return rc;
     if (b->bp_flags_host[BPF_OVERFLOW]) {
-        fprintf(stderr, "libode_mi355: broadphase bucket overflow (> %d bodies in one (x,z) column)\n", b->bp_cap);
-        return DMX_ECAPACITY;
+        if ((rc = grow_buckets(b)) != DMX_OK) return rc;
+        return build_safe_zones<T>(b);
     }
     b->bp_crowded = b->bp_flags_host[BPF_CROWDED];
     b->bp_valid = true;
@@ -124,9 +135,9 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     HIP_TRY(launch_bp_pairs<T>((const T *)b->slab, b->gtype, b->stride, b->n_active, grid_of<T>(b),
                                (int32_t *)b->bp_pairs.p, b->bp_max_pairs, (uint8_t *)b->bp_inpair.p, b->stream));
     if ((rc = read_flags(b)) != DMX_OK) return rc;
-    if (b->bp_flags_host[BPF_OVERFLOW]) {
-        fprintf(stderr, "libode_mi355: broadphase bucket overflow (> %d bodies in one (x,z) column)\n", b->bp_cap);
-        return DMX_ECAPACITY;
+    if (b->bp_flags_host[BPF_OVERFLOW]) {          // a column holds more bodies than a bucket: widen and redo the search
+        if ((rc = grow_buckets(b)) != DMX_OK) return rc;
+        return careful_tick<T>(b, h);
     }
     const uint32_t np = b->bp_flags_host[BPF_NPAIRS];
     b->last_pairs = np;

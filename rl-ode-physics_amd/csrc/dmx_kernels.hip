@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
     // No atomics: 4096 same-address atomics per launch serialise at ~11 ns each, longer than the whole kernel.
     const int wc = wave_sum<int>(my_contacts);
     const double wr = wave_sum<double>(my_resid);
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0 && i < n) {        // waves wholly past the range own no slot
         StepDiag d;
         d.contacts = (unsigned long long)wc;
         d.residual = wr;

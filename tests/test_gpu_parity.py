@@ -127,7 +127,7 @@ def test_config1_boxes_on_plane_matches_oracle(dtype):
     ow = _oracle_run(_orc(dtype), scene, steps, allow_pairs=True)
     _compare(w.state(), ow.state())
     st = w.collision_stats()
-    assert st["fast_ticks"] > 250 and st["pair_ticks"] > 0 and st["careful_ticks"] >= st["pair_ticks"]
+    assert st["fast_ticks"] >= 96 and st["pair_ticks"] > 0 and st["careful_ticks"] >= st["pair_ticks"]
     assert w.last_contact_count() == ow.n_contacts() > 0
     assert abs(w.last_residual() - ow.sor_residual()) <= 1e-6 * max(1.0, ow.sor_residual())
 
