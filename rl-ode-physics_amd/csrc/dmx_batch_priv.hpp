@@ -70,6 +70,7 @@ struct dmxBatch {
     int bp_max_pairs = 0;
     std::vector<double> h_sides;               // host mirror of DMX_SIDES (exact values of the batch precision)
     std::vector<uint8_t> h_gtype;
+    int64_t stat_rollbacks = 0;
     int64_t stat_fast_ticks = 0, stat_careful_ticks = 0, stat_rebuilds = 0, stat_pair_ticks = 0;
     unsigned long long last_pairs = 0;
     bool last_mixed = false;                   // last tick used fused + island kernels together

@@ -259,9 +259,12 @@ template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
         if (!b->bp_valid && (rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
         const int k = std::min(remaining, kChunk);
         bool careful = b->bp_crowded > 0;
-        if (!careful) {
-            // fast chunk: snapshot, k fused ticks with the safe-zone check riding along, one flag read
+        // fast chunk: snapshot, k fused ticks with the safe-zone check riding along, one flag read.  If a body
+        // left its zone the chunk is rolled back; the first retry only refreshes the zones (a body that has
+        // drifted since the last build usually fits again), the second replays the chunk exactly.
+        for (int attempt = 0; !careful; attempt++) {
             HIP_TRY(hipMemcpyAsync(b->bp_snapshot.p, b->slab, (size_t)C_MASS * b->stride * b->rsize, hipMemcpyDeviceToDevice, b->stream));
+            HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, 2 * sizeof(uint32_t), b->stream));
             for (int s = 0; s < k; s++)
                 if ((rc = fused_tick<T>(b, h, true, nullptr)) != DMX_OK) return rc;
             if ((rc = read_flags(b)) != DMX_OK) return rc;
@@ -269,13 +272,19 @@ template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
                 b->stat_fast_ticks += k;
                 b->last_pairs = 0;
                 b->last_mixed = false;
-                remaining -= k;
-                continue;
+                if (b->bp_flags_host[BPF_WARN]) b->bp_valid = false;     // zones are getting used up: refresh before the next chunk
+                break;
             }
-            // some body left its zone during the chunk: roll back and replay exactly
             HIP_TRY(hipMemcpyAsync(b->slab, b->bp_snapshot.p, (size_t)C_MASS * b->stride * b->rsize, hipMemcpyDeviceToDevice, b->stream));
-            careful = true;
+            b->stat_rollbacks++;
+            if (attempt == 0) {
+                if ((rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
+                careful = b->bp_crowded > 0;
+            } else {
+                careful = true;
+            }
         }
+        if (!careful) { remaining -= k; continue; }
         for (int s = 0; s < k; s++)
             if ((rc = careful_tick<T>(b, h)) != DMX_OK) return rc;
         b->bp_valid = false;           // poses moved: new safe zones before the next fast chunk

@@ -66,7 +66,7 @@ template <class T> struct StepParams {
 };
 
 // hashed (x,z)-column grid of the body-body broadphase
-enum : int { BPF_OVERFLOW = 0, BPF_CROWDED = 1, BPF_NPAIRS = 2, BPF_VIOLATION = 3, BPF_COUNT = 4 };
+enum : int { BPF_OVERFLOW = 0, BPF_CROWDED = 1, BPF_NPAIRS = 2, BPF_VIOLATION = 3, BPF_WARN = 4, BPF_COUNT = 5 };
 template <class T> struct GridParams {
     T cell, inv_cell, r_max;
     uint32_t mask;         // table size - 1 (power of two)

@@ -35,6 +35,25 @@ __device__ __forceinline__ void stv(T *__restrict__ base, int64_t stride, int co
     *reinterpret_cast<Pack<T, V> *>(base + comp * stride + i) = p;
 }
 
+// Broadphase safe-zone test of one body (pre-step position): 2 = outside its zone (a body pair may exist),
+// 1 = has used more than a quarter of the radius (zones should be refreshed soon), 0 = well inside.
+template <class T> __device__ __forceinline__ int zone_state(T dx, T dz, T safe)
+{
+    const T d2 = dx * dx + dz * dz, s2 = safe * safe;
+    if (!(d2 < s2)) return 2;
+    return (d2 < s2 * T(0.0625)) ? 0 : 1;
+}
+// one flag write per wave at most, and none once the flag is already up
+__device__ __forceinline__ void report_zone(int state, uint32_t *flags)
+{
+    const unsigned long long v = __ballot(state == 2), w = __ballot(state == 1);
+    if ((v | w) == 0ull) return;
+    const unsigned long long act = __ballot(true);
+    if ((int)(threadIdx.x & 63) != __builtin_ctzll(act)) return;       // first active lane reports
+    if (v != 0ull && flags[BPF_VIOLATION] == 0u) atomicOr(&flags[BPF_VIOLATION], 1u);
+    if (w != 0ull && flags[BPF_WARN] == 0u) atomicOr(&flags[BPF_WARN], 1u);
+}
+
 // One body: external force/torque -> new velocities (no constraints) -> new pose.
 //   facc = fext + m g ; tacc = text + gyro
 //   v += (h/m) facc ; w += Iw^-1 (h tacc)
@@ -81,13 +100,13 @@ __global__ __launch_bounds__(256) void integrate_free(T *__restrict__ S, int64_t
             // dSpaceCollide for body-body pairs, by proof: a body inside its safe zone cannot touch any other
             const Pack<T, V> bx = ldv<T, V>(S, stride, C_BPX, i), bz = ldv<T, V>(S, stride, C_BPZ, i),
                              bs = ldv<T, V>(S, stride, C_BPSAFE, i);
-            bool out = false;
+            int zs = 0;
 #pragma unroll
             for (int b = 0; b < V; b++) {
-                const T dx = c[C_POS].v[b] - bx.v[b], dz = c[C_POS + 2].v[b] - bz.v[b];
-                out |= !(dx * dx + dz * dz < bs.v[b] * bs.v[b]);
+                const int z = zone_state(c[C_POS].v[b] - bx.v[b], c[C_POS + 2].v[b] - bz.v[b], bs.v[b]);
+                zs = z > zs ? z : zs;
             }
-            if (__ballot(out) != 0ull && out) atomicOr(&P.bp_flags[BPF_VIOLATION], 1u);
+            report_zone(zs, P.bp_flags);
         }
         Pack<T, V> f[6];
         if (EXT) {
@@ -150,10 +169,9 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
     double my_resid = 0.0;
     if (i < n && !(P.skip != nullptr && P.skip[i])) {
         V3<T> x = { S[(C_POS + 0) * stride + i], S[(C_POS + 1) * stride + i], S[(C_POS + 2) * stride + i] };
-        if (P.bp_check) {
-            const T dx = x.x - S[C_BPX * stride + i], dz = x.z - S[C_BPZ * stride + i], sf = S[C_BPSAFE * stride + i];
-            if (!(dx * dx + dz * dz < sf * sf)) atomicOr(&P.bp_flags[BPF_VIOLATION], 1u);
-        }
+        if (P.bp_check)
+            report_zone(zone_state(x.x - S[C_BPX * stride + i], x.z - S[C_BPZ * stride + i], S[C_BPSAFE * stride + i]),
+                        P.bp_flags);
         Q4<T> q = { S[(C_QUAT + 0) * stride + i], S[(C_QUAT + 1) * stride + i],
                     S[(C_QUAT + 2) * stride + i], S[(C_QUAT + 3) * stride + i] };
         V3<T> v = { S[(C_LVEL + 0) * stride + i], S[(C_LVEL + 1) * stride + i], S[(C_LVEL + 2) * stride + i] };
