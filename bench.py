@@ -35,12 +35,23 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--side", type=int, default=0, help="grid side (bodies = side^2 per GPU); 0 = config default")
     ap.add_argument("--exchange", default="boundary", choices=["boundary", "none"])
-    ap.add_argument("--graph-steps", type=int, default=10, help="ticks per captured HIP graph when exchanging (0 = eager)")
+    ap.add_argument("--graph-steps", type=int, default=0, help="ticks per captured HIP graph when exchanging (0 = eager)")
+    ap.add_argument("--no-body-collisions", action="store_true", help="skip the body-body broadphase proof (caller asserts single-body islands)")
     ap.add_argument("--force-exchange", action="store_true", help="run the exchange path even with one rank (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gyro", type=int, default=2, choices=[0, 1, 2], help="0 off, 1 explicit, 2 implicit (ODE default)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
+
+
+def pmc_traffic(kind, dtype, n):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), if one
+    exists for this workload: (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md."""
+    path = os.path.join(ROOT, "profiles", f"hbm_pmc_{kind}_{dtype}_{n}.json")
+    try:
+        return json.load(open(path))["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(pkg, scene, dtype, kind, budget_s):
@@ -105,6 +116,8 @@ def main():
     if exchanging:
         w.set_active_count(scene.n)         # the slots behind are ghosts of the neighbours' boundary rows
     w.set_gyro_mode(a.gyro)
+    if a.no_body_collisions or exchanging:
+        w.set_body_collisions(False)        # the sharded range stepper does not carry the safe-zone check yet
     stream = torch.cuda.Stream()            # a real (non-null) stream: the batch launches on it and the
     torch.cuda.set_stream(stream)           # timing events below are recorded on it, so they bracket the kernels
     assert stream.cuda_stream != 0
@@ -148,6 +161,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    stats = w.collision_stats()
     total_bodies = scene.n * world
     value = total_bodies * a.steps / dt
     kernel_s = dev_ms * 1e-3 / a.steps                       # average launch duration, HIP events on the launch stream
@@ -163,10 +177,14 @@ def main():
                                   + (f"boundary rows all-gathered over RCCL every tick, overlapped with the interior"
                                      f"{', HIP-graph replay' if graphed else ''}" if stepper.exchange is not None
                                      else "no exchange (one rank)" if world == 1 else "no exchange"),
+                   "collide": ("body-body pairs: none by assertion (check off)" if (a.no_body_collisions or exchanging) else
+                               f"body-body pairs proven absent per tick by broadphase safe zones ({stats['fast_ticks']} fast ticks, "
+                               f"{stats['careful_ticks']} exact-search ticks, {stats['rebuilds']} zone rebuilds, {stats['pair_ticks']} ticks with pairs)")
+                              + ("; ground plane fused into the step kernel" if kind == "plane" else ""),
                    "integrator": "QuickStep semantics: gravity + implicit gyroscopic torque + semi-implicit Euler + "
                                  "quaternion renormalise" + ("; box-plane contacts, 20 SOR sweeps" if kind == "plane" else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kind, a.dtype, scene.n),
                      "kernel": "integrate_free" if kind == "free" else "step_plane",
                      "kernel_us": kernel_s * 1e6,
                      "algorithmic_bytes_per_body_step": BYTES_PER_BODY_STEP[kind] * rsize},

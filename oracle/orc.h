@@ -81,6 +81,7 @@ void orc_world_set_gyro_mode(orc_world *w, int mode);
 /* contact surface applied by the built-in near callback (main.c:684-687) */
 void orc_world_set_surface(orc_world *w, int mode, real mu, real bounce, real bounce_vel);
 void orc_world_set_max_contacts(orc_world *w, int n);    /* main.c:675 (8) */
+void orc_world_set_broadphase(orc_world *w, int mode);   /* 0 auto, 1 sweep, 2 grid: same pair set either way */
 void orc_rand_seed(uint32_t s);                          /* [ODE-recall] dRandSetSeed */
 
 /* bodies ----------------------------------------------------------------- */

@@ -321,13 +321,69 @@ void orc_collide_all(orc_world *w)
         for (int k = 0; k < nbb; k++)
             if (pair_passes(&w->geoms[g], &w->geoms[bb[k].g])) PUSH_PAIR(g, bb[k].g);
     }
-    /* sweep along x over the finite AABBs */
-    qsort(bb, (size_t)nbb, sizeof(aabb_t), cmp_aabb);
-    for (int i = 0; i < nbb; i++) {
-        for (int j = i + 1; j < nbb && bb[j].lo[0] <= bb[i].hi[0]; j++) {
-            if (bb[j].lo[1] > bb[i].hi[1] || bb[i].lo[1] > bb[j].hi[1]) continue;
-            if (bb[j].lo[2] > bb[i].hi[2] || bb[i].lo[2] > bb[j].hi[2]) continue;
-            if (pair_passes(&w->geoms[bb[i].g], &w->geoms[bb[j].g])) { PUSH_PAIR(bb[i].g, bb[j].g); w->last_body_pairs++; }
+    /* finite AABBs: uniform (x,z) cell grid when the scene is large and evenly sized (what ODE's hash space
+       does with its cell levels), else a sweep along x.  Both enumerate exactly the overlapping AABB pairs. */
+    int used_grid = 0;
+    if (w->bp_mode == 2 || (w->bp_mode == 0 && nbb >= 2048)) {
+        real cell = 0, minx = bb[0].lo[0], maxx = bb[0].hi[0], minz = bb[0].lo[2], maxz = bb[0].hi[2];
+        for (int i = 0; i < nbb; i++) {
+            real ex = bb[i].hi[0] - bb[i].lo[0], ez = bb[i].hi[2] - bb[i].lo[2];
+            if (ex > cell) cell = ex;
+            if (ez > cell) cell = ez;
+            if (bb[i].lo[0] < minx) minx = bb[i].lo[0];
+            if (bb[i].hi[0] > maxx) maxx = bb[i].hi[0];
+            if (bb[i].lo[2] < minz) minz = bb[i].lo[2];
+            if (bb[i].hi[2] > maxz) maxz = bb[i].hi[2];
+        }
+        double fx = cell > 0 ? ((double)maxx - minx) / cell + 1 : 0, fz = cell > 0 ? ((double)maxz - minz) / cell + 1 : 0;
+        if (cell > 0 && fx * fz <= 16.0e6 && (w->bp_mode == 2 || fx * fz >= nbb / 16.0)) {
+            int nx = (int)fx + 1, nz = (int)fz + 1;
+            size_t ncell = (size_t)nx * nz;
+            int *start = (int *)calloc(ncell + 1, sizeof(int));
+            int *cellof = (int *)malloc((size_t)nbb * sizeof(int));
+            int *order = (int *)malloc((size_t)nbb * sizeof(int));
+            real inv = R(1.0) / cell;
+            for (int i = 0; i < nbb; i++) {
+                /* bin by the AABB centre; overlapping AABBs are then at most one cell apart */
+                int ix = (int)((R(0.5) * (bb[i].lo[0] + bb[i].hi[0]) - minx) * inv);
+                int iz = (int)((R(0.5) * (bb[i].lo[2] + bb[i].hi[2]) - minz) * inv);
+                cellof[i] = iz * nx + ix;
+                start[cellof[i] + 1]++;
+            }
+            for (size_t c = 0; c < ncell; c++) start[c + 1] += start[c];
+            int *fill = (int *)malloc(ncell * sizeof(int));
+            memcpy(fill, start, ncell * sizeof(int));
+            for (int i = 0; i < nbb; i++) order[fill[cellof[i]]++] = i;
+            for (int i = 0; i < nbb; i++) {
+                int ix = cellof[i] % nx, iz = cellof[i] / nx;
+                for (int dz = -1; dz <= 1; dz++) {
+                    if (iz + dz < 0 || iz + dz >= nz) continue;
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (ix + dx < 0 || ix + dx >= nx) continue;
+                        int c = (iz + dz) * nx + ix + dx;
+                        for (int t = start[c]; t < start[c + 1]; t++) {
+                            int j = order[t];
+                            if (j <= i) continue;
+                            if (bb[j].lo[0] > bb[i].hi[0] || bb[i].lo[0] > bb[j].hi[0]) continue;
+                            if (bb[j].lo[1] > bb[i].hi[1] || bb[i].lo[1] > bb[j].hi[1]) continue;
+                            if (bb[j].lo[2] > bb[i].hi[2] || bb[i].lo[2] > bb[j].hi[2]) continue;
+                            if (pair_passes(&w->geoms[bb[i].g], &w->geoms[bb[j].g])) { PUSH_PAIR(bb[i].g, bb[j].g); w->last_body_pairs++; }
+                        }
+                    }
+                }
+            }
+            free(fill); free(order); free(cellof); free(start);
+            used_grid = 1;
+        }
+    }
+    if (!used_grid) {
+        qsort(bb, (size_t)nbb, sizeof(aabb_t), cmp_aabb);
+        for (int i = 0; i < nbb; i++) {
+            for (int j = i + 1; j < nbb && bb[j].lo[0] <= bb[i].hi[0]; j++) {
+                if (bb[j].lo[1] > bb[i].hi[1] || bb[i].lo[1] > bb[j].hi[1]) continue;
+                if (bb[j].lo[2] > bb[i].hi[2] || bb[i].lo[2] > bb[j].hi[2]) continue;
+                if (pair_passes(&w->geoms[bb[i].g], &w->geoms[bb[j].g])) { PUSH_PAIR(bb[i].g, bb[j].g); w->last_body_pairs++; }
+            }
         }
     }
     /* canonical order: ascending (g1,g2), g1 < g2 */

@@ -63,6 +63,7 @@ class Oracle:
         sig("orc_world_set_gyro_mode", None, P, C.c_int)
         sig("orc_world_set_surface", None, P, C.c_int, real, real, real)
         sig("orc_world_set_max_contacts", None, P, C.c_int)
+        sig("orc_world_set_broadphase", None, P, C.c_int)
         sig("orc_rand_seed", None, C.c_uint32)
         sig("orc_body_create", C.c_int, P)
         sig("orc_body_set_position", None, P, C.c_int, real, real, real)

@@ -45,6 +45,7 @@ struct orc_world {
     int row_order, gyro_mode;
     int surf_mode; real surf_mu, surf_bounce, surf_bounce_vel;
     int max_contacts;
+    int bp_mode;              /* broadphase: 0 auto, 1 sweep along x, 2 uniform (x,z) grid */
 
     orc_body *bodies; int nb, cap_b;
     orc_geom *geoms;  int ng, cap_g;

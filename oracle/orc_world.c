@@ -52,6 +52,7 @@ void orc_world_set_gyro_mode(orc_world *w, int mode) { w->gyro_mode = mode; }
 void orc_world_set_surface(orc_world *w, int mode, real mu, real bounce, real bounce_vel)
 { w->surf_mode = mode; w->surf_mu = mu; w->surf_bounce = bounce; w->surf_bounce_vel = bounce_vel; }
 void orc_world_set_max_contacts(orc_world *w, int n) { w->max_contacts = n; }
+void orc_world_set_broadphase(orc_world *w, int mode) { w->bp_mode = mode; }
 
 /* ---- bodies ------------------------------------------------------------ */
 int orc_body_create(orc_world *w)

@@ -295,3 +295,26 @@ def test_ode_row_order_mode_close_to_fixed(orc64):
         return w.state()
     a, b = run(oc.ORDER_FIXED), run(oc.ORDER_ODE)
     assert np.allclose(a[0], b[0], atol=5e-3)
+
+
+# ---------------------------------------------------------------- oracle broadphase variants enumerate the same pairs
+def test_grid_and_sweep_broadphase_agree(orc64):
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    s = pkg.scenes.box_grid(24, 24, seed=11, y_range=(0.8, 4.0), spin=True, box_mass=True).astype("float64")
+    s.avel *= 3.0
+
+    def run(mode):
+        w = orc64.world()
+        orc64.lib.orc_world_set_broadphase(w.w, mode)
+        w.add_plane(*s.plane)
+        w.add_boxes(s.pos, s.quat, s.lvel, s.avel, s.mass[:, 0], s.inertia, s.sides)
+        pairs = 0
+        for _ in range(300):
+            w.tick(H)
+            pairs += w.n_body_pairs()
+        return w.state(), pairs
+    (a, pa), (b, pb) = run(1), run(2)
+    assert pa == pb > 0
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
