@@ -163,3 +163,60 @@ def test_growth_beyond_512_bodies(tmp_path):
     got = _run_harness(exe, _scene_text(dt, steps, True, [], bodies))
     ref, _ = _oracle_poses("float64", dt, steps, True, [], bodies)
     assert np.array_equal(got, ref)
+
+
+# ------------------------------------------------------------------------------------------------ ODE API details (GPU)
+def _ode(single=False):
+    import ctypes as C
+    pkg._lib.load()
+    lib = C.CDLL(os.path.join(PKG, "libode_mi355_single.so" if single else "libode_mi355.so"))
+    real = C.c_float if single else C.c_double
+    P = C.c_void_p
+    for name, res, args in [
+        ("dWorldCreate", P, []), ("dWorldDestroy", None, [P]), ("dWorldSetGravity", None, [P, real, real, real]),
+        ("dWorldQuickStep", C.c_int, [P, real]), ("dBodyCreate", P, [P]), ("dBodyDestroy", None, [P]),
+        ("dBodySetPosition", None, [P, real, real, real]), ("dBodySetLinearVel", None, [P, real, real, real]),
+        ("dBodyGetPosition", C.POINTER(real), [P]), ("dBodyGetLinearVel", C.POINTER(real), [P]),
+        ("dBodyGetRotation", C.POINTER(real), [P]), ("dBodySetKinematic", None, [P]), ("dBodyAddForce", None, [P, real, real, real]),
+        ("dBodySetAngularVel", None, [P, real, real, real]),
+        ("dmxWorldSnapshotTransforms", C.c_int, [P, C.POINTER(P), C.c_int, C.POINTER(real)]),
+    ]:
+        f = getattr(lib, name); f.restype = res; f.argtypes = args
+    return lib, real
+
+
+@pytest.mark.gpu
+def test_ode_api_forces_kinematic_slot_reuse_and_snapshot():
+    import ctypes as C
+    lib, real = _ode()
+    h = 1.0 / 60.0
+    w = lib.dWorldCreate()
+    lib.dWorldSetGravity(w, 0.0, -9.8, 0.0)
+    a, k, f = lib.dBodyCreate(w), lib.dBodyCreate(w), lib.dBodyCreate(w)
+    lib.dBodySetPosition(a, 1.0, 10.0, 0.0)
+    lib.dBodySetPosition(k, 2.0, 5.0, 0.0); lib.dBodySetKinematic(k); lib.dBodySetLinearVel(k, 0.5, 0.0, 0.0)
+    lib.dBodySetPosition(f, 3.0, 0.0, 0.0); lib.dBodyAddForce(f, 6.0, 9.8, 0.0)      # cancels gravity for one tick
+    lib.dBodySetAngularVel(a, 0.0, 2.0, 0.0)
+    assert lib.dWorldQuickStep(w, h) == 1
+    pa, pk, pf = (lib.dBodyGetPosition(x) for x in (a, k, f))
+    assert abs(pa[1] - (10.0 - 9.8 * h * h)) < 1e-12                       # KAT-1, one tick
+    assert abs(pk[0] - (2.0 + 0.5 * h)) < 1e-15 and pk[1] == 5.0          # kinematic: moves with its velocity, ignores gravity
+    vf = lib.dBodyGetLinearVel(f)
+    assert abs(vf[0] - 6.0 * h) < 1e-15 and abs(vf[1]) < 1e-15             # force applied ...
+    lib.dWorldQuickStep(w, h)
+    vf = lib.dBodyGetLinearVel(f)
+    assert abs(vf[0] - 6.0 * h) < 1e-15 and abs(vf[1] + 9.8 * h) < 1e-15   # ... exactly once
+    # device-side GetTransformMat for a list of bodies
+    ids = (C.c_void_p * 2)(a, k)
+    out = (real * 32)()
+    assert lib.dmxWorldSnapshotTransforms(w, ids, 2, out) == 1
+    R, p = lib.dBodyGetRotation(a), lib.dBodyGetPosition(a)
+    assert list(out[:16]) == [R[0], R[4], R[8], 0, R[1], R[5], R[9], 0, R[2], R[6], R[10], 0, p[0], p[1], p[2], 1]
+    assert out[16 + 12] == lib.dBodyGetPosition(k)[0]
+    # destroy + create reuses the slot; the new body starts from ODE's defaults
+    lib.dBodyDestroy(a)
+    n = lib.dBodyCreate(w)
+    lib.dWorldQuickStep(w, h)
+    pn = lib.dBodyGetPosition(n)
+    assert abs(pn[1] + 9.8 * h * h) < 1e-15 and pn[0] == 0.0
+    lib.dWorldDestroy(w)
