@@ -30,11 +30,12 @@ template <class T> __device__ __forceinline__ T bound_radius(int gt, const T *S,
 
 // bodies [0,n) -> buckets of their (x,z) column
 template <class T>
-__global__ __launch_bounds__(256) void bp_insert(const T *__restrict__ S, const uint8_t *__restrict__ gtype,
+__global__ __launch_bounds__(256) void bp_insert(T *__restrict__ S, const uint8_t *__restrict__ gtype,
                                                  int64_t stride, int64_t n, GridParams<T> G)
 {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n || gtype[i] == GEOM_NONE) return;
+    S[C_BPR * stride + i] = bound_radius<T>(gtype[i], S, stride, i);      // neighbours read this instead of 3 sides + sqrt
     const int ix = (int)floor((double)(S[(C_POS + 0) * stride + i] * G.inv_cell));
     const int iz = (int)floor((double)(S[(C_POS + 2) * stride + i] * G.inv_cell));
     const uint32_t h = cell_hash(ix, iz, G.mask);
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uin
                     const int64_t j = G.items[(size_t)h * G.cap + s];
                     if (j == i) continue;
                     const T ddx = S[(C_POS + 0) * stride + j] - x, ddz = S[(C_POS + 2) * stride + j] - z;
-                    const T g = tsqrt<T>(ddx * ddx + ddz * ddz) - ri - bound_radius<T>(gtype[j], S, stride, j);
+                    const T g = tsqrt<T>(ddx * ddx + ddz * ddz) - ri - S[C_BPR * stride + j];
                     if (g < gap) gap = g;
                 }
             }
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void bp_pairs(const T *__restrict__ S, const u
 static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 template <class T>
-hipError_t launch_bp_insert(const T *S, const uint8_t *gtype, int64_t stride, int64_t n, const GridParams<T> &G, hipStream_t st)
+hipError_t launch_bp_insert(T *S, const uint8_t *gtype, int64_t stride, int64_t n, const GridParams<T> &G, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL((bp_insert<T>), dim3(nblk(n)), dim3(256), 0, st, S, gtype, stride, n, G);
@@ -159,7 +160,7 @@ hipError_t launch_bp_pairs(const T *S, const uint8_t *gtype, int64_t stride, int
 }
 
 #define DMX_BP_INST(T)                                                                                              \
-    template hipError_t launch_bp_insert<T>(const T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, hipStream_t); \
+    template hipError_t launch_bp_insert<T>(T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, hipStream_t); \
     template hipError_t launch_bp_safe_zone<T>(T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, hipStream_t);    \
     template hipError_t launch_bp_pairs<T>(const T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, int32_t *,     \
                                            int, uint8_t *, hipStream_t);

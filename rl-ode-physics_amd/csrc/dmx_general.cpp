@@ -93,7 +93,7 @@ template <class T> int fill_grid(dmxBatch *b)
     const GridParams<T> G = grid_of<T>(b);
     HIP_TRY(hipMemsetAsync(b->bp_count.p, 0, ((size_t)b->bp_mask + 1) * sizeof(uint32_t), b->stream));
     HIP_TRY(hipMemsetAsync(b->bp_flags.p, 0, BPF_COUNT * sizeof(uint32_t), b->stream));
-    HIP_TRY(launch_bp_insert<T>((const T *)b->slab, b->gtype, b->stride, b->n, G, b->stream));   // ghosts included
+    HIP_TRY(launch_bp_insert<T>((T *)b->slab, b->gtype, b->stride, b->n, G, b->stream));   // ghosts included
     return DMX_OK;
 }
 

@@ -22,7 +22,8 @@ enum : int {
     C_BPX = 26,      // broadphase safe zone: build position x, z and radius (see dmx_broadphase.hip)
     C_BPZ = 27,
     C_BPSAFE = 28,
-    C_COUNT = 29
+    C_BPR = 29,      // bounding-sphere radius (refreshed by bp_insert)
+    C_COUNT = 30
 };
 
 enum : int { GEOM_NONE = 0, GEOM_SPHERE = 1, GEOM_BOX = 2 };
@@ -88,7 +89,7 @@ template <class T>
 hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
                           StepDiag *diag, hipStream_t st);
 template <class T>
-hipError_t launch_bp_insert(const T *S, const uint8_t *gtype, int64_t stride, int64_t n, const GridParams<T> &G, hipStream_t st);
+hipError_t launch_bp_insert(T *S, const uint8_t *gtype, int64_t stride, int64_t n, const GridParams<T> &G, hipStream_t st);
 template <class T>
 hipError_t launch_bp_safe_zone(T *S, const uint8_t *gtype, int64_t stride, int64_t n_active, const GridParams<T> &G, hipStream_t st);
 template <class T>

@@ -85,8 +85,8 @@ __device__ __forceinline__ void free_body_step(V3<T> &x, Q4<T> &q, V3<T> &v, V3<
 // integrate_free: contact-free tick (BASELINE config 2/4).  Algorithmic traffic per body-step:
 // read 13 state + 4 constant reals, write 13 state reals = 30 reals (120 B f32 / 240 B f64).
 // ---------------------------------------------------------------------------------------------
-template <class T, int V, bool EXT>
-__global__ __launch_bounds__(256) void integrate_free(T *__restrict__ S, int64_t stride, int64_t nvec,
+template <class T, int V, bool EXT, int MINW>
+__global__ __launch_bounds__(256, MINW) void integrate_free(T *__restrict__ S, int64_t stride, int64_t nvec,
                                                       StepParams<T> P)
 {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nvec;
@@ -433,17 +433,21 @@ hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, co
 {
     if (!P.plane_on) {
         constexpr int VMAX = 16 / sizeof(T);
-        const int V = P.skip != nullptr ? 1 : (P.vec == 1 || P.vec == 2 || P.vec == VMAX) ? P.vec : VMAX;
+        // default: 8 B per lane (f32: 2 bodies, f64: 1).  16 B per lane needs 146 VGPRs (3 waves/SIMD, 1024 blocks = 1.33
+        // residency rounds); 8 B fits 112 (4 waves/SIMD, 2048 blocks = 2 full rounds) and measured 4-10 % faster at 1 M bodies.
+        const int VDEF = VMAX / 2;
+        const int V = P.skip != nullptr ? 1 : (P.vec == 1 || P.vec == 2 || P.vec == VMAX) ? P.vec : VDEF;
         const int64_t nvec = (n + V - 1) / V;     // pad bodies up to `stride` are valid memory
         const unsigned grid = blocks_for(nvec, 256);
-#define DMX_LAUNCH_FREE(VV)                                                                                      \
-    do {                                                                                                         \
-        if (ext) hipLaunchKernelGGL((integrate_free<T, VV, true>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P);  \
-        else     hipLaunchKernelGGL((integrate_free<T, VV, false>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P); \
+#define DMX_LAUNCH_FREE(VV, MW)                                                                                      \
+    do {                                                                                                             \
+        if (ext) hipLaunchKernelGGL((integrate_free<T, VV, true, MW>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P);  \
+        else     hipLaunchKernelGGL((integrate_free<T, VV, false, MW>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P); \
     } while (0)
-        if (V == 1) DMX_LAUNCH_FREE(1);
-        else if (V == 2) DMX_LAUNCH_FREE(2);
-        else DMX_LAUNCH_FREE(VMAX);
+        const int mw = P.variant;     // launch tuning: minimum waves per SIMD the register allocator must leave room for
+        if (V == 1) { if (mw == 8) DMX_LAUNCH_FREE(1, 8); else if (mw == 6) DMX_LAUNCH_FREE(1, 6); else DMX_LAUNCH_FREE(1, 1); }
+        else if (V == 2) { if (mw == 4) DMX_LAUNCH_FREE(2, 4); else if (mw == 5) DMX_LAUNCH_FREE(2, 5); else if (mw == 6) DMX_LAUNCH_FREE(2, 6); else DMX_LAUNCH_FREE(2, 1); }
+        else { if (mw == 4) DMX_LAUNCH_FREE(VMAX, 4); else if (mw == 3) DMX_LAUNCH_FREE(VMAX, 3); else DMX_LAUNCH_FREE(VMAX, 1); }
 #undef DMX_LAUNCH_FREE
     } else {
         const unsigned grid = blocks_for(n, 256);
