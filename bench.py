@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--side", type=int, default=0, help="grid side (bodies = side^2 per GPU); 0 = config default")
     ap.add_argument("--exchange", default="boundary", choices=["boundary", "none"])
-    ap.add_argument("--graph-steps", type=int, default=0, help="ticks per captured HIP graph when exchanging (0 = eager)")
+    ap.add_argument("--graph-steps", type=int, default=8, help="ticks per captured HIP graph when exchanging (0 = eager)")
     ap.add_argument("--no-body-collisions", action="store_true", help="skip the body-body broadphase proof (caller asserts single-body islands)")
     ap.add_argument("--force-exchange", action="store_true", help="run the exchange path even with one rank (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,10 +124,11 @@ def main():
     w.set_stream(stream.cuda_stream)
 
     stepper = pkg.shard.ShardedStepper(w, layout, rank, world,
-                                       exchange=a.exchange if exchanging else "none", device=torch.device("cuda", local_rank))
+                                       exchange=a.exchange if exchanging else "none", device=torch.device("cuda", local_rank),
+                                       stream=stream)
     if a.force_exchange and world == 1 and exchanging:
         # one-rank group: the collective degenerates to a copy, every other step of the path is exercised
-        stepper.exchange = pkg.shard.BoundaryExchange(pkg.shard.DeviceOps(w, torch.device("cuda", local_rank)), layout, 0, 1)
+        stepper.exchange = pkg.shard.BoundaryExchange(pkg.shard.DeviceOps(w, torch.device("cuda", local_rank), stream), layout, 0, 1)
 
     def run(nsteps):
         stepper.run(H, nsteps)
@@ -151,6 +152,7 @@ def main():
     t0 = time.perf_counter()
     e0.record(stream)
     run(a.steps)
+    stepper.drain()                         # the last tick's exchange is part of the timed work
     e1.record(stream)
     fence()
     dt = time.perf_counter() - t0
@@ -174,7 +176,7 @@ def main():
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": workload, "bodies_per_gpu": scene.n, "bodies_total": total_bodies, "dt": "1/60",
                    "parallelism": f"islands sharded over {world} GPU(s), one slab per rank; "
-                                  + (f"boundary rows all-gathered over RCCL every tick, overlapped with the interior"
+                                  + (f"boundary rows all-gathered over RCCL every tick on a side stream, overlapped with the next tick"
                                      f"{', HIP-graph replay' if graphed else ''}" if stepper.exchange is not None
                                      else "no exchange (one rank)" if world == 1 else "no exchange"),
                    "collide": ("body-body pairs: none by assertion (check off)" if (a.no_body_collisions or exchanging) else

@@ -146,6 +146,9 @@ int dmxBatchDownloadTransforms(dmxBatchID b, void *out_host, int64_t first, int6
  * (13 reals) of the listed bodies into a contiguous device buffer (count x 13, AoS) and back */
 int dmxBatchGatherBodies(dmxBatchID b, const int32_t *idx_dev, int64_t count, void *out_dev);
 int dmxBatchScatterBodies(dmxBatchID b, const int32_t *idx_dev, int64_t count, const void *in_dev);
+/* scatter on a caller-chosen hipStream_t (the exchange's side stream): ghost slots are never touched by the step
+ * kernels, so they can be refreshed while the batch's own stream integrates the next tick */
+int dmxBatchScatterBodiesOnStream(dmxBatchID b, const int32_t *idx_dev, int64_t count, const void *in_dev, void *hip_stream);
 
 const char *dmxVersion(void);
 

@@ -20,6 +20,7 @@ BATCH_SYMBOLS = [
     "dmxBatchDownloadTransforms", "dmxBatchGatherBodies", "dmxBatchScatterBodies",
     "dmxBatchStepJoints", "dmxBatchUploadBodyFlags", "dmxBatchSetActiveCount", "dmxBatchStepRange",
     "dmxBatchGetStream", "dmxBatchSetBodyCollisions", "dmxBatchCollisionStats",
+    "dmxBatchScatterBodiesOnStream",
 ]
 
 _lib = None
@@ -84,5 +85,6 @@ def load():
     sig("dmxBatchGetStream", I, P, C.POINTER(P))
     sig("dmxBatchSetBodyCollisions", I, P, I)
     sig("dmxBatchCollisionStats", I, P, C.POINTER(L))
+    sig("dmxBatchScatterBodiesOnStream", I, P, P, L, P, P)
     _lib = lib
     return lib

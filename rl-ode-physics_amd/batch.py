@@ -143,6 +143,9 @@ class BatchWorld:
     def scatter_bodies(self, idx_ptr, count, in_ptr):
         _check(self.lib.dmxBatchScatterBodies(self.h, idx_ptr, count, in_ptr), "dmxBatchScatterBodies")
 
+    def scatter_bodies_on(self, stream_handle, idx_ptr, count, in_ptr):
+        _check(self.lib.dmxBatchScatterBodiesOnStream(self.h, idx_ptr, count, in_ptr, stream_handle), "dmxBatchScatterBodiesOnStream")
+
     def step_timed(self, h, nsteps):
         ms = C.c_float()
         _check(self.lib.dmxBatchStepTimed(self.h, h, nsteps, C.byref(ms)), "dmxBatchStepTimed")

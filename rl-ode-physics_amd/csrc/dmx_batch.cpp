@@ -455,14 +455,27 @@ extern "C" int dmxBatchGatherBodies(dmxBatchID b, const int32_t *idx_dev, int64_
     return DMX_OK;
 }
 
-extern "C" int dmxBatchScatterBodies(dmxBatchID b, const int32_t *idx_dev, int64_t count, const void *in_dev)
+static int scatter_on(dmxBatch *b, const int32_t *idx_dev, int64_t count, const void *in_dev, hipStream_t st)
 {
     if (!b || count < 0 || (count > 0 && (!idx_dev || !in_dev))) return DMX_EINVAL;
     b->bp_valid = false;
     HIP_TRY(hipSetDevice(b->device));
     if (b->precision == DMX_F32)
-        HIP_TRY(launch_scatter<float>((float *)b->slab, b->stride, idx_dev, count, (const float *)in_dev, b->stream));
+        HIP_TRY(launch_scatter<float>((float *)b->slab, b->stride, idx_dev, count, (const float *)in_dev, st));
     else
-        HIP_TRY(launch_scatter<double>((double *)b->slab, b->stride, idx_dev, count, (const double *)in_dev, b->stream));
+        HIP_TRY(launch_scatter<double>((double *)b->slab, b->stride, idx_dev, count, (const double *)in_dev, st));
     return DMX_OK;
+}
+
+extern "C" int dmxBatchScatterBodies(dmxBatchID b, const int32_t *idx_dev, int64_t count, const void *in_dev)
+{
+    return scatter_on(b, idx_dev, count, in_dev, b ? b->stream : nullptr);
+}
+
+// same, on a caller-chosen HIP stream: lets the boundary exchange write ghost slots from a side stream while the
+// batch's own stream is already integrating the next tick (ghost slots are never touched by the step kernels)
+extern "C" int dmxBatchScatterBodiesOnStream(dmxBatchID b, const int32_t *idx_dev, int64_t count, const void *in_dev,
+                                             void *hip_stream)
+{
+    return scatter_on(b, idx_dev, count, in_dev, (hipStream_t)hip_stream);
 }

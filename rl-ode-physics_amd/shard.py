@@ -3,22 +3,26 @@
 Dynamics islands are independent -- static geometry does not link islands -- so a scene shards across
 GPUs as whole islands, one process per GPU.  For the grid scenes rank r owns one slab of `rows` grid rows
 stacked along z.  The only data a neighbour ever needs is the state of the bodies next to the shared slab
-face (they are the ones a body-body broadphase on the neighbour can reach): the slab's first and last
-row.  Each tick every rank
+face (the ones a body-body broadphase on the neighbour can reach): the slab's first and last row.
 
-  1. steps its two boundary rows                                   (dmxBatchStepRange)
-  2. packs their 13-real state into one buffer                     (dmxBatchGatherBodies)
-  3. all-gathers the buffers over RCCL / xGMI, asynchronously      (torch.distributed, backend nccl)
-  4. steps the slab interior while the collective is in flight     (dmxBatchStepRange)
-  5. writes the neighbours' rows into its ghost slots              (dmxBatchScatterBodies)
+Every tick each rank
+  1. steps its slab                                           (one fused kernel, batch stream)
+  2. packs the 13-real state of its two boundary rows          (dmxBatchGatherBodies, batch stream)
+  3. all-gathers the packed rows over RCCL / xGMI              (torch.distributed, side stream)
+  4. writes its neighbours' rows into its ghost slots          (dmxBatchScatterBodiesOnStream, side stream)
+Steps 3-4 of tick k run on the side stream while the batch stream already integrates tick k+1: ghost slots
+([n_active, n) of the batch) are never read or written by the step kernels, and the pack of tick k+1 waits for
+exchange k to have drained the send / receive buffers.  Consumers of ghost state (broadphase rebuild / pair
+search) wait for the in-flight exchange first (`drain()`).
 
-Ghost slots live behind the rank's own bodies ([n_active, n) of the batch) and are never stepped.
-For slabs that are farther apart than a broadphase cell (BASELINE configs[3], >= 10 m) the boundary set
-is empty and `exchange="none"` skips steps 2-3-5.
+For slabs farther apart than a broadphase cell (BASELINE configs[3], >= 10 m) the boundary set is empty and
+`exchange="none"` skips steps 2-4.
 
-The exchange is written against a tiny `ops` interface (gather / scatter / buffers) so the index logic
-runs unchanged on CPU tensors with the gloo backend in tests (tests/test_shard_gloo.py).
+The exchange is written against a tiny `ops` interface (gather / scatter / buffers / streams) so the index
+logic and the collective run unchanged on CPU tensors with the gloo backend (tests/test_shard_gloo.py).
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -48,12 +52,17 @@ class SlabLayout:
 
 
 class DeviceOps:
-    """gather/scatter through the C ABI on the batch's HIP stream; buffers are torch CUDA tensors."""
+    """gather on the batch's HIP stream, scatter on the side stream; buffers are torch CUDA tensors."""
 
-    def __init__(self, world_batch, device):
+    def __init__(self, world_batch, device, main_stream):
         self.w = world_batch
         self.device = device
         self.torch_dtype = torch.float32 if world_batch.dtype.itemsize == 4 else torch.float64
+        self.main = main_stream                      # the stream the batch launches on
+        self.side = torch.cuda.Stream(device=device)
+        self.packed = torch.cuda.Event()
+        self.done = torch.cuda.Event()
+        self.have_done = False
 
     def empty(self, *shape):
         return torch.empty(shape, dtype=self.torch_dtype, device=self.device)
@@ -66,7 +75,27 @@ class DeviceOps:
 
     def scatter(self, idx, src):
         assert src.is_contiguous()
-        self.w.scatter_bodies(idx.data_ptr(), idx.numel(), src.data_ptr())
+        self.w.scatter_bodies_on(self.side.cuda_stream, idx.data_ptr(), idx.numel(), src.data_ptr())
+
+    # -- stream choreography -------------------------------------------------------------------------------
+    def before_pack(self):
+        if self.have_done:
+            self.main.wait_event(self.done)          # exchange k-1 has released send / recv
+
+    def after_pack(self):
+        self.packed.record(self.main)
+        self.side.wait_event(self.packed)
+
+    def side_stream(self):
+        return torch.cuda.stream(self.side)
+
+    def after_exchange(self):
+        self.done.record(self.side)
+        self.have_done = True
+
+    def drain(self):
+        if self.have_done:
+            self.main.wait_event(self.done)
 
 
 class BoundaryExchange:
@@ -80,81 +109,84 @@ class BoundaryExchange:
         # all_gather_into_tensor wants the ranks' buffers concatenated along dim 0
         self.recv_flat = ops.empty(world_size * layout.n_send, STATE_REALS)
         self.recv = self.recv_flat.view(world_size, layout.n_send, STATE_REALS)
-        self.work = None
 
     def pack(self):
+        self.ops.before_pack()
         self.ops.gather(self.send_idx, self.send)
-
-    def start(self):
-        """All-gather every rank's boundary rows; returns immediately (the collective runs on RCCL's stream)."""
-        self.work = dist.all_gather_into_tensor(self.recv_flat, self.send, group=self.group, async_op=True)
-
-    def finish(self):
-        if self.work is not None:
-            self.work.wait()
-            self.work = None
-        side = self.L.side
-        if self.rank > 0:                                   # lower neighbour's upper row
-            self.ops.scatter(self.ghost_lo, self.recv[self.rank - 1, side:2 * side])
-        if self.rank < self.world - 1:                      # upper neighbour's lower row
-            self.ops.scatter(self.ghost_hi, self.recv[self.rank + 1, 0:side])
+        self.ops.after_pack()
 
     def exchange(self):
+        """All-gather every rank's boundary rows and refresh the ghost slots (on the ops' side stream)."""
+        with self.ops.side_stream():
+            dist.all_gather_into_tensor(self.recv_flat, self.send, group=self.group)
+            side = self.L.side
+            if self.rank > 0:                                   # lower neighbour's upper row
+                self.ops.scatter(self.ghost_lo, self.recv[self.rank - 1, side:2 * side])
+            if self.rank < self.world - 1:                      # upper neighbour's lower row
+                self.ops.scatter(self.ghost_hi, self.recv[self.rank + 1, 0:side])
+        self.ops.after_exchange()
+
+    def tick(self):
         self.pack()
-        self.start()
-        self.finish()
+        self.exchange()
+
+    def drain(self):
+        self.ops.drain()
 
 
 class ShardedStepper:
-    """One rank's tick loop: boundary rows first, exchange overlapped with the interior."""
+    """One rank's tick loop: step the slab, then hand the boundary rows to the side-stream exchange."""
 
-    def __init__(self, world_batch, layout, rank, world_size, exchange="boundary", device=None):
+    def __init__(self, world_batch, layout, rank, world_size, exchange="boundary", device=None, stream=None):
         self.w, self.L = world_batch, layout
         self.exchange = None
         if world_size > 1 and exchange == "boundary":
-            self.exchange = BoundaryExchange(DeviceOps(world_batch, device), layout, rank, world_size)
+            self.exchange = BoundaryExchange(DeviceOps(world_batch, device, stream), layout, rank, world_size)
         self.graph = None
         self.graph_steps = 0
 
     def tick(self, h):
-        w, L = self.w, self.L
-        if self.exchange is None:
-            w.step(h, 1)
-            return
-        w.step_range(h, 0, L.side, reset_diag=True)
-        w.step_range(h, L.n - L.side, L.side)
-        self.exchange.pack()
-        self.exchange.start()
-        first, count = L.interior
-        w.step_range(h, first, count)
-        self.exchange.finish()
+        self.w.step(h, 1)
+        if self.exchange is not None:
+            self.exchange.tick()
 
     def run(self, h, nsteps):
         if self.exchange is None:
             self.w.step(h, nsteps)          # the C loop: no per-tick host work
             return
         if self.graph is not None:
-            reps, rest = divmod(nsteps, self.graph_steps)
+            reps, nsteps = divmod(nsteps, self.graph_steps)
             for _ in range(reps):
                 self.graph.replay()
-            nsteps = rest
         for _ in range(nsteps):
             self.tick(h)
 
+    def drain(self):
+        if self.exchange is not None:
+            self.exchange.drain()
+
     def capture(self, h, steps_per_graph, stream):
-        """Capture `steps_per_graph` ticks (kernels + the RCCL all-gather) into one HIP graph so a replay
-        costs one host call; returns False (and stays eager) if capture is not possible."""
+        """Capture `steps_per_graph` ticks (kernels, the RCCL all-gather and the stream choreography) into one
+        HIP graph so a replay costs one host call; returns False (and stays eager) if capture is not possible."""
         if self.exchange is None:
             return False
+        ops = self.exchange.ops
         try:
+            ops.drain()
+            torch.cuda.synchronize()
+            ops.have_done = False                      # no event edges from outside the capture
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=stream):
                 for _ in range(steps_per_graph):
                     self.tick(h)
+                ops.drain()                            # the side stream rejoins before the capture ends
+            ops.have_done = False
             self.graph, self.graph_steps = g, steps_per_graph
             return True
         except Exception as e:      # noqa: BLE001 -- capture support varies; eager is always correct
             self.graph = None
-            torch.cuda.synchronize()
+            ops.have_done = False
+            with contextlib.suppress(Exception):
+                torch.cuda.synchronize()
             print(f"[shard] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", flush=True)
             return False

@@ -34,6 +34,16 @@ class HostOps:
     def scatter(self, idx, src):
         self.state[idx] = src
 
+    # the stream choreography of DeviceOps has nothing to order on the host
+    def before_pack(self): pass
+    def after_pack(self): pass
+    def after_exchange(self): pass
+    def drain(self): pass
+
+    def side_stream(self):
+        import contextlib
+        return contextlib.nullcontext()
+
 
 def _value(rank, slot, comp):
     return 1000.0 * rank + slot + comp / 16.0
@@ -52,10 +62,7 @@ def _worker(rank, world, port, side, rows, ticks, q):
         ex = shard.BoundaryExchange(HostOps(state), L, rank, world)
         for t in range(ticks):
             state[:L.n] += 0.5                       # "step": every own body changes each tick
-            ex.pack()
-            ex.start()
-            state[L.side:L.n - L.side] += 0.0        # interior work would overlap here
-            ex.finish()
+            ex.tick()                                # pack -> all_gather -> scatter into the ghost slots
         q.put((rank, state.numpy().copy()))
     finally:
         dist.destroy_process_group()
