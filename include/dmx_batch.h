@@ -99,6 +99,9 @@ int dmxBatchSynchronize(dmxBatchID b);
  * a multiple of 4 (or n).  dmxBatchStepRange steps one tick over [first, first+count) only, so boundary
  * rows can be stepped (and sent) before the interior; first/count must be multiples of 16 B / sizeof(real). */
 int dmxBatchSetActiveCount(dmxBatchID b, int64_t n_active);
+/* boundary-row pack fused into the step kernels: every whole-slab tick also writes the new 13-real state of bodies
+ * [0, lo_count) and [hi_first, n_active) to out_dev (AoS, lower rows first), ready for the all-gather; NULL = off */
+int dmxBatchSetBoundaryPack(dmxBatchID b, void *out_dev, int64_t lo_count, int64_t hi_first);
 int dmxBatchStepRange(dmxBatchID b, double h, int64_t first, int64_t count, int reset_diag);
 /* run on a caller-owned hipStream_t (e.g. the framework's current stream); NULL restores the batch's own */
 int dmxBatchSetStream(dmxBatchID b, void *hip_stream);

@@ -20,7 +20,7 @@ BATCH_SYMBOLS = [
     "dmxBatchDownloadTransforms", "dmxBatchGatherBodies", "dmxBatchScatterBodies",
     "dmxBatchStepJoints", "dmxBatchUploadBodyFlags", "dmxBatchSetActiveCount", "dmxBatchStepRange",
     "dmxBatchGetStream", "dmxBatchSetBodyCollisions", "dmxBatchCollisionStats",
-    "dmxBatchScatterBodiesOnStream",
+    "dmxBatchScatterBodiesOnStream", "dmxBatchSetBoundaryPack",
 ]
 
 _lib = None
@@ -86,5 +86,6 @@ def load():
     sig("dmxBatchSetBodyCollisions", I, P, I)
     sig("dmxBatchCollisionStats", I, P, C.POINTER(L))
     sig("dmxBatchScatterBodiesOnStream", I, P, P, L, P, P)
+    sig("dmxBatchSetBoundaryPack", I, P, P, L, L)
     _lib = lib
     return lib

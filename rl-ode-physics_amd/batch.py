@@ -146,6 +146,9 @@ class BatchWorld:
     def scatter_bodies_on(self, stream_handle, idx_ptr, count, in_ptr):
         _check(self.lib.dmxBatchScatterBodiesOnStream(self.h, idx_ptr, count, in_ptr, stream_handle), "dmxBatchScatterBodiesOnStream")
 
+    def set_boundary_pack(self, out_ptr, lo_count, hi_first):
+        _check(self.lib.dmxBatchSetBoundaryPack(self.h, out_ptr, lo_count, hi_first), "dmxBatchSetBoundaryPack")
+
     def step_timed(self, h, nsteps):
         ms = C.c_float()
         _check(self.lib.dmxBatchStepTimed(self.h, h, nsteps, C.byref(ms)), "dmxBatchStepTimed")

@@ -274,7 +274,8 @@ extern "C" void *dmxBatchDevicePtr(dmxBatchID b, int field, int component)
 // ---- stepping ----------------------------------------------------------------------------------
 template <class T> static int step_t(dmxBatch *b, double h, int nsteps, int64_t first, int64_t count, bool reset_diag)
 {
-    const StepParams<T> P = dmx_make_params<T>(b, h);
+    StepParams<T> P = dmx_make_params<T>(b, h);
+    if (first != 0) P.pack_out = nullptr;      // the boundary pack is defined on whole-slab launches only
     for (int s = 0; s < nsteps; s++) {
         (void)reset_diag;   // every wave overwrites its own slot each tick: nothing to clear
         HIP_TRY(launch_step<T>((T *)b->slab + first, b->gtype + first, b->stride, count, P, b->ext_pending,
@@ -310,6 +311,13 @@ extern "C" int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6])
     if (!b || !out) return DMX_EINVAL;
     out[0] = b->stat_fast_ticks; out[1] = b->stat_careful_ticks; out[2] = b->stat_rebuilds;
     out[3] = b->stat_pair_ticks; out[4] = (int64_t)b->last_pairs; out[5] = (int64_t)b->bp_crowded;
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchSetBoundaryPack(dmxBatchID b, void *out_dev, int64_t lo_count, int64_t hi_first)
+{
+    if (!b || lo_count < 0 || hi_first < lo_count || hi_first > b->n_active) return DMX_EINVAL;
+    b->pack_out = out_dev; b->pack_lo = lo_count; b->pack_hi = hi_first;
     return DMX_OK;
 }
 

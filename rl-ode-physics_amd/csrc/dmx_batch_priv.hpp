@@ -24,6 +24,7 @@ using namespace dmx;
 
 struct dmxBatch {
     int64_t n = 0, stride = 0;
+    void *pack_out = nullptr; int64_t pack_lo = 0, pack_hi = 0;   // dmxBatchSetBoundaryPack
     int64_t n_active = 0;            // bodies [0, n_active) are stepped; the rest are ghost slots
     int precision = DMX_F32;
     int device = 0;
@@ -114,6 +115,7 @@ template <class T> inline StepParams<T> dmx_make_params(dmxBatch *b, double h)
     P.bp_check = 0;          // set by the collision-aware tick (dmx_general.cpp)
     P.bp_flags = nullptr;
     P.skip = nullptr;
+    P.pack_out = (T *)b->pack_out; P.pack_lo = b->pack_lo; P.pack_hi = b->pack_hi;
     return P;
 }
 

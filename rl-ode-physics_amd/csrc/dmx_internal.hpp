@@ -64,6 +64,9 @@ template <class T> struct StepParams {
     int bp_check;       // 1: test every body against its broadphase safe zone (pre-step position)
     uint32_t *bp_flags; // device flags (BPF_*), written when a body has left its safe zone
     const uint8_t *skip; // per-body: 1 = stepped by the island path this tick, leave untouched (may be null)
+    // boundary-row pack for the multi-GPU exchange (null = off): bodies i < pack_lo and i >= pack_hi also write
+    // their new 13-real state to pack_out[slot*13 ..], slot = i (lower row) or pack_lo + i - pack_hi (upper row)
+    T *pack_out; int64_t pack_lo, pack_hi;
 };
 
 // hashed (x,z)-column grid of the body-body broadphase

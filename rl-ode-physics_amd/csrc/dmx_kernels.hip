@@ -54,6 +54,21 @@ __device__ __forceinline__ void report_zone(int state, uint32_t *flags)
     if (w != 0ull && flags[BPF_WARN] == 0u) atomicOr(&flags[BPF_WARN], 1u);
 }
 
+// multi-GPU boundary rows: the new state also goes, AoS, to the exchange's send buffer
+template <class T>
+__device__ __forceinline__ void pack_boundary(const StepParams<T> &P, int64_t i, const V3<T> &x, const Q4<T> &q,
+                                              const V3<T> &v, const V3<T> &w)
+{
+    if (P.pack_out == nullptr) return;
+    int64_t slot;
+    if (i < P.pack_lo) slot = i;
+    else if (i >= P.pack_hi) slot = P.pack_lo + (i - P.pack_hi);
+    else return;
+    T *o = P.pack_out + slot * C_MASS;
+    o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = q.w; o[4] = q.x; o[5] = q.y; o[6] = q.z;
+    o[7] = v.x; o[8] = v.y; o[9] = v.z; o[10] = w.x; o[11] = w.y; o[12] = w.z;
+}
+
 // One body: external force/torque -> new velocities (no constraints) -> new pose.
 //   facc = fext + m g ; tacc = text + gyro
 //   v += (h/m) facc ; w += Iw^-1 (h tacc)
@@ -126,6 +141,7 @@ __global__ __launch_bounds__(256, MINW) void integrate_free(T *__restrict__ S, i
                 tacc = { f[3].v[b], f[4].v[b], f[5].v[b] };
             }
             free_body_step(x, q, v, w, c[C_MASS].v[b], Ib, facc, tacc, P.g, P.h, P.gyro);
+            pack_boundary(P, i + b, x, q, v, w);
             c[C_POS].v[b] = x.x; c[C_POS + 1].v[b] = x.y; c[C_POS + 2].v[b] = x.z;
             c[C_QUAT].v[b] = q.w; c[C_QUAT + 1].v[b] = q.x; c[C_QUAT + 2].v[b] = q.y; c[C_QUAT + 3].v[b] = q.z;
             c[C_LVEL].v[b] = v.x; c[C_LVEL + 1].v[b] = v.y; c[C_LVEL + 2].v[b] = v.z;
@@ -332,6 +348,7 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
         w.x += dw.x; w.y += dw.y; w.z += dw.z;
         x.x += h * v.x; x.y += h * v.y; x.z += h * v.z;
         integrate_quat(q, w, h);
+        pack_boundary(P, i, x, q, v, w);
 
         S[(C_POS + 0) * stride + i] = x.x; S[(C_POS + 1) * stride + i] = x.y; S[(C_POS + 2) * stride + i] = x.z;
         S[(C_QUAT + 0) * stride + i] = q.w; S[(C_QUAT + 1) * stride + i] = q.x;

@@ -6,13 +6,14 @@ stacked along z.  The only data a neighbour ever needs is the state of the bodie
 face (the ones a body-body broadphase on the neighbour can reach): the slab's first and last row.
 
 Every tick each rank
-  1. steps its slab                                           (one fused kernel, batch stream)
-  2. packs the 13-real state of its two boundary rows          (dmxBatchGatherBodies, batch stream)
+  1. steps its slab; the step kernel also writes the new 13-real state of the two boundary rows, packed,
+     into the send buffer                                     (dmxBatchSetBoundaryPack, batch stream)
+  2. (hosts without the fused pack, e.g. the CPU test double, gather the rows explicitly)
   3. all-gathers the packed rows over RCCL / xGMI              (torch.distributed, side stream)
   4. writes its neighbours' rows into its ghost slots          (dmxBatchScatterBodiesOnStream, side stream)
 Steps 3-4 of tick k run on the side stream while the batch stream already integrates tick k+1: ghost slots
 ([n_active, n) of the batch) are never read or written by the step kernels, and the pack of tick k+1 waits for
-exchange k to have drained the send / receive buffers.  Consumers of ghost state (broadphase rebuild / pair
+exchange k-1 to have drained the (double-buffered) send buffer.  Consumers of ghost state (broadphase rebuild / pair
 search) wait for the in-flight exchange first (`drain()`).
 
 For slabs farther apart than a broadphase cell (BASELINE configs[3], >= 10 m) the boundary set is empty and
@@ -61,14 +62,20 @@ class DeviceOps:
         self.main = main_stream                      # the stream the batch launches on
         self.side = torch.cuda.Stream(device=device)
         self.packed = torch.cuda.Event()
-        self.done = torch.cuda.Event()
-        self.have_done = False
+        self.done = [torch.cuda.Event(), torch.cuda.Event()]     # per send buffer: "the exchange that read it finished"
+        self.have_done = [False, False]
 
     def empty(self, *shape):
         return torch.empty(shape, dtype=self.torch_dtype, device=self.device)
 
     def index(self, arr):
         return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(self.device)
+
+    fused_pack = True      # the step kernel fills the send buffer itself
+
+    def arm_pack(self, out, layout):
+        """Point the next whole-slab tick's boundary pack at `out`."""
+        self.w.set_boundary_pack(out.data_ptr(), layout.side, layout.n - layout.side)
 
     def gather(self, idx, out):
         self.w.gather_bodies(idx.data_ptr(), idx.numel(), out.data_ptr())
@@ -78,9 +85,9 @@ class DeviceOps:
         self.w.scatter_bodies_on(self.side.cuda_stream, idx.data_ptr(), idx.numel(), src.data_ptr())
 
     # -- stream choreography -------------------------------------------------------------------------------
-    def before_pack(self):
-        if self.have_done:
-            self.main.wait_event(self.done)          # exchange k-1 has released send / recv
+    def before_pack(self, k=0):
+        if self.have_done[k & 1]:
+            self.main.wait_event(self.done[k & 1])   # exchange k-2 (same send buffer) has finished; k-1 may still run
 
     def after_pack(self):
         self.packed.record(self.main)
@@ -89,13 +96,17 @@ class DeviceOps:
     def side_stream(self):
         return torch.cuda.stream(self.side)
 
-    def after_exchange(self):
-        self.done.record(self.side)
-        self.have_done = True
+    def after_exchange(self, k=0):
+        self.done[k & 1].record(self.side)
+        self.have_done[k & 1] = True
 
     def drain(self):
-        if self.have_done:
-            self.main.wait_event(self.done)
+        for b in (0, 1):
+            if self.have_done[b]:
+                self.main.wait_event(self.done[b])
+
+    def forget(self):
+        self.have_done = [False, False]
 
 
 class BoundaryExchange:
@@ -105,14 +116,28 @@ class BoundaryExchange:
         self.send_idx = ops.index(layout.send_idx)
         self.ghost_lo = ops.index(layout.ghost_lo)
         self.ghost_hi = ops.index(layout.ghost_hi)
-        self.send = ops.empty(layout.n_send, STATE_REALS)
+        # two send buffers: tick k's step kernel fills one while exchange k-1 still reads the other
+        self.sends = [ops.empty(layout.n_send, STATE_REALS), ops.empty(layout.n_send, STATE_REALS)]
+        self.k = 0
+        self.fused = bool(getattr(ops, "fused_pack", False))
         # all_gather_into_tensor wants the ranks' buffers concatenated along dim 0
         self.recv_flat = ops.empty(world_size * layout.n_send, STATE_REALS)
         self.recv = self.recv_flat.view(world_size, layout.n_send, STATE_REALS)
 
+    @property
+    def send(self):
+        return self.sends[self.k & 1]
+
+    def before_step(self):
+        """Called before the tick's step kernel is enqueued: make sure this tick's send buffer is free and, with a
+        fused pack, aim the step kernel at it."""
+        self.ops.before_pack(self.k)
+        if self.fused:
+            self.ops.arm_pack(self.send, self.L)
+
     def pack(self):
-        self.ops.before_pack()
-        self.ops.gather(self.send_idx, self.send)
+        if not self.fused:
+            self.ops.gather(self.send_idx, self.send)
         self.ops.after_pack()
 
     def exchange(self):
@@ -124,9 +149,12 @@ class BoundaryExchange:
                 self.ops.scatter(self.ghost_lo, self.recv[self.rank - 1, side:2 * side])
             if self.rank < self.world - 1:                      # upper neighbour's lower row
                 self.ops.scatter(self.ghost_hi, self.recv[self.rank + 1, 0:side])
-        self.ops.after_exchange()
+        self.ops.after_exchange(self.k)
+        self.k += 1
 
     def tick(self):
+        """pack + exchange for hosts that do not interleave a step kernel (tests)."""
+        self.before_step()
         self.pack()
         self.exchange()
 
@@ -146,9 +174,14 @@ class ShardedStepper:
         self.graph_steps = 0
 
     def tick(self, h):
+        ex = self.exchange
+        if ex is None:
+            self.w.step(h, 1)
+            return
+        ex.before_step()
         self.w.step(h, 1)
-        if self.exchange is not None:
-            self.exchange.tick()
+        ex.pack()
+        ex.exchange()
 
     def run(self, h, nsteps):
         if self.exchange is None:
@@ -174,18 +207,18 @@ class ShardedStepper:
         try:
             ops.drain()
             torch.cuda.synchronize()
-            ops.have_done = False                      # no event edges from outside the capture
+            ops.forget()                               # no event edges from outside the capture
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=stream):
                 for _ in range(steps_per_graph):
                     self.tick(h)
                 ops.drain()                            # the side stream rejoins before the capture ends
-            ops.have_done = False
+            ops.forget()
             self.graph, self.graph_steps = g, steps_per_graph
             return True
         except Exception as e:      # noqa: BLE001 -- capture support varies; eager is always correct
             self.graph = None
-            ops.have_done = False
+            ops.forget()
             with contextlib.suppress(Exception):
                 torch.cuda.synchronize()
             print(f"[shard] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", flush=True)

@@ -392,3 +392,24 @@ def test_slabs_of_config4_step_independently():
         part = _gpu_run(scene.slice(r * per, (r + 1) * per), "float64", 100).state()
         for x, y in zip(whole, part):
             assert np.array_equal(x[r * per:(r + 1) * per], y)
+
+
+def test_fused_boundary_pack_matches_state():
+    """dmxBatchSetBoundaryPack: the step kernels drop the boundary rows' new state, packed, into the send buffer."""
+    import torch
+    for plane, dtype, tdt in ((False, "float32", torch.float32), (True, "float64", torch.float64)):
+        scene = pkg.scenes.box_grid(64, 8, seed=9, y_range=(0.7, 3.0), spin=True, box_mass=True, plane=plane).astype(dtype)
+        L = pkg.shard.SlabLayout(64, 8)
+        w = pkg.BatchWorld(L.n_total, dtype=dtype)
+        w.load_scene(scene)
+        w.set_active_count(scene.n)
+        w.set_body_collisions(False)
+        buf = torch.full((L.n_send, 13), -7.0, dtype=tdt, device="cuda")
+        w.set_boundary_pack(buf.data_ptr(), L.side, L.n - L.side)
+        w.step(H, 25)
+        w.synchronize()
+        st = np.concatenate(w.state(), axis=1)
+        assert np.array_equal(buf.cpu().numpy(), st[L.send_idx])
+        w.set_boundary_pack(None, 0, 0)
+        w.step(H, 1); w.synchronize()
+        assert np.array_equal(buf.cpu().numpy(), st[L.send_idx])          # untouched once the pack is off

@@ -35,9 +35,9 @@ class HostOps:
         self.state[idx] = src
 
     # the stream choreography of DeviceOps has nothing to order on the host
-    def before_pack(self): pass
+    def before_pack(self, k=0): pass
     def after_pack(self): pass
-    def after_exchange(self): pass
+    def after_exchange(self, k=0): pass
     def drain(self): pass
 
     def side_stream(self):
