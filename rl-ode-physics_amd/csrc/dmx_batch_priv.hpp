@@ -67,6 +67,7 @@ struct dmxBatch {
     double bp_rmax = 0;
     uint32_t bp_mask = 0; int bp_cap = 8;
     DevBuf bp_count, bp_items, bp_flags, bp_pairs, bp_inpair, bp_snapshot, bp_idx, bp_gather;
+    DevBuf np_pos, np_normal, np_depth, np_count, np_pairs;   // device narrowphase output of the exact tick
     uint32_t *bp_flags_host = nullptr;         // pinned
     int bp_max_pairs = 0;
     std::vector<double> h_sides;               // host mirror of DMX_SIDES (exact values of the batch precision)
@@ -79,7 +80,10 @@ struct dmxBatch {
 };
 
 int dmx_ensure_dev(dmxBatch::DevBuf &d, size_t bytes);
-int dmx_step_joints(dmxBatch *b, double h, int64_t n_joints, const dmxContactJoint *joints, const uint8_t *include);
+// contact geometry that already lives on the device (device narrowphase): joint k's pos/normal/depth are entry src[k]
+struct DevGeometry { const void *pos, *normal, *depth; const int32_t *src; };
+int dmx_step_joints(dmxBatch *b, double h, int64_t n_joints, const dmxContactJoint *joints, const uint8_t *include,
+                    const DevGeometry *geo);
 // body-body collision handling of the batch tick (dmx_general.cpp)
 int dmx_step_collide(dmxBatch *b, double h, int nsteps);
 

@@ -9,15 +9,14 @@
 //
 // Careful mode (a body left its zone, or bodies are crowded): the chunk is rolled back to its snapshot and
 // replayed tick by tick: exact device pair search (bp_insert + bp_pairs) -> pair count to the host -> for
-// bodies in pairs, host narrowphase (the same __host__ __device__ colliders) + island grouping, solved on
-// the device by solve_islands; every other body takes the fused kernel with those bodies masked out.
+// bodies in pairs, device narrowphase (np_plane, np_pairs) -> contact counts to the host -> island grouping
+// (integer bookkeeping) -> solve_islands on the device; every other body takes the fused kernel with those bodies masked out.
 // Both modes give the same bits as the sequential CPU oracle.
 #include <string.h>
 #include <algorithm>
 #include <cmath>
 
 #include "dmx_batch_priv.hpp"
-#include "dmx_collide.hpp"
 
 namespace {
 
@@ -166,75 +165,52 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     inv.erase(std::unique(inv.begin(), inv.end()), inv.end());
     const int64_t ninv = (int64_t)inv.size();
 
-    // ---- their current state (13 reals each) to the host -------------------------------------------------
+    // ---- device narrowphase: ground-plane contacts of those bodies (4 slots each), then the pairs' contacts
+    //      (8 slots each); only the integer counts come back to the host --------------------------------------
+    const int base = 4 * (int)ninv;
+    const size_t nslots = (size_t)base + (size_t)8 * np;
     if ((rc = dmx_ensure_dev(b->bp_idx, (size_t)ninv * sizeof(int32_t))) != DMX_OK) return rc;
-    if ((rc = dmx_ensure_dev(b->bp_gather, (size_t)ninv * C_MASS * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->np_pairs, (size_t)2 * np * sizeof(int32_t))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->np_pos, nslots * 3 * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->np_normal, nslots * 3 * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->np_depth, nslots * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->np_count, ((size_t)ninv + np) * sizeof(int32_t))) != DMX_OK) return rc;
+    for (uint32_t k = 0; k < np; k++) { pr[2 * k] = pairs[k].first; pr[2 * k + 1] = pairs[k].second; }   // sorted now
     HIP_TRY(hipMemcpyAsync(b->bp_idx.p, inv.data(), (size_t)ninv * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(launch_gather<T>((const T *)b->slab, b->stride, (const int32_t *)b->bp_idx.p, ninv, (T *)b->bp_gather.p, b->stream));
-    std::vector<T> st((size_t)ninv * C_MASS);
-    HIP_TRY(hipMemcpyAsync(st.data(), b->bp_gather.p, st.size() * sizeof(T), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->np_pairs.p, pr.data(), pr.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+    const StepParams<T> P = dmx_make_params<T>(b, h);
+    int32_t *cnt_dev = (int32_t *)b->np_count.p;
+    HIP_TRY(launch_np_plane<T>((const T *)b->slab, b->gtype, b->stride, (const int32_t *)b->bp_idx.p, (int)ninv, P,
+                               (T *)b->np_pos.p, (T *)b->np_normal.p, (T *)b->np_depth.p, cnt_dev, b->stream));
+    HIP_TRY(launch_np_pairs<T>((const T *)b->slab, b->gtype, b->stride, (const int32_t *)b->np_pairs.p, (int)np,
+                               b->max_contacts, base, (T *)b->np_pos.p, (T *)b->np_normal.p, (T *)b->np_depth.p,
+                               cnt_dev + ninv, b->stream));
+    std::vector<int32_t> cnt((size_t)ninv + np);
+    HIP_TRY(hipMemcpyAsync(cnt.data(), cnt_dev, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
 
-    struct Pose { V3<T> x; M3<T> R; T side[3]; int gt; };
-    std::vector<Pose> pose((size_t)ninv);
+    // ---- the tick's contact joints for those bodies, in creation order: ground-plane contacts by body, then
+    //      body pairs (what NearCallback would have created, main.c:674-693).  Geometry is referenced by slot. ----
     std::vector<uint8_t> include((size_t)b->n, 0);
-    for (int64_t k = 0; k < ninv; k++) {
-        const T *s = &st[(size_t)k * C_MASS];
-        Pose &p = pose[(size_t)k];
-        p.x = { s[0], s[1], s[2] };
-        p.R = quat_to_R(Q4<T>{ s[3], s[4], s[5], s[6] });
-        const int32_t id = inv[(size_t)k];
-        for (int a = 0; a < 3; a++) p.side[a] = (T)b->h_sides[(size_t)3 * id + a];
-        p.gt = b->h_gtype[(size_t)id];
-        include[(size_t)id] = 1;
-    }
-    auto pose_of = [&](int32_t id) -> const Pose & {
-        return pose[(size_t)(std::lower_bound(inv.begin(), inv.end(), id) - inv.begin())];
-    };
-
-    // ---- the tick's contact joints for those bodies, in creation order: ground-plane contacts by body,
-    //      then body pairs (what NearCallback would have created, main.c:674-693) --------------------------
+    for (int32_t id : inv) include[(size_t)id] = 1;
     std::vector<dmxContactJoint> joints;
-    auto push = [&](const V3<T> &pos, const V3<T> &nrm, T depth, int32_t b1, int32_t b2) {
+    std::vector<int32_t> src;
+    auto push = [&](int32_t slot, int32_t b1, int32_t b2) {
         dmxContactJoint j;
-        j.pos[0] = pos.x; j.pos[1] = pos.y; j.pos[2] = pos.z;
-        j.normal[0] = nrm.x; j.normal[1] = nrm.y; j.normal[2] = nrm.z;
-        j.depth = depth; j.body1 = b1; j.body2 = b2;
+        memset(&j, 0, sizeof(j));
+        j.body1 = b1; j.body2 = b2;
         j.mode = b->surf_mode; j.mu = b->mu; j.bounce = b->bounce; j.bounce_vel = b->bounce_vel;
-        j.soft_erp = 0; j.soft_cfm = 0;
         joints.push_back(j);
+        src.push_back(slot);
     };
-    if (b->plane_on) {
-        T pl[4];
-        dmx_normalize_plane<T>(b->plane, pl);
-        const V3<T> pn = { pl[0], pl[1], pl[2] };
-        for (int64_t k = 0; k < ninv; k++) {
-            const Pose &p = pose[(size_t)k];
-            V3<T> cp[4]; T cd[4];
-            int nc = 0;
-            if (p.gt == GEOM_BOX) nc = box_plane(p.x, p.R, p.side, pn, pl[3], b->max_contacts, cp, cd);
-            else if (p.gt == GEOM_SPHERE) nc = sphere_plane(p.x, p.side[0], pn, pl[3], cp, cd);
-            for (int c = 0; c < nc; c++) push(cp[c], pn, cd[c], inv[(size_t)k], -1);
-        }
-    }
-    for (auto &pq : pairs) {
-        const Pose &A = pose_of(pq.first), &B = pose_of(pq.second);
-        ContactPoint<T> c[8];
-        int nc = 0;
-        bool flip = false;       // collider exists only for the swapped class order: swap, then negate the normal
-        if (A.gt == GEOM_BOX && B.gt == GEOM_BOX) nc = box_box(A.x, A.R, A.side, B.x, B.R, B.side, b->max_contacts, c);
-        else if (A.gt == GEOM_SPHERE && B.gt == GEOM_SPHERE) nc = sphere_sphere(A.x, A.side[0], B.x, B.side[0], c);
-        else if (A.gt == GEOM_SPHERE && B.gt == GEOM_BOX) nc = sphere_box(A.x, A.side[0], B.x, B.R, B.side, c);
-        else if (A.gt == GEOM_BOX && B.gt == GEOM_SPHERE) { nc = sphere_box(B.x, B.side[0], A.x, A.R, A.side, c); flip = true; }
-        if (nc > b->max_contacts) nc = b->max_contacts;
-        for (int k = 0; k < nc; k++) {
-            const V3<T> nrm = flip ? V3<T>{ -c[k].normal.x, -c[k].normal.y, -c[k].normal.z } : c[k].normal;
-            push(c[k].pos, nrm, c[k].depth, pq.first, pq.second);
-        }
-    }
+    for (int64_t k = 0; k < ninv; k++)
+        for (int c = 0; c < cnt[(size_t)k]; c++) push(4 * (int32_t)k + c, inv[(size_t)k], -1);
+    for (uint32_t p = 0; p < np; p++)
+        for (int c = 0; c < cnt[(size_t)ninv + p]; c++) push(base + 8 * (int32_t)p + c, pairs[p].first, pairs[p].second);
+    const DevGeometry geo = { b->np_pos.p, b->np_normal.p, b->np_depth.p, src.data() };
 
     // ---- islands of the bodies in pairs on the device; everyone else through the fused kernel -------------
-    if ((rc = dmx_step_joints(b, h, (int64_t)joints.size(), joints.data(), include.data())) != DMX_OK) return rc;
+    if ((rc = dmx_step_joints(b, h, (int64_t)joints.size(), joints.data(), include.data(), &geo)) != DMX_OK) return rc;
     if ((rc = fused_tick<T>(b, h, false, (const uint8_t *)b->bp_inpair.p)) != DMX_OK) return rc;
     b->last_islands = false;
     b->last_mixed = true;

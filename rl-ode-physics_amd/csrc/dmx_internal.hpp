@@ -41,6 +41,8 @@ template <class T> struct IslandSet {
     const int *con_off;    // [n_islands+1] into the contact arrays
     const int *row_off;    // [n_islands+1] into rows (3 rows reserved per contact)
     const T *cpos, *cnormal, *cdepth;             // 3, 3, 1 per contact
+    const int *csrc;       // optional: contact c's geometry lives at index csrc[c] of gpos/gnormal/gdepth (device narrowphase output)
+    const T *gpos, *gnormal, *gdepth;
     const int *cb1, *cb2, *cmode;
     const T *cmu, *cbounce, *cbounce_vel, *csoft_erp, *csoft_cfm;
     T *rows;               // scratch: 29 reals per row
@@ -98,6 +100,14 @@ hipError_t launch_bp_safe_zone(T *S, const uint8_t *gtype, int64_t stride, int64
 template <class T>
 hipError_t launch_bp_pairs(const T *S, const uint8_t *gtype, int64_t stride, int64_t n_active, const GridParams<T> &G,
                            int32_t *pairs, int max_pairs, uint8_t *inpair, hipStream_t st);
+// device narrowphase of the exact tick: ground-plane contacts of the listed bodies (4 slots each) and contacts of the
+// listed body pairs (8 slots each) into one geometry array; counts per body / per pair
+template <class T>
+hipError_t launch_np_plane(const T *S, const uint8_t *gtype, int64_t stride, const int32_t *bodies, int nb,
+                           const StepParams<T> &P, T *gpos, T *gnormal, T *gdepth, int32_t *count, hipStream_t st);
+template <class T>
+hipError_t launch_np_pairs(const T *S, const uint8_t *gtype, int64_t stride, const int32_t *pairs, int np, int maxc,
+                           int base_slot, T *gpos, T *gnormal, T *gdepth, int32_t *count, hipStream_t st);
 template <class T>
 hipError_t launch_pack_transforms(const T *S, int64_t stride, int64_t first, int64_t count, T *out, hipStream_t st);
 template <class T>

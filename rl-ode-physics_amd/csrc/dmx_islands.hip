@@ -78,8 +78,10 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
         const int ci = c0 + c;
         const int s1 = I.cb1[ci], s2 = I.cb2[ci];
         const int l1 = I.local[s1], l2 = s2 >= 0 ? I.local[s2] : -1;
-        const V3<T> normal = ld3(I.cnormal + 3 * (size_t)ci);
-        const V3<T> cpos = ld3(I.cpos + 3 * (size_t)ci);
+        const bool ind = I.csrc != nullptr;
+        const size_t gi = ind ? (size_t)I.csrc[ci] : (size_t)ci;
+        const V3<T> normal = ld3((ind ? I.gnormal : I.cnormal) + 3 * gi);
+        const V3<T> cpos = ld3((ind ? I.gpos : I.cpos) + 3 * gi);
         const V3<T> x1 = { S[(C_POS + 0) * stride + s1], S[(C_POS + 1) * stride + s1], S[(C_POS + 2) * stride + s1] };
         const V3<T> c1 = { cpos.x - x1.x, cpos.y - x1.y, cpos.z - x1.z };
         V3<T> c2 = { T(0), T(0), T(0) };
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
                 T erp = P.erp;
                 if (mode & SURF_SOFT_ERP) erp = I.csoft_erp[ci];
                 if (mode & SURF_SOFT_CFM) cfm = I.csoft_cfm[ci];
-                T depth = I.cdepth[ci];
+                T depth = ind ? I.gdepth[gi] : I.cdepth[ci];
                 if (depth < 0) depth = 0;
                 cval = (hinv * erp) * depth;
                 if (mode & SURF_BOUNCE) {

@@ -31,7 +31,7 @@ int ensure_pinned(void **p, size_t *have, size_t bytes)
 }
 
 template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const dmxContactJoint *joints,
-                                     const uint8_t *include)
+                                     const uint8_t *include, const DevGeometry *geo)
 {
     const int n = (int)b->n;
     // previous tick's async copies read the pinned staging buffers: drain before refilling
@@ -68,8 +68,8 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     for (int s = 0; s < n; s++)
         if (live(s) && island_of[(size_t)s] < 0) island_of[(size_t)s] = island_of[(size_t)uf.find(s)];
 
-    // int staging: body_off[ni+1] bodies[nlive] con_off[ni+1] row_off[ni+1] cb1[nc] cb2[nc] cmode[nc]
-    const size_t n_int = (size_t)3 * (ni + 1) + (size_t)nlive + (size_t)3 * nc;
+    // int staging: body_off[ni+1] bodies[nlive] con_off[ni+1] row_off[ni+1] cb1[nc] cb2[nc] cmode[nc] csrc[nc]
+    const size_t n_int = (size_t)3 * (ni + 1) + (size_t)nlive + (size_t)4 * nc;
     // real staging: cpos[3nc] cnormal[3nc] cdepth cmu cbounce cbounce_vel csoft_erp csoft_cfm [nc each]
     const size_t n_real = (size_t)12 * nc;
     int rc;
@@ -78,7 +78,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     int *hi = (int *)b->jh_int;
     T *hr = (T *)b->jh_real;
     int *body_off = hi, *bodies = body_off + (ni + 1), *con_off = bodies + nlive, *row_off = con_off + (ni + 1);
-    int *cb1 = row_off + (ni + 1), *cb2 = cb1 + nc, *cmode = cb2 + nc;
+    int *cb1 = row_off + (ni + 1), *cb2 = cb1 + nc, *cmode = cb2 + nc, *csrc = cmode + nc;
     T *cpos = hr, *cnormal = cpos + 3 * (size_t)nc, *cdepth = cnormal + 3 * (size_t)nc, *cmu = cdepth + nc,
       *cbounce = cmu + nc, *cbv = cbounce + nc, *cserp = cbv + nc, *cscfm = cserp + nc;
 
@@ -97,6 +97,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
             const int d = cfill[(size_t)island_of[(size_t)c.b1]]++;
             const dmxContactJoint &j = *c.j;
             cb1[d] = c.b1; cb2[d] = c.b2; cmode[d] = j.mode;
+            csrc[d] = geo ? geo->src[(size_t)(c.j - joints)] : 0;
             for (int k = 0; k < 3; k++) {
                 cpos[3 * (size_t)d + k] = (T)j.pos[k];
                 const T nk = (T)j.normal[k];
@@ -124,6 +125,9 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     I.n_islands = ni;
     I.body_off = di; I.bodies = di + (ni + 1); I.con_off = I.bodies + nlive; I.row_off = I.con_off + (ni + 1);
     I.cb1 = I.row_off + (ni + 1); I.cb2 = I.cb1 + nc; I.cmode = I.cb2 + nc;
+    I.csrc = geo ? I.cmode + nc : nullptr;
+    I.gpos = geo ? (const T *)geo->pos : nullptr; I.gnormal = geo ? (const T *)geo->normal : nullptr;
+    I.gdepth = geo ? (const T *)geo->depth : nullptr;
     I.cpos = dr; I.cnormal = dr + 3 * (size_t)nc; I.cdepth = I.cnormal + 3 * (size_t)nc; I.cmu = I.cdepth + nc;
     I.cbounce = I.cmu + nc; I.cbounce_vel = I.cbounce + nc; I.csoft_erp = I.cbounce_vel + nc; I.csoft_cfm = I.csoft_erp + nc;
     I.rows = (T *)b->jd_rows.p; I.rowjb = (int *)b->jd_rowjb.p; I.bscr = (T *)b->jd_bscr.p; I.local = (int *)b->jd_local.p;
@@ -139,15 +143,16 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
 
 }  // namespace
 
-int dmx_step_joints(dmxBatch *b, double h, int64_t n_joints, const dmxContactJoint *joints, const uint8_t *include)
+int dmx_step_joints(dmxBatch *b, double h, int64_t n_joints, const dmxContactJoint *joints, const uint8_t *include,
+                    const DevGeometry *geo)
 {
-    return b->precision == DMX_F32 ? step_joints_t<float>(b, h, n_joints, joints, include)
-                                   : step_joints_t<double>(b, h, n_joints, joints, include);
+    return b->precision == DMX_F32 ? step_joints_t<float>(b, h, n_joints, joints, include, geo)
+                                   : step_joints_t<double>(b, h, n_joints, joints, include, geo);
 }
 
 extern "C" int dmxBatchStepJoints(dmxBatchID b, double h, int64_t n_joints, const dmxContactJoint *joints)
 {
     if (!b || !(h > 0) || n_joints < 0 || (n_joints > 0 && !joints)) return DMX_EINVAL;
     HIP_TRY(hipSetDevice(b->device));
-    return dmx_step_joints(b, h, n_joints, joints, nullptr);
+    return dmx_step_joints(b, h, n_joints, joints, nullptr, nullptr);
 }
