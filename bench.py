@@ -70,6 +70,39 @@ def cpu_baseline(pkg, scene, dtype, kind, budget_s):
                       f"-O2 single thread, {t:.1f} s"}
 
 
+def cpu_baseline_all_cores(scene, dtype, kind, budget_s):
+    """The same oracle, one independent slice of the scene per host core (islands are independent), one child
+    process per core (oracle/cpu_worker.py); None if a child fails or overruns."""
+    import subprocess
+    import tempfile
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    per = scene.n // cores
+    plane = np.array(scene.plane if scene.plane is not None else [], dtype=np.float64)
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = []
+        for c in range(cores):
+            sl = slice(c * per, (c + 1) * per)
+            path = os.path.join(tmp, f"slice{c}.npz")
+            np.savez(path, pos=scene.pos[sl], quat=scene.quat[sl], lvel=scene.lvel[sl], avel=scene.avel[sl],
+                     mass=scene.mass[sl, 0], inertia=scene.inertia[sl], sides=scene.sides[sl], plane=plane)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), path, dtype,
+                                           str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+        rate = 0.0
+        for p in procs:
+            try:
+                out, _ = p.communicate(timeout=5 * budget_s + 90)
+                n, t = out.split()
+                rate += float(n) / float(t)
+            except Exception:      # noqa: BLE001 -- a baseline line must never take the bench down
+                for q in procs:
+                    if q.poll() is None:
+                        q.kill()
+                return None
+    return {"value": rate, "unit": "body-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} processes x {per} bodies of the same scene ({kind}), each the single-thread oracle for "
+                      f"~{budget_s:.0f} s; rates summed"}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -193,6 +226,9 @@ def main():
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, scene, dtype, kind, a.cpu_seconds)
+        allc = cpu_baseline_all_cores(scene, dtype, kind, min(6.0, a.cpu_seconds))
+        if allc is not None:
+            out["cpu_baseline_all_cores"] = allc
     if rank == 0:
         print(json.dumps(out), flush=True)
     w.close()
