@@ -16,8 +16,8 @@
 #define orc_atan2 atan2
 #endif
 
-static real dot44(const real *a, const real *b) { return a[0] * b[0] + a[4] * b[4] + a[8] * b[8]; }
-static real dot41(const real *a, const real *b) { return a[0] * b[0] + a[4] * b[1] + a[8] * b[2]; }
+static real dot44(const real *a, const real *b) { return FMA(a[8], b[8], FMA(a[4], b[4], a[0] * b[0])); }
+static real dot41(const real *a, const real *b) { return FMA(a[8], b[2], FMA(a[4], b[1], a[0] * b[0])); }
 
 /* dLineClosestApproach */
 static void line_closest_approach(const real *pa, const real *ua, const real *pb, const real *ub,

@@ -27,24 +27,32 @@
 
 #define R(i)   ((real)(i))
 
+/* The step is specified with fused multiply-adds in its dot products, cross products and a*x+y updates
+ * (one rounding per fma, z-term last), in the oracle and in the HIP kernels alike: FMA(a,b,c) = a*b + c. */
+#ifdef ORC_SINGLE
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+#else
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
+#endif
+
 /* dCalcVectorDot3: a0*b0 + a1*b1 + a2*b2, summed left to right */
 static inline real orc_dot3(const real *a, const real *b)
 {
-    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    return FMA(a[2], b[2], FMA(a[1], b[1], a[0] * b[0]));
 }
 
 /* dCalcVectorDot3_14: b strided by 4 (a column of a 3x4 matrix) */
 static inline real orc_dot3_14(const real *a, const real *b)
 {
-    return a[0] * b[0] + a[1] * b[4] + a[2] * b[8];
+    return FMA(a[2], b[8], FMA(a[1], b[4], a[0] * b[0]));
 }
 
 /* dCalcVectorCross3: a = b x c */
 static inline void orc_cross3(real *a, const real *b, const real *c)
 {
-    a[0] = b[1] * c[2] - b[2] * c[1];
-    a[1] = b[2] * c[0] - b[0] * c[2];
-    a[2] = b[0] * c[1] - b[1] * c[0];
+    a[0] = FMA(b[1], c[2], -(b[2] * c[1]));
+    a[1] = FMA(b[2], c[0], -(b[0] * c[2]));
+    a[2] = FMA(b[0], c[1], -(b[1] * c[0]));
 }
 
 /* dMultiply0_331: a = B * c, B 3x4 */
@@ -92,9 +100,10 @@ static inline void orc_mul2_333(real *A, const real *B, const real *C)
 /* dCalcMatrix3Det */
 static inline real orc_det3(const real *m)
 {
-    return m[0] * (m[5] * m[10] - m[9] * m[6])
-         - m[1] * (m[4] * m[10] - m[8] * m[6])
-         + m[2] * (m[4] * m[9] - m[8] * m[5]);
+    real m0 = FMA(m[5], m[10], -(m[9] * m[6]));
+    real m1 = FMA(m[4], m[10], -(m[8] * m[6]));
+    real m2 = FMA(m[4], m[9], -(m[8] * m[5]));
+    return FMA(m[2], m2, FMA(-m[1], m1, m[0] * m0));
 }
 
 /* dInvertMatrix3: closed-form adjugate / det; returns 0 if singular */
@@ -103,17 +112,17 @@ static inline int orc_invert3(real *dst, const real *ma)
     real det = orc_det3(ma);
     if (det == 0) return 0;
     real dr = R(1.0) / det;
-    dst[0]  = (ma[5] * ma[10] - ma[6] * ma[9]) * dr;
-    dst[1]  = (ma[9] * ma[2] - ma[1] * ma[10]) * dr;
-    dst[2]  = (ma[1] * ma[6] - ma[5] * ma[2]) * dr;
+    dst[0]  = FMA(ma[5], ma[10], -(ma[6] * ma[9])) * dr;
+    dst[1]  = FMA(ma[9], ma[2], -(ma[1] * ma[10])) * dr;
+    dst[2]  = FMA(ma[1], ma[6], -(ma[5] * ma[2])) * dr;
     dst[3]  = 0;
-    dst[4]  = (ma[6] * ma[8] - ma[4] * ma[10]) * dr;
-    dst[5]  = (ma[0] * ma[10] - ma[8] * ma[2]) * dr;
-    dst[6]  = (ma[4] * ma[2] - ma[0] * ma[6]) * dr;
+    dst[4]  = FMA(ma[6], ma[8], -(ma[4] * ma[10])) * dr;
+    dst[5]  = FMA(ma[0], ma[10], -(ma[8] * ma[2])) * dr;
+    dst[6]  = FMA(ma[4], ma[2], -(ma[0] * ma[6])) * dr;
     dst[7]  = 0;
-    dst[8]  = (ma[4] * ma[9] - ma[8] * ma[5]) * dr;
-    dst[9]  = (ma[8] * ma[1] - ma[0] * ma[9]) * dr;
-    dst[10] = (ma[0] * ma[5] - ma[1] * ma[4]) * dr;
+    dst[8]  = FMA(ma[4], ma[9], -(ma[8] * ma[5])) * dr;
+    dst[9]  = FMA(ma[8], ma[1], -(ma[0] * ma[9])) * dr;
+    dst[10] = FMA(ma[0], ma[5], -(ma[1] * ma[4])) * dr;
     dst[11] = 0;
     return 1;
 }
@@ -125,15 +134,15 @@ static inline void orc_q_to_R(const real *q, real *Rm)
     real qq2 = 2 * q[2] * q[2];
     real qq3 = 2 * q[3] * q[3];
     Rm[0]  = 1 - qq2 - qq3;
-    Rm[1]  = 2 * (q[1] * q[2] - q[0] * q[3]);
-    Rm[2]  = 2 * (q[1] * q[3] + q[0] * q[2]);
+    Rm[1]  = 2 * FMA(q[1], q[2], -(q[0] * q[3]));
+    Rm[2]  = 2 * FMA(q[1], q[3], q[0] * q[2]);
     Rm[3]  = 0;
-    Rm[4]  = 2 * (q[1] * q[2] + q[0] * q[3]);
+    Rm[4]  = 2 * FMA(q[1], q[2], q[0] * q[3]);
     Rm[5]  = 1 - qq1 - qq3;
-    Rm[6]  = 2 * (q[2] * q[3] - q[0] * q[1]);
+    Rm[6]  = 2 * FMA(q[2], q[3], -(q[0] * q[1]));
     Rm[7]  = 0;
-    Rm[8]  = 2 * (q[1] * q[3] - q[0] * q[2]);
-    Rm[9]  = 2 * (q[2] * q[3] + q[0] * q[1]);
+    Rm[8]  = 2 * FMA(q[1], q[3], -(q[0] * q[2]));
+    Rm[9]  = 2 * FMA(q[2], q[3], q[0] * q[1]);
     Rm[10] = 1 - qq1 - qq2;
     Rm[11] = 0;
 }
@@ -178,7 +187,7 @@ static inline void orc_R_to_q(const real *Rm, real *q)
 /* dNormalize4 (_dSafeNormalize4 + fallback to identity) */
 static inline void orc_normalize4(real *a)
 {
-    real l = orc_dot3(a, a) + a[3] * a[3];
+    real l = FMA(a[3], a[3], FMA(a[2], a[2], FMA(a[1], a[1], a[0] * a[0])));
     if (l > 0) {
         l = R(1.0) / orc_sqrt(l);   /* dRecipSqrt */
         a[0] *= l; a[1] *= l; a[2] *= l; a[3] *= l;
@@ -190,10 +199,10 @@ static inline void orc_normalize4(real *a)
 /* dDQfromW / dWtoDQ: dq = 1/2 (0,w) (x) q */
 static inline void orc_w_to_dq(const real *w, const real *q, real *dq)
 {
-    dq[0] = R(0.5) * (-w[0] * q[1] - w[1] * q[2] - w[2] * q[3]);
-    dq[1] = R(0.5) * ( w[0] * q[0] + w[1] * q[3] - w[2] * q[2]);
-    dq[2] = R(0.5) * (-w[0] * q[3] + w[1] * q[0] + w[2] * q[1]);
-    dq[3] = R(0.5) * ( w[0] * q[2] - w[1] * q[1] + w[2] * q[0]);
+    dq[0] = R(0.5) * FMA(-w[2], q[3], FMA(-w[1], q[2], -w[0] * q[1]));
+    dq[1] = R(0.5) * FMA(-w[2], q[2], FMA( w[1], q[3],  w[0] * q[0]));
+    dq[2] = R(0.5) * FMA( w[2], q[1], FMA( w[1], q[0], -w[0] * q[3]));
+    dq[3] = R(0.5) * FMA( w[2], q[0], FMA(-w[1], q[1],  w[0] * q[2]));
 }
 
 /* dPlaneSpace: p,q orthonormal to unit n */

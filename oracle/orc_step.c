@@ -57,10 +57,10 @@ static void need_rows(size_t m)
 /* dxStepBody: x += h v; q += h * 1/2 (0,w) q; normalise; R = R(q) */
 static void step_body(orc_body *b, real h)
 {
-    for (int j = 0; j < 3; j++) b->pos[j] += h * b->lvel[j];
+    for (int j = 0; j < 3; j++) b->pos[j] = FMA(h, b->lvel[j], b->pos[j]);
     real dq[4];
     orc_w_to_dq(b->avel, b->q, dq);
-    for (int j = 0; j < 4; j++) b->q[j] += h * dq[j];
+    for (int j = 0; j < 4; j++) b->q[j] = FMA(h, dq[j], b->q[j]);
     orc_normalize4(b->q);
     orc_q_to_R(b->q, b->R);
 }
@@ -87,7 +87,7 @@ static void gyro_torque(const orc_world *w, orc_body *b, real h)
     It[1] = L[2];  It[2] = -L[1];
     It[4] = -L[2]; It[6] = L[0];
     It[8] = L[1];  It[9] = -L[0];
-    for (int i = 0; i < 12; i++) It[i] = It[i] * h + I[i];
+    for (int i = 0; i < 12; i++) It[i] = FMA(It[i], h, I[i]);
     real hinv = R(1.0) / h;
     L[0] *= hinv; L[1] *= hinv; L[2] *= hinv;
     real itInv[12];
@@ -141,7 +141,7 @@ static void contact_rows(const orc_world *w, const orc_joint *j, int lb1, int lb
     real pushout = k_erp * depth;
     S.c[r] = pushout;                    /* max_vel = infinity */
     if (j->mode & ORC_CONTACT_BOUNCE) {
-        real outgoing = orc_dot3(J, B1->lvel) + orc_dot3(J + 3, B1->avel);
+        real outgoing = orc_dot3(J, B1->lvel) + orc_dot3(J + 3, B1->avel);   /* two fused dots, then one add */
         if (B2) outgoing += orc_dot3(J + 6, B2->lvel) + orc_dot3(J + 9, B2->avel);
         if (j->bounce_vel >= 0 && (-outgoing) > j->bounce_vel) {
             real newc = -j->bounce * outgoing;
@@ -199,9 +199,9 @@ static double sor_lcp(const orc_world *w, int m, int nb, const int *ibody)
     for (int i = 0; i < m; i++) {
         const real *ip = iMJ + 12 * (size_t)i, *jp = J + 12 * (size_t)i;
         real sum = 0;
-        for (int j = 0; j < 6; j++) sum += ip[j] * jp[j];
+        for (int j = 0; j < 6; j++) sum = FMA(ip[j], jp[j], sum);
         if (jb[2 * i + 1] >= 0)
-            for (int j = 6; j < 12; j++) sum += ip[j] * jp[j];
+            for (int j = 6; j < 12; j++) sum = FMA(ip[j], jp[j], sum);
         Ad[i] = w->sor_w / (sum + S.cfm[i]);
     }
     /* scale J and b by Ad; Ad *= cfm */
@@ -233,13 +233,13 @@ static double sor_lcp(const orc_world *w, int m, int nb, const int *ibody)
             real *fc1 = fc + 6 * (size_t)b1;
             real *fc2 = b2 >= 0 ? fc + 6 * (size_t)b2 : NULL;
             real old_lambda = lambda[idx];
-            real delta = b[idx] - old_lambda * Ad[idx];
+            real delta = FMA(-old_lambda, Ad[idx], b[idx]);
             const real *jp = J + 12 * (size_t)idx;
-            delta -= fc1[0] * jp[0] + fc1[1] * jp[1] + fc1[2] * jp[2] +
-                     fc1[3] * jp[3] + fc1[4] * jp[4] + fc1[5] * jp[5];
+            delta -= FMA(fc1[5], jp[5], FMA(fc1[4], jp[4], FMA(fc1[3], jp[3],
+                     FMA(fc1[2], jp[2], FMA(fc1[1], jp[1], fc1[0] * jp[0])))));
             if (fc2)
-                delta -= fc2[0] * jp[6] + fc2[1] * jp[7] + fc2[2] * jp[8] +
-                         fc2[3] * jp[9] + fc2[4] * jp[10] + fc2[5] * jp[11];
+                delta -= FMA(fc2[5], jp[11], FMA(fc2[4], jp[10], FMA(fc2[3], jp[9],
+                         FMA(fc2[2], jp[8], FMA(fc2[1], jp[7], fc2[0] * jp[6])))));
             real lo_act, hi_act;
             if (S.findex[idx] >= 0) {
                 hi_act = orc_fabs(S.hi[idx] * lambda[S.findex[idx]]);
@@ -250,8 +250,8 @@ static double sor_lcp(const orc_world *w, int m, int nb, const int *ibody)
             else if (new_lambda > hi_act) { delta = hi_act - old_lambda; lambda[idx] = hi_act; }
             else lambda[idx] = new_lambda;
             const real *ip = iMJ + 12 * (size_t)idx;
-            for (int k = 0; k < 6; k++) fc1[k] += delta * ip[k];
-            if (fc2) for (int k = 0; k < 6; k++) fc2[k] += delta * ip[6 + k];
+            for (int k = 0; k < 6; k++) fc1[k] = FMA(delta, ip[k], fc1[k]);
+            if (fc2) for (int k = 0; k < 6; k++) fc2[k] = FMA(delta, ip[6 + k], fc2[k]);
             if (last) resid += (double)orc_fabs(delta);
         }
     }
@@ -266,7 +266,7 @@ static void step_island(orc_world *w, const int *ibody, int nb, const int *ijoin
     for (int i = 0; i < nb; i++) {
         orc_body *b = &w->bodies[ibody[i]];
         if (!(b->flags & (ORC_BODY_NOGRAVITY | ORC_BODY_KINEMATIC)))
-            for (int j = 0; j < 3; j++) b->facc[j] += b->mass * w->gravity[j];
+            for (int j = 0; j < 3; j++) b->facc[j] = FMA(b->mass, w->gravity[j], b->facc[j]);
         real tmp[12];
         if (b->flags & ORC_BODY_KINEMATIC) {
             memset(S.invI + 12 * (size_t)i, 0, 12 * sizeof(real));
@@ -294,21 +294,21 @@ static void step_island(orc_world *w, const int *ibody, int nb, const int *ijoin
             const orc_body *b = &w->bodies[ibody[i]];
             real im = (b->flags & ORC_BODY_KINEMATIC) ? 0 : b->invMass;
             real *t = S.tmp1 + 6 * (size_t)i;
-            for (int j = 0; j < 3; j++) t[j] = b->facc[j] * im + b->lvel[j] * stepsize1;
+            for (int j = 0; j < 3; j++) t[j] = FMA(b->facc[j], im, b->lvel[j] * stepsize1);
             orc_mul0_331(t + 3, S.invI + 12 * (size_t)i, b->tacc);
-            for (int j = 0; j < 3; j++) t[3 + j] += b->avel[j] * stepsize1;
+            for (int j = 0; j < 3; j++) t[3 + j] = FMA(b->avel[j], stepsize1, t[3 + j]);
         }
         for (int i = 0; i < m; i++) {
             const real *jp = S.J + 12 * (size_t)i;
             int b1 = S.jb[2 * i], b2 = S.jb[2 * i + 1];
             real sum = 0;
             const real *in = S.tmp1 + 6 * (size_t)b1;
-            for (int j = 0; j < 6; j++) sum += jp[j] * in[j];
+            for (int j = 0; j < 6; j++) sum = FMA(jp[j], in[j], sum);
             if (b2 >= 0) {
                 in = S.tmp1 + 6 * (size_t)b2;
-                for (int j = 0; j < 6; j++) sum += jp[6 + j] * in[j];
+                for (int j = 0; j < 6; j++) sum = FMA(jp[6 + j], in[j], sum);
             }
-            S.rhs[i] = S.c[i] * stepsize1 - sum;
+            S.rhs[i] = FMA(S.c[i], stepsize1, -sum);
             S.cfm[i] *= stepsize1;
         }
         w->last_residual += sor_lcp(w, m, nb, ibody);
@@ -316,8 +316,8 @@ static void step_island(orc_world *w, const int *ibody, int nb, const int *ijoin
         for (int i = 0; i < nb; i++) {
             orc_body *b = &w->bodies[ibody[i]];
             const real *cf = S.fc + 6 * (size_t)i;
-            for (int j = 0; j < 3; j++) b->lvel[j] += h * cf[j];
-            for (int j = 0; j < 3; j++) b->avel[j] += h * cf[3 + j];
+            for (int j = 0; j < 3; j++) b->lvel[j] = FMA(h, cf[j], b->lvel[j]);
+            for (int j = 0; j < 3; j++) b->avel[j] = FMA(h, cf[3 + j], b->avel[j]);
         }
     }
     /* v += h invM fe; integrate; clear accumulators */
@@ -325,7 +325,7 @@ static void step_island(orc_world *w, const int *ibody, int nb, const int *ijoin
         orc_body *b = &w->bodies[ibody[i]];
         if (!(b->flags & ORC_BODY_KINEMATIC)) {
             real im = b->invMass;
-            for (int j = 0; j < 3; j++) b->lvel[j] += h * im * b->facc[j];
+            for (int j = 0; j < 3; j++) b->lvel[j] = FMA(h * im, b->facc[j], b->lvel[j]);
             for (int j = 0; j < 3; j++) b->tacc[j] *= h;
             orc_muladd0_331(b->avel, S.invI + 12 * (size_t)i, b->tacc);
         }

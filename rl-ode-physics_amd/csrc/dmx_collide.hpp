@@ -24,12 +24,12 @@ template <class T>
 DMX_HD int box_plane(const V3<T> &pos, const M3<T> &R, const T side[3], const V3<T> &n, T d, int maxc,
                      V3<T> cp[4], T cd[4])
 {
-    const T Q1 = n.x * R.m[0][0] + n.y * R.m[1][0] + n.z * R.m[2][0];
-    const T Q2 = n.x * R.m[0][1] + n.y * R.m[1][1] + n.z * R.m[2][1];
-    const T Q3 = n.x * R.m[0][2] + n.y * R.m[1][2] + n.z * R.m[2][2];
+    const T Q1 = dot(n, colv(R, 0));
+    const T Q2 = dot(n, colv(R, 1));
+    const T Q3 = dot(n, colv(R, 2));
     const T A[3] = { side[0] * Q1, side[1] * Q2, side[2] * Q3 };
     const T B[3] = { tabs(A[0]), tabs(A[1]), tabs(A[2]) };
-    const T depth = d + T(0.5) * (B[0] + B[1] + B[2]) - (n.x * pos.x + n.y * pos.y + n.z * pos.z);
+    const T depth = d + T(0.5) * (B[0] + B[1] + B[2]) - dot(n, pos);
     if (depth < 0) return 0;
     if (maxc < 1) maxc = 1;
     if (maxc > 4) maxc = 4;
@@ -83,7 +83,7 @@ DMX_HD int box_plane(const V3<T> &pos, const M3<T> &R, const T side[3], const V3
 template <class T>
 DMX_HD int sphere_plane(const V3<T> &pos, T radius, const V3<T> &n, T d, V3<T> cp[4], T cd[4])
 {
-    const T k = pos.x * n.x + pos.y * n.y + pos.z * n.z;
+    const T k = dot(pos, n);
     const T depth = d - k + radius;
     if (depth >= 0) {
         cp[0] = { pos.x - n.x * radius, pos.y - n.y * radius, pos.z - n.z * radius };

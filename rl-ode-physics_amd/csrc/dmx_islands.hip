@@ -20,7 +20,7 @@ enum : int { BW_INVI = 0, BW_FACC = 9, BW_TACC = 12, BW_INVM = 15, BW_FC = 16, B
 
 template <class T> __device__ __forceinline__ V3<T> ld3(const T *p) { return { p[0], p[1], p[2] }; }
 template <class T> __device__ __forceinline__ void st3(T *p, const V3<T> &v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
-template <class T> __device__ __forceinline__ T dot3p(const T *a, const V3<T> &b) { return a[0] * b.x + a[1] * b.y + a[2] * b.z; }
+template <class T> __device__ __forceinline__ T dot3p(const T *a, const V3<T> &b) { return fma_(a[2], b.z, fma_(a[1], b.y, a[0] * b.x)); }
 
 template <class T>
 __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uint8_t *__restrict__ bflags,
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
         V3<T> facc = { S[(C_FORCE + 0) * stride + s], S[(C_FORCE + 1) * stride + s], S[(C_FORCE + 2) * stride + s] };
         V3<T> tacc = { S[(C_TORQUE + 0) * stride + s], S[(C_TORQUE + 1) * stride + s], S[(C_TORQUE + 2) * stride + s] };
         const bool kin = fl & BF_KINEMATIC;
-        if (!kin && !(fl & BF_NOGRAVITY)) { facc.x += mass * P.g.x; facc.y += mass * P.g.y; facc.z += mass * P.g.z; }
+        if (!kin && !(fl & BF_NOGRAVITY)) { facc.x = fma_(mass, P.g.x, facc.x); facc.y = fma_(mass, P.g.y, facc.y); facc.z = fma_(mass, P.g.z, facc.z); }
         M3<T> invIw;
         if (kin) {
             for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) invIw.m[i][j] = T(0);
@@ -152,14 +152,15 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
             const T im = b[BW_INVM];
             const V3<T> v = { S[(C_LVEL + 0) * stride + s], S[(C_LVEL + 1) * stride + s], S[(C_LVEL + 2) * stride + s] };
             const V3<T> w = { S[(C_AVEL + 0) * stride + s], S[(C_AVEL + 1) * stride + s], S[(C_AVEL + 2) * stride + s] };
-            b[BW_TMP + 0] = b[BW_FACC + 0] * im + v.x * hinv;
-            b[BW_TMP + 1] = b[BW_FACC + 1] * im + v.y * hinv;
-            b[BW_TMP + 2] = b[BW_FACC + 2] * im + v.z * hinv;
+            b[BW_TMP + 0] = fma_(b[BW_FACC + 0], im, v.x * hinv);
+            b[BW_TMP + 1] = fma_(b[BW_FACC + 1], im, v.y * hinv);
+            b[BW_TMP + 2] = fma_(b[BW_FACC + 2], im, v.z * hinv);
             const V3<T> tacc = ld3(b + BW_TACC);
             b[BW_TMP + 3] = dot3p(b + BW_INVI + 0, tacc);
             b[BW_TMP + 4] = dot3p(b + BW_INVI + 3, tacc);
             b[BW_TMP + 5] = dot3p(b + BW_INVI + 6, tacc);
-            b[BW_TMP + 3] += w.x * hinv; b[BW_TMP + 4] += w.y * hinv; b[BW_TMP + 5] += w.z * hinv;
+            b[BW_TMP + 3] = fma_(w.x, hinv, b[BW_TMP + 3]); b[BW_TMP + 4] = fma_(w.y, hinv, b[BW_TMP + 4]);
+            b[BW_TMP + 5] = fma_(w.z, hinv, b[BW_TMP + 5]);
         }
         for (int i = 0; i < m; i++) {
             T *row = rows + (size_t)i * RW_COUNT;
@@ -167,12 +168,12 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
             const int l1 = jb[2 * i], l2 = jb[2 * i + 1];
             T sum = T(0);
             const T *in = bs + (size_t)l1 * BW_COUNT + BW_TMP;
-            for (int j = 0; j < 6; j++) sum += J[j] * in[j];
+            for (int j = 0; j < 6; j++) sum = fma_(J[j], in[j], sum);
             if (l2 >= 0) {
                 in = bs + (size_t)l2 * BW_COUNT + BW_TMP;
-                for (int j = 0; j < 6; j++) sum += J[6 + j] * in[j];
+                for (int j = 0; j < 6; j++) sum = fma_(J[6 + j], in[j], sum);
             }
-            row[RW_RHS] = row[RW_RHS] * hinv - sum;
+            row[RW_RHS] = fma_(row[RW_RHS], hinv, -sum);
             row[RW_AD] *= hinv;
         }
         // ---- iMJ = M^-1 J^T ; Ad = w / (J iMJ + cfm) ; J *= Ad ; rhs *= Ad ; Ad *= cfm --------------------
@@ -193,8 +194,8 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
                 for (int j = 6; j < 12; j++) iMJ[j] = T(0);
             }
             T sum = T(0);
-            for (int j = 0; j < 6; j++) sum += iMJ[j] * J[j];
-            if (l2 >= 0) for (int j = 6; j < 12; j++) sum += iMJ[j] * J[j];
+            for (int j = 0; j < 6; j++) sum = fma_(iMJ[j], J[j], sum);
+            if (l2 >= 0) for (int j = 6; j < 12; j++) sum = fma_(iMJ[j], J[j], sum);
             const T cfm = row[RW_AD];
             const T ad = P.sor_w / (sum + cfm);
             for (int j = 0; j < 12; j++) J[j] *= ad;
@@ -211,17 +212,17 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
                 T *fc1 = bs + (size_t)l1 * BW_COUNT + BW_FC;
                 T *fc2 = l2 >= 0 ? bs + (size_t)l2 * BW_COUNT + BW_FC : nullptr;
                 const T old = row[RW_LAM];
-                T delta = row[RW_RHS] - old * row[RW_AD];
-                delta -= fc1[0] * J[0] + fc1[1] * J[1] + fc1[2] * J[2] + fc1[3] * J[3] + fc1[4] * J[4] + fc1[5] * J[5];
+                T delta = fma_(-old, row[RW_AD], row[RW_RHS]);
+                delta -= fma_(fc1[5], J[5], fma_(fc1[4], J[4], fma_(fc1[3], J[3], fma_(fc1[2], J[2], fma_(fc1[1], J[1], fc1[0] * J[0])))));
                 if (fc2)
-                    delta -= fc2[0] * J[6] + fc2[1] * J[7] + fc2[2] * J[8] + fc2[3] * J[9] + fc2[4] * J[10] + fc2[5] * J[11];
+                    delta -= fma_(fc2[5], J[11], fma_(fc2[4], J[10], fma_(fc2[3], J[9], fma_(fc2[2], J[8], fma_(fc2[1], J[7], fc2[0] * J[6])))));
                 const T lo = row[RW_LO], hi = row[RW_HI];
                 const T nl = old + delta;
                 if (nl < lo) { delta = lo - old; row[RW_LAM] = lo; }
                 else if (nl > hi) { delta = hi - old; row[RW_LAM] = hi; }
                 else row[RW_LAM] = nl;
-                for (int j = 0; j < 6; j++) fc1[j] += delta * iMJ[j];
-                if (fc2) for (int j = 0; j < 6; j++) fc2[j] += delta * iMJ[6 + j];
+                for (int j = 0; j < 6; j++) fc1[j] = fma_(delta, iMJ[j], fc1[j]);
+                if (fc2) for (int j = 0; j < 6; j++) fc2[j] = fma_(delta, iMJ[6 + j], fc2[j]);
                 if (last) resid += (double)tabs(delta);
             }
         }
@@ -237,17 +238,17 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
         V3<T> v = { S[(C_LVEL + 0) * stride + s], S[(C_LVEL + 1) * stride + s], S[(C_LVEL + 2) * stride + s] };
         V3<T> w = { S[(C_AVEL + 0) * stride + s], S[(C_AVEL + 1) * stride + s], S[(C_AVEL + 2) * stride + s] };
         if (m > 0) {
-            v.x += h * b[BW_FC + 0]; v.y += h * b[BW_FC + 1]; v.z += h * b[BW_FC + 2];
-            w.x += h * b[BW_FC + 3]; w.y += h * b[BW_FC + 4]; w.z += h * b[BW_FC + 5];
+            v.x = fma_(h, b[BW_FC + 0], v.x); v.y = fma_(h, b[BW_FC + 1], v.y); v.z = fma_(h, b[BW_FC + 2], v.z);
+            w.x = fma_(h, b[BW_FC + 3], w.x); w.y = fma_(h, b[BW_FC + 4], w.y); w.z = fma_(h, b[BW_FC + 5], w.z);
         }
         if (!(bflags[s] & BF_KINEMATIC)) {
             const T hm = h * b[BW_INVM];
-            v.x += hm * b[BW_FACC + 0]; v.y += hm * b[BW_FACC + 1]; v.z += hm * b[BW_FACC + 2];
+            v.x = fma_(hm, b[BW_FACC + 0], v.x); v.y = fma_(hm, b[BW_FACC + 1], v.y); v.z = fma_(hm, b[BW_FACC + 2], v.z);
             V3<T> tacc = ld3(b + BW_TACC);
             tacc.x *= h; tacc.y *= h; tacc.z *= h;
             w.x += dot3p(b + BW_INVI + 0, tacc); w.y += dot3p(b + BW_INVI + 3, tacc); w.z += dot3p(b + BW_INVI + 6, tacc);
         }
-        x.x += h * v.x; x.y += h * v.y; x.z += h * v.z;
+        x.x = fma_(h, v.x, x.x); x.y = fma_(h, v.y, x.y); x.z = fma_(h, v.z, x.z);
         integrate_quat(q, w, h);
         S[(C_POS + 0) * stride + s] = x.x; S[(C_POS + 1) * stride + s] = x.y; S[(C_POS + 2) * stride + s] = x.z;
         S[(C_QUAT + 0) * stride + s] = q.w; S[(C_QUAT + 1) * stride + s] = q.x;

@@ -81,18 +81,18 @@ __device__ __forceinline__ void free_body_step(V3<T> &x, Q4<T> &q, V3<T> &v, V3<
     const M3<T> R = quat_to_R(q);
     const T invMass = T(1) / mass;
     const V3<T> invIb = { T(1) / Ib.x, T(1) / Ib.y, T(1) / Ib.z };
-    facc.x += mass * g.x; facc.y += mass * g.y; facc.z += mass * g.z;
+    facc.x = fma_(mass, g.x, facc.x); facc.y = fma_(mass, g.y, facc.y); facc.z = fma_(mass, g.z, facc.z);
     const M3<T> invIw = rotate_diag(R, invIb);
     if (gyro != 0) {
         const M3<T> Iw = rotate_diag(R, Ib);
         add_gyro_torque(tacc, Iw, w, h, gyro);
     }
     const T hm = h * invMass;
-    v.x += hm * facc.x; v.y += hm * facc.y; v.z += hm * facc.z;
+    v.x = fma_(hm, facc.x, v.x); v.y = fma_(hm, facc.y, v.y); v.z = fma_(hm, facc.z, v.z);
     tacc.x *= h; tacc.y *= h; tacc.z *= h;
     const V3<T> dw = mulv(invIw, tacc);
     w.x += dw.x; w.y += dw.y; w.z += dw.z;
-    x.x += h * v.x; x.y += h * v.y; x.z += h * v.z;
+    x.x = fma_(h, v.x, x.x); x.y = fma_(h, v.y, x.y); x.z = fma_(h, v.z, x.z);
     integrate_quat(q, w, h);
 }
 
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
         const M3<T> R = quat_to_R(q);
         const T invMass = T(1) / mass;
         const V3<T> invIb = { T(1) / Ib.x, T(1) / Ib.y, T(1) / Ib.z };
-        facc.x += mass * P.g.x; facc.y += mass * P.g.y; facc.z += mass * P.g.z;
+        facc.x = fma_(mass, P.g.x, facc.x); facc.y = fma_(mass, P.g.y, facc.y); facc.z = fma_(mass, P.g.z, facc.z);
         const M3<T> invIw = rotate_diag(R, invIb);
         if (P.gyro != 0) {
             const M3<T> Iw = rotate_diag(R, Ib);
@@ -233,10 +233,10 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
             dir[0] = P.pn;
             plane_space(P.pn, dir[1], dir[2]);
             // v/h + M^-1 f
-            const V3<T> tl = { facc.x * invMass + v.x * hinv, facc.y * invMass + v.y * hinv,
-                               facc.z * invMass + v.z * hinv };
+            const V3<T> tl = { fma_(facc.x, invMass, v.x * hinv), fma_(facc.y, invMass, v.y * hinv),
+                               fma_(facc.z, invMass, v.z * hinv) };
             V3<T> ta = mulv(invIw, tacc);
-            ta.x += w.x * hinv; ta.y += w.y * hinv; ta.z += w.z * hinv;
+            ta.x = fma_(w.x, hinv, ta.x); ta.y = fma_(w.y, hinv, ta.y); ta.z = fma_(w.z, hinv, ta.z);
             const V3<T> iml[3] = { { invMass * dir[0].x, invMass * dir[0].y, invMass * dir[0].z },
                                    { invMass * dir[1].x, invMass * dir[1].y, invMass * dir[1].z },
                                    { invMass * dir[2].x, invMass * dir[2].y, invMass * dir[2].z } };
@@ -273,15 +273,14 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
                                     }
                                 }
                             }
-                            T sum = T(0);
-                            sum += dir[dnum].x * tl.x; sum += dir[dnum].y * tl.y; sum += dir[dnum].z * tl.z;
-                            sum += ja.x * ta.x; sum += ja.y * ta.y; sum += ja.z * ta.z;
-                            const T b = c * hinv - sum;
+                            T sum = dir[dnum].x * tl.x;
+                            sum = fma_(dir[dnum].y, tl.y, sum); sum = fma_(dir[dnum].z, tl.z, sum);
+                            sum = fma_(ja.x, ta.x, sum); sum = fma_(ja.y, ta.y, sum); sum = fma_(ja.z, ta.z, sum);
+                            const T b = fma_(c, hinv, -sum);
                             const V3<T> ima = mulv(invIw, ja);
-                            T s2 = T(0);
-                            s2 += iml[dnum].x * dir[dnum].x; s2 += iml[dnum].y * dir[dnum].y;
-                            s2 += iml[dnum].z * dir[dnum].z;
-                            s2 += ima.x * ja.x; s2 += ima.y * ja.y; s2 += ima.z * ja.z;
+                            T s2 = iml[dnum].x * dir[dnum].x;
+                            s2 = fma_(iml[dnum].y, dir[dnum].y, s2); s2 = fma_(iml[dnum].z, dir[dnum].z, s2);
+                            s2 = fma_(ima.x, ja.x, s2); s2 = fma_(ima.y, ja.y, s2); s2 = fma_(ima.z, ja.z, s2);
                             const T ad = P.sor_w / (s2 + cfm);
                             Ad[r] = ad;
                             Ja[r] = { ja.x * ad, ja.y * ad, ja.z * ad };
@@ -314,11 +313,10 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
                             const int r = 3 * k + dnum;
                             if (dnum < rpc) {
                                 const T old = lam[r];
-                                T delta = rhs[r] - old * adcfm[r];
+                                T delta = fma_(-old, adcfm[r], rhs[r]);
                                 const T ad = Ad[r];
-                                delta -= fl.x * (dir[dnum].x * ad) + fl.y * (dir[dnum].y * ad) +
-                                         fl.z * (dir[dnum].z * ad) + fa.x * Ja[r].x + fa.y * Ja[r].y +
-                                         fa.z * Ja[r].z;
+                                delta -= fma_(fa.z, Ja[r].z, fma_(fa.y, Ja[r].y, fma_(fa.x, Ja[r].x,
+                                         fma_(fl.z, dir[dnum].z * ad, fma_(fl.y, dir[dnum].y * ad, fl.x * (dir[dnum].x * ad))))));
                                 const T nl = old + delta;
                                 const T lo = dnum == 0 ? T(0) : lo_f, hi = dnum == 0 ? hi_n : hi_f;
                                 const bool below = nl < lo, above = nl > hi;
@@ -326,8 +324,10 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
                                 delta = below ? lo - old : (above ? hi - old : delta);
                                 delta = act ? delta : T(0);
                                 lam[r] = act ? nlam : old;
-                                fl.x += delta * iml[dnum].x; fl.y += delta * iml[dnum].y; fl.z += delta * iml[dnum].z;
-                                fa.x += delta * iMa[r].x; fa.y += delta * iMa[r].y; fa.z += delta * iMa[r].z;
+                                fl.x = fma_(delta, iml[dnum].x, fl.x); fl.y = fma_(delta, iml[dnum].y, fl.y);
+                                fl.z = fma_(delta, iml[dnum].z, fl.z);
+                                fa.x = fma_(delta, iMa[r].x, fa.x); fa.y = fma_(delta, iMa[r].y, fa.y);
+                                fa.z = fma_(delta, iMa[r].z, fa.z);
                                 rsum += tabs(delta);
                             }
                         }
@@ -336,17 +336,17 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
             }
             my_resid = (double)rsum;      // |delta lambda| summed over the last sweep
             // v += h * (M^-1 J^T lambda)
-            v.x += h * fl.x; v.y += h * fl.y; v.z += h * fl.z;
-            w.x += h * fa.x; w.y += h * fa.y; w.z += h * fa.z;
+            v.x = fma_(h, fl.x, v.x); v.y = fma_(h, fl.y, v.y); v.z = fma_(h, fl.z, v.z);
+            w.x = fma_(h, fa.x, w.x); w.y = fma_(h, fa.y, w.y); w.z = fma_(h, fa.z, w.z);
         }
 
         // ---- v += h M^-1 f_ext ; integrate ----------------------------------------------------
         const T hm = h * invMass;
-        v.x += hm * facc.x; v.y += hm * facc.y; v.z += hm * facc.z;
+        v.x = fma_(hm, facc.x, v.x); v.y = fma_(hm, facc.y, v.y); v.z = fma_(hm, facc.z, v.z);
         tacc.x *= h; tacc.y *= h; tacc.z *= h;
         const V3<T> dw = mulv(invIw, tacc);
         w.x += dw.x; w.y += dw.y; w.z += dw.z;
-        x.x += h * v.x; x.y += h * v.y; x.z += h * v.z;
+        x.x = fma_(h, v.x, x.x); x.y = fma_(h, v.y, x.y); x.z = fma_(h, v.z, x.z);
         integrate_quat(q, w, h);
         pack_boundary(P, i, x, q, v, w);
 

@@ -2,7 +2,7 @@
 // the host side of the ODE-compatible API.  3x3 matrices are row-major without
 // padding; quaternions are (w,x,y,z) as in ODE.  Every expression is written in
 // the evaluation order the step is specified with (left-to-right sums, no FMA:
-// the library is built with -ffp-contract=off) so results are reproducible
+// the library is built with -ffp-contract=off; fused multiply-adds are explicit, fma_) so results are reproducible
 // bit-for-bit across host and device.
 #pragma once
 
@@ -20,21 +20,25 @@ template <class T> DMX_HD T tsqrt(T x);
 template <> DMX_HD float  tsqrt<float>(float x)   { return __builtin_sqrtf(x); }
 template <> DMX_HD double tsqrt<double>(double x) { return __builtin_sqrt(x); }
 template <class T> DMX_HD T tabs(T x) { return x < T(0) ? -x : x; }
+// The step is specified with fused multiply-adds in its dot products, cross products and a*x+y updates (one
+// rounding per fma, z-term last); everything else is a plain rounded operation (-ffp-contract=off).
+DMX_HD float  fma_(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
+DMX_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 template <class T> struct V3 { T x, y, z; };
 template <class T> struct Q4 { T w, x, y, z; };
 template <class T> struct M3 { T m[3][3]; };
 
-template <class T> DMX_HD T dot(const V3<T> &a, const V3<T> &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T> DMX_HD T dot(const V3<T> &a, const V3<T> &b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 template <class T> DMX_HD V3<T> cross(const V3<T> &b, const V3<T> &c)
 {
-    return { b.y * c.z - b.z * c.y, b.z * c.x - b.x * c.z, b.x * c.y - b.y * c.x };
+    return { fma_(b.y, c.z, -(b.z * c.y)), fma_(b.z, c.x, -(b.x * c.z)), fma_(b.x, c.y, -(b.y * c.x)) };
 }
 template <class T> DMX_HD V3<T> mulv(const M3<T> &B, const V3<T> &c)
 {
-    return { B.m[0][0] * c.x + B.m[0][1] * c.y + B.m[0][2] * c.z,
-             B.m[1][0] * c.x + B.m[1][1] * c.y + B.m[1][2] * c.z,
-             B.m[2][0] * c.x + B.m[2][1] * c.y + B.m[2][2] * c.z };
+    return { fma_(B.m[0][2], c.z, fma_(B.m[0][1], c.y, B.m[0][0] * c.x)),
+             fma_(B.m[1][2], c.z, fma_(B.m[1][1], c.y, B.m[1][0] * c.x)),
+             fma_(B.m[2][2], c.z, fma_(B.m[2][1], c.y, B.m[2][0] * c.x)) };
 }
 // A = B * C
 template <class T> DMX_HD M3<T> mul(const M3<T> &B, const M3<T> &C)
@@ -44,7 +48,7 @@ template <class T> DMX_HD M3<T> mul(const M3<T> &B, const M3<T> &C)
     for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++)
-            A.m[i][j] = B.m[i][0] * C.m[0][j] + B.m[i][1] * C.m[1][j] + B.m[i][2] * C.m[2][j];
+            A.m[i][j] = fma_(B.m[i][2], C.m[2][j], fma_(B.m[i][1], C.m[1][j], B.m[i][0] * C.m[0][j]));
     return A;
 }
 
@@ -54,13 +58,13 @@ template <class T> DMX_HD M3<T> quat_to_R(const Q4<T> &q)
     T qq1 = 2 * q.x * q.x, qq2 = 2 * q.y * q.y, qq3 = 2 * q.z * q.z;
     M3<T> R;
     R.m[0][0] = 1 - qq2 - qq3;
-    R.m[0][1] = 2 * (q.x * q.y - q.w * q.z);
-    R.m[0][2] = 2 * (q.x * q.z + q.w * q.y);
-    R.m[1][0] = 2 * (q.x * q.y + q.w * q.z);
+    R.m[0][1] = 2 * fma_(q.x, q.y, -(q.w * q.z));
+    R.m[0][2] = 2 * fma_(q.x, q.z, q.w * q.y);
+    R.m[1][0] = 2 * fma_(q.x, q.y, q.w * q.z);
     R.m[1][1] = 1 - qq1 - qq3;
-    R.m[1][2] = 2 * (q.y * q.z - q.w * q.x);
-    R.m[2][0] = 2 * (q.x * q.z - q.w * q.y);
-    R.m[2][1] = 2 * (q.y * q.z + q.w * q.x);
+    R.m[1][2] = 2 * fma_(q.y, q.z, -(q.w * q.x));
+    R.m[2][0] = 2 * fma_(q.x, q.z, -(q.w * q.y));
+    R.m[2][1] = 2 * fma_(q.y, q.z, q.w * q.x);
     R.m[2][2] = 1 - qq1 - qq2;
     return R;
 }
@@ -104,7 +108,7 @@ template <class T> DMX_HD Q4<T> R_to_quat(const M3<T> &R)
 
 template <class T> DMX_HD void normalize(Q4<T> &q)
 {
-    T l = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    T l = fma_(q.z, q.z, fma_(q.y, q.y, fma_(q.x, q.x, q.w * q.w)));
     if (l > 0) {
         l = T(1) / tsqrt<T>(l);
         q.w *= l; q.x *= l; q.y *= l; q.z *= l;
@@ -127,9 +131,10 @@ template <class T> DMX_HD M3<T> rotate_diag(const M3<T> &R, const V3<T> &d)
 
 template <class T> DMX_HD T det3(const M3<T> &a)
 {
-    return a.m[0][0] * (a.m[1][1] * a.m[2][2] - a.m[2][1] * a.m[1][2])
-         - a.m[0][1] * (a.m[1][0] * a.m[2][2] - a.m[2][0] * a.m[1][2])
-         + a.m[0][2] * (a.m[1][0] * a.m[2][1] - a.m[2][0] * a.m[1][1]);
+    const T m0 = fma_(a.m[1][1], a.m[2][2], -(a.m[2][1] * a.m[1][2]));
+    const T m1 = fma_(a.m[1][0], a.m[2][2], -(a.m[2][0] * a.m[1][2]));
+    const T m2 = fma_(a.m[1][0], a.m[2][1], -(a.m[2][0] * a.m[1][1]));
+    return fma_(a.m[0][2], m2, fma_(-a.m[0][1], m1, a.m[0][0] * m0));
 }
 
 // closed-form inverse (adjugate / determinant); false when singular
@@ -138,15 +143,15 @@ template <class T> DMX_HD bool invert3(M3<T> &d, const M3<T> &a)
     T det = det3(a);
     if (det == 0) return false;
     T r = T(1) / det;
-    d.m[0][0] = (a.m[1][1] * a.m[2][2] - a.m[1][2] * a.m[2][1]) * r;
-    d.m[0][1] = (a.m[2][1] * a.m[0][2] - a.m[0][1] * a.m[2][2]) * r;
-    d.m[0][2] = (a.m[0][1] * a.m[1][2] - a.m[1][1] * a.m[0][2]) * r;
-    d.m[1][0] = (a.m[1][2] * a.m[2][0] - a.m[1][0] * a.m[2][2]) * r;
-    d.m[1][1] = (a.m[0][0] * a.m[2][2] - a.m[2][0] * a.m[0][2]) * r;
-    d.m[1][2] = (a.m[1][0] * a.m[0][2] - a.m[0][0] * a.m[1][2]) * r;
-    d.m[2][0] = (a.m[1][0] * a.m[2][1] - a.m[2][0] * a.m[1][1]) * r;
-    d.m[2][1] = (a.m[2][0] * a.m[0][1] - a.m[0][0] * a.m[2][1]) * r;
-    d.m[2][2] = (a.m[0][0] * a.m[1][1] - a.m[0][1] * a.m[1][0]) * r;
+    d.m[0][0] = fma_(a.m[1][1], a.m[2][2], -(a.m[1][2] * a.m[2][1])) * r;
+    d.m[0][1] = fma_(a.m[2][1], a.m[0][2], -(a.m[0][1] * a.m[2][2])) * r;
+    d.m[0][2] = fma_(a.m[0][1], a.m[1][2], -(a.m[1][1] * a.m[0][2])) * r;
+    d.m[1][0] = fma_(a.m[1][2], a.m[2][0], -(a.m[1][0] * a.m[2][2])) * r;
+    d.m[1][1] = fma_(a.m[0][0], a.m[2][2], -(a.m[2][0] * a.m[0][2])) * r;
+    d.m[1][2] = fma_(a.m[1][0], a.m[0][2], -(a.m[0][0] * a.m[1][2])) * r;
+    d.m[2][0] = fma_(a.m[1][0], a.m[2][1], -(a.m[2][0] * a.m[1][1])) * r;
+    d.m[2][1] = fma_(a.m[2][0], a.m[0][1], -(a.m[0][0] * a.m[2][1])) * r;
+    d.m[2][2] = fma_(a.m[0][0], a.m[1][1], -(a.m[0][1] * a.m[1][0])) * r;
     return true;
 }
 
@@ -168,7 +173,7 @@ template <class T> DMX_HD void add_gyro_torque(V3<T> &tacc, const M3<T> &Iw, con
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) It.m[i][j] = It.m[i][j] * h + Iw.m[i][j];
+        for (int j = 0; j < 3; j++) It.m[i][j] = fma_(It.m[i][j], h, Iw.m[i][j]);
     T hinv = T(1) / h;
     L.x *= hinv; L.y *= hinv; L.z *= hinv;
     M3<T> inv;
@@ -182,11 +187,11 @@ template <class T> DMX_HD void add_gyro_torque(V3<T> &tacc, const M3<T> &Iw, con
 // q += h * 1/2 (0,w) (x) q ; renormalise
 template <class T> DMX_HD void integrate_quat(Q4<T> &q, const V3<T> &w, T h)
 {
-    T d0 = T(0.5) * (-w.x * q.x - w.y * q.y - w.z * q.z);
-    T d1 = T(0.5) * ( w.x * q.w + w.y * q.z - w.z * q.y);
-    T d2 = T(0.5) * (-w.x * q.z + w.y * q.w + w.z * q.x);
-    T d3 = T(0.5) * ( w.x * q.y - w.y * q.x + w.z * q.w);
-    q.w += h * d0; q.x += h * d1; q.y += h * d2; q.z += h * d3;
+    T d0 = T(0.5) * fma_(-w.z, q.z, fma_(-w.y, q.y, -w.x * q.x));
+    T d1 = T(0.5) * fma_(-w.z, q.y, fma_( w.y, q.z,  w.x * q.w));
+    T d2 = T(0.5) * fma_( w.z, q.x, fma_( w.y, q.w, -w.x * q.z));
+    T d3 = T(0.5) * fma_( w.z, q.w, fma_(-w.y, q.x,  w.x * q.y));
+    q.w = fma_(h, d0, q.w); q.x = fma_(h, d1, q.x); q.y = fma_(h, d2, q.y); q.z = fma_(h, d3, q.z);
     normalize(q);
 }
 
