@@ -49,6 +49,10 @@ template <class T> struct IslandSet {
     int *rowjb;            // scratch: 2 ints per row
     T *bscr;               // scratch: 28 reals per island body
     int *local;            // scratch: per slot, index of the body inside its island
+    // large islands (solve_island_wg): per island -1 or the start of its level offsets in lev_off; per large island its
+    // island index and level count; lev_rows = island-relative row indices grouped by level; crow = first row of a contact
+    const int *big; int n_big; const int *big_list; const int *lev_count; const int *lev_off; const int *lev_rows;
+    const int *crow;
 };
 
 template <class T> struct StepParams {

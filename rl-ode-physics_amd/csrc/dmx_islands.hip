@@ -2,10 +2,14 @@
 // explicit contact list (the contact joints of dJointCreateContact + dJointAttach,
 // /root/reference/src/main.c:690-691, or the device narrowphase's output).
 //
-// One lane owns one island and runs the SOR sweep over its rows in creation order, exactly as a
-// sequential Gauss-Seidel does, so results do not depend on how islands are spread over the GPU.
-// Rows and per-body scratch live in HBM/L2 (islands of the compat path hold <= a few hundred rows);
-// parallelism is across islands.  Single bodies resting on the ground plane never come here: they take
+// The SOR sweep is a sequential Gauss-Seidel over the island's rows in creation order.  Two kernels run the
+// same per-body / per-contact / per-row phase functions and therefore give the same bits:
+//   solve_islands    -- one lane per island: plenty of small islands in flight at once;
+//   solve_island_wg  -- one workgroup per LARGE island (a pile): every phase is spread over the workgroup's lanes;
+//                       the sweep follows a level schedule (row r's level = 1 + the latest level of an earlier row
+//                       sharing a body with r): rows of one level touch disjoint bodies, so updating them
+//                       concurrently gives exactly the sequential result; one barrier per level.
+// Rows and per-body scratch live in HBM/L2.  Single bodies resting on the ground plane never come here: they take
 // the fused register-resident path (step_plane).
 #include <hip/hip_runtime.h>
 #include "dmx_internal.hpp"
@@ -21,7 +25,226 @@ enum : int { BW_INVI = 0, BW_FACC = 9, BW_TACC = 12, BW_INVM = 15, BW_FC = 16, B
 template <class T> __device__ __forceinline__ V3<T> ld3(const T *p) { return { p[0], p[1], p[2] }; }
 template <class T> __device__ __forceinline__ void st3(T *p, const V3<T> &v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
 template <class T> __device__ __forceinline__ T dot3p(const T *a, const V3<T> &b) { return fma_(a[2], b.z, fma_(a[1], b.y, a[0] * b.x)); }
+template <class T> __device__ __forceinline__ V3<T> ldS(const T *S, int64_t stride, int c0, int s)
+{
+    return { S[(c0 + 0) * stride + s], S[(c0 + 1) * stride + s], S[(c0 + 2) * stride + s] };
+}
 
+// ---- stage 0, body k of the island: gravity, world-frame inverse inertia, gyroscopic torque ---------------
+template <class T>
+__device__ __forceinline__ void stage_body(const T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I,
+                                           const StepParams<T> &P, T *b, int s, int k)
+{
+    I.local[s] = k;
+    const uint8_t fl = bflags[s];
+    const Q4<T> q = { S[(C_QUAT + 0) * stride + s], S[(C_QUAT + 1) * stride + s],
+                      S[(C_QUAT + 2) * stride + s], S[(C_QUAT + 3) * stride + s] };
+    const V3<T> w = ldS(S, stride, C_AVEL, s);
+    const T mass = S[C_MASS * stride + s];
+    const V3<T> Ib = ldS(S, stride, C_INERTIA, s);
+    V3<T> facc = ldS(S, stride, C_FORCE, s), tacc = ldS(S, stride, C_TORQUE, s);
+    const bool kin = fl & BF_KINEMATIC;
+    if (!kin && !(fl & BF_NOGRAVITY)) { facc.x = fma_(mass, P.g.x, facc.x); facc.y = fma_(mass, P.g.y, facc.y); facc.z = fma_(mass, P.g.z, facc.z); }
+    M3<T> invIw;
+    if (kin) {
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) invIw.m[i][j] = T(0);
+        b[BW_INVM] = T(0);
+    } else {
+        const M3<T> R = quat_to_R(q);
+        const V3<T> invIb = { T(1) / Ib.x, T(1) / Ib.y, T(1) / Ib.z };
+        invIw = rotate_diag(R, invIb);
+        if (P.gyro != 0 && !(fl & BF_NOGYRO)) {
+            const M3<T> Iw = rotate_diag(R, Ib);
+            add_gyro_torque(tacc, Iw, w, P.h, P.gyro);
+        }
+        b[BW_INVM] = T(1) / mass;
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) b[BW_INVI + 3 * i + j] = invIw.m[i][j];
+    st3(b + BW_FACC, facc);
+    st3(b + BW_TACC, tacc);
+    for (int j = 0; j < 6; j++) b[BW_FC + j] = T(0);
+}
+
+template <class T> __device__ __forceinline__ int contact_rpc(const IslandSet<T> &I, int ci)
+{
+    return I.cmu[ci] > 0 ? 3 : 1;
+}
+
+// ---- rows of contact ci (normal + 2 friction when mu > 0), written at island-relative row m -----------------
+template <class T>
+__device__ __forceinline__ void contact_rows(const T *S, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
+                                             T *rows, int *jb, int ci, int m, T hinv)
+{
+    const int s1 = I.cb1[ci], s2 = I.cb2[ci];
+    const int l1 = I.local[s1], l2 = s2 >= 0 ? I.local[s2] : -1;
+    const bool ind = I.csrc != nullptr;
+    const size_t gi = ind ? (size_t)I.csrc[ci] : (size_t)ci;
+    const V3<T> normal = ld3((ind ? I.gnormal : I.cnormal) + 3 * gi);
+    const V3<T> cpos = ld3((ind ? I.gpos : I.cpos) + 3 * gi);
+    const V3<T> x1 = ldS(S, stride, C_POS, s1);
+    const V3<T> c1 = { cpos.x - x1.x, cpos.y - x1.y, cpos.z - x1.z };
+    V3<T> c2 = { T(0), T(0), T(0) };
+    if (s2 >= 0) {
+        const V3<T> x2 = ldS(S, stride, C_POS, s2);
+        c2 = { cpos.x - x2.x, cpos.y - x2.y, cpos.z - x2.z };
+    }
+    const int mode = I.cmode[ci];
+    T mu = I.cmu[ci];
+    if (mu < 0) mu = 0;
+    const int rpc = mu > 0 ? 3 : 1;
+    V3<T> dir[3];
+    dir[0] = normal;
+    if (rpc == 3) plane_space(normal, dir[1], dir[2]);
+    for (int dnum = 0; dnum < rpc; dnum++) {
+        T *row = rows + (size_t)(m + dnum) * RW_COUNT;
+        jb[2 * (m + dnum)] = l1; jb[2 * (m + dnum) + 1] = l2;
+        T *J = row + RW_J;
+        st3(J, dir[dnum]);
+        st3(J + 3, cross(c1, dir[dnum]));
+        if (s2 >= 0) {
+            J[6] = -dir[dnum].x; J[7] = -dir[dnum].y; J[8] = -dir[dnum].z;
+            const V3<T> a = cross(c2, dir[dnum]);
+            J[9] = -a.x; J[10] = -a.y; J[11] = -a.z;
+        } else {
+            for (int j = 6; j < 12; j++) J[j] = T(0);
+        }
+        T cval = T(0), cfm = P.cfm;
+        if (dnum == 0) {
+            T erp = P.erp;
+            if (mode & SURF_SOFT_ERP) erp = I.csoft_erp[ci];
+            if (mode & SURF_SOFT_CFM) cfm = I.csoft_cfm[ci];
+            T depth = ind ? I.gdepth[gi] : I.cdepth[ci];
+            if (depth < 0) depth = 0;
+            cval = (hinv * erp) * depth;
+            if (mode & SURF_BOUNCE) {
+                T outgoing = dot3p(J, ldS(S, stride, C_LVEL, s1)) + dot3p(J + 3, ldS(S, stride, C_AVEL, s1));
+                if (s2 >= 0) outgoing += dot3p(J + 6, ldS(S, stride, C_LVEL, s2)) + dot3p(J + 9, ldS(S, stride, C_AVEL, s2));
+                const T bv = I.cbounce_vel[ci];
+                if (bv >= 0 && (-outgoing) > bv) {
+                    const T newc = -I.cbounce[ci] * outgoing;
+                    if (newc > cval) cval = newc;
+                }
+            }
+            row[RW_LO] = T(0); row[RW_HI] = Limits<T>::inf();
+        } else {
+            row[RW_LO] = -mu; row[RW_HI] = mu;
+        }
+        row[RW_RHS] = cval;     // c for now
+        row[RW_AD] = cfm;       // cfm for now
+        row[RW_LAM] = T(0);
+    }
+}
+
+// ---- v/h + M^-1 f of body k ------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void body_tmp(const T *S, int64_t stride, T *b, int s, T hinv)
+{
+    const T im = b[BW_INVM];
+    const V3<T> v = ldS(S, stride, C_LVEL, s), w = ldS(S, stride, C_AVEL, s);
+    b[BW_TMP + 0] = fma_(b[BW_FACC + 0], im, v.x * hinv);
+    b[BW_TMP + 1] = fma_(b[BW_FACC + 1], im, v.y * hinv);
+    b[BW_TMP + 2] = fma_(b[BW_FACC + 2], im, v.z * hinv);
+    const V3<T> tacc = ld3(b + BW_TACC);
+    b[BW_TMP + 3] = dot3p(b + BW_INVI + 0, tacc);
+    b[BW_TMP + 4] = dot3p(b + BW_INVI + 3, tacc);
+    b[BW_TMP + 5] = dot3p(b + BW_INVI + 6, tacc);
+    b[BW_TMP + 3] = fma_(w.x, hinv, b[BW_TMP + 3]); b[BW_TMP + 4] = fma_(w.y, hinv, b[BW_TMP + 4]);
+    b[BW_TMP + 5] = fma_(w.z, hinv, b[BW_TMP + 5]);
+}
+
+// ---- row i: rhs = c/h - J (v/h + M^-1 f); cfm /= h; iMJ = M^-1 J^T; Ad = w/(J iMJ + cfm); J *= Ad; rhs *= Ad; Ad *= cfm
+template <class T>
+__device__ __forceinline__ void row_setup(T *rows, const int *jb, const T *bs, int i, T hinv, T sor_w)
+{
+    T *row = rows + (size_t)i * RW_COUNT;
+    T *J = row + RW_J, *iMJ = row + RW_IMJ;
+    const int l1 = jb[2 * i], l2 = jb[2 * i + 1];
+    T sum = T(0);
+    const T *in = bs + (size_t)l1 * BW_COUNT + BW_TMP;
+    for (int j = 0; j < 6; j++) sum = fma_(J[j], in[j], sum);
+    if (l2 >= 0) {
+        in = bs + (size_t)l2 * BW_COUNT + BW_TMP;
+        for (int j = 0; j < 6; j++) sum = fma_(J[6 + j], in[j], sum);
+    }
+    row[RW_RHS] = fma_(row[RW_RHS], hinv, -sum);
+    row[RW_AD] *= hinv;
+
+    const T *b1 = bs + (size_t)l1 * BW_COUNT;
+    for (int j = 0; j < 3; j++) iMJ[j] = b1[BW_INVM] * J[j];
+    const V3<T> ja1 = ld3(J + 3);
+    iMJ[3] = dot3p(b1 + BW_INVI + 0, ja1); iMJ[4] = dot3p(b1 + BW_INVI + 3, ja1); iMJ[5] = dot3p(b1 + BW_INVI + 6, ja1);
+    if (l2 >= 0) {
+        const T *b2 = bs + (size_t)l2 * BW_COUNT;
+        for (int j = 0; j < 3; j++) iMJ[6 + j] = b2[BW_INVM] * J[6 + j];
+        const V3<T> ja2 = ld3(J + 9);
+        iMJ[9] = dot3p(b2 + BW_INVI + 0, ja2); iMJ[10] = dot3p(b2 + BW_INVI + 3, ja2); iMJ[11] = dot3p(b2 + BW_INVI + 6, ja2);
+    } else {
+        for (int j = 6; j < 12; j++) iMJ[j] = T(0);
+    }
+    T s2 = T(0);
+    for (int j = 0; j < 6; j++) s2 = fma_(iMJ[j], J[j], s2);
+    if (l2 >= 0) for (int j = 6; j < 12; j++) s2 = fma_(iMJ[j], J[j], s2);
+    const T cfm = row[RW_AD];
+    const T ad = sor_w / (s2 + cfm);
+    for (int j = 0; j < 12; j++) J[j] *= ad;
+    row[RW_RHS] *= ad;
+    row[RW_AD] = ad * cfm;
+}
+
+// ---- one SOR row update; returns |delta lambda| -----------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ T row_sor(T *rows, const int *jb, T *bs, int i)
+{
+    T *row = rows + (size_t)i * RW_COUNT;
+    const T *J = row + RW_J, *iMJ = row + RW_IMJ;
+    const int l1 = jb[2 * i], l2 = jb[2 * i + 1];
+    T *fc1 = bs + (size_t)l1 * BW_COUNT + BW_FC;
+    T *fc2 = l2 >= 0 ? bs + (size_t)l2 * BW_COUNT + BW_FC : nullptr;
+    const T old = row[RW_LAM];
+    T delta = fma_(-old, row[RW_AD], row[RW_RHS]);
+    delta -= fma_(fc1[5], J[5], fma_(fc1[4], J[4], fma_(fc1[3], J[3], fma_(fc1[2], J[2], fma_(fc1[1], J[1], fc1[0] * J[0])))));
+    if (fc2)
+        delta -= fma_(fc2[5], J[11], fma_(fc2[4], J[10], fma_(fc2[3], J[9], fma_(fc2[2], J[8], fma_(fc2[1], J[7], fc2[0] * J[6])))));
+    const T lo = row[RW_LO], hi = row[RW_HI];
+    const T nl = old + delta;
+    if (nl < lo) { delta = lo - old; row[RW_LAM] = lo; }
+    else if (nl > hi) { delta = hi - old; row[RW_LAM] = hi; }
+    else row[RW_LAM] = nl;
+    for (int j = 0; j < 6; j++) fc1[j] = fma_(delta, iMJ[j], fc1[j]);
+    if (fc2) for (int j = 0; j < 6; j++) fc2[j] = fma_(delta, iMJ[6 + j], fc2[j]);
+    return tabs(delta);
+}
+
+// ---- body k: v += h cforce ; v += h M^-1 f ; integrate ; clear accumulators -------------------------------------
+template <class T>
+__device__ __forceinline__ void finish_body(T *S, const uint8_t *bflags, int64_t stride, const T *b, int s, bool has_rows, T h)
+{
+    V3<T> x = ldS(S, stride, C_POS, s);
+    Q4<T> q = { S[(C_QUAT + 0) * stride + s], S[(C_QUAT + 1) * stride + s],
+                S[(C_QUAT + 2) * stride + s], S[(C_QUAT + 3) * stride + s] };
+    V3<T> v = ldS(S, stride, C_LVEL, s), w = ldS(S, stride, C_AVEL, s);
+    if (has_rows) {
+        v.x = fma_(h, b[BW_FC + 0], v.x); v.y = fma_(h, b[BW_FC + 1], v.y); v.z = fma_(h, b[BW_FC + 2], v.z);
+        w.x = fma_(h, b[BW_FC + 3], w.x); w.y = fma_(h, b[BW_FC + 4], w.y); w.z = fma_(h, b[BW_FC + 5], w.z);
+    }
+    if (!(bflags[s] & BF_KINEMATIC)) {
+        const T hm = h * b[BW_INVM];
+        v.x = fma_(hm, b[BW_FACC + 0], v.x); v.y = fma_(hm, b[BW_FACC + 1], v.y); v.z = fma_(hm, b[BW_FACC + 2], v.z);
+        V3<T> tacc = ld3(b + BW_TACC);
+        tacc.x *= h; tacc.y *= h; tacc.z *= h;
+        w.x += dot3p(b + BW_INVI + 0, tacc); w.y += dot3p(b + BW_INVI + 3, tacc); w.z += dot3p(b + BW_INVI + 6, tacc);
+    }
+    x.x = fma_(h, v.x, x.x); x.y = fma_(h, v.y, x.y); x.z = fma_(h, v.z, x.z);
+    integrate_quat(q, w, h);
+    S[(C_POS + 0) * stride + s] = x.x; S[(C_POS + 1) * stride + s] = x.y; S[(C_POS + 2) * stride + s] = x.z;
+    S[(C_QUAT + 0) * stride + s] = q.w; S[(C_QUAT + 1) * stride + s] = q.x;
+    S[(C_QUAT + 2) * stride + s] = q.y; S[(C_QUAT + 3) * stride + s] = q.z;
+    S[(C_LVEL + 0) * stride + s] = v.x; S[(C_LVEL + 1) * stride + s] = v.y; S[(C_LVEL + 2) * stride + s] = v.z;
+    S[(C_AVEL + 0) * stride + s] = w.x; S[(C_AVEL + 1) * stride + s] = w.y; S[(C_AVEL + 2) * stride + s] = w.z;
+    for (int j = 0; j < 6; j++) S[(C_FORCE + j) * stride + s] = T(0);
+}
+
+// ================================================================================ one lane per island
 template <class T>
 __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uint8_t *__restrict__ bflags,
                                                     int64_t stride, IslandSet<T> I, StepParams<T> P,
@@ -29,6 +252,7 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
 {
     const int isl = blockIdx.x * blockDim.x + threadIdx.x;
     if (isl >= I.n_islands) return;
+    if (I.big != nullptr && I.big[isl] >= 0) return;          // a workgroup owns this one (solve_island_wg)
     const T h = P.h, hinv = T(1) / h;
     const int b0 = I.body_off[isl], nb = I.body_off[isl + 1] - b0;
     const int c0 = I.con_off[isl], nc = I.con_off[isl + 1] - c0;
@@ -37,230 +261,80 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
     T *rows = I.rows + (size_t)r0 * RW_COUNT;
     int *jb = I.rowjb + 2 * (size_t)r0;
 
-    // ---- stage 0: gravity, world-frame inverse inertia, gyroscopic torque --------------------------
-    for (int k = 0; k < nb; k++) {
-        const int s = I.bodies[b0 + k];
-        I.local[s] = k;
-        const uint8_t fl = bflags[s];
-        T *b = bs + (size_t)k * BW_COUNT;
-        const Q4<T> q = { S[(C_QUAT + 0) * stride + s], S[(C_QUAT + 1) * stride + s],
-                          S[(C_QUAT + 2) * stride + s], S[(C_QUAT + 3) * stride + s] };
-        const V3<T> w = { S[(C_AVEL + 0) * stride + s], S[(C_AVEL + 1) * stride + s], S[(C_AVEL + 2) * stride + s] };
-        const T mass = S[C_MASS * stride + s];
-        const V3<T> Ib = { S[(C_INERTIA + 0) * stride + s], S[(C_INERTIA + 1) * stride + s], S[(C_INERTIA + 2) * stride + s] };
-        V3<T> facc = { S[(C_FORCE + 0) * stride + s], S[(C_FORCE + 1) * stride + s], S[(C_FORCE + 2) * stride + s] };
-        V3<T> tacc = { S[(C_TORQUE + 0) * stride + s], S[(C_TORQUE + 1) * stride + s], S[(C_TORQUE + 2) * stride + s] };
-        const bool kin = fl & BF_KINEMATIC;
-        if (!kin && !(fl & BF_NOGRAVITY)) { facc.x = fma_(mass, P.g.x, facc.x); facc.y = fma_(mass, P.g.y, facc.y); facc.z = fma_(mass, P.g.z, facc.z); }
-        M3<T> invIw;
-        if (kin) {
-            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) invIw.m[i][j] = T(0);
-            b[BW_INVM] = T(0);
-        } else {
-            const M3<T> R = quat_to_R(q);
-            const V3<T> invIb = { T(1) / Ib.x, T(1) / Ib.y, T(1) / Ib.z };
-            invIw = rotate_diag(R, invIb);
-            if (P.gyro != 0 && !(fl & BF_NOGYRO)) {
-                const M3<T> Iw = rotate_diag(R, Ib);
-                add_gyro_torque(tacc, Iw, w, h, P.gyro);
-            }
-            b[BW_INVM] = T(1) / mass;
-        }
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) b[BW_INVI + 3 * i + j] = invIw.m[i][j];
-        st3(b + BW_FACC, facc);
-        st3(b + BW_TACC, tacc);
-        for (int j = 0; j < 6; j++) b[BW_FC + j] = T(0);
-    }
-
-    // ---- rows from contact joints (normal + 2 friction when mu > 0) ------------------------------------
+    for (int k = 0; k < nb; k++) stage_body(S, bflags, stride, I, P, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], k);
     int m = 0;
     for (int c = 0; c < nc; c++) {
-        const int ci = c0 + c;
-        const int s1 = I.cb1[ci], s2 = I.cb2[ci];
-        const int l1 = I.local[s1], l2 = s2 >= 0 ? I.local[s2] : -1;
-        const bool ind = I.csrc != nullptr;
-        const size_t gi = ind ? (size_t)I.csrc[ci] : (size_t)ci;
-        const V3<T> normal = ld3((ind ? I.gnormal : I.cnormal) + 3 * gi);
-        const V3<T> cpos = ld3((ind ? I.gpos : I.cpos) + 3 * gi);
-        const V3<T> x1 = { S[(C_POS + 0) * stride + s1], S[(C_POS + 1) * stride + s1], S[(C_POS + 2) * stride + s1] };
-        const V3<T> c1 = { cpos.x - x1.x, cpos.y - x1.y, cpos.z - x1.z };
-        V3<T> c2 = { T(0), T(0), T(0) };
-        if (s2 >= 0) {
-            const V3<T> x2 = { S[(C_POS + 0) * stride + s2], S[(C_POS + 1) * stride + s2], S[(C_POS + 2) * stride + s2] };
-            c2 = { cpos.x - x2.x, cpos.y - x2.y, cpos.z - x2.z };
-        }
-        const int mode = I.cmode[ci];
-        T mu = I.cmu[ci];
-        if (mu < 0) mu = 0;
-        const int rpc = mu > 0 ? 3 : 1;
-        V3<T> dir[3];
-        dir[0] = normal;
-        if (rpc == 3) plane_space(normal, dir[1], dir[2]);
-        for (int dnum = 0; dnum < rpc; dnum++) {
-            T *row = rows + (size_t)(m + dnum) * RW_COUNT;
-            jb[2 * (m + dnum)] = l1; jb[2 * (m + dnum) + 1] = l2;
-            T *J = row + RW_J;
-            st3(J, dir[dnum]);
-            st3(J + 3, cross(c1, dir[dnum]));
-            if (s2 >= 0) {
-                J[6] = -dir[dnum].x; J[7] = -dir[dnum].y; J[8] = -dir[dnum].z;
-                const V3<T> a = cross(c2, dir[dnum]);
-                J[9] = -a.x; J[10] = -a.y; J[11] = -a.z;
-            } else {
-                for (int j = 6; j < 12; j++) J[j] = T(0);
-            }
-            T cval = T(0), cfm = P.cfm;
-            if (dnum == 0) {
-                T erp = P.erp;
-                if (mode & SURF_SOFT_ERP) erp = I.csoft_erp[ci];
-                if (mode & SURF_SOFT_CFM) cfm = I.csoft_cfm[ci];
-                T depth = ind ? I.gdepth[gi] : I.cdepth[ci];
-                if (depth < 0) depth = 0;
-                cval = (hinv * erp) * depth;
-                if (mode & SURF_BOUNCE) {
-                    const V3<T> v1 = { S[(C_LVEL + 0) * stride + s1], S[(C_LVEL + 1) * stride + s1], S[(C_LVEL + 2) * stride + s1] };
-                    const V3<T> w1 = { S[(C_AVEL + 0) * stride + s1], S[(C_AVEL + 1) * stride + s1], S[(C_AVEL + 2) * stride + s1] };
-                    T outgoing = dot3p(J, v1) + dot3p(J + 3, w1);
-                    if (s2 >= 0) {
-                        const V3<T> v2 = { S[(C_LVEL + 0) * stride + s2], S[(C_LVEL + 1) * stride + s2], S[(C_LVEL + 2) * stride + s2] };
-                        const V3<T> w2 = { S[(C_AVEL + 0) * stride + s2], S[(C_AVEL + 1) * stride + s2], S[(C_AVEL + 2) * stride + s2] };
-                        outgoing += dot3p(J + 6, v2) + dot3p(J + 9, w2);
-                    }
-                    const T bv = I.cbounce_vel[ci];
-                    if (bv >= 0 && (-outgoing) > bv) {
-                        const T newc = -I.cbounce[ci] * outgoing;
-                        if (newc > cval) cval = newc;
-                    }
-                }
-                row[RW_LO] = T(0); row[RW_HI] = Limits<T>::inf();
-            } else {
-                row[RW_LO] = -mu; row[RW_HI] = mu;
-            }
-            row[RW_RHS] = cval;     // c for now
-            row[RW_AD] = cfm;       // cfm for now
-            row[RW_LAM] = T(0);
-        }
-        m += rpc;
+        contact_rows(S, stride, I, P, rows, jb, c0 + c, m, hinv);
+        m += contact_rpc(I, c0 + c);
     }
-
     double resid = 0.0;
     if (m > 0) {
-        // ---- rhs = c/h - J (v/h + M^-1 f) ; cfm /= h -----------------------------------------------------
-        for (int k = 0; k < nb; k++) {
-            const int s = I.bodies[b0 + k];
-            T *b = bs + (size_t)k * BW_COUNT;
-            const T im = b[BW_INVM];
-            const V3<T> v = { S[(C_LVEL + 0) * stride + s], S[(C_LVEL + 1) * stride + s], S[(C_LVEL + 2) * stride + s] };
-            const V3<T> w = { S[(C_AVEL + 0) * stride + s], S[(C_AVEL + 1) * stride + s], S[(C_AVEL + 2) * stride + s] };
-            b[BW_TMP + 0] = fma_(b[BW_FACC + 0], im, v.x * hinv);
-            b[BW_TMP + 1] = fma_(b[BW_FACC + 1], im, v.y * hinv);
-            b[BW_TMP + 2] = fma_(b[BW_FACC + 2], im, v.z * hinv);
-            const V3<T> tacc = ld3(b + BW_TACC);
-            b[BW_TMP + 3] = dot3p(b + BW_INVI + 0, tacc);
-            b[BW_TMP + 4] = dot3p(b + BW_INVI + 3, tacc);
-            b[BW_TMP + 5] = dot3p(b + BW_INVI + 6, tacc);
-            b[BW_TMP + 3] = fma_(w.x, hinv, b[BW_TMP + 3]); b[BW_TMP + 4] = fma_(w.y, hinv, b[BW_TMP + 4]);
-            b[BW_TMP + 5] = fma_(w.z, hinv, b[BW_TMP + 5]);
-        }
-        for (int i = 0; i < m; i++) {
-            T *row = rows + (size_t)i * RW_COUNT;
-            const T *J = row + RW_J;
-            const int l1 = jb[2 * i], l2 = jb[2 * i + 1];
-            T sum = T(0);
-            const T *in = bs + (size_t)l1 * BW_COUNT + BW_TMP;
-            for (int j = 0; j < 6; j++) sum = fma_(J[j], in[j], sum);
-            if (l2 >= 0) {
-                in = bs + (size_t)l2 * BW_COUNT + BW_TMP;
-                for (int j = 0; j < 6; j++) sum = fma_(J[6 + j], in[j], sum);
-            }
-            row[RW_RHS] = fma_(row[RW_RHS], hinv, -sum);
-            row[RW_AD] *= hinv;
-        }
-        // ---- iMJ = M^-1 J^T ; Ad = w / (J iMJ + cfm) ; J *= Ad ; rhs *= Ad ; Ad *= cfm --------------------
-        for (int i = 0; i < m; i++) {
-            T *row = rows + (size_t)i * RW_COUNT;
-            T *J = row + RW_J, *iMJ = row + RW_IMJ;
-            const int l1 = jb[2 * i], l2 = jb[2 * i + 1];
-            const T *b1 = bs + (size_t)l1 * BW_COUNT;
-            for (int j = 0; j < 3; j++) iMJ[j] = b1[BW_INVM] * J[j];
-            const V3<T> ja1 = ld3(J + 3);
-            iMJ[3] = dot3p(b1 + BW_INVI + 0, ja1); iMJ[4] = dot3p(b1 + BW_INVI + 3, ja1); iMJ[5] = dot3p(b1 + BW_INVI + 6, ja1);
-            if (l2 >= 0) {
-                const T *b2 = bs + (size_t)l2 * BW_COUNT;
-                for (int j = 0; j < 3; j++) iMJ[6 + j] = b2[BW_INVM] * J[6 + j];
-                const V3<T> ja2 = ld3(J + 9);
-                iMJ[9] = dot3p(b2 + BW_INVI + 0, ja2); iMJ[10] = dot3p(b2 + BW_INVI + 3, ja2); iMJ[11] = dot3p(b2 + BW_INVI + 6, ja2);
-            } else {
-                for (int j = 6; j < 12; j++) iMJ[j] = T(0);
-            }
-            T sum = T(0);
-            for (int j = 0; j < 6; j++) sum = fma_(iMJ[j], J[j], sum);
-            if (l2 >= 0) for (int j = 6; j < 12; j++) sum = fma_(iMJ[j], J[j], sum);
-            const T cfm = row[RW_AD];
-            const T ad = P.sor_w / (sum + cfm);
-            for (int j = 0; j < 12; j++) J[j] *= ad;
-            row[RW_RHS] *= ad;
-            row[RW_AD] = ad * cfm;
-        }
-        // ---- SOR-PGS sweeps, rows in creation order ------------------------------------------------------
+        for (int k = 0; k < nb; k++) body_tmp(S, stride, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], hinv);
+        for (int i = 0; i < m; i++) row_setup(rows, jb, bs, i, hinv, P.sor_w);
         for (int it = 0; it < P.iters; it++) {
             const bool last = (it == P.iters - 1);
             for (int i = 0; i < m; i++) {
-                T *row = rows + (size_t)i * RW_COUNT;
-                const T *J = row + RW_J, *iMJ = row + RW_IMJ;
-                const int l1 = jb[2 * i], l2 = jb[2 * i + 1];
-                T *fc1 = bs + (size_t)l1 * BW_COUNT + BW_FC;
-                T *fc2 = l2 >= 0 ? bs + (size_t)l2 * BW_COUNT + BW_FC : nullptr;
-                const T old = row[RW_LAM];
-                T delta = fma_(-old, row[RW_AD], row[RW_RHS]);
-                delta -= fma_(fc1[5], J[5], fma_(fc1[4], J[4], fma_(fc1[3], J[3], fma_(fc1[2], J[2], fma_(fc1[1], J[1], fc1[0] * J[0])))));
-                if (fc2)
-                    delta -= fma_(fc2[5], J[11], fma_(fc2[4], J[10], fma_(fc2[3], J[9], fma_(fc2[2], J[8], fma_(fc2[1], J[7], fc2[0] * J[6])))));
-                const T lo = row[RW_LO], hi = row[RW_HI];
-                const T nl = old + delta;
-                if (nl < lo) { delta = lo - old; row[RW_LAM] = lo; }
-                else if (nl > hi) { delta = hi - old; row[RW_LAM] = hi; }
-                else row[RW_LAM] = nl;
-                for (int j = 0; j < 6; j++) fc1[j] = fma_(delta, iMJ[j], fc1[j]);
-                if (fc2) for (int j = 0; j < 6; j++) fc2[j] = fma_(delta, iMJ[6 + j], fc2[j]);
-                if (last) resid += (double)tabs(delta);
+                const T d = row_sor(rows, jb, bs, i);
+                if (last) resid += (double)d;
             }
         }
     }
-
-    // ---- v += h cforce ; v += h M^-1 f ; integrate ; clear accumulators -------------------------------------
-    for (int k = 0; k < nb; k++) {
-        const int s = I.bodies[b0 + k];
-        const T *b = bs + (size_t)k * BW_COUNT;
-        V3<T> x = { S[(C_POS + 0) * stride + s], S[(C_POS + 1) * stride + s], S[(C_POS + 2) * stride + s] };
-        Q4<T> q = { S[(C_QUAT + 0) * stride + s], S[(C_QUAT + 1) * stride + s],
-                    S[(C_QUAT + 2) * stride + s], S[(C_QUAT + 3) * stride + s] };
-        V3<T> v = { S[(C_LVEL + 0) * stride + s], S[(C_LVEL + 1) * stride + s], S[(C_LVEL + 2) * stride + s] };
-        V3<T> w = { S[(C_AVEL + 0) * stride + s], S[(C_AVEL + 1) * stride + s], S[(C_AVEL + 2) * stride + s] };
-        if (m > 0) {
-            v.x = fma_(h, b[BW_FC + 0], v.x); v.y = fma_(h, b[BW_FC + 1], v.y); v.z = fma_(h, b[BW_FC + 2], v.z);
-            w.x = fma_(h, b[BW_FC + 3], w.x); w.y = fma_(h, b[BW_FC + 4], w.y); w.z = fma_(h, b[BW_FC + 5], w.z);
-        }
-        if (!(bflags[s] & BF_KINEMATIC)) {
-            const T hm = h * b[BW_INVM];
-            v.x = fma_(hm, b[BW_FACC + 0], v.x); v.y = fma_(hm, b[BW_FACC + 1], v.y); v.z = fma_(hm, b[BW_FACC + 2], v.z);
-            V3<T> tacc = ld3(b + BW_TACC);
-            tacc.x *= h; tacc.y *= h; tacc.z *= h;
-            w.x += dot3p(b + BW_INVI + 0, tacc); w.y += dot3p(b + BW_INVI + 3, tacc); w.z += dot3p(b + BW_INVI + 6, tacc);
-        }
-        x.x = fma_(h, v.x, x.x); x.y = fma_(h, v.y, x.y); x.z = fma_(h, v.z, x.z);
-        integrate_quat(q, w, h);
-        S[(C_POS + 0) * stride + s] = x.x; S[(C_POS + 1) * stride + s] = x.y; S[(C_POS + 2) * stride + s] = x.z;
-        S[(C_QUAT + 0) * stride + s] = q.w; S[(C_QUAT + 1) * stride + s] = q.x;
-        S[(C_QUAT + 2) * stride + s] = q.y; S[(C_QUAT + 3) * stride + s] = q.z;
-        S[(C_LVEL + 0) * stride + s] = v.x; S[(C_LVEL + 1) * stride + s] = v.y; S[(C_LVEL + 2) * stride + s] = v.z;
-        S[(C_AVEL + 0) * stride + s] = w.x; S[(C_AVEL + 1) * stride + s] = w.y; S[(C_AVEL + 2) * stride + s] = w.z;
-        for (int j = 0; j < 6; j++) S[(C_FORCE + j) * stride + s] = T(0);
-    }
+    for (int k = 0; k < nb; k++) finish_body(S, bflags, stride, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], m > 0, h);
     if (nc > 0) {
         atomicAdd(&diag->contacts, (unsigned long long)nc);
         atomicAdd(&diag->residual, resid);
     }
+}
+
+// ================================================================================ one workgroup per large island
+constexpr int WG = 256;
+
+template <class T>
+__global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const uint8_t *__restrict__ bflags,
+                                                      int64_t stride, IslandSet<T> I, StepParams<T> P,
+                                                      StepDiag *__restrict__ diag)
+{
+    const int isl = I.big_list[blockIdx.x];
+    const int tid = threadIdx.x;
+    const T h = P.h, hinv = T(1) / h;
+    const int b0 = I.body_off[isl], nb = I.body_off[isl + 1] - b0;
+    const int c0 = I.con_off[isl], nc = I.con_off[isl + 1] - c0;
+    const int r0 = I.row_off[isl];
+    T *bs = I.bscr + (size_t)b0 * BW_COUNT;
+    T *rows = I.rows + (size_t)r0 * RW_COUNT;
+    int *jb = I.rowjb + 2 * (size_t)r0;
+    const int lv0 = I.big[isl];                               // this island's slice of the level schedule
+    const int nlev = I.lev_count[blockIdx.x];
+    const int *lev_off = I.lev_off + lv0;                     // [nlev+1], offsets into lev_rows (island-relative rows)
+    const int m = lev_off[nlev] - lev_off[0];
+
+    for (int k = tid; k < nb; k += WG) stage_body(S, bflags, stride, I, P, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], k);
+    __syncthreads();
+    for (int c = tid; c < nc; c += WG) contact_rows(S, stride, I, P, rows, jb, c0 + c, I.crow[c0 + c], hinv);
+    for (int k = tid; k < nb; k += WG) body_tmp(S, stride, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], hinv);
+    __syncthreads();
+    for (int i = tid; i < m; i += WG) row_setup(rows, jb, bs, i, hinv, P.sor_w);
+    __syncthreads();
+
+    double resid = 0.0;
+    for (int it = 0; it < P.iters; it++) {
+        const bool last = (it == P.iters - 1);
+        for (int lv = 0; lv < nlev; lv++) {
+            const int a = lev_off[lv], e = lev_off[lv + 1];
+            for (int t = a + tid; t < e; t += WG) {
+                const T d = row_sor(rows, jb, bs, I.lev_rows[t]);
+                if (last) resid += (double)d;
+            }
+            __syncthreads();                                  // the next level reads the fc this one wrote
+        }
+    }
+    for (int k = tid; k < nb; k += WG) finish_body(S, bflags, stride, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], m > 0, h);
+
+    // residual: wave reduction, then one atomic per wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) resid += __shfl_xor(resid, o, 64);
+    if ((tid & 63) == 0) atomicAdd(&diag->residual, resid);
+    if (tid == 0) atomicAdd(&diag->contacts, (unsigned long long)nc);
 }
 
 template <class T>
@@ -268,8 +342,12 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
                           StepDiag *diag, hipStream_t st)
 {
     if (I.n_islands <= 0) return hipSuccess;
-    const unsigned grid = (unsigned)((I.n_islands + 63) / 64);
-    hipLaunchKernelGGL((solve_islands<T>), dim3(grid), dim3(64), 0, st, S, bflags, stride, I, P, diag);
+    if (I.n_big < I.n_islands) {
+        const unsigned grid = (unsigned)((I.n_islands + 63) / 64);
+        hipLaunchKernelGGL((solve_islands<T>), dim3(grid), dim3(64), 0, st, S, bflags, stride, I, P, diag);
+    }
+    if (I.n_big > 0)
+        hipLaunchKernelGGL((solve_island_wg<T>), dim3((unsigned)I.n_big), dim3(WG), 0, st, S, bflags, stride, I, P, diag);
     return hipGetLastError();
 }
 

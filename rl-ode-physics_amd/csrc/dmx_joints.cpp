@@ -12,6 +12,13 @@
 
 namespace {
 
+// islands with at least this many rows get a workgroup and a level schedule (DMX_BIG_ISLAND_ROWS overrides, for tests)
+int big_island_rows()
+{
+    static const int v = [] { const char *e = getenv("DMX_BIG_ISLAND_ROWS"); return e ? atoi(e) : 384; }();
+    return v;
+}
+
 struct UnionFind {
     std::vector<int> p;
     explicit UnionFind(size_t n) : p(n) { std::iota(p.begin(), p.end(), 0); }
@@ -68,8 +75,67 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     for (int s = 0; s < n; s++)
         if (live(s) && island_of[(size_t)s] < 0) island_of[(size_t)s] = island_of[(size_t)uf.find(s)];
 
-    // int staging: body_off[ni+1] bodies[nlive] con_off[ni+1] row_off[ni+1] cb1[nc] cb2[nc] cmode[nc] csrc[nc]
-    const size_t n_int = (size_t)3 * (ni + 1) + (size_t)nlive + (size_t)4 * nc;
+    // ---- which islands are large enough for a workgroup, and their level schedules (integers only) ------------
+    // contacts are not yet in island order here; gather per-island contact lists in creation order first
+    std::vector<int> con_start((size_t)ni + 1, 0);
+    for (const CJ &c : cj) con_start[(size_t)island_of[(size_t)c.b1] + 1]++;
+    for (int i = 0; i < ni; i++) con_start[(size_t)i + 1] += con_start[(size_t)i];
+    std::vector<int> con_sorted((size_t)nc);          // cj indices grouped by island, creation order inside
+    {
+        std::vector<int> f(con_start.begin(), con_start.end() - 1);
+        for (int k = 0; k < nc; k++) con_sorted[(size_t)f[(size_t)island_of[(size_t)cj[(size_t)k].b1]]++] = k;
+    }
+    std::vector<int> crow_h((size_t)nc, 0);           // island-relative first row of each (sorted) contact
+    std::vector<int> big_h((size_t)ni, -1), big_list_h, lev_count_h, lev_off_h, lev_rows_h;
+    {
+        std::vector<int> last((size_t)n, -1);         // per slot: level of the latest row touching the body
+        for (int i = 0; i < ni; i++) {
+            int m = 0;
+            for (int d = con_start[(size_t)i]; d < con_start[(size_t)i + 1]; d++) {
+                crow_h[(size_t)d] = m;
+                m += cj[(size_t)con_sorted[(size_t)d]].j->mu > 0 ? 3 : 1;
+            }
+            if (m < big_island_rows()) continue;
+            // row r's level = 1 + the latest level of an earlier row sharing a body with it
+            std::vector<int> lvl((size_t)m);
+            int nlev = 0, r = 0;
+            for (int d = con_start[(size_t)i]; d < con_start[(size_t)i + 1]; d++) {
+                const CJ &c = cj[(size_t)con_sorted[(size_t)d]];
+                const int rpc = c.j->mu > 0 ? 3 : 1;
+                for (int q = 0; q < rpc; q++, r++) {
+                    int lv = last[(size_t)c.b1];
+                    if (c.b2 >= 0 && last[(size_t)c.b2] > lv) lv = last[(size_t)c.b2];
+                    lv += 1;
+                    lvl[(size_t)r] = lv;
+                    last[(size_t)c.b1] = lv;
+                    if (c.b2 >= 0) last[(size_t)c.b2] = lv;
+                    if (lv + 1 > nlev) nlev = lv + 1;
+                }
+            }
+            for (int d = con_start[(size_t)i]; d < con_start[(size_t)i + 1]; d++) {      // reset for the next island
+                const CJ &c = cj[(size_t)con_sorted[(size_t)d]];
+                last[(size_t)c.b1] = -1;
+                if (c.b2 >= 0) last[(size_t)c.b2] = -1;
+            }
+            big_h[(size_t)i] = (int)lev_off_h.size();
+            big_list_h.push_back(i);
+            lev_count_h.push_back(nlev);
+            const int base = (int)lev_rows_h.size();
+            std::vector<int> cnt((size_t)nlev + 1, 0);
+            for (int q = 0; q < m; q++) cnt[(size_t)lvl[(size_t)q] + 1]++;
+            for (int q = 0; q < nlev; q++) cnt[(size_t)q + 1] += cnt[(size_t)q];
+            for (int q = 0; q <= nlev; q++) lev_off_h.push_back(base + cnt[(size_t)q]);
+            lev_rows_h.resize((size_t)base + m);
+            std::vector<int> f(cnt.begin(), cnt.end() - 1);
+            for (int q = 0; q < m; q++) lev_rows_h[(size_t)base + f[(size_t)lvl[(size_t)q]]++] = q;
+        }
+    }
+    const int n_big = (int)big_list_h.size();
+
+    // int staging: body_off[ni+1] bodies[nlive] con_off[ni+1] row_off[ni+1] cb1[nc] cb2[nc] cmode[nc] csrc[nc] crow[nc]
+    //              big[ni] big_list[n_big] lev_count[n_big] lev_off[..] lev_rows[..]
+    const size_t n_int = (size_t)3 * (ni + 1) + (size_t)nlive + (size_t)5 * nc + (size_t)ni + (size_t)2 * n_big +
+                         lev_off_h.size() + lev_rows_h.size();
     // real staging: cpos[3nc] cnormal[3nc] cdepth cmu cbounce cbounce_vel csoft_erp csoft_cfm [nc each]
     const size_t n_real = (size_t)12 * nc;
     int rc;
@@ -78,7 +144,14 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     int *hi = (int *)b->jh_int;
     T *hr = (T *)b->jh_real;
     int *body_off = hi, *bodies = body_off + (ni + 1), *con_off = bodies + nlive, *row_off = con_off + (ni + 1);
-    int *cb1 = row_off + (ni + 1), *cb2 = cb1 + nc, *cmode = cb2 + nc, *csrc = cmode + nc;
+    int *cb1 = row_off + (ni + 1), *cb2 = cb1 + nc, *cmode = cb2 + nc, *csrc = cmode + nc, *crow = csrc + nc;
+    int *big = crow + nc, *big_list = big + ni, *lev_count = big_list + n_big, *lev_off = lev_count + n_big;
+    int *lev_rows = lev_off + lev_off_h.size();
+    if (nc) memcpy(crow, crow_h.data(), (size_t)nc * sizeof(int));
+    if (ni) memcpy(big, big_h.data(), (size_t)ni * sizeof(int));
+    if (n_big) { memcpy(big_list, big_list_h.data(), (size_t)n_big * sizeof(int)); memcpy(lev_count, lev_count_h.data(), (size_t)n_big * sizeof(int)); }
+    if (!lev_off_h.empty()) memcpy(lev_off, lev_off_h.data(), lev_off_h.size() * sizeof(int));
+    if (!lev_rows_h.empty()) memcpy(lev_rows, lev_rows_h.data(), lev_rows_h.size() * sizeof(int));
     T *cpos = hr, *cnormal = cpos + 3 * (size_t)nc, *cdepth = cnormal + 3 * (size_t)nc, *cmu = cdepth + nc,
       *cbounce = cmu + nc, *cbv = cbounce + nc, *cserp = cbv + nc, *cscfm = cserp + nc;
 
@@ -126,6 +199,9 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     I.body_off = di; I.bodies = di + (ni + 1); I.con_off = I.bodies + nlive; I.row_off = I.con_off + (ni + 1);
     I.cb1 = I.row_off + (ni + 1); I.cb2 = I.cb1 + nc; I.cmode = I.cb2 + nc;
     I.csrc = geo ? I.cmode + nc : nullptr;
+    I.crow = I.cmode + 2 * (size_t)nc;
+    I.big = I.crow + nc; I.n_big = n_big; I.big_list = I.big + ni; I.lev_count = I.big_list + n_big;
+    I.lev_off = I.lev_count + n_big; I.lev_rows = I.lev_off + lev_off_h.size();
     I.gpos = geo ? (const T *)geo->pos : nullptr; I.gnormal = geo ? (const T *)geo->normal : nullptr;
     I.gdepth = geo ? (const T *)geo->depth : nullptr;
     I.cpos = dr; I.cnormal = dr + 3 * (size_t)nc; I.cdepth = I.cnormal + 3 * (size_t)nc; I.cmu = I.cdepth + nc;

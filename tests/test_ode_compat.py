@@ -119,8 +119,9 @@ def test_reference_spawner_draws():
 
 
 # ------------------------------------------------------------------------------------------------ GPU
-def _run_harness(exe, text):
-    p = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=600)
+def _run_harness(exe, text, env=None):
+    p = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=600,
+                       env=None if env is None else {**os.environ, **env})
     assert p.returncode == 0, p.stderr[-2000:]
     return np.array([[float(v) for v in line.split()] for line in p.stdout.strip().splitlines()])
 
@@ -142,6 +143,21 @@ def test_reference_scene_through_ode_api_matches_oracle(tmp_path, single):
     assert got.shape == ref.shape
     assert np.all(np.isfinite(got))
     assert np.array_equal(got.astype(ref.dtype), ref), np.abs(got - ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("big_rows", ["12", "96"])
+def test_large_islands_take_the_workgroup_kernel_with_identical_bits(tmp_path, big_rows):
+    """A pile in the reference's pen (floor + walls): its island is solved by solve_island_wg under a level
+    schedule; the result must equal the sequential sweep of the oracle bit for bit."""
+    statics = pkg.scenes.reference_map()
+    bodies = pkg.scenes.reference_spawn(120, seed=11, y_range=(1.5, 6.0))
+    dt, steps = 1.0 / 120.0, 300
+    exe = _build_harness(str(tmp_path), False)
+    got = _run_harness(exe, _scene_text(dt, steps, False, statics, bodies), env={"DMX_BIG_ISLAND_ROWS": big_rows})
+    ref, ow = _oracle_poses("float64", dt, steps, False, statics, bodies)
+    assert ow.n_contacts() > 100 and ow.n_body_pairs() > 20
+    assert np.array_equal(got, ref), np.abs(got - ref).max()
 
 
 @pytest.mark.gpu
