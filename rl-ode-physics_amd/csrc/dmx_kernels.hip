@@ -16,6 +16,7 @@
 // HBM-bound (30 reals per body-step); step_plane is VALU/latency bound
 // (20 SOR sweeps over <= 12 rows held in registers).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "dmx_internal.hpp"
 #include "dmx_math.hpp"
 #include "dmx_collide.hpp"
@@ -302,12 +303,14 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
             for (int k = 0; k < MAXC; k++)
                 if (__ballot(nc > k) != 0ull) ncu = k + 1;
             T rsum = T(0);
-            for (int it = 0; it < P.iters; it++) {
-                rsum = T(0);
+            // One sweep over the wave's rows.  FAST: every active lane has the wave's contact count and the friction
+            // rows are unbounded (mu = inf, the reference's surface): no lane masking, no friction clamp.
+            // LAST: only the final sweep tallies |delta lambda|.  Same arithmetic in every variant.
+            auto sweep = [&](auto FAST, auto LAST) {
 #pragma unroll
                 for (int k = 0; k < MAXC; k++) {
                     if (k < ncu) {
-                        const bool act = k < nc;
+                        const bool act = decltype(FAST)::value ? true : (k < nc);
 #pragma unroll
                         for (int dnum = 0; dnum < 3; dnum++) {
                             const int r = 3 * k + dnum;
@@ -318,21 +321,37 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
                                 delta -= fma_(fa.z, Ja[r].z, fma_(fa.y, Ja[r].y, fma_(fa.x, Ja[r].x,
                                          fma_(fl.z, dir[dnum].z * ad, fma_(fl.y, dir[dnum].y * ad, fl.x * (dir[dnum].x * ad))))));
                                 const T nl = old + delta;
-                                const T lo = dnum == 0 ? T(0) : lo_f, hi = dnum == 0 ? hi_n : hi_f;
-                                const bool below = nl < lo, above = nl > hi;
-                                T nlam = below ? lo : (above ? hi : nl);
-                                delta = below ? lo - old : (above ? hi - old : delta);
-                                delta = act ? delta : T(0);
-                                lam[r] = act ? nlam : old;
+                                T nlam = nl;
+                                if (dnum == 0 || !decltype(FAST)::value) {
+                                    const T lo = dnum == 0 ? T(0) : lo_f, hi = dnum == 0 ? hi_n : hi_f;
+                                    const bool below = nl < lo, above = nl > hi;
+                                    nlam = below ? lo : (above ? hi : nl);
+                                    delta = below ? lo - old : (above ? hi - old : delta);
+                                }
+                                if (!decltype(FAST)::value) {
+                                    delta = act ? delta : T(0);
+                                    nlam = act ? nlam : old;
+                                }
+                                lam[r] = nlam;
                                 fl.x = fma_(delta, iml[dnum].x, fl.x); fl.y = fma_(delta, iml[dnum].y, fl.y);
                                 fl.z = fma_(delta, iml[dnum].z, fl.z);
                                 fa.x = fma_(delta, iMa[r].x, fa.x); fa.y = fma_(delta, iMa[r].y, fa.y);
                                 fa.z = fma_(delta, iMa[r].z, fa.z);
-                                rsum += tabs(delta);
+                                if (decltype(LAST)::value) rsum += tabs(delta);
                             }
                         }
                     }
                 }
+            };
+            using std::true_type;
+            using std::false_type;
+            const bool fast = (__ballot(nc != ncu) == 0ull) && !(P.mu < Limits<T>::inf());   // wave-uniform
+            if (fast) {
+                for (int it = 0; it + 1 < P.iters; it++) sweep(true_type{}, false_type{});
+                if (P.iters > 0) sweep(true_type{}, true_type{});
+            } else {
+                for (int it = 0; it + 1 < P.iters; it++) sweep(false_type{}, false_type{});
+                if (P.iters > 0) sweep(false_type{}, true_type{});
             }
             my_resid = (double)rsum;      // |delta lambda| summed over the last sweep
             // v += h * (M^-1 J^T lambda)
