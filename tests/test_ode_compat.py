@@ -97,6 +97,20 @@ def test_ode_symbols_exported(libname):
         assert hasattr(lib, n)
 
 
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/main.c"), reason="reference tree not present on this box")
+def test_reference_symbol_list_is_what_main_c_calls():
+    """Reads the reference's main.c as text: every ODE function it calls is in REFERENCE_SYMBOLS, and every ODE
+    type / constant / field it names is spelled out in include/ode/*.h."""
+    src = open("/root/reference/src/main.c").read()
+    called = set(re.findall(r"\b(d[A-Z]\w*)\s*\(", src))          # dBodyAddForce sits in a // comment (main.c:532)
+    assert called == set(REFERENCE_SYMBOLS)
+    hdr = "".join(open(os.path.join(ROOT, "include", "ode", h)).read() for h in ("common.h", "ode.h"))
+    for ident in sorted(set(re.findall(r"\b(d[A-Z]\w*)\b", src)) - called):
+        assert re.search(r"\b%s\b" % ident, hdr), f"main.c names {ident}; include/ode does not define it"
+    for field in set(re.findall(r"\.(surface|geom|mode|mu|bounce_vel|bounce|soft_cfm|soft_erp|depth|normal|pos)\b", src)):
+        assert re.search(r"\b%s\b" % field, hdr)
+
+
 @pytest.mark.parametrize("single", [False, True])
 def test_reference_call_sequence_compiles_and_links(tmp_path, single):
     exe = _build_harness(str(tmp_path), single)
