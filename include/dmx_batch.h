@@ -86,7 +86,12 @@ int dmxBatchSetPlane(dmxBatchID b, double a, double bb, double c, double d, int 
 int dmxBatchUpload(dmxBatchID b, int field, const void *host_aos, int64_t first, int64_t count);
 int dmxBatchDownload(dmxBatchID b, int field, void *host_aos, int64_t first, int64_t count);
 int dmxBatchUploadGeomType(dmxBatchID b, const uint8_t *types, int64_t first, int64_t count);
-/* device-resident SoA component c of a field (stride between components = dmxBatchStride) */
+/* device address of component c of a field for body 0.  The slab is tiled: bodies are stored in tiles of
+ * DMX_SLAB_TILE; inside a tile each of the DMX_SLAB_COMPONENTS components holds DMX_SLAB_TILE consecutive
+ * reals, so body i's value sits (i / DMX_SLAB_TILE) * DMX_SLAB_COMPONENTS * DMX_SLAB_TILE + i % DMX_SLAB_TILE
+ * reals after the returned address.  dmxBatchStride = bodies the slab is allocated for (a multiple of 256). */
+#define DMX_SLAB_TILE       64
+#define DMX_SLAB_COMPONENTS 30
 void *dmxBatchDevicePtr(dmxBatchID b, int field, int component);
 int64_t dmxBatchStride(dmxBatchID b);
 

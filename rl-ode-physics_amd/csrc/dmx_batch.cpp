@@ -35,17 +35,15 @@ static int ensure_stage(dmxBatch *b, size_t bytes)
     return DMX_OK;
 }
 
+static_assert(DMX_SLAB_TILE == SLAB_TILE && DMX_SLAB_COMPONENTS == C_COUNT, "include/dmx_batch.h documents the slab tiling");
+
 template <class T> static int fill_defaults(dmxBatch *b)
 {
     // every slot, pad included: mass 1, inertia 1 (dBodyCreate default), q = identity
-    std::vector<T> host((size_t)b->stride);
-    T *S = (T *)b->slab;
     HIP_TRY(hipMemsetAsync(b->slab, 0, (size_t)C_COUNT * b->stride * sizeof(T), b->stream));
-    for (auto &x : host) x = T(1);
     const int ones[] = { C_QUAT, C_MASS, C_INERTIA, C_INERTIA + 1, C_INERTIA + 2 };
     for (int c : ones)
-        HIP_TRY(hipMemcpyAsync(S + (size_t)c * b->stride, host.data(), (size_t)b->stride * sizeof(T),
-                               hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(launch_fill_component<T>((T *)b->slab, c, T(1), b->stride, b->stream));
     HIP_TRY(hipMemsetAsync(b->gtype, 0, (size_t)b->stride, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return DMX_OK;
@@ -74,7 +72,8 @@ extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int dev
     b->rsize = precision == DMX_F32 ? 4 : 8;
     b->cfm = precision == DMX_F32 ? 1e-5 : 1e-10;      // dWorldCreate default per precision [ODE]
     if (const char *v = getenv("DMX_VEC")) b->vec = atoi(v);
-    if (const char *v = getenv("DMX_PLANE_VARIANT")) b->variant = atoi(v);
+    if (const char *v = getenv("DMX_MIN_WAVES")) b->min_waves = atoi(v);
+    if (const char *v = getenv("DMX_TUNE")) b->tune = atoi(v);
     int rc = DMX_OK;
     do {
         if (hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = DMX_EHIP; break; }
@@ -269,7 +268,7 @@ int dmx_ensure_dev(dmxBatch::DevBuf &d, size_t bytes)
 extern "C" void *dmxBatchDevicePtr(dmxBatchID b, int field, int component)
 {
     if (!b || field < 0 || field >= DMX_NFIELDS || component < 0 || component >= k_field_k[field]) return nullptr;
-    return (char *)b->slab + (size_t)(k_field_comp0[field] + component) * b->stride * b->rsize;
+    return (char *)b->slab + (size_t)slab_ix(k_field_comp0[field] + component, 0) * b->rsize;
 }
 
 // ---- stepping ----------------------------------------------------------------------------------
@@ -279,7 +278,7 @@ template <class T> static int step_t(dmxBatch *b, double h, int nsteps, int64_t 
     if (first != 0) P.pack_out = nullptr;      // the boundary pack is defined on whole-slab launches only
     for (int s = 0; s < nsteps; s++) {
         (void)reset_diag;   // every wave overwrites its own slot each tick: nothing to clear
-        HIP_TRY(launch_step<T>((T *)b->slab + first, b->gtype + first, b->stride, count, P, b->ext_pending,
+        HIP_TRY(launch_step<T>((T *)b->slab + slab_ix(0, first), b->gtype + first, b->stride, count, P, b->ext_pending,
                                b->diag + first / 64, b->stream));
     }
     b->stepped_with_plane = b->plane_on != 0;

@@ -51,7 +51,7 @@ struct dmxBatch {
     double mu = __builtin_huge_val(), bounce = 0.2, bounce_vel = 0.1;   // main.c:685-687
     int max_contacts = 8;                               // main.c:675
     bool ext_pending = false;
-    int variant = 0;                 // DMX_PLANE_VARIANT launch-tuning override for step_plane
+    int min_waves = 0, tune = 0;     // DMX_MIN_WAVES / DMX_TUNE launch-tuning overrides (see StepParams)
     int vec = 0;                     // DMX_VEC launch-tuning override (bodies per lane), 0 = 16 B per lane
     bool stepped_with_plane = false;
     // general island path (explicit contact joints)
@@ -63,6 +63,7 @@ struct dmxBatch {
     // body-body broadphase (dmx_broadphase.hip / dmx_general.cpp)
     int bp_enabled = 1;                        // dmxBatchSetBodyCollisions
     bool bp_valid = false;                     // safe zones match the current constant data
+    int bp_chunk = 0;                          // current fast-chunk length in ticks (adaptive, dmx_general.cpp)
     uint32_t bp_crowded = 0;                   // bodies whose safe radius is <= 0 at the last build
     double bp_rmax = 0;
     uint32_t bp_mask = 0; int bp_cap = 8;
@@ -115,7 +116,8 @@ template <class T> inline StepParams<T> dmx_make_params(dmxBatch *b, double h)
     P.mu = (T)b->mu; P.bounce = (T)b->bounce; P.bounce_vel = (T)b->bounce_vel;
     P.max_contacts = b->max_contacts;
     P.vec = b->vec;
-    P.variant = b->variant;
+    P.min_waves = b->min_waves;
+    P.tune = b->tune;
     P.bp_check = 0;          // set by the collision-aware tick (dmx_general.cpp)
     P.bp_flags = nullptr;
     P.skip = nullptr;

@@ -22,9 +22,9 @@ __device__ __forceinline__ uint32_t cell_hash(int ix, int iz, uint32_t mask)
 
 template <class T> __device__ __forceinline__ T bound_radius(int gt, const T *S, int64_t stride, int64_t i)
 {
-    const T sx = S[(C_SIDES + 0) * stride + i];
+    const T sx = S[slab_ix(C_SIDES + 0, i)];
     if (gt == GEOM_SPHERE) return sx;
-    const T sy = S[(C_SIDES + 1) * stride + i], sz = S[(C_SIDES + 2) * stride + i];
+    const T sy = S[slab_ix(C_SIDES + 1, i)], sz = S[slab_ix(C_SIDES + 2, i)];
     return T(0.5) * tsqrt<T>(sx * sx + sy * sy + sz * sz);
 }
 
@@ -35,9 +35,9 @@ __global__ __launch_bounds__(256) void bp_insert(T *__restrict__ S, const uint8_
 {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n || gtype[i] == GEOM_NONE) return;
-    S[C_BPR * stride + i] = bound_radius<T>(gtype[i], S, stride, i);      // neighbours read this instead of 3 sides + sqrt
-    const int ix = (int)floor((double)(S[(C_POS + 0) * stride + i] * G.inv_cell));
-    const int iz = (int)floor((double)(S[(C_POS + 2) * stride + i] * G.inv_cell));
+    S[slab_ix(C_BPR, i)] = bound_radius<T>(gtype[i], S, stride, i);      // neighbours read this instead of 3 sides + sqrt
+    const int ix = (int)floor((double)(S[slab_ix(C_POS + 0, i)] * G.inv_cell));
+    const int iz = (int)floor((double)(S[slab_ix(C_POS + 2, i)] * G.inv_cell));
     const uint32_t h = cell_hash(ix, iz, G.mask);
     const uint32_t slot = atomicAdd(&G.count[h], 1u);
     if (slot < (uint32_t)G.cap) G.items[(size_t)h * G.cap + slot] = (int32_t)i;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uin
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n_active) return;
     const int gt = gtype[i];
-    const T x = S[(C_POS + 0) * stride + i], z = S[(C_POS + 2) * stride + i];
+    const T x = S[slab_ix(C_POS + 0, i)], z = S[slab_ix(C_POS + 2, i)];
     T safe = Limits<T>::inf();
     if (gt != GEOM_NONE) {
         const T ri = bound_radius<T>(gt, S, stride, i);
@@ -67,31 +67,31 @@ __global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uin
                 for (uint32_t s = 0; s < cnt; s++) {
                     const int64_t j = G.items[(size_t)h * G.cap + s];
                     if (j == i) continue;
-                    const T ddx = S[(C_POS + 0) * stride + j] - x, ddz = S[(C_POS + 2) * stride + j] - z;
-                    const T g = tsqrt<T>(ddx * ddx + ddz * ddz) - ri - S[C_BPR * stride + j];
+                    const T ddx = S[slab_ix(C_POS + 0, j)] - x, ddz = S[slab_ix(C_POS + 2, j)] - z;
+                    const T g = tsqrt<T>(ddx * ddx + ddz * ddz) - ri - S[slab_ix(C_BPR, j)];
                     if (g < gap) gap = g;
                 }
             }
         safe = T(0.5) * gap;
         if (!(safe > 0)) atomicAdd(&G.flags[BPF_CROWDED], 1u);
     }
-    S[C_BPX * stride + i] = x;
-    S[C_BPZ * stride + i] = z;
-    S[C_BPSAFE * stride + i] = safe;
+    S[slab_ix(C_BPX, i)] = x;
+    S[slab_ix(C_BPZ, i)] = z;
+    S[slab_ix(C_BPSAFE, i)] = safe;
 }
 
 template <class T> __device__ __forceinline__ void body_aabb(const T *S, const uint8_t *gtype, int64_t stride,
                                                              int64_t i, T lo[3], T hi[3])
 {
-    const T p[3] = { S[(C_POS + 0) * stride + i], S[(C_POS + 1) * stride + i], S[(C_POS + 2) * stride + i] };
+    const T p[3] = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
     T r[3];
     if (gtype[i] == GEOM_SPHERE) {
-        r[0] = r[1] = r[2] = S[(C_SIDES + 0) * stride + i];
+        r[0] = r[1] = r[2] = S[slab_ix(C_SIDES + 0, i)];
     } else {
-        const Q4<T> q = { S[(C_QUAT + 0) * stride + i], S[(C_QUAT + 1) * stride + i],
-                          S[(C_QUAT + 2) * stride + i], S[(C_QUAT + 3) * stride + i] };
+        const Q4<T> q = { S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)],
+                          S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] };
         const M3<T> R = quat_to_R(q);
-        const T s[3] = { S[(C_SIDES + 0) * stride + i], S[(C_SIDES + 1) * stride + i], S[(C_SIDES + 2) * stride + i] };
+        const T s[3] = { S[slab_ix(C_SIDES + 0, i)], S[slab_ix(C_SIDES + 1, i)], S[slab_ix(C_SIDES + 2, i)] };
         for (int a = 0; a < 3; a++)
             r[a] = T(0.5) * (tabs(R.m[a][0] * s[0]) + tabs(R.m[a][1] * s[1]) + tabs(R.m[a][2] * s[2]));
     }
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(256) void bp_pairs(const T *__restrict__ S, const u
     if (i >= n_active || gtype[i] == GEOM_NONE) return;
     T lo[3], hi[3];
     body_aabb<T>(S, gtype, stride, i, lo, hi);
-    const int ix = (int)floor((double)(S[(C_POS + 0) * stride + i] * G.inv_cell));
-    const int iz = (int)floor((double)(S[(C_POS + 2) * stride + i] * G.inv_cell));
+    const int ix = (int)floor((double)(S[slab_ix(C_POS + 0, i)] * G.inv_cell));
+    const int iz = (int)floor((double)(S[slab_ix(C_POS + 2, i)] * G.inv_cell));
     for (int dz = -1; dz <= 1; dz++)
         for (int dx = -1; dx <= 1; dx++) {
             const uint32_t h = cell_hash(ix + dx, iz + dz, G.mask);
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256) void bp_pairs(const T *__restrict__ S, const u
                 const int64_t j = G.items[(size_t)h * G.cap + s];
                 if (j <= i) continue;                       // each unordered pair once
                 // hashed buckets can mix columns: keep only true 3x3 neighbours so (i,j) is met in one cell only
-                const int jx = (int)floor((double)(S[(C_POS + 0) * stride + j] * G.inv_cell));
-                const int jz = (int)floor((double)(S[(C_POS + 2) * stride + j] * G.inv_cell));
+                const int jx = (int)floor((double)(S[slab_ix(C_POS + 0, j)] * G.inv_cell));
+                const int jz = (int)floor((double)(S[slab_ix(C_POS + 2, j)] * G.inv_cell));
                 if (jx != ix + dx || jz != iz + dz) continue;
                 T lo2[3], hi2[3];
                 body_aabb<T>(S, gtype, stride, j, lo2, hi2);

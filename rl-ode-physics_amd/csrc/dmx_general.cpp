@@ -20,7 +20,8 @@
 
 namespace {
 
-constexpr int kChunk = 32;          // ticks between violation-flag reads in fast mode
+constexpr int kChunk = 32;          // ticks between violation-flag reads in fast mode: the starting length ...
+constexpr int kChunkMax = 256;      // ... doubled after every clean chunk up to this, back to kChunk after a rollback
 constexpr int kBucketCap = 8;
 constexpr double kSkin = 1.25;      // cell = kSkin * largest bounding-sphere diameter
 
@@ -233,13 +234,14 @@ template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
             continue;
         }
         if (!b->bp_valid && (rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
-        const int k = std::min(remaining, kChunk);
+        if (b->bp_chunk < kChunk) b->bp_chunk = kChunk;
+        int k = std::min(remaining, b->bp_chunk);
         bool careful = b->bp_crowded > 0;
         // fast chunk: snapshot, k fused ticks with the safe-zone check riding along, one flag read.  If a body
         // left its zone the chunk is rolled back; the first retry only refreshes the zones (a body that has
         // drifted since the last build usually fits again), the second replays the chunk exactly.
         for (int attempt = 0; !careful; attempt++) {
-            HIP_TRY(hipMemcpyAsync(b->bp_snapshot.p, b->slab, (size_t)C_MASS * b->stride * b->rsize, hipMemcpyDeviceToDevice, b->stream));
+            HIP_TRY(launch_copy_state<T>((T *)b->slab, (T *)b->bp_snapshot.p, b->stride, true, b->stream));
             HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, 2 * sizeof(uint32_t), b->stream));
             // Without a ground plane and with gravity along y nothing acts horizontally: every body's (x,z) moves on a
             // straight line during the chunk, and a disc is convex, so a body inside its zone at the chunk's first and
@@ -253,10 +255,13 @@ template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
                 b->last_pairs = 0;
                 b->last_mixed = false;
                 if (b->bp_flags_host[BPF_WARN]) b->bp_valid = false;     // zones are getting used up: refresh before the next chunk
+                else if (k == b->bp_chunk) b->bp_chunk = std::min(2 * b->bp_chunk, kChunkMax);   // quiet scene: snapshot and read the flag less often
                 break;
             }
-            HIP_TRY(hipMemcpyAsync(b->slab, b->bp_snapshot.p, (size_t)C_MASS * b->stride * b->rsize, hipMemcpyDeviceToDevice, b->stream));
+            HIP_TRY(launch_copy_state<T>((T *)b->slab, (T *)b->bp_snapshot.p, b->stride, false, b->stream));
             b->stat_rollbacks++;
+            b->bp_chunk = kChunk;
+            k = std::min(k, kChunk);            // the retry (and an exact replay, if it comes to that) covers a short chunk
             if (attempt == 0) {
                 if ((rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
                 careful = b->bp_crowded > 0;

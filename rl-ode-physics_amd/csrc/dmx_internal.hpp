@@ -8,7 +8,15 @@
 
 namespace dmx {
 
-// SoA component indices inside the body slab (component c of body i at S[c*stride + i])
+// Body slab layout: tiles of SLAB_TILE consecutive bodies; inside a tile the C_COUNT components are stored one
+// after another, SLAB_TILE reals each (array-of-structures-of-arrays).  A wavefront stepping 64 consecutive
+// bodies therefore reads and writes ONE contiguous run of memory (17 x 256 B in, 13 x 256 B out in f32)
+// instead of 30 streams a whole component array apart: on MI355X that lifts the free-flight pass from
+// about 5.6 to about 7.1 TB/s at 1 Mi bodies (scripts/ubench_layout.hip, profiles/r01_layout_ubench.txt).
+// The slab is allocated for `stride` bodies = the body count rounded up to 256; pad bodies are valid,
+// inert memory (mass 1, unit quaternion).
+constexpr int SLAB_TILE = 64, SLAB_TILE_LOG2 = 6;
+static_assert((1 << SLAB_TILE_LOG2) == SLAB_TILE, "tile size is a power of two");
 enum : int {
     C_POS = 0,       // 3
     C_QUAT = 3,      // 4  (w,x,y,z)
@@ -25,6 +33,12 @@ enum : int {
     C_BPR = 29,      // bounding-sphere radius (refreshed by bp_insert)
     C_COUNT = 30
 };
+
+// index of component c of body i in the slab
+__host__ __device__ __forceinline__ int64_t slab_ix(int c, int64_t i)
+{
+    return (i >> SLAB_TILE_LOG2) * (int64_t)(C_COUNT * SLAB_TILE) + (int64_t)c * SLAB_TILE + (i & (SLAB_TILE - 1));
+}
 
 enum : int { GEOM_NONE = 0, GEOM_SPHERE = 1, GEOM_BOX = 2 };
 enum : int { SURF_BOUNCE = 0x004, SURF_SOFT_ERP = 0x008, SURF_SOFT_CFM = 0x010 };
@@ -66,7 +80,8 @@ template <class T> struct StepParams {
     int surf_mode; T mu, bounce, bounce_vel;   // contact surface (NearCallback, main.c:684-687)
     int max_contacts;
     int vec;            // launch tuning: bodies per lane in integrate_free (0 = 16 B per lane)
-    int variant;        // launch tuning: step_plane variant (0 = default)
+    int min_waves;      // launch tuning (env DMX_MIN_WAVES): waves per SIMD the register allocator must leave room for, 0 = default
+    int tune;           // launch tuning (env DMX_TUNE): experiment bits, 0 = default
     int bp_check;       // 1: test every body against its broadphase safe zone (pre-step position)
     uint32_t *bp_flags; // device flags (BPF_*), written when a body has left its safe zone
     const uint8_t *skip; // per-body: 1 = stepped by the island path this tick, leave untouched (may be null)
@@ -118,6 +133,11 @@ template <class T>
 hipError_t launch_gather(const T *S, int64_t stride, const int32_t *idx, int64_t count, T *out, hipStream_t st);
 template <class T>
 hipError_t launch_scatter(T *S, int64_t stride, const int32_t *idx, int64_t count, const T *in, hipStream_t st);
+template <class T>
+hipError_t launch_fill_component(T *S, int c, T value, int64_t n, hipStream_t st);
+// rollback snapshot of the 13 state components of bodies [0, n_bodies): save = slab -> packed, else packed -> slab
+template <class T>
+hipError_t launch_copy_state(T *S, T *packed, int64_t n_bodies, bool save, hipStream_t st);
 template <class T>
 hipError_t launch_aos_to_soa(T *S, int64_t stride, int comp0, int k, int64_t first, int64_t count, const T *aos,
                              hipStream_t st);

@@ -27,7 +27,7 @@ template <class T> __device__ __forceinline__ void st3(T *p, const V3<T> &v) { p
 template <class T> __device__ __forceinline__ T dot3p(const T *a, const V3<T> &b) { return fma_(a[2], b.z, fma_(a[1], b.y, a[0] * b.x)); }
 template <class T> __device__ __forceinline__ V3<T> ldS(const T *S, int64_t stride, int c0, int s)
 {
-    return { S[(c0 + 0) * stride + s], S[(c0 + 1) * stride + s], S[(c0 + 2) * stride + s] };
+    return { S[slab_ix(c0 + 0, s)], S[slab_ix(c0 + 1, s)], S[slab_ix(c0 + 2, s)] };
 }
 
 // ---- stage 0, body k of the island: gravity, world-frame inverse inertia, gyroscopic torque ---------------
@@ -37,10 +37,10 @@ __device__ __forceinline__ void stage_body(const T *S, const uint8_t *bflags, in
 {
     I.local[s] = k;
     const uint8_t fl = bflags[s];
-    const Q4<T> q = { S[(C_QUAT + 0) * stride + s], S[(C_QUAT + 1) * stride + s],
-                      S[(C_QUAT + 2) * stride + s], S[(C_QUAT + 3) * stride + s] };
+    const Q4<T> q = { S[slab_ix(C_QUAT + 0, s)], S[slab_ix(C_QUAT + 1, s)],
+                      S[slab_ix(C_QUAT + 2, s)], S[slab_ix(C_QUAT + 3, s)] };
     const V3<T> w = ldS(S, stride, C_AVEL, s);
-    const T mass = S[C_MASS * stride + s];
+    const T mass = S[slab_ix(C_MASS, s)];
     const V3<T> Ib = ldS(S, stride, C_INERTIA, s);
     V3<T> facc = ldS(S, stride, C_FORCE, s), tacc = ldS(S, stride, C_TORQUE, s);
     const bool kin = fl & BF_KINEMATIC;
@@ -220,8 +220,8 @@ template <class T>
 __device__ __forceinline__ void finish_body(T *S, const uint8_t *bflags, int64_t stride, const T *b, int s, bool has_rows, T h)
 {
     V3<T> x = ldS(S, stride, C_POS, s);
-    Q4<T> q = { S[(C_QUAT + 0) * stride + s], S[(C_QUAT + 1) * stride + s],
-                S[(C_QUAT + 2) * stride + s], S[(C_QUAT + 3) * stride + s] };
+    Q4<T> q = { S[slab_ix(C_QUAT + 0, s)], S[slab_ix(C_QUAT + 1, s)],
+                S[slab_ix(C_QUAT + 2, s)], S[slab_ix(C_QUAT + 3, s)] };
     V3<T> v = ldS(S, stride, C_LVEL, s), w = ldS(S, stride, C_AVEL, s);
     if (has_rows) {
         v.x = fma_(h, b[BW_FC + 0], v.x); v.y = fma_(h, b[BW_FC + 1], v.y); v.z = fma_(h, b[BW_FC + 2], v.z);
@@ -236,12 +236,12 @@ __device__ __forceinline__ void finish_body(T *S, const uint8_t *bflags, int64_t
     }
     x.x = fma_(h, v.x, x.x); x.y = fma_(h, v.y, x.y); x.z = fma_(h, v.z, x.z);
     integrate_quat(q, w, h);
-    S[(C_POS + 0) * stride + s] = x.x; S[(C_POS + 1) * stride + s] = x.y; S[(C_POS + 2) * stride + s] = x.z;
-    S[(C_QUAT + 0) * stride + s] = q.w; S[(C_QUAT + 1) * stride + s] = q.x;
-    S[(C_QUAT + 2) * stride + s] = q.y; S[(C_QUAT + 3) * stride + s] = q.z;
-    S[(C_LVEL + 0) * stride + s] = v.x; S[(C_LVEL + 1) * stride + s] = v.y; S[(C_LVEL + 2) * stride + s] = v.z;
-    S[(C_AVEL + 0) * stride + s] = w.x; S[(C_AVEL + 1) * stride + s] = w.y; S[(C_AVEL + 2) * stride + s] = w.z;
-    for (int j = 0; j < 6; j++) S[(C_FORCE + j) * stride + s] = T(0);
+    S[slab_ix(C_POS + 0, s)] = x.x; S[slab_ix(C_POS + 1, s)] = x.y; S[slab_ix(C_POS + 2, s)] = x.z;
+    S[slab_ix(C_QUAT + 0, s)] = q.w; S[slab_ix(C_QUAT + 1, s)] = q.x;
+    S[slab_ix(C_QUAT + 2, s)] = q.y; S[slab_ix(C_QUAT + 3, s)] = q.z;
+    S[slab_ix(C_LVEL + 0, s)] = v.x; S[slab_ix(C_LVEL + 1, s)] = v.y; S[slab_ix(C_LVEL + 2, s)] = v.z;
+    S[slab_ix(C_AVEL + 0, s)] = w.x; S[slab_ix(C_AVEL + 1, s)] = w.y; S[slab_ix(C_AVEL + 2, s)] = w.z;
+    for (int j = 0; j < 6; j++) S[slab_ix(C_FORCE + j, s)] = T(0);
 }
 
 // ================================================================================ one lane per island

@@ -6,11 +6,10 @@
 // dJointGroupEmpty -- for scenes whose dynamics islands are single bodies
 // (free bodies, and bodies in contact with the static ground plane only).
 //
-// Data layout: one slab `S` of `real`, structure-of-arrays, component c of
-// body i at S[c * stride + i]; stride is the body count rounded up to 256 so
-// every component array is 1 KiB aligned and pad bodies are valid, inert
-// memory (mass 1, unit quaternion).  Loads are 16 B per lane
-// (global_load_dwordx4): V = 4 bodies per lane in f32, 2 in f64.
+// Data layout: one slab `S` of `real` in tiles of 64 bodies x 30 components
+// (dmx_internal.hpp: component c of body i at S[slab_ix(c, i)]), so that a
+// wavefront's 30 component accesses fall in one contiguous 7.5 KiB (f32) run.
+// A lane owns V consecutive bodies (V divides the tile).
 //
 // No MFMA: there is no dense contraction on this path.  integrate_free is
 // HBM-bound (30 reals per body-step); step_plane is VALU/latency bound
@@ -28,12 +27,12 @@ template <class T, int V> struct alignas(sizeof(T) * V) Pack { T v[V]; };
 template <class T, int V>
 __device__ __forceinline__ Pack<T, V> ldv(const T *__restrict__ base, int64_t stride, int comp, int64_t i)
 {
-    return *reinterpret_cast<const Pack<T, V> *>(base + comp * stride + i);
+    return *reinterpret_cast<const Pack<T, V> *>(base + slab_ix(comp, i));
 }
 template <class T, int V>
 __device__ __forceinline__ void stv(T *__restrict__ base, int64_t stride, int comp, int64_t i, const Pack<T, V> &p)
 {
-    *reinterpret_cast<Pack<T, V> *>(base + comp * stride + i) = p;
+    *reinterpret_cast<Pack<T, V> *>(base + slab_ix(comp, i)) = p;
 }
 
 // Broadphase safe-zone test of one body (pre-step position): 2 = outside its zone (a body pair may exist),
@@ -185,24 +184,24 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
     int my_contacts = 0;
     double my_resid = 0.0;
     if (i < n && !(P.skip != nullptr && P.skip[i])) {
-        V3<T> x = { S[(C_POS + 0) * stride + i], S[(C_POS + 1) * stride + i], S[(C_POS + 2) * stride + i] };
+        V3<T> x = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
         if (P.bp_check)
-            report_zone(zone_state(x.x - S[C_BPX * stride + i], x.z - S[C_BPZ * stride + i], S[C_BPSAFE * stride + i]),
+            report_zone(zone_state(x.x - S[slab_ix(C_BPX, i)], x.z - S[slab_ix(C_BPZ, i)], S[slab_ix(C_BPSAFE, i)]),
                         P.bp_flags);
-        Q4<T> q = { S[(C_QUAT + 0) * stride + i], S[(C_QUAT + 1) * stride + i],
-                    S[(C_QUAT + 2) * stride + i], S[(C_QUAT + 3) * stride + i] };
-        V3<T> v = { S[(C_LVEL + 0) * stride + i], S[(C_LVEL + 1) * stride + i], S[(C_LVEL + 2) * stride + i] };
-        V3<T> w = { S[(C_AVEL + 0) * stride + i], S[(C_AVEL + 1) * stride + i], S[(C_AVEL + 2) * stride + i] };
-        const T mass = S[C_MASS * stride + i];
-        const V3<T> Ib = { S[(C_INERTIA + 0) * stride + i], S[(C_INERTIA + 1) * stride + i],
-                           S[(C_INERTIA + 2) * stride + i] };
-        const T side[3] = { S[(C_SIDES + 0) * stride + i], S[(C_SIDES + 1) * stride + i],
-                            S[(C_SIDES + 2) * stride + i] };
+        Q4<T> q = { S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)],
+                    S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] };
+        V3<T> v = { S[slab_ix(C_LVEL + 0, i)], S[slab_ix(C_LVEL + 1, i)], S[slab_ix(C_LVEL + 2, i)] };
+        V3<T> w = { S[slab_ix(C_AVEL + 0, i)], S[slab_ix(C_AVEL + 1, i)], S[slab_ix(C_AVEL + 2, i)] };
+        const T mass = S[slab_ix(C_MASS, i)];
+        const V3<T> Ib = { S[slab_ix(C_INERTIA + 0, i)], S[slab_ix(C_INERTIA + 1, i)],
+                           S[slab_ix(C_INERTIA + 2, i)] };
+        const T side[3] = { S[slab_ix(C_SIDES + 0, i)], S[slab_ix(C_SIDES + 1, i)],
+                            S[slab_ix(C_SIDES + 2, i)] };
         const int gt = gtype[i];
         V3<T> facc = { T(0), T(0), T(0) }, tacc = { T(0), T(0), T(0) };
         if (EXT) {
-            facc = { S[(C_FORCE + 0) * stride + i], S[(C_FORCE + 1) * stride + i], S[(C_FORCE + 2) * stride + i] };
-            tacc = { S[(C_TORQUE + 0) * stride + i], S[(C_TORQUE + 1) * stride + i], S[(C_TORQUE + 2) * stride + i] };
+            facc = { S[slab_ix(C_FORCE + 0, i)], S[slab_ix(C_FORCE + 1, i)], S[slab_ix(C_FORCE + 2, i)] };
+            tacc = { S[slab_ix(C_TORQUE + 0, i)], S[slab_ix(C_TORQUE + 1, i)], S[slab_ix(C_TORQUE + 2, i)] };
         }
 
         const T h = P.h;
@@ -369,14 +368,14 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
         integrate_quat(q, w, h);
         pack_boundary(P, i, x, q, v, w);
 
-        S[(C_POS + 0) * stride + i] = x.x; S[(C_POS + 1) * stride + i] = x.y; S[(C_POS + 2) * stride + i] = x.z;
-        S[(C_QUAT + 0) * stride + i] = q.w; S[(C_QUAT + 1) * stride + i] = q.x;
-        S[(C_QUAT + 2) * stride + i] = q.y; S[(C_QUAT + 3) * stride + i] = q.z;
-        S[(C_LVEL + 0) * stride + i] = v.x; S[(C_LVEL + 1) * stride + i] = v.y; S[(C_LVEL + 2) * stride + i] = v.z;
-        S[(C_AVEL + 0) * stride + i] = w.x; S[(C_AVEL + 1) * stride + i] = w.y; S[(C_AVEL + 2) * stride + i] = w.z;
+        S[slab_ix(C_POS + 0, i)] = x.x; S[slab_ix(C_POS + 1, i)] = x.y; S[slab_ix(C_POS + 2, i)] = x.z;
+        S[slab_ix(C_QUAT + 0, i)] = q.w; S[slab_ix(C_QUAT + 1, i)] = q.x;
+        S[slab_ix(C_QUAT + 2, i)] = q.y; S[slab_ix(C_QUAT + 3, i)] = q.z;
+        S[slab_ix(C_LVEL + 0, i)] = v.x; S[slab_ix(C_LVEL + 1, i)] = v.y; S[slab_ix(C_LVEL + 2, i)] = v.z;
+        S[slab_ix(C_AVEL + 0, i)] = w.x; S[slab_ix(C_AVEL + 1, i)] = w.y; S[slab_ix(C_AVEL + 2, i)] = w.z;
         if (EXT) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) S[(C_FORCE + k) * stride + i] = T(0);
+            for (int k = 0; k < 6; k++) S[slab_ix(C_FORCE + k, i)] = T(0);
         }
     }
     // ---- diagnostics: wavefront reduction (__shfl_xor), one plain store per wave into the wave's own slot.
@@ -401,18 +400,39 @@ __global__ __launch_bounds__(256) void pack_transforms(const T *__restrict__ S, 
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= count) return;
     const int64_t i = first + t;
-    const Q4<T> q = { S[(C_QUAT + 0) * stride + i], S[(C_QUAT + 1) * stride + i],
-                      S[(C_QUAT + 2) * stride + i], S[(C_QUAT + 3) * stride + i] };
+    const Q4<T> q = { S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)],
+                      S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] };
     const M3<T> R = quat_to_R(q);
     T *o = out + 16 * t;
     o[0] = R.m[0][0]; o[1] = R.m[1][0]; o[2] = R.m[2][0]; o[3] = T(0);
     o[4] = R.m[0][1]; o[5] = R.m[1][1]; o[6] = R.m[2][1]; o[7] = T(0);
     o[8] = R.m[0][2]; o[9] = R.m[1][2]; o[10] = R.m[2][2]; o[11] = T(0);
-    o[12] = S[(C_POS + 0) * stride + i]; o[13] = S[(C_POS + 1) * stride + i];
-    o[14] = S[(C_POS + 2) * stride + i]; o[15] = T(1);
+    o[12] = S[slab_ix(C_POS + 0, i)]; o[13] = S[slab_ix(C_POS + 1, i)];
+    o[14] = S[slab_ix(C_POS + 2, i)]; o[15] = T(1);
 }
 
 // gather / scatter the 13 state reals of listed bodies (boundary exchange between GPUs)
+// fill component c of every allocated body (pad included) with one value
+template <class T>
+__global__ __launch_bounds__(256) void fill_component(T *__restrict__ S, int c, T value, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) S[slab_ix(c, i)] = value;
+}
+
+// Rollback snapshot of the 13 state components (the first C_MASS reals x SLAB_TILE of every tile are one
+// contiguous run): `packed` holds them tile after tile.  save: slab -> packed, else packed -> slab.
+template <class T>
+__global__ __launch_bounds__(256) void copy_state(T *__restrict__ S, T *__restrict__ packed, int64_t n_elems, bool save)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_elems) return;
+    constexpr int64_t run = (int64_t)C_MASS * SLAB_TILE;
+    const int64_t s = (t / run) * (int64_t)(C_COUNT * SLAB_TILE) + t % run;
+    if (save) packed[t] = S[s];
+    else      S[s] = packed[t];
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void gather_bodies(const T *__restrict__ S, int64_t stride,
                                                      const int32_t *__restrict__ idx, int64_t count,
@@ -422,7 +442,7 @@ __global__ __launch_bounds__(256) void gather_bodies(const T *__restrict__ S, in
     if (t >= count * C_MASS) return;
     const int64_t b = t / C_MASS;
     const int c = (int)(t - b * C_MASS);
-    out[t] = S[c * stride + idx[b]];
+    out[t] = S[slab_ix(c, idx[b])];
 }
 template <class T>
 __global__ __launch_bounds__(256) void scatter_bodies(T *__restrict__ S, int64_t stride,
@@ -433,7 +453,7 @@ __global__ __launch_bounds__(256) void scatter_bodies(T *__restrict__ S, int64_t
     if (t >= count * C_MASS) return;
     const int64_t b = t / C_MASS;
     const int c = (int)(t - b * C_MASS);
-    S[c * stride + idx[b]] = in[t];
+    S[slab_ix(c, idx[b])] = in[t];
 }
 
 // AoS (n x k) <-> SoA component arrays, used by upload/download through a staging buffer
@@ -445,7 +465,7 @@ __global__ __launch_bounds__(256) void aos_to_soa(T *__restrict__ S, int64_t str
     if (t >= count * k) return;
     const int64_t b = t / k;
     const int c = (int)(t - b * k);
-    S[(comp0 + c) * stride + first + b] = aos[t];
+    S[slab_ix(comp0 + c, first + b)] = aos[t];
 }
 template <class T>
 __global__ __launch_bounds__(256) void soa_to_aos(const T *__restrict__ S, int64_t stride, int comp0, int k,
@@ -455,7 +475,7 @@ __global__ __launch_bounds__(256) void soa_to_aos(const T *__restrict__ S, int64
     if (t >= count * k) return;
     const int64_t b = t / k;
     const int c = (int)(t - b * k);
-    aos[t] = S[(comp0 + c) * stride + first + b];
+    aos[t] = S[slab_ix(comp0 + c, first + b)];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -469,9 +489,10 @@ hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, co
 {
     if (!P.plane_on) {
         constexpr int VMAX = 16 / sizeof(T);
-        // default: 8 B per lane (f32: 2 bodies, f64: 1).  16 B per lane needs 146 VGPRs (3 waves/SIMD, 1024 blocks = 1.33
-        // residency rounds); 8 B fits 112 (4 waves/SIMD, 2048 blocks = 2 full rounds) and measured 4-10 % faster at 1 M bodies.
-        const int VDEF = VMAX / 2;
+        // default: one body per lane.  On the tiled slab a wave's 17 loads already cover one contiguous run, so wider
+        // per-lane loads buy nothing, and V = 1 keeps the kernel at 67 VGPRs (7 waves/SIMD): measured 21.1 / 22.2 / 22.4 us
+        // per tick for V = 1 / 2 / 4 at 1 Mi f32 bodies (profiles/r01_integrate_free_tiled_sweep.txt).
+        const int VDEF = 1;
         const int V = P.skip != nullptr ? 1 : (P.vec == 1 || P.vec == 2 || P.vec == VMAX) ? P.vec : VDEF;
         const int64_t nvec = (n + V - 1) / V;     // pad bodies up to `stride` are valid memory
         const unsigned grid = blocks_for(nvec, 256);
@@ -480,7 +501,7 @@ hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, co
         if (ext) hipLaunchKernelGGL((integrate_free<T, VV, true, MW>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P);  \
         else     hipLaunchKernelGGL((integrate_free<T, VV, false, MW>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P); \
     } while (0)
-        const int mw = P.variant;     // launch tuning: minimum waves per SIMD the register allocator must leave room for
+        const int mw = P.min_waves;   // launch tuning: minimum waves per SIMD the register allocator must leave room for
         if (V == 1) { if (mw == 8) DMX_LAUNCH_FREE(1, 8); else if (mw == 6) DMX_LAUNCH_FREE(1, 6); else DMX_LAUNCH_FREE(1, 1); }
         else if (V == 2) { if (mw == 4) DMX_LAUNCH_FREE(2, 4); else if (mw == 5) DMX_LAUNCH_FREE(2, 5); else if (mw == 6) DMX_LAUNCH_FREE(2, 6); else DMX_LAUNCH_FREE(2, 1); }
         else { if (mw == 4) DMX_LAUNCH_FREE(VMAX, 4); else if (mw == 3) DMX_LAUNCH_FREE(VMAX, 3); else DMX_LAUNCH_FREE(VMAX, 1); }
@@ -492,7 +513,7 @@ hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, co
         if (ext) hipLaunchKernelGGL((step_plane<T, true, MW>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag);  \
         else     hipLaunchKernelGGL((step_plane<T, false, MW>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag); \
     } while (0)
-        switch (P.variant) {
+        switch (P.min_waves) {
         case 1: DMX_LAUNCH_PLANE(1); break;
         case 2: DMX_LAUNCH_PLANE(2); break;
         default:
@@ -510,6 +531,21 @@ hipError_t launch_pack_transforms(const T *S, int64_t stride, int64_t first, int
     hipLaunchKernelGGL((pack_transforms<T>), dim3(blocks_for(count, 256)), dim3(256), 0, st, S, stride, first, count, out);
     return hipGetLastError();
 }
+template <class T>
+hipError_t launch_fill_component(T *S, int c, T value, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL((fill_component<T>), dim3(blocks_for(n, 256)), dim3(256), 0, st, S, c, value, n);
+    return hipGetLastError();
+}
+
+template <class T>
+hipError_t launch_copy_state(T *S, T *packed, int64_t n_bodies, bool save, hipStream_t st)
+{
+    const int64_t n_elems = (n_bodies + SLAB_TILE - 1) / SLAB_TILE * C_MASS * SLAB_TILE;
+    hipLaunchKernelGGL((copy_state<T>), dim3(blocks_for(n_elems, 256)), dim3(256), 0, st, S, packed, n_elems, save);
+    return hipGetLastError();
+}
+
 template <class T>
 hipError_t launch_gather(const T *S, int64_t stride, const int32_t *idx, int64_t count, T *out, hipStream_t st)
 {
@@ -548,7 +584,9 @@ hipError_t launch_soa_to_aos(const T *S, int64_t stride, int comp0, int k, int64
     template hipError_t launch_gather<T>(const T *, int64_t, const int32_t *, int64_t, T *, hipStream_t);          \
     template hipError_t launch_scatter<T>(T *, int64_t, const int32_t *, int64_t, const T *, hipStream_t);         \
     template hipError_t launch_aos_to_soa<T>(T *, int64_t, int, int, int64_t, int64_t, const T *, hipStream_t);    \
-    template hipError_t launch_soa_to_aos<T>(const T *, int64_t, int, int, int64_t, int64_t, T *, hipStream_t);
+    template hipError_t launch_soa_to_aos<T>(const T *, int64_t, int, int, int64_t, int64_t, T *, hipStream_t);     \
+    template hipError_t launch_fill_component<T>(T *, int, T, int64_t, hipStream_t);                                \
+    template hipError_t launch_copy_state<T>(T *, T *, int64_t, bool, hipStream_t);
 DMX_INSTANTIATE(float)
 DMX_INSTANTIATE(double)
 

@@ -15,10 +15,10 @@ template <class T>
 __device__ __forceinline__ BodyGeom<T> load_geom(const T *S, const uint8_t *gtype, int64_t stride, int64_t i)
 {
     BodyGeom<T> g;
-    g.x = { S[(C_POS + 0) * stride + i], S[(C_POS + 1) * stride + i], S[(C_POS + 2) * stride + i] };
-    g.R = quat_to_R(Q4<T>{ S[(C_QUAT + 0) * stride + i], S[(C_QUAT + 1) * stride + i],
-                           S[(C_QUAT + 2) * stride + i], S[(C_QUAT + 3) * stride + i] });
-    for (int a = 0; a < 3; a++) g.side[a] = S[(C_SIDES + a) * stride + i];
+    g.x = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
+    g.R = quat_to_R(Q4<T>{ S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)],
+                           S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] });
+    for (int a = 0; a < 3; a++) g.side[a] = S[slab_ix(C_SIDES + a, i)];
     g.gt = gtype[i];
     return g;
 }
