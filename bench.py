@@ -35,8 +35,10 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--side", type=int, default=0, help="grid side (bodies = side^2 per GPU); 0 = config default")
     ap.add_argument("--exchange", default="boundary", choices=["boundary", "none"])
-    ap.add_argument("--graph-steps", type=int, default=8, help="ticks per captured HIP graph when exchanging (0 = eager)")
+    ap.add_argument("--graph-steps", type=int, default=16, help="ticks per captured HIP graph when exchanging (0 = eager)")
     ap.add_argument("--no-body-collisions", action="store_true", help="skip the body-body broadphase proof (caller asserts single-body islands)")
+    ap.add_argument("--exchange-every-tick", action="store_true",
+                    help="all-gather the boundary rows every tick even where the collision proof only needs them at chunk ends")
     ap.add_argument("--force-exchange", action="store_true", help="run the exchange path even with one rank (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gyro", type=int, default=2, choices=[0, 1, 2], help="0 off, 1 explicit, 2 implicit (ODE default)")
@@ -149,19 +151,23 @@ def main():
     if exchanging:
         w.set_active_count(scene.n)         # the slots behind are ghosts of the neighbours' boundary rows
     w.set_gyro_mode(a.gyro)
-    if a.no_body_collisions or exchanging:
-        w.set_body_collisions(False)        # the sharded range stepper does not carry the safe-zone check yet
+    collide = not a.no_body_collisions
+    if not collide:
+        w.set_body_collisions(False)
     stream = torch.cuda.Stream()            # a real (non-null) stream: the batch launches on it and the
     torch.cuda.set_stream(stream)           # timing events below are recorded on it, so they bracket the kernels
     assert stream.cuda_stream != 0
     w.set_stream(stream.cuda_stream)
 
-    stepper = pkg.shard.ShardedStepper(w, layout, rank, world,
-                                       exchange=a.exchange if exchanging else "none", device=torch.device("cuda", local_rank),
-                                       stream=stream)
+    forced_ops = None
     if a.force_exchange and world == 1 and exchanging:
         # one-rank group: the collective degenerates to a copy, every other step of the path is exercised
-        stepper.exchange = pkg.shard.BoundaryExchange(pkg.shard.DeviceOps(w, torch.device("cuda", local_rank), stream), layout, 0, 1)
+        forced_ops = pkg.shard.DeviceOps(w, torch.device("cuda", local_rank), stream)
+    stepper = pkg.shard.ShardedStepper(w, layout, rank, world,
+                                       exchange=a.exchange if exchanging else "none", device=torch.device("cuda", local_rank),
+                                       stream=stream, collide=collide and exchanging,
+                                       geometry=(scene.sides, scene.gtype), ops=forced_ops,
+                                       exchange_every_tick=a.exchange_every_tick)
 
     def run(nsteps):
         stepper.run(H, nsteps)
@@ -181,6 +187,7 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    ex0 = stepper.exchange.count if stepper.exchange is not None else 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record(stream)
@@ -190,6 +197,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)
+    n_exchanges = (a.steps if graphed else stepper.exchange.count - ex0) if stepper.exchange is not None else 0
 
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -209,10 +217,12 @@ def main():
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": workload, "bodies_per_gpu": scene.n, "bodies_total": total_bodies, "dt": "1/60",
                    "parallelism": f"islands sharded over {world} GPU(s), one slab per rank; "
-                                  + (f"boundary rows all-gathered over RCCL every tick on a side stream, overlapped with the next tick"
-                                     f"{', HIP-graph replay' if graphed else ''}" if stepper.exchange is not None
+                                  + (f"boundary rows all-gathered over RCCL on a side stream, overlapped with the next tick"
+                                     f"{', HIP-graph replay' if graphed else ''}: {n_exchanges} exchanges in the {a.steps} timed ticks "
+                                     f"({'every tick' if n_exchanges >= a.steps else 'at the end of every collision-proof chunk: inside a ballistic chunk nothing reads the ghost rows'})"
+                                     if stepper.exchange is not None
                                      else "no exchange (one rank)" if world == 1 else "no exchange"),
-                   "collide": ("body-body pairs: none by assertion (check off)" if (a.no_body_collisions or exchanging) else
+                   "collide": ("body-body pairs: none by assertion (check off)" if a.no_body_collisions else
                                f"body-body pairs proven absent per tick by broadphase safe zones ({stats['fast_ticks']} fast ticks, "
                                f"{stats['careful_ticks']} exact-search ticks, {stats['rebuilds']} zone rebuilds, {stats['pair_ticks']} ticks with pairs)")
                               + ("; ground plane fused into the step kernel" if kind == "plane" else ""),

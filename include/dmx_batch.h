@@ -36,7 +36,8 @@ enum {
     DMX_EHIP = -2,        /* a HIP call failed */
     DMX_EINVAL = -3,      /* bad argument */
     DMX_ENOMEM = -4,
-    DMX_ECAPACITY = -5    /* a fixed-size device table overflowed (broadphase bucket / pair buffer) */
+    DMX_ECAPACITY = -5,   /* a fixed-size device table overflowed (broadphase bucket / pair buffer) */
+    DMX_ECROSS = -6       /* two bodies owned by different ranks touch: the island has to be migrated to one owner */
 };
 
 /* per-body fields (k = components per body) */
@@ -123,6 +124,36 @@ int dmxBatchStepTimed(dmxBatchID b, double h, int nsteps, float *ms);
  * pairs, [4] body pairs in the last tick, [5] crowded bodies at the last rebuild. */
 int dmxBatchSetBodyCollisions(dmxBatchID b, int enable);
 int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6]);
+
+/* ---- the collision-checked tick loop in pieces.  dmxBatchStep(b, h, n) with body collisions enabled runs, inside
+ * the library: [zones, snapshot] -> k checked ticks -> one flag read -> commit, or roll back and replay exactly.  A
+ * caller that has work of its own between ticks -- the multi-GPU boundary exchange, which refreshes the ghost slots
+ * [active count, body count) every tick -- drives the same steps itself:
+ *   ChunkBegin   rebuild stale safe zones (ghost slots included), snapshot the state, clear the violation flag;
+ *                *exact_only = 1 when the fast path may not be used (crowded bodies, pending external forces),
+ *                *ballistic = 1 when bodies move on straight horizontal lines, so checking the chunk's first
+ *                and last tick proves the ticks between
+ *   ChunkTick    one fused tick of the active bodies, with or without the safe-zone check
+ *   CheckZonesOnStream  the check alone for slots [first, first+count), on the caller's stream (ghost slots after
+ *                their refresh)
+ *   RefreshGhostsOnStream  the per-tick ghost refresh in one launch on the caller's stream: the lower neighbour's rows
+ *                (13 reals per body, as GatherBodies / the boundary pack lay them out) into slots [first,
+ *                first+count_lo), the upper neighbour's into the count_hi slots behind; a NULL source leaves its
+ *                range untouched; check = 1 also tests the new positions against the slots' zones
+ *   ChunkEnd     wait for the batch stream and report the flags; the caller combines them over ranks
+ *   ChunkCommit  account `ticks` fast ticks; refresh_zones = 1 schedules a zone rebuild (the warn flag was up)
+ *   ChunkRollback  restore the snapshot (zones are rebuilt at the next ChunkBegin)
+ *   ExactTick    one tick with the exact pair search / narrowphase / island solve; DMX_ECROSS if a pair involves
+ *                a ghost slot */
+int dmxBatchChunkBegin(dmxBatchID b, int *exact_only, int *ballistic);
+int dmxBatchChunkTick(dmxBatchID b, double h, int check);
+int dmxBatchCheckZonesOnStream(dmxBatchID b, void *hip_stream, int64_t first, int64_t count);
+int dmxBatchRefreshGhostsOnStream(dmxBatchID b, void *hip_stream, int64_t first, int64_t count_lo, const void *src_lo,
+                                  int64_t count_hi, const void *src_hi, int check);
+int dmxBatchChunkEnd(dmxBatchID b, int *violated, int *warn);
+int dmxBatchChunkCommit(dmxBatchID b, int ticks, int refresh_zones);
+int dmxBatchChunkRollback(dmxBatchID b);
+int dmxBatchExactTick(dmxBatchID b, double h);
 
 /* ---- explicit contact joints: the callback form of the tick.  The reference's near callback makes one
  * dJointCreateContact + dJointAttach per contact (main.c:683-692) and then calls dWorldStep (main.c:213);

@@ -21,6 +21,8 @@ BATCH_SYMBOLS = [
     "dmxBatchStepJoints", "dmxBatchUploadBodyFlags", "dmxBatchSetActiveCount", "dmxBatchStepRange",
     "dmxBatchGetStream", "dmxBatchSetBodyCollisions", "dmxBatchCollisionStats",
     "dmxBatchScatterBodiesOnStream", "dmxBatchSetBoundaryPack",
+    "dmxBatchChunkBegin", "dmxBatchChunkTick", "dmxBatchCheckZonesOnStream", "dmxBatchChunkEnd",
+    "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream",
 ]
 
 _lib = None
@@ -87,5 +89,13 @@ def load():
     sig("dmxBatchCollisionStats", I, P, C.POINTER(L))
     sig("dmxBatchScatterBodiesOnStream", I, P, P, L, P, P)
     sig("dmxBatchSetBoundaryPack", I, P, P, L, L)
+    sig("dmxBatchChunkBegin", I, P, C.POINTER(I), C.POINTER(I))
+    sig("dmxBatchChunkTick", I, P, D, I)
+    sig("dmxBatchCheckZonesOnStream", I, P, P, L, L)
+    sig("dmxBatchChunkEnd", I, P, C.POINTER(I), C.POINTER(I))
+    sig("dmxBatchChunkCommit", I, P, I, I)
+    sig("dmxBatchChunkRollback", I, P)
+    sig("dmxBatchExactTick", I, P, D)
+    sig("dmxBatchRefreshGhostsOnStream", I, P, P, L, L, P, L, P, I)
     _lib = lib
     return lib

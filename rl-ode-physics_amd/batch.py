@@ -131,6 +131,38 @@ class BatchWorld:
         _check(self.lib.dmxBatchCollisionStats(self.h, out), "dmxBatchCollisionStats")
         return dict(zip(("fast_ticks", "careful_ticks", "rebuilds", "pair_ticks", "last_pairs", "crowded"), out))
 
+    # -- the collision-checked loop in pieces (include/dmx_batch.h), for callers with per-tick work of their own --
+    def chunk_begin(self):
+        """-> (exact_only, ballistic)"""
+        e, bl = C.c_int(), C.c_int()
+        _check(self.lib.dmxBatchChunkBegin(self.h, C.byref(e), C.byref(bl)), "dmxBatchChunkBegin")
+        return bool(e.value), bool(bl.value)
+
+    def chunk_tick(self, h, check=True):
+        _check(self.lib.dmxBatchChunkTick(self.h, h, int(check)), "dmxBatchChunkTick")
+
+    def check_zones_on(self, stream_handle, first, count):
+        _check(self.lib.dmxBatchCheckZonesOnStream(self.h, stream_handle, first, count), "dmxBatchCheckZonesOnStream")
+
+    def refresh_ghosts_on(self, stream_handle, first, count_lo, src_lo, count_hi, src_hi, check):
+        _check(self.lib.dmxBatchRefreshGhostsOnStream(self.h, stream_handle, first, count_lo, src_lo, count_hi, src_hi, int(check)),
+               "dmxBatchRefreshGhostsOnStream")
+
+    def chunk_end(self):
+        """-> (violated, warn); waits for the batch stream"""
+        v, w = C.c_int(), C.c_int()
+        _check(self.lib.dmxBatchChunkEnd(self.h, C.byref(v), C.byref(w)), "dmxBatchChunkEnd")
+        return bool(v.value), bool(w.value)
+
+    def chunk_commit(self, ticks, refresh_zones=False):
+        _check(self.lib.dmxBatchChunkCommit(self.h, ticks, int(refresh_zones)), "dmxBatchChunkCommit")
+
+    def chunk_rollback(self):
+        _check(self.lib.dmxBatchChunkRollback(self.h), "dmxBatchChunkRollback")
+
+    def exact_tick(self, h):
+        _check(self.lib.dmxBatchExactTick(self.h, h), "dmxBatchExactTick")
+
     def set_active_count(self, n_active):
         _check(self.lib.dmxBatchSetActiveCount(self.h, n_active), "dmxBatchSetActiveCount")
 

@@ -306,6 +306,64 @@ extern "C" int dmxBatchSetBodyCollisions(dmxBatchID b, int enable)
     return DMX_OK;
 }
 
+// ---- the collision-checked loop in pieces (include/dmx_batch.h) --------------------------------
+extern "C" int dmxBatchChunkBegin(dmxBatchID b, int *exact_only, int *ballistic)
+{
+    if (!b || !exact_only || !ballistic) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    return dmx_chunk_begin(b, exact_only, ballistic);
+}
+extern "C" int dmxBatchChunkTick(dmxBatchID b, double h, int check)
+{
+    if (!b || !(h > 0)) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    return dmx_chunk_tick(b, h, check);
+}
+extern "C" int dmxBatchCheckZonesOnStream(dmxBatchID b, void *hip_stream, int64_t first, int64_t count)
+{
+    if (!b || first < 0 || count < 0 || first + count > b->n) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    return dmx_check_zones(b, (hipStream_t)hip_stream, first, count);
+}
+extern "C" int dmxBatchRefreshGhostsOnStream(dmxBatchID b, void *hip_stream, int64_t first, int64_t count_lo,
+                                            const void *src_lo, int64_t count_hi, const void *src_hi, int check)
+{
+    if (!b || first < b->n_active || count_lo < 0 || count_hi < 0 || first + count_lo + count_hi > b->n) return DMX_EINVAL;
+    if (check && !b->bp_flags.p) return DMX_EINVAL;          // no chunk begun: there are no zones to test against
+    HIP_TRY(hipSetDevice(b->device));
+    uint32_t *flags = (uint32_t *)b->bp_flags.p;
+    if (b->precision == DMX_F32)
+        HIP_TRY(launch_refresh_ghosts<float>((float *)b->slab, first, count_lo, (const float *)src_lo, count_hi, (const float *)src_hi,
+                                             check, flags, (hipStream_t)hip_stream));
+    else
+        HIP_TRY(launch_refresh_ghosts<double>((double *)b->slab, first, count_lo, (const double *)src_lo, count_hi, (const double *)src_hi,
+                                              check, flags, (hipStream_t)hip_stream));
+    return DMX_OK;
+}
+extern "C" int dmxBatchChunkEnd(dmxBatchID b, int *violated, int *warn)
+{
+    if (!b || !violated || !warn) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    return dmx_chunk_end(b, violated, warn);
+}
+extern "C" int dmxBatchChunkCommit(dmxBatchID b, int ticks, int refresh_zones)
+{
+    if (!b || ticks < 0) return DMX_EINVAL;
+    return dmx_chunk_commit(b, ticks, refresh_zones);
+}
+extern "C" int dmxBatchChunkRollback(dmxBatchID b)
+{
+    if (!b) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    return dmx_chunk_rollback(b);
+}
+extern "C" int dmxBatchExactTick(dmxBatchID b, double h)
+{
+    if (!b || !(h > 0)) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    return dmx_exact_tick(b, h);
+}
+
 extern "C" int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6])
 {
     if (!b || !out) return DMX_EINVAL;

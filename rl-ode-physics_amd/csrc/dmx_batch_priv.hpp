@@ -87,6 +87,14 @@ int dmx_step_joints(dmxBatch *b, double h, int64_t n_joints, const dmxContactJoi
                     const DevGeometry *geo);
 // body-body collision handling of the batch tick (dmx_general.cpp)
 int dmx_step_collide(dmxBatch *b, double h, int nsteps);
+// the collision-checked loop in pieces (dmx_general.cpp)
+int dmx_chunk_begin(dmxBatch *b, int *exact_only, int *ballistic);
+int dmx_chunk_tick(dmxBatch *b, double h, int check);
+int dmx_check_zones(dmxBatch *b, hipStream_t st, int64_t first, int64_t count);
+int dmx_chunk_end(dmxBatch *b, int *violated, int *warn);
+int dmx_chunk_commit(dmxBatch *b, int ticks, int refresh_zones);
+int dmx_chunk_rollback(dmxBatch *b);
+int dmx_exact_tick(dmxBatch *b, double h);
 
 
 template <class T> inline void dmx_normalize_plane(const double in[4], T out[4])

@@ -103,7 +103,8 @@ template <class T> int build_safe_zones(dmxBatch *b)
     int rc = ensure_buffers(b);
     if (rc != DMX_OK) return rc;
     if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
-    HIP_TRY(launch_bp_safe_zone<T>((T *)b->slab, b->gtype, b->stride, b->n_active, grid_of<T>(b), b->stream));
+    // ghost slots [n_active, n) get zones too: the caller that refreshes them checks them (dmxBatchCheckZonesOnStream)
+    HIP_TRY(launch_bp_safe_zone<T>((T *)b->slab, b->gtype, b->stride, b->n, grid_of<T>(b), b->stream));
     if ((rc = read_flags(b)) != DMX_OK) return rc;
     if (b->bp_flags_host[BPF_OVERFLOW]) {
         if ((rc = grow_buckets(b)) != DMX_OK) return rc;
@@ -159,6 +160,12 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     std::vector<std::pair<int32_t, int32_t>> pairs(np);
     for (uint32_t k = 0; k < np; k++) pairs[k] = { pr[2 * k], pr[2 * k + 1] };
     std::sort(pairs.begin(), pairs.end());
+    for (auto &p : pairs)
+        if (p.first >= b->n_active || p.second >= b->n_active) {
+            fprintf(stderr, "libode_mi355: bodies %d and %d touch across two ranks' slabs; an island spanning ranks has to be "
+                            "migrated to one owner first\n", p.first, p.second);
+            return DMX_ECROSS;
+        }
     std::vector<int32_t> inv;
     inv.reserve((size_t)2 * np);
     for (auto &p : pairs) { inv.push_back(p.first); inv.push_back(p.second); }
@@ -280,9 +287,92 @@ template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
     return DMX_OK;
 }
 
+// ---- the same loop in pieces, for a caller that interleaves its own per-tick work (shard.py's exchange) ----
+template <class T> int chunk_begin_t(dmxBatch *b, int *exact_only, int *ballistic)
+{
+    int rc;
+    if ((rc = ensure_buffers(b)) != DMX_OK) return rc;
+    if (!b->bp_valid && (rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
+    *exact_only = (b->bp_crowded > 0 || b->ext_pending) ? 1 : 0;
+    *ballistic = (!b->plane_on && b->g[0] == 0.0 && b->g[2] == 0.0) ? 1 : 0;
+    HIP_TRY(launch_copy_state<T>((T *)b->slab, (T *)b->bp_snapshot.p, b->stride, true, b->stream));
+    HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, 2 * sizeof(uint32_t), b->stream));
+    return DMX_OK;
+}
+
+template <class T> int chunk_rollback_t(dmxBatch *b)
+{
+    HIP_TRY(launch_copy_state<T>((T *)b->slab, (T *)b->bp_snapshot.p, b->stride, false, b->stream));
+    b->stat_rollbacks++;
+    b->bp_valid = false;
+    return DMX_OK;
+}
+
+template <class T> int check_zones_t(dmxBatch *b, hipStream_t st, int64_t first, int64_t count)
+{
+    HIP_TRY(launch_check_zones<T>((const T *)b->slab, first, count, (uint32_t *)b->bp_flags.p, st));
+    return DMX_OK;
+}
+
 }  // namespace
 
 int dmx_step_collide(dmxBatch *b, double h, int nsteps)
 {
     return b->precision == DMX_F32 ? step_collide_t<float>(b, h, nsteps) : step_collide_t<double>(b, h, nsteps);
+}
+
+int dmx_chunk_begin(dmxBatch *b, int *exact_only, int *ballistic)
+{
+    return b->precision == DMX_F32 ? chunk_begin_t<float>(b, exact_only, ballistic) : chunk_begin_t<double>(b, exact_only, ballistic);
+}
+
+int dmx_chunk_tick(dmxBatch *b, double h, int check)
+{
+    if (!b->bp_flags.p) return DMX_EINVAL;          // no chunk begun
+    const int rc = b->precision == DMX_F32 ? fused_tick<float>(b, h, check != 0, nullptr) : fused_tick<double>(b, h, check != 0, nullptr);
+    b->stepped_with_plane = b->plane_on != 0;
+    b->last_islands = false;
+    b->last_mixed = false;
+    b->last_pairs = 0;
+    return rc;
+}
+
+int dmx_check_zones(dmxBatch *b, hipStream_t st, int64_t first, int64_t count)
+{
+    if (!b->bp_flags.p) return DMX_EINVAL;
+    return b->precision == DMX_F32 ? check_zones_t<float>(b, st, first, count) : check_zones_t<double>(b, st, first, count);
+}
+
+int dmx_chunk_end(dmxBatch *b, int *violated, int *warn)
+{
+    if (!b->bp_flags.p) return DMX_EINVAL;
+    const int rc = read_flags(b);
+    if (rc != DMX_OK) return rc;
+    *violated = b->bp_flags_host[BPF_VIOLATION] ? 1 : 0;
+    *warn = b->bp_flags_host[BPF_WARN] ? 1 : 0;
+    return DMX_OK;
+}
+
+int dmx_chunk_commit(dmxBatch *b, int ticks, int refresh_zones)
+{
+    b->stat_fast_ticks += ticks;
+    if (refresh_zones) b->bp_valid = false;
+    return DMX_OK;
+}
+
+int dmx_chunk_rollback(dmxBatch *b)
+{
+    if (!b->bp_snapshot.p) return DMX_EINVAL;
+    return b->precision == DMX_F32 ? chunk_rollback_t<float>(b) : chunk_rollback_t<double>(b);
+}
+
+int dmx_exact_tick(dmxBatch *b, double h)
+{
+    int rc = ensure_buffers(b);
+    if (rc != DMX_OK) return rc;
+    rc = b->precision == DMX_F32 ? careful_tick<float>(b, h) : careful_tick<double>(b, h);
+    b->bp_valid = false;
+    b->stepped_with_plane = b->plane_on != 0 || b->last_mixed;
+    b->last_islands = false;
+    return rc;
 }

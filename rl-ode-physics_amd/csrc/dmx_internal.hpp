@@ -133,6 +133,14 @@ template <class T>
 hipError_t launch_gather(const T *S, int64_t stride, const int32_t *idx, int64_t count, T *out, hipStream_t st);
 template <class T>
 hipError_t launch_scatter(T *S, int64_t stride, const int32_t *idx, int64_t count, const T *in, hipStream_t st);
+// safe-zone test of slots [first, first+count) only (no integration): raises BPF_VIOLATION / BPF_WARN in `flags`
+template <class T>
+hipError_t launch_check_zones(const T *S, int64_t first, int64_t count, uint32_t *flags, hipStream_t st);
+// ghost slots [first, first+count_lo) <- src_lo, the next count_hi <- src_hi (13-real AoS rows; null = leave alone), with
+// an optional safe-zone test of the new positions
+template <class T>
+hipError_t launch_refresh_ghosts(T *S, int64_t first, int64_t count_lo, const T *src_lo, int64_t count_hi, const T *src_hi,
+                                 int check, uint32_t *flags, hipStream_t st);
 template <class T>
 hipError_t launch_fill_component(T *S, int c, T value, int64_t n, hipStream_t st);
 // rollback snapshot of the 13 state components of bodies [0, n_bodies): save = slab -> packed, else packed -> slab

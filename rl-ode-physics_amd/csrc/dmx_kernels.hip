@@ -412,6 +412,43 @@ __global__ __launch_bounds__(256) void pack_transforms(const T *__restrict__ S, 
 }
 
 // gather / scatter the 13 state reals of listed bodies (boundary exchange between GPUs)
+// safe-zone test only, for slots the step kernels do not own (ghosts of a neighbour rank's boundary bodies)
+template <class T>
+__global__ __launch_bounds__(256) void check_zones(const T *__restrict__ S, int64_t first, int64_t count, uint32_t *flags)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int zs = 0;
+    if (t < count) {
+        const int64_t i = first + t;
+        zs = zone_state(S[slab_ix(C_POS + 0, i)] - S[slab_ix(C_BPX, i)], S[slab_ix(C_POS + 2, i)] - S[slab_ix(C_BPZ, i)],
+                        S[slab_ix(C_BPSAFE, i)]);
+    }
+    report_zone(zs, flags);
+}
+
+// Ghost refresh of the multi-GPU exchange, one launch per tick: the lower neighbour's rows (AoS, 13 reals per body) go
+// to slots [first, first+count_lo), the upper neighbour's to the count_hi slots behind them; a null source leaves its
+// range alone (no neighbour on that side).  With `check` the new (x,z) is tested against the slot's safe zone.
+template <class T>
+__global__ __launch_bounds__(256) void refresh_ghosts(T *__restrict__ S, int64_t first, int64_t count_lo,
+                                                      const T *__restrict__ src_lo, int64_t count_hi,
+                                                      const T *__restrict__ src_hi, int check, uint32_t *flags)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int zs = 0;
+    if (t < count_lo + count_hi) {
+        const T *src = t < count_lo ? src_lo : src_hi;
+        if (src != nullptr) {
+            const T *p = src + (t < count_lo ? t : t - count_lo) * C_MASS;
+            const int64_t i = first + t;
+#pragma unroll
+            for (int c = 0; c < C_MASS; c++) S[slab_ix(c, i)] = p[c];
+            if (check) zs = zone_state(p[0] - S[slab_ix(C_BPX, i)], p[2] - S[slab_ix(C_BPZ, i)], S[slab_ix(C_BPSAFE, i)]);
+        }
+    }
+    if (check) report_zone(zs, flags);
+}
+
 // fill component c of every allocated body (pad included) with one value
 template <class T>
 __global__ __launch_bounds__(256) void fill_component(T *__restrict__ S, int c, T value, int64_t n)
@@ -532,6 +569,24 @@ hipError_t launch_pack_transforms(const T *S, int64_t stride, int64_t first, int
     return hipGetLastError();
 }
 template <class T>
+hipError_t launch_check_zones(const T *S, int64_t first, int64_t count, uint32_t *flags, hipStream_t st)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL((check_zones<T>), dim3(blocks_for(count, 256)), dim3(256), 0, st, S, first, count, flags);
+    return hipGetLastError();
+}
+
+template <class T>
+hipError_t launch_refresh_ghosts(T *S, int64_t first, int64_t count_lo, const T *src_lo, int64_t count_hi, const T *src_hi,
+                                 int check, uint32_t *flags, hipStream_t st)
+{
+    if (count_lo + count_hi <= 0) return hipSuccess;
+    hipLaunchKernelGGL((refresh_ghosts<T>), dim3(blocks_for(count_lo + count_hi, 256)), dim3(256), 0, st, S, first, count_lo,
+                       src_lo, count_hi, src_hi, check, flags);
+    return hipGetLastError();
+}
+
+template <class T>
 hipError_t launch_fill_component(T *S, int c, T value, int64_t n, hipStream_t st)
 {
     hipLaunchKernelGGL((fill_component<T>), dim3(blocks_for(n, 256)), dim3(256), 0, st, S, c, value, n);
@@ -586,7 +641,9 @@ hipError_t launch_soa_to_aos(const T *S, int64_t stride, int comp0, int k, int64
     template hipError_t launch_aos_to_soa<T>(T *, int64_t, int, int, int64_t, int64_t, const T *, hipStream_t);    \
     template hipError_t launch_soa_to_aos<T>(const T *, int64_t, int, int, int64_t, int64_t, T *, hipStream_t);     \
     template hipError_t launch_fill_component<T>(T *, int, T, int64_t, hipStream_t);                                \
-    template hipError_t launch_copy_state<T>(T *, T *, int64_t, bool, hipStream_t);
+    template hipError_t launch_copy_state<T>(T *, T *, int64_t, bool, hipStream_t);                                 \
+    template hipError_t launch_check_zones<T>(const T *, int64_t, int64_t, uint32_t *, hipStream_t);               \
+    template hipError_t launch_refresh_ghosts<T>(T *, int64_t, int64_t, const T *, int64_t, const T *, int, uint32_t *, hipStream_t);
 DMX_INSTANTIATE(float)
 DMX_INSTANTIATE(double)
 

@@ -19,6 +19,13 @@ search) wait for the in-flight exchange first (`drain()`).
 For slabs farther apart than a broadphase cell (BASELINE configs[3], >= 10 m) the boundary set is empty and
 `exchange="none"` skips steps 2-4.
 
+Body-body collisions (dSpaceCollide for body pairs) ride along as in the single-GPU loop: every body, ghosts included,
+carries a broadphase safe zone; the step kernel checks the rank's own bodies, a small kernel on the side stream checks
+the ghost slots right after their refresh.  Ticks run in chunks; at a chunk's end the ranks OR their violation flags
+(one tiny all-reduce) and either all commit or all roll back to the chunk's snapshot and replay it -- first with fresh
+zones, then tick by tick on the exact path (pair search, narrowphase, island solve).  A pair of bodies owned by two
+different ranks is reported (DMX_ECROSS): migrating an island to one owner is not built yet.
+
 The exchange is written against a tiny `ops` interface (gather / scatter / buffers / streams) so the index
 logic and the collective run unchanged on CPU tensors with the gloo backend (tests/test_shard_gloo.py).
 """
@@ -62,8 +69,13 @@ class DeviceOps:
         self.main = main_stream                      # the stream the batch launches on
         self.side = torch.cuda.Stream(device=device)
         self.packed = torch.cuda.Event()
-        self.done = [torch.cuda.Event(), torch.cuda.Event()]     # per send buffer: "the exchange that read it finished"
-        self.have_done = [False, False]
+        self.set_ring(2)
+
+    def set_ring(self, ring):
+        """one event per send buffer: "the exchange that read it finished" """
+        self.ring = int(ring)
+        self.done = [torch.cuda.Event() for _ in range(self.ring)]
+        self.have_done = [False] * self.ring
 
     def empty(self, *shape):
         return torch.empty(shape, dtype=self.torch_dtype, device=self.device)
@@ -86,8 +98,8 @@ class DeviceOps:
 
     # -- stream choreography -------------------------------------------------------------------------------
     def before_pack(self, k=0):
-        if self.have_done[k & 1]:
-            self.main.wait_event(self.done[k & 1])   # exchange k-2 (same send buffer) has finished; k-1 may still run
+        if self.have_done[k % self.ring]:
+            self.main.wait_event(self.done[k % self.ring])   # the exchange that last read this send buffer has finished; later ones may still run
 
     def after_pack(self):
         self.packed.record(self.main)
@@ -97,16 +109,36 @@ class DeviceOps:
         return torch.cuda.stream(self.side)
 
     def after_exchange(self, k=0):
-        self.done[k & 1].record(self.side)
-        self.have_done[k & 1] = True
+        self.done[k % self.ring].record(self.side)
+        self.have_done[k % self.ring] = True
+        self.last = k % self.ring
 
     def drain(self):
-        for b in (0, 1):
-            if self.have_done[b]:
-                self.main.wait_event(self.done[b])
+        if any(self.have_done):
+            self.main.wait_event(self.done[self.last])       # the side stream is in order: its newest exchange covers the older ones
 
     def forget(self):
-        self.have_done = [False, False]
+        self.have_done = [False] * self.ring
+
+    def disarm_pack(self):
+        self.w.set_boundary_pack(0, 0, 0)
+
+    def refresh_ghosts(self, first, count_lo, src_lo, count_hi, src_hi, check):
+        """both neighbours' rows into the ghost slots (and their zone test) in one launch on the side stream"""
+        ptr = lambda t: None if t is None else t.data_ptr()
+        self.w.refresh_ghosts_on(self.side.cuda_stream, first, count_lo, ptr(src_lo), count_hi, ptr(src_hi), check)
+
+    def check_ghosts(self, first, count):
+        """safe-zone test of the freshly written ghost slots, behind the scatter on the side stream"""
+        self.w.check_zones_on(self.side.cuda_stream, first, count)
+
+    def any_rank(self, flag, group=None):
+        """logical OR of a host flag over the ranks"""
+        if dist.get_world_size(group) == 1:
+            return bool(flag)
+        t = torch.tensor([int(bool(flag))], dtype=torch.int32, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return bool(t.item())
 
 
 class BoundaryExchange:
@@ -116,41 +148,82 @@ class BoundaryExchange:
         self.send_idx = ops.index(layout.send_idx)
         self.ghost_lo = ops.index(layout.ghost_lo)
         self.ghost_hi = ops.index(layout.ghost_hi)
-        # two send buffers: tick k's step kernel fills one while exchange k-1 still reads the other
-        self.sends = [ops.empty(layout.n_send, STATE_REALS), ops.empty(layout.n_send, STATE_REALS)]
+        # a ring of send buffers: tick k's step kernel fills one while earlier exchanges still read the others
         self.k = 0
+        self.count = 0            # exchanges issued (a captured graph counts its ticks once, at capture)
+        self.set_ring(2)
         self.fused = bool(getattr(ops, "fused_pack", False))
         # all_gather_into_tensor wants the ranks' buffers concatenated along dim 0
         self.recv_flat = ops.empty(world_size * layout.n_send, STATE_REALS)
         self.recv = self.recv_flat.view(world_size, layout.n_send, STATE_REALS)
 
+    def set_ring(self, ring):
+        """(Re)size the ring of send buffers (tick k packs into buffer k mod ring and waits only for the exchange that
+        last read that buffer)."""
+        self.ops.drain()
+        self.sends = [self.ops.empty(self.L.n_send, STATE_REALS) for _ in range(int(ring))]
+        if hasattr(self.ops, "set_ring"):
+            self.ops.set_ring(ring)
+
     @property
     def send(self):
-        return self.sends[self.k & 1]
+        return self.sends[self.k % len(self.sends)]
 
-    def before_step(self):
+    def before_step(self, fused=None):
         """Called before the tick's step kernel is enqueued: make sure this tick's send buffer is free and, with a
-        fused pack, aim the step kernel at it."""
+        fused pack, aim the step kernel at it (fused=False: the tick's kernels do not pack, `pack` will gather)."""
+        fused = self.fused if fused is None else (fused and self.fused)
         self.ops.before_pack(self.k)
-        if self.fused:
+        if fused:
             self.ops.arm_pack(self.send, self.L)
+        elif self.fused:
+            self.ops.disarm_pack()
 
-    def pack(self):
-        if not self.fused:
+    def pack(self, fused=None):
+        fused = self.fused if fused is None else (fused and self.fused)
+        if not fused:
             self.ops.gather(self.send_idx, self.send)
         self.ops.after_pack()
 
-    def exchange(self):
-        """All-gather every rank's boundary rows and refresh the ghost slots (on the ops' side stream)."""
+    def exchange(self, check_ghosts=False):
+        """All-gather every rank's boundary rows and refresh the ghost slots (on the ops' side stream); with
+        check_ghosts the refreshed slots are tested against their broadphase safe zones there too."""
         with self.ops.side_stream():
             dist.all_gather_into_tensor(self.recv_flat, self.send, group=self.group)
             side = self.L.side
-            if self.rank > 0:                                   # lower neighbour's upper row
-                self.ops.scatter(self.ghost_lo, self.recv[self.rank - 1, side:2 * side])
-            if self.rank < self.world - 1:                      # upper neighbour's lower row
-                self.ops.scatter(self.ghost_hi, self.recv[self.rank + 1, 0:side])
+            lo = self.recv[self.rank - 1, side:2 * side] if self.rank > 0 else None           # lower neighbour's upper row
+            hi = self.recv[self.rank + 1, 0:side] if self.rank < self.world - 1 else None     # upper neighbour's lower row
+            if hasattr(self.ops, "refresh_ghosts"):
+                if lo is not None or hi is not None:
+                    self.ops.refresh_ghosts(self.L.n, side, lo, side, hi, check_ghosts)
+            else:
+                if lo is not None:
+                    self.ops.scatter(self.ghost_lo, lo)
+                if hi is not None:
+                    self.ops.scatter(self.ghost_hi, hi)
+                if check_ghosts:
+                    self.ops.check_ghosts(self.L.n, 2 * side)
         self.ops.after_exchange(self.k)
         self.k += 1
+        self.count += 1
+
+    def share_geometry(self, upload_ghost, sides, gtype):
+        """Once, at set-up: the neighbours' boundary bodies' extents and geometry types into the ghost slots, so the
+        broadphase sees the ghosts at their true size.  sides [n,3] / gtype [n] describe this rank's own bodies;
+        upload_ghost(first_slot, sides_rows, gtype_rows) writes ghost slots."""
+        L, side = self.L, self.L.side
+        mine = self.ops.empty(L.n_send, 4)
+        rows = np.concatenate([np.asarray(sides)[L.send_idx], np.asarray(gtype, dtype=np.float64)[L.send_idx, None]], axis=1)
+        mine.copy_(torch.from_numpy(np.ascontiguousarray(rows)).to(mine.dtype))
+        flat = self.ops.empty(self.world * L.n_send, 4)
+        dist.all_gather_into_tensor(flat, mine, group=self.group)
+        got = flat.view(self.world, L.n_send, 4).cpu().numpy()
+        if self.rank > 0:
+            r = got[self.rank - 1, side:2 * side]
+            upload_ghost(int(L.ghost_lo[0]), r[:, :3], r[:, 3].astype(np.uint8))
+        if self.rank < self.world - 1:
+            r = got[self.rank + 1, 0:side]
+            upload_ghost(int(L.ghost_hi[0]), r[:, :3], r[:, 3].astype(np.uint8))
 
     def tick(self):
         """pack + exchange for hosts that do not interleave a step kernel (tests)."""
@@ -163,58 +236,160 @@ class BoundaryExchange:
 
 
 class ShardedStepper:
-    """One rank's tick loop: step the slab, then hand the boundary rows to the side-stream exchange."""
+    """One rank's tick loop: step the slab, then hand the boundary rows to the side-stream exchange.
 
-    def __init__(self, world_batch, layout, rank, world_size, exchange="boundary", device=None, stream=None):
+    collide=True carries the body-body collision proof through the loop (module docstring); geometry=(sides, gtype)
+    of this rank's bodies is then shared with the neighbours once so their ghosts have the right extents."""
+
+    CHUNK_MIN, CHUNK_MAX = 32, 256
+
+    def __init__(self, world_batch, layout, rank, world_size, exchange="boundary", device=None, stream=None,
+                 collide=False, geometry=None, ops=None, group=None, exchange_every_tick=False):
         self.w, self.L = world_batch, layout
         self.exchange = None
-        if world_size > 1 and exchange == "boundary":
-            self.exchange = BoundaryExchange(DeviceOps(world_batch, device, stream), layout, rank, world_size)
+        if (world_size > 1 and exchange == "boundary") or ops is not None:
+            ops = ops if ops is not None else DeviceOps(world_batch, device, stream)
+            self.exchange = BoundaryExchange(ops, layout, rank, world_size, group=group)
         self.graph = None
         self.graph_steps = 0
+        self.collide = bool(collide) and self.exchange is not None
+        self.exchange_every_tick = bool(exchange_every_tick)
+        self.chunk = self.CHUNK_MIN
+        self.ballistic_graph = None
+        if self.collide and geometry is not None:
+            sides, gtype = geometry
 
-    def tick(self, h):
+            def upload_ghost(first, s_rows, g_rows):
+                from .batch import SIDES
+                world_batch.upload(SIDES, s_rows, first=first)
+                world_batch.upload_geom_type(g_rows, first=first)
+            self.exchange.share_geometry(upload_ghost, sides, gtype)
+
+    # -- one tick ------------------------------------------------------------------------------------------
+    def tick(self, h, check=None):
+        """step + pack + exchange; check (collide mode): run the safe-zone test in this tick"""
         ex = self.exchange
         if ex is None:
             self.w.step(h, 1)
             return
         ex.before_step()
-        self.w.step(h, 1)
+        if self.collide:
+            self.w.chunk_tick(h, bool(check))
+        else:
+            self.w.step(h, 1)
         ex.pack()
+        ex.exchange(check_ghosts=self.collide and bool(check))
+
+    def exact_tick(self, h):
+        """one tick on the exact path: the pair search reads the ghost slots, islands are solved by their own
+        kernels, so the boundary rows are gathered after the tick instead of packed inside the step kernel"""
+        ex = self.exchange
+        ex.drain()
+        ex.before_step(fused=False)
+        self.w.exact_tick(h)
+        ex.pack(fused=False)
         ex.exchange()
 
+    # -- the loop ------------------------------------------------------------------------------------------
     def run(self, h, nsteps):
         if self.exchange is None:
             self.w.step(h, nsteps)          # the C loop: no per-tick host work
             return
+        if self.collide:
+            remaining = nsteps
+            while remaining > 0:
+                k = self.chunk
+                if self.graph is not None:
+                    k = max(1, k // self.graph_steps) * self.graph_steps + 1      # whole replays + the tested last tick
+                remaining -= self._chunk(h, min(remaining, k))
+            return
         if self.graph is not None:
             reps, nsteps = divmod(nsteps, self.graph_steps)
             for _ in range(reps):
-                self.graph.replay()
+                self._replay()
         for _ in range(nsteps):
             self.tick(h)
+
+    def _replay(self):
+        self.exchange.ops.drain()       # eager exchanges still in flight use the ring too: let them finish first
+        self.graph.replay()
+
+    def _fast_ticks(self, h, k, ballistic):
+        """k ticks of one chunk.
+
+        Ballistic chunks (no ground plane, gravity along y: every body, ghosts included, moves on a straight horizontal
+        line) are proven by the test at their first and last tick alone, and nothing else reads the ghost slots inside a
+        chunk -- so only the chunk's last tick exchanges (`exchange_every_tick` forces the per-tick exchange anyway).
+        Otherwise every tick is tested and exchanged."""
+        if ballistic and not self.exchange_every_tick:
+            if self.exchange.fused:
+                self.exchange.ops.disarm_pack()
+            for s in range(k - 1):
+                self.w.chunk_tick(h, s == 0)
+            self.tick(h, check=True)
+            return
+        g = self.graph_steps if (self.graph is not None and self.ballistic_graph == ballistic) else 0
+        reps = (k - 1) // g if g else 0          # keep at least one eager tick: the chunk's last tick is always tested
+        for _ in range(reps):
+            self._replay()
+        done = reps * g
+        for s in range(done, k):
+            self.tick(h, check=(not ballistic) or s == 0 or s == k - 1)
+
+    def _chunk(self, h, k):
+        """Run up to k ticks as one chunk; returns the ticks actually advanced."""
+        ex, w, ops = self.exchange, self.w, self.exchange.ops
+        for attempt in range(3):
+            ex.drain()                           # zones, snapshot and flag reset see the last exchange's ghost rows
+            exact_only, ballistic = w.chunk_begin()
+            if ops.any_rank(exact_only, ex.group) or attempt == 2:
+                break                            # crowded bodies or pending forces somewhere: everyone steps exactly
+            self._fast_ticks(h, k, ballistic)
+            ex.drain()
+            violated, warn = w.chunk_end()
+            if not ops.any_rank(violated, ex.group):
+                w.chunk_commit(k, refresh_zones=warn)
+                if not warn and k >= self.chunk:
+                    self.chunk = min(2 * self.chunk, self.CHUNK_MAX)
+                return k
+            # some body on some rank left its zone: every rank returns to the chunk's start (ghost slots included)
+            w.chunk_rollback()
+            self.chunk = self.CHUNK_MIN
+            k = min(k, self.CHUNK_MIN)
+        for _ in range(k):
+            self.exact_tick(h)
+        return k
 
     def drain(self):
         if self.exchange is not None:
             self.exchange.drain()
 
-    def capture(self, h, steps_per_graph, stream):
+    def capture(self, h, steps_per_graph, stream, ring=2):
         """Capture `steps_per_graph` ticks (kernels, the RCCL all-gather and the stream choreography) into one
-        HIP graph so a replay costs one host call; returns False (and stays eager) if capture is not possible."""
+        HIP graph so a replay costs one host call; returns False (and stays eager) if capture is not possible.
+        `ring` send buffers: 2 measured best (27.7 us/tick at 1 Mi bodies against 28-33 for deeper rings, which
+        lengthen the graph's side branch -- profiles/r01_exchange_ring_ab.txt)."""
         if self.exchange is None:
             return False
         ops = self.exchange.ops
         try:
             ops.drain()
             torch.cuda.synchronize()
+            self.exchange.set_ring(ring)
+            ballistic = None
+            if self.collide:
+                _, ballistic = self.w.chunk_begin()        # buffers exist before the capture; nothing is advanced
+                if ballistic and not self.exchange_every_tick:
+                    return False                           # one exchange per chunk: nothing worth capturing
+            torch.cuda.synchronize()
             ops.forget()                               # no event edges from outside the capture
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=stream):
-                for _ in range(steps_per_graph):
-                    self.tick(h)
+                for s in range(steps_per_graph):
+                    self.tick(h, check=(not ballistic) or s == 0)
                 ops.drain()                            # the side stream rejoins before the capture ends
             ops.forget()
-            self.graph, self.graph_steps = g, steps_per_graph
+            self.graph, self.graph_steps, self.ballistic_graph = g, steps_per_graph, ballistic
             return True
         except Exception as e:      # noqa: BLE001 -- capture support varies; eager is always correct
             self.graph = None

@@ -432,3 +432,96 @@ def test_midair_collisions_in_free_flight():
     _compare(w.state(), ow.state())
     st = w.collision_stats()
     assert st["pair_ticks"] > 0 and st["careful_ticks"] >= st["pair_ticks"]
+
+
+# ----------------------------------------------------------------- sharded loop with the collision proof
+def _one_rank_group():
+    import socket
+    import torch.distributed as dist
+    import os
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    return dist
+
+
+@pytest.mark.parametrize("graph_steps,speed", [(0, 3.0), (8, 3.0), (8, 0.1), (0, 0.1)])
+def test_sharded_loop_carries_the_collision_proof(graph_steps, speed):
+    """shard.ShardedStepper(collide=True) on a one-rank group (the collective degenerates to a copy): chunks, ghost
+    checks, collective rollback and exact replay give the oracle's bits, mid-air box-box contacts included."""
+    import torch
+    scene = pkg.scenes.box_grid(16, 16, seed=13, y_range=(10.0, 12.0), spin=True, box_mass=True, plane=False).astype("float64")
+    rng = np.random.default_rng(5)
+    scene.lvel[:, 0] = rng.uniform(-speed, speed, scene.n)
+    scene.lvel[:, 2] = rng.uniform(-speed, speed, scene.n)
+    steps = 150
+    ow = _oracle_build(_orc("float64"), scene)
+    ow.run(H, steps)
+    dist = _one_rank_group()
+    try:
+        L = pkg.shard.SlabLayout(16, 16)
+        w = pkg.BatchWorld(L.n_total, dtype="float64")
+        w.load_scene(scene)
+        w.set_active_count(scene.n)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            w.set_stream(stream.cuda_stream)
+            ops = pkg.shard.DeviceOps(w, torch.device("cuda", 0), stream)
+            st = pkg.shard.ShardedStepper(w, L, 0, 1, collide=True, geometry=(scene.sides, scene.gtype), ops=ops)
+            if graph_steps:
+                st.capture(H, graph_steps, stream)
+            st.run(H, steps)
+            st.drain()
+            w.synchronize()
+            got = [a[:scene.n] for a in w.state()]
+            stats = w.collision_stats()
+        _compare(got, ow.state())
+        assert stats["fast_ticks"] + stats["careful_ticks"] >= steps
+        if speed > 1.0:
+            assert stats["pair_ticks"] > 0            # fast sideways motion: most chunks end in an exact replay
+        else:
+            assert stats["fast_ticks"] >= 64          # slow drift: quiet chunks commit on the fast path
+        w.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ghost_slots_are_checked_and_cross_rank_pairs_are_reported():
+    import torch
+    scene = pkg.scenes.box_grid(8, 4, seed=3, y_range=(5.0, 6.0), spin=False, plane=False).astype("float32")
+    L = pkg.shard.SlabLayout(8, 4)
+    w = pkg.BatchWorld(L.n_total, dtype="float32")
+    w.load_scene(scene)
+    # ghosts: a row of boxes one pitch beyond the slab's last row (what the upper neighbour would send)
+    g = scene.slice(scene.n - 8, scene.n)
+    gpos = g.pos.copy(); gpos[:, 2] += 2.5
+    first = int(L.ghost_hi[0])
+    w.upload(pkg.batch.POS, gpos, first=first)
+    w.upload(pkg.batch.SIDES, g.sides, first=first)
+    w.upload_geom_type(g.gtype, first=first)
+    w.set_active_count(scene.n)
+    assert w.chunk_begin() == (False, True)
+    s = torch.cuda.Stream()
+    w.check_zones_on(s.cuda_stream, scene.n, 2 * L.side)
+    s.synchronize()
+    assert w.chunk_end() == (False, False)
+    # a ghost arrives 1 m closer than where its zone was built: outside the zone
+    state = np.concatenate([gpos, g.quat, g.lvel, g.avel], axis=1).astype(np.float32)
+    state[3, 2] -= 1.0
+    idx = torch.arange(first, first + 8, dtype=torch.int32, device="cuda")
+    src = torch.from_numpy(state).cuda()
+    w.scatter_bodies(idx.data_ptr(), 8, src.data_ptr())
+    w.synchronize()
+    w.check_zones_on(s.cuda_stream, scene.n, 2 * L.side)
+    s.synchronize()
+    violated, _ = w.chunk_end()
+    assert violated
+    # and one that overlaps a body of this rank: the exact tick refuses (island spanning two ranks)
+    state[3, 2] = scene.pos[scene.n - 8 + 3, 2] + 0.1
+    state[3, 1] = scene.pos[scene.n - 8 + 3, 1]
+    src = torch.from_numpy(state).cuda()
+    w.scatter_bodies(idx.data_ptr(), 8, src.data_ptr())
+    w.synchronize()
+    with pytest.raises(pkg.batch.DmxError, match="-6"):
+        w.exact_tick(H)
+    w.close()

@@ -34,6 +34,14 @@ class HostOps:
     def scatter(self, idx, src):
         self.state[idx] = src
 
+    def check_ghosts(self, first, count):
+        self.ghost_checks = getattr(self, "ghost_checks", 0) + 1
+
+    def any_rank(self, flag, group=None):
+        t = torch.tensor([int(bool(flag))], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return bool(t.item())
+
     # the stream choreography of DeviceOps has nothing to order on the host
     def before_pack(self, k=0): pass
     def after_pack(self): pass
@@ -114,3 +122,103 @@ def test_slab_layout_partitions_the_slab():
     assert np.array_equal(np.sort(covered), np.arange(L.n))                    # boundary rows + interior = every body once
     assert first % 4 == 0 and count % 4 == 0 and L.n % 4 == 0                  # 16 B packs never straddle a range
     assert L.n_total == L.n + 2 * L.side and L.ghost_lo[0] == L.n
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the collision-checked chunk loop of ShardedStepper, with a host double of the batch: every tick adds 0.5 to the
+# rank's own rows; "a body leaves its safe zone" on one rank at one tick of the fast path
+class HostWorld:
+    def __init__(self, state, n, violate_at=None):
+        self.state, self.n = state, n
+        self.t = 0
+        self.violate_at = violate_at        # global tick index at which the fast path raises the flag, or None
+        self.flag = False
+        self.snap = None
+        self.log = {"fast": 0, "exact": 0, "rollbacks": 0, "begins": 0, "checked": 0}
+
+    def chunk_begin(self):
+        self.snap = (self.state.clone(), self.t)
+        self.flag = False
+        self.log["begins"] += 1
+        return False, True                  # not exact-only, ballistic
+
+    def chunk_tick(self, h, check=True):
+        self.state[:self.n] += 0.5
+        if check:
+            self.log["checked"] += 1
+        # a ballistic chunk only looks at its first and last tick: the body is outside from violate_at onwards
+        if check and self.violate_at is not None and self.t >= self.violate_at:
+            self.flag = True
+        self.t += 1
+
+    def chunk_end(self):
+        return self.flag, False
+
+    def chunk_commit(self, ticks, refresh_zones=False):
+        self.log["fast"] += ticks
+
+    def chunk_rollback(self):
+        self.state.copy_(self.snap[0])
+        self.t = self.snap[1]
+        self.log["rollbacks"] += 1
+
+    def exact_tick(self, h):
+        self.state[:self.n] += 0.5
+        self.t += 1
+        self.log["exact"] += 1
+
+
+def _chunk_worker(rank, world, port, side, rows, ticks, violate, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L = shard.SlabLayout(side, rows)
+        state = torch.full((L.n_total, shard.STATE_REALS), -1.0, dtype=torch.float64)
+        slot = torch.arange(L.n, dtype=torch.float64)[:, None]
+        comp = torch.arange(shard.STATE_REALS, dtype=torch.float64)[None, :]
+        state[:L.n] = 1000.0 * rank + slot + comp / 16.0
+        w = HostWorld(state, L.n, violate_at=violate[1] if violate and violate[0] == rank else None)
+        ops = HostOps(state)
+        st = shard.ShardedStepper(w, L, rank, world, collide=True, ops=ops)
+        st.run(1.0 / 60, ticks)
+        q.put((rank, state.numpy().copy(), dict(w.log), st.chunk, getattr(ops, "ghost_checks", 0)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("violate", [None, (1, 40)])
+def test_chunked_collision_loop_commits_or_rolls_back_on_every_rank(violate):
+    world, side, rows, ticks = 2, 8, 5, 100
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, world, port, side, rows, ticks, violate, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: rest for r, *rest in (q.get(timeout=60) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    L = shard.SlabLayout(side, rows)
+    comp = np.arange(shard.STATE_REALS) / 16.0
+    for r in range(world):
+        st, log, chunk, ghost_checks = got[r]
+        own = 1000.0 * r + np.arange(L.n)[:, None] + comp[None, :] + 0.5 * ticks
+        assert np.array_equal(st[:L.n], own)                       # every tick applied exactly once, rollbacks included
+        other = 1 - r
+        ghost = L.ghost_hi if r == 0 else L.ghost_lo
+        src = L.lower if r == 0 else L.upper
+        assert np.array_equal(st[ghost], 1000.0 * other + src[:, None] + comp[None, :] + 0.5 * ticks)
+        assert log["fast"] + log["exact"] == ticks
+        assert ghost_checks > 0
+    if violate is None:
+        # chunks of 32, 64 and the remaining 4 ticks; first and last tick of each are checked
+        assert all(got[r][1]["rollbacks"] == 0 and got[r][1]["exact"] == 0 for r in range(world))
+        assert got[0][1]["begins"] == 3 and got[0][1]["checked"] == 6
+    else:
+        # rank 1's body is out from tick 40 on: the chunk holding it is rolled back on BOTH ranks, retried once with
+        # fresh zones (the double raises the flag again), then replayed exactly; later chunks hit it again
+        assert got[0][1]["rollbacks"] == got[1][1]["rollbacks"] >= 2
+        assert got[0][1]["exact"] == got[1][1]["exact"] >= 32
+        assert got[0][1]["fast"] == got[1][1]["fast"] >= 32
