@@ -132,13 +132,14 @@ class DeviceOps:
         """safe-zone test of the freshly written ghost slots, behind the scatter on the side stream"""
         self.w.check_zones_on(self.side.cuda_stream, first, count)
 
-    def any_rank(self, flag, group=None):
-        """logical OR of a host flag over the ranks"""
+    def any_rank(self, flags, group=None):
+        """element-wise logical OR of a few host flags over the ranks (one small all-reduce)"""
+        flags = [bool(f) for f in flags]
         if dist.get_world_size(group) == 1:
-            return bool(flag)
-        t = torch.tensor([int(bool(flag))], dtype=torch.int32, device=self.device)
+            return flags
+        t = torch.tensor([int(f) for f in flags], dtype=torch.int32, device=self.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        return bool(t.item())
+        return [bool(v) for v in t.tolist()]
 
 
 class BoundaryExchange:
@@ -169,6 +170,12 @@ class BoundaryExchange:
     def send(self):
         return self.sends[self.k % len(self.sends)]
 
+    def _all_gather(self, out, mine):
+        if hasattr(self.ops, "all_gather"):
+            self.ops.all_gather(out, mine, self.group)     # a host that needs staging (tests on a backend without device collectives)
+        else:
+            dist.all_gather_into_tensor(out, mine, group=self.group)
+
     def before_step(self, fused=None):
         """Called before the tick's step kernel is enqueued: make sure this tick's send buffer is free and, with a
         fused pack, aim the step kernel at it (fused=False: the tick's kernels do not pack, `pack` will gather)."""
@@ -189,7 +196,7 @@ class BoundaryExchange:
         """All-gather every rank's boundary rows and refresh the ghost slots (on the ops' side stream); with
         check_ghosts the refreshed slots are tested against their broadphase safe zones there too."""
         with self.ops.side_stream():
-            dist.all_gather_into_tensor(self.recv_flat, self.send, group=self.group)
+            self._all_gather(self.recv_flat, self.send)
             side = self.L.side
             lo = self.recv[self.rank - 1, side:2 * side] if self.rank > 0 else None           # lower neighbour's upper row
             hi = self.recv[self.rank + 1, 0:side] if self.rank < self.world - 1 else None     # upper neighbour's lower row
@@ -216,7 +223,7 @@ class BoundaryExchange:
         rows = np.concatenate([np.asarray(sides)[L.send_idx], np.asarray(gtype, dtype=np.float64)[L.send_idx, None]], axis=1)
         mine.copy_(torch.from_numpy(np.ascontiguousarray(rows)).to(mine.dtype))
         flat = self.ops.empty(self.world * L.n_send, 4)
-        dist.all_gather_into_tensor(flat, mine, group=self.group)
+        self._all_gather(flat, mine)
         got = flat.view(self.world, L.n_send, 4).cpu().numpy()
         if self.rank > 0:
             r = got[self.rank - 1, side:2 * side]
@@ -342,13 +349,18 @@ class ShardedStepper:
         for attempt in range(3):
             ex.drain()                           # zones, snapshot and flag reset see the last exchange's ghost rows
             exact_only, ballistic = w.chunk_begin()
-            if ops.any_rank(exact_only, ex.group) or attempt == 2:
+            # every decision that shapes the loop (path, chunk length, exchange cadence) is taken on flags OR-ed over the
+            # ranks, so all ranks issue the same sequence of collectives
+            exact_only, ballistic_all = ops.any_rank([exact_only, not ballistic], ex.group)
+            ballistic = not ballistic_all
+            if exact_only or attempt == 2:
                 break                            # crowded bodies or pending forces somewhere: everyone steps exactly
             self._fast_ticks(h, k, ballistic)
             ex.drain()
-            violated, warn = w.chunk_end()
-            if not ops.any_rank(violated, ex.group):
-                w.chunk_commit(k, refresh_zones=warn)
+            violated, warn_here = w.chunk_end()
+            violated, warn = ops.any_rank([violated, warn_here], ex.group)
+            if not violated:
+                w.chunk_commit(k, refresh_zones=warn_here)
                 if not warn and k >= self.chunk:
                     self.chunk = min(2 * self.chunk, self.CHUNK_MAX)
                 return k

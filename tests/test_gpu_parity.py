@@ -516,6 +516,20 @@ def test_ghost_slots_are_checked_and_cross_rank_pairs_are_reported():
     s.synchronize()
     violated, _ = w.chunk_end()
     assert violated
+    # the fused per-tick refresh: rows back where the zones were built -> clean; one row displaced -> violation
+    w.chunk_rollback(); w.chunk_begin()
+    good = np.concatenate([gpos, g.quat, g.lvel, g.avel], axis=1).astype(np.float32)
+    src = torch.from_numpy(good).cuda()
+    w.refresh_ghosts_on(s.cuda_stream, scene.n, L.side, None, L.side, src.data_ptr(), True)
+    s.synchronize()
+    assert w.chunk_end() == (False, False)
+    assert np.array_equal(w.download(pkg.batch.POS, first, 8), gpos.astype(np.float32))
+    assert np.all(w.download(pkg.batch.POS, scene.n, 8) == 0)                  # the lower range had no source: untouched
+    bad = good.copy(); bad[5, 0] += 1.0
+    src = torch.from_numpy(bad).cuda()
+    w.refresh_ghosts_on(s.cuda_stream, scene.n, L.side, None, L.side, src.data_ptr(), True)
+    s.synchronize()
+    assert w.chunk_end()[0]
     # and one that overlaps a body of this rank: the exact tick refuses (island spanning two ranks)
     state[3, 2] = scene.pos[scene.n - 8 + 3, 2] + 0.1
     state[3, 1] = scene.pos[scene.n - 8 + 3, 1]
@@ -525,3 +539,119 @@ def test_ghost_slots_are_checked_and_cross_rank_pairs_are_reported():
     with pytest.raises(pkg.batch.DmxError, match="-6"):
         w.exact_tick(H)
     w.close()
+
+
+# ----------------------------------------------------------------- two ranks on one GPU (collectives staged through gloo)
+def _two_rank_worker(rank, port, steps, speed, out_q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        from __graft_entry__ import load_package
+        p = load_package()
+
+        class StagedOps(p.shard.DeviceOps):
+            """the device ops with the collectives staged through host memory, so two ranks can share one GPU (RCCL wants
+            one device per rank); everything else -- pack, ghost refresh, zone checks, streams -- is the product path"""
+
+            def all_gather(self, out, mine, group=None):
+                torch.cuda.current_stream().synchronize()
+                h = mine.cpu()
+                o = torch.empty((out.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
+                dist.all_gather_into_tensor(o, h, group=group)
+                out.copy_(o)
+
+            def any_rank(self, flags, group=None):
+                t = torch.tensor([int(bool(f)) for f in flags], dtype=torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+                return [bool(v) for v in t.tolist()]
+
+        nx, rows = 16, 8
+        full = _two_rank_scene(p, nx, rows, speed)
+        scene = full.slice(rank * nx * rows, (rank + 1) * nx * rows)
+        L = p.shard.SlabLayout(nx, rows)
+        w = p.BatchWorld(L.n_total, dtype="float64")
+        w.load_scene(scene)
+        w.set_active_count(scene.n)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            w.set_stream(stream.cuda_stream)
+            ops = StagedOps(w, torch.device("cuda", 0), stream)
+            st = p.shard.ShardedStepper(w, L, rank, 2, collide=True, geometry=(scene.sides, scene.gtype), ops=ops)
+            st.run(H, steps)
+            st.drain()
+            w.synchronize()
+            state = [a.copy() for a in w.state()]
+            stats = w.collision_stats()
+        out_q.put((rank, state, stats, st.exchange.count))
+        w.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _two_rank_scene(p, nx, rows, speed):
+    scene = p.scenes.box_grid(nx, 2 * rows, seed=21, y_range=(10.0, 12.0), spin=True, box_mass=True, plane=False).astype("float64")
+    rng = np.random.default_rng(7)
+    scene.lvel[:, 0] = rng.uniform(-speed, speed, scene.n)
+    scene.lvel[:, 2] = rng.uniform(-speed, speed, scene.n)
+    # keep the four rows either side of the shared face slow (a fast body covers 6 m = 2.4 rows in the run): bodies may
+    # collide inside a slab, never across the face
+    z_row = np.arange(scene.n) // nx
+    near_face = (z_row >= rows - 4) & (z_row < rows + 4)
+    scene.lvel[near_face, 0] *= 0.02
+    scene.lvel[near_face, 2] *= 0.02
+    return scene
+
+
+@pytest.mark.parametrize("speed", [0.1, 3.0])
+def test_two_ranks_share_the_gpu_and_match_the_unsharded_oracle(speed):
+    """Two processes, one slab each, one GPU: the whole N>1 loop (geometry sharing, boundary pack, ghost refresh and
+    ghost zone checks, collective rollback, exact replay with per-tick exchange) against the oracle stepping the full
+    scene in one world."""
+    import socket
+    import torch.multiprocessing as mp
+    steps, nx, rows = 120, 16, 8
+    full = _two_rank_scene(pkg, nx, rows, speed)
+    ow = _oracle_build(_orc("float64"), full)
+    pairs = 0
+    for _ in range(steps):
+        ow.tick(H)
+        pairs += ow.n_body_pairs()
+    ref = ow.state()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, port, steps, speed, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = {}
+    try:
+        for _ in range(2):
+            r, state, stats, n_ex = q.get(timeout=150)
+            got[r] = (state, stats, n_ex)
+        for pr in procs:
+            pr.join(timeout=60)
+            assert pr.exitcode == 0
+    finally:
+        for pr in procs:
+            if pr.is_alive():
+                pr.terminate()
+    L = pkg.shard.SlabLayout(nx, rows)
+    for r in range(2):
+        state, stats, n_ex = got[r]
+        lo, hi = r * L.n, (r + 1) * L.n
+        _compare([a[:L.n] for a in state], [a[lo:hi] for a in ref])
+        # the ghost rows hold the neighbour's boundary row as of the last tick
+        other = 1 - r
+        ghost = L.ghost_hi if r == 0 else L.ghost_lo
+        src = (L.lower if r == 0 else L.upper) + other * L.n
+        _compare([a[ghost] for a in state], [a[src] for a in ref])
+        assert stats["fast_ticks"] + stats["careful_ticks"] >= steps
+    if speed > 1.0:
+        assert pairs > 0 and got[0][1]["pair_ticks"] + got[1][1]["pair_ticks"] > 0
+        assert got[0][2] == got[1][2] > 4                  # rolled-back chunks replay with an exchange every tick
+    else:
+        # quiet chunks exchange once, at their end; a chunk that ends in an exact replay exchanges every tick
+        assert got[0][1]["fast_ticks"] >= 64 and got[0][2] == got[1][2] < steps // 2

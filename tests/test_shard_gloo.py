@@ -37,10 +37,10 @@ class HostOps:
     def check_ghosts(self, first, count):
         self.ghost_checks = getattr(self, "ghost_checks", 0) + 1
 
-    def any_rank(self, flag, group=None):
-        t = torch.tensor([int(bool(flag))], dtype=torch.int32)
+    def any_rank(self, flags, group=None):
+        t = torch.tensor([int(bool(f)) for f in flags], dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        return bool(t.item())
+        return [bool(v) for v in t.tolist()]
 
     # the stream choreography of DeviceOps has nothing to order on the host
     def before_pack(self, k=0): pass
@@ -128,8 +128,9 @@ def test_slab_layout_partitions_the_slab():
 # the collision-checked chunk loop of ShardedStepper, with a host double of the batch: every tick adds 0.5 to the
 # rank's own rows; "a body leaves its safe zone" on one rank at one tick of the fast path
 class HostWorld:
-    def __init__(self, state, n, violate_at=None):
+    def __init__(self, state, n, violate_at=None, warn=False):
         self.state, self.n = state, n
+        self.warn = warn                    # this rank's zones are "getting used up" at every chunk end
         self.t = 0
         self.violate_at = violate_at        # global tick index at which the fast path raises the flag, or None
         self.flag = False
@@ -152,7 +153,7 @@ class HostWorld:
         self.t += 1
 
     def chunk_end(self):
-        return self.flag, False
+        return self.flag, self.warn
 
     def chunk_commit(self, ticks, refresh_zones=False):
         self.log["fast"] += ticks
@@ -178,7 +179,8 @@ def _chunk_worker(rank, world, port, side, rows, ticks, violate, q):
         slot = torch.arange(L.n, dtype=torch.float64)[:, None]
         comp = torch.arange(shard.STATE_REALS, dtype=torch.float64)[None, :]
         state[:L.n] = 1000.0 * rank + slot + comp / 16.0
-        w = HostWorld(state, L.n, violate_at=violate[1] if violate and violate[0] == rank else None)
+        # rank 1 alone sees the warn flag: chunk lengths must still stay in lockstep (they shape the collective sequence)
+        w = HostWorld(state, L.n, violate_at=violate[1] if violate and violate[0] == rank else None, warn=(rank == 1))
         ops = HostOps(state)
         st = shard.ShardedStepper(w, L, rank, world, collide=True, ops=ops)
         st.run(1.0 / 60, ticks)
@@ -213,9 +215,10 @@ def test_chunked_collision_loop_commits_or_rolls_back_on_every_rank(violate):
         assert log["fast"] + log["exact"] == ticks
         assert ghost_checks > 0
     if violate is None:
-        # chunks of 32, 64 and the remaining 4 ticks; first and last tick of each are checked
+        # a warn anywhere keeps every rank's chunks at 32 ticks: 32, 32, 32 and the remaining 4; first and last tick of
+        # each are checked
         assert all(got[r][1]["rollbacks"] == 0 and got[r][1]["exact"] == 0 for r in range(world))
-        assert got[0][1]["begins"] == 3 and got[0][1]["checked"] == 6
+        assert all(got[r][1]["begins"] == 4 and got[r][1]["checked"] == 8 for r in range(world))
     else:
         # rank 1's body is out from tick 40 on: the chunk holding it is rolled back on BOTH ranks, retried once with
         # fresh zones (the double raises the flag again), then replayed exactly; later chunks hit it again
