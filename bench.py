@@ -144,6 +144,9 @@ def main():
         workload = f"configs[2]: {side * side} boxes on the ground plane per GPU, 20 SOR iterations, dt=1/60"
         scene = pkg.scenes.box_grid(side, side, seed=1 + rank, y_range=(1.0, 3.0), spin=False, plane=True).astype(dtype)
 
+    # configs[3] layout: rank r's slab sits r slab-depths (+ 10 m) further along z, so the slabs are disjoint islands and
+    # a neighbour's boundary row (this rank's ghosts) lies >= 10 m beyond this rank's own last row
+    scene.pos[:, 2] += rank * (side * pkg.scenes.PITCH + 10.0)
     layout = pkg.shard.SlabLayout(side, side)
     exchanging = use_dist and a.exchange == "boundary"
     w = pkg.BatchWorld(layout.n_total if exchanging else scene.n, dtype=dtype, device=local_rank)
