@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--no-body-collisions", action="store_true", help="skip the body-body broadphase proof (caller asserts single-body islands)")
     ap.add_argument("--exchange-every-tick", action="store_true",
                     help="all-gather the boundary rows every tick even where the collision proof only needs them at chunk ends")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N>1 ranks all on cuda:0 with the collectives staged through gloo: a functional rehearsal of the "
+                         "multi-GPU loop on a one-GPU box, not a measurement")
     ap.add_argument("--force-exchange", action="store_true", help="run the exchange path even with one rank (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gyro", type=int, default=2, choices=[0, 1, 2], help="0 off, 1 explicit, 2 implicit (ODE default)")
@@ -123,12 +126,17 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(1)
+    if a.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or a.force_exchange
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     dtype = "float32" if a.dtype == "f32" else "float64"
     rsize = np.dtype(dtype).itemsize
@@ -163,6 +171,8 @@ def main():
     w.set_stream(stream.cuda_stream)
 
     forced_ops = None
+    if a.rehearse_on_one_gpu and exchanging:
+        forced_ops = pkg.shard.StagedDeviceOps(w, torch.device("cuda", 0), stream)
     if a.force_exchange and world == 1 and exchanging:
         # one-rank group: the collective degenerates to a copy, every other step of the path is exercised
         forced_ops = pkg.shard.DeviceOps(w, torch.device("cuda", local_rank), stream)
@@ -203,7 +213,7 @@ def main():
     n_exchanges = (a.steps if graphed else stepper.exchange.count - ex0) if stepper.exchange is not None else 0
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if a.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -217,7 +227,7 @@ def main():
         "metric": "body-steps/sec at 1M rigid bodies, dt=1/60",
         "value": value, "unit": "body-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, collectives staged through host memory; not a measurement)" if a.rehearse_on_one_gpu else ""),
         "config": {"workload": workload, "bodies_per_gpu": scene.n, "bodies_total": total_bodies, "dt": "1/60",
                    "parallelism": f"islands sharded over {world} GPU(s), one slab per rank; "
                                   + (f"boundary rows all-gathered over RCCL on a side stream, overlapped with the next tick"

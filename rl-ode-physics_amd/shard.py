@@ -142,6 +142,24 @@ class DeviceOps:
         return [bool(v) for v in t.tolist()]
 
 
+class StagedDeviceOps(DeviceOps):
+    """DeviceOps with the collectives staged through host memory (a gloo group): lets several ranks share one GPU, which
+    RCCL does not allow -- for rehearsing the N>1 loop on a box with fewer GPUs than ranks (tests, `bench.py
+    --rehearse-on-one-gpu`).  Everything but the collective itself is the product path."""
+
+    def all_gather(self, out, mine, group=None):
+        torch.cuda.current_stream().synchronize()
+        h = mine.cpu()
+        o = torch.empty((out.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
+        dist.all_gather_into_tensor(o, h, group=group)
+        out.copy_(o)
+
+    def any_rank(self, flags, group=None):
+        t = torch.tensor([int(bool(f)) for f in flags], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return [bool(v) for v in t.tolist()]
+
+
 class BoundaryExchange:
     def __init__(self, ops, layout, rank, world_size, group=None):
         self.ops, self.L, self.rank, self.world = ops, layout, rank, world_size
@@ -232,6 +250,14 @@ class BoundaryExchange:
             r = got[self.rank + 1, 0:side]
             upload_ghost(int(L.ghost_hi[0]), r[:, :3], r[:, 3].astype(np.uint8))
 
+    def prime(self):
+        """Set-up: one exchange of the current boundary rows, so the ghost slots hold the neighbours' bodies where they
+        are (not at the origin) before the first broadphase build."""
+        self.before_step(fused=False)
+        self.pack(fused=False)
+        self.exchange()
+        self.drain()
+
     def tick(self):
         """pack + exchange for hosts that do not interleave a step kernel (tests)."""
         self.before_step()
@@ -271,6 +297,8 @@ class ShardedStepper:
                 world_batch.upload(SIDES, s_rows, first=first)
                 world_batch.upload_geom_type(g_rows, first=first)
             self.exchange.share_geometry(upload_ghost, sides, gtype)
+        if self.collide:
+            self.exchange.prime()
 
     # -- one tick ------------------------------------------------------------------------------------------
     def tick(self, h, check=None):

@@ -552,22 +552,6 @@ def _two_rank_worker(rank, port, steps, speed, out_q):
         from __graft_entry__ import load_package
         p = load_package()
 
-        class StagedOps(p.shard.DeviceOps):
-            """the device ops with the collectives staged through host memory, so two ranks can share one GPU (RCCL wants
-            one device per rank); everything else -- pack, ghost refresh, zone checks, streams -- is the product path"""
-
-            def all_gather(self, out, mine, group=None):
-                torch.cuda.current_stream().synchronize()
-                h = mine.cpu()
-                o = torch.empty((out.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
-                dist.all_gather_into_tensor(o, h, group=group)
-                out.copy_(o)
-
-            def any_rank(self, flags, group=None):
-                t = torch.tensor([int(bool(f)) for f in flags], dtype=torch.int32)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-                return [bool(v) for v in t.tolist()]
-
         nx, rows = 16, 8
         full = _two_rank_scene(p, nx, rows, speed)
         scene = full.slice(rank * nx * rows, (rank + 1) * nx * rows)
@@ -578,7 +562,7 @@ def _two_rank_worker(rank, port, steps, speed, out_q):
         stream = torch.cuda.Stream()
         with torch.cuda.stream(stream):
             w.set_stream(stream.cuda_stream)
-            ops = StagedOps(w, torch.device("cuda", 0), stream)
+            ops = p.shard.StagedDeviceOps(w, torch.device("cuda", 0), stream)
             st = p.shard.ShardedStepper(w, L, rank, 2, collide=True, geometry=(scene.sides, scene.gtype), ops=ops)
             st.run(H, steps)
             st.drain()
