@@ -57,7 +57,8 @@ enum {
 };
 
 /* geometry class per body (uint8 array) */
-enum { DMX_GEOM_NONE = 0, DMX_GEOM_SPHERE = 1, DMX_GEOM_BOX = 2 };   /* BodyType, inc/body.h:14-18 */
+enum { DMX_GEOM_NONE = 0, DMX_GEOM_SPHERE = 1, DMX_GEOM_BOX = 2,     /* BodyType, inc/body.h:14-18 */
+       DMX_GEOM_CONVEX = 3 };  /* a convex hull (BASELINE configs[4]); the reference itself creates none */
 
 enum { DMX_GYRO_OFF = 0, DMX_GYRO_EXPLICIT = 1, DMX_GYRO_IMPLICIT = 2 };
 
@@ -87,6 +88,13 @@ int dmxBatchSetPlane(dmxBatchID b, double a, double bb, double c, double d, int 
 int dmxBatchUpload(dmxBatchID b, int field, const void *host_aos, int64_t first, int64_t count);
 int dmxBatchDownload(dmxBatchID b, int field, void *host_aos, int64_t first, int64_t count);
 int dmxBatchUploadGeomType(dmxBatchID b, const uint8_t *types, int64_t first, int64_t count);
+/* dCreateConvex's point set for every DMX_GEOM_CONVEX body of the batch: n_points body-frame points (3 doubles each;
+ * origin = centre of mass, e.g. from dmxHullBuild in dmx_hull.h).  *radius_out (may be NULL) = the hull's bounding
+ * radius: upload it as sides[0] of every convex body (the broadphase reads it there, as it does a sphere's radius).
+ * Contacts: convex against the ground plane as ODE's dCollideConvexPlane makes them (the hull's points in array order,
+ * the first max_contacts <= 8 on or below the plane); a convex body has no collider against other bodies (ODE's
+ * dCollideConvexBox is an empty stub; convex-convex / convex-sphere are not built). */
+int dmxBatchSetConvexHull(dmxBatchID b, int32_t n_points, const double *points_xyz, double *radius_out);
 /* device address of component c of a field for body 0.  The slab is tiled: bodies are stored in tiles of
  * DMX_SLAB_TILE; inside a tile each of the DMX_SLAB_COMPONENTS components holds DMX_SLAB_TILE consecutive
  * reals, so body i's value sits (i / DMX_SLAB_TILE) * DMX_SLAB_COMPONENTS * DMX_SLAB_TILE + i % DMX_SLAB_TILE

@@ -40,8 +40,9 @@ typedef double real;
 extern "C" {
 #endif
 
-/* ---- geometry classes (subset the reference uses: main.c:717,720,743) ---- */
-enum { ORC_GEOM_SPHERE = 0, ORC_GEOM_BOX = 1, ORC_GEOM_PLANE = 2 };
+/* ---- geometry classes (subset the reference uses: main.c:717,720,743; CONVEX for BASELINE configs[4], which the
+ *      reference itself never creates -- SURVEY.md F9) ---- */
+enum { ORC_GEOM_SPHERE = 0, ORC_GEOM_BOX = 1, ORC_GEOM_PLANE = 2, ORC_GEOM_CONVEX = 3 };
 
 /* ---- contact surface mode bits [ODE-recall contact.h] ---- */
 enum { ORC_CONTACT_BOUNCE = 0x004 };
@@ -127,6 +128,11 @@ int  orc_world_body_count(orc_world *w);
 void orc_world_add_boxes(orc_world *w, int n, const real *pos, const real *quat,
                          const real *lvel, const real *avel, const real *mass,
                          const real *idiag, const real *sides);
+/* convex bodies share one hull: n body-frame points, 3 reals each (dCreateConvex's points array [ODE-recall]) */
+void orc_world_set_hull(orc_world *w, int n, const real *points);
+int  orc_geom_create_convex(orc_world *w);
+void orc_world_add_convex(orc_world *w, int n, const real *pos, const real *quat,
+                          const real *lvel, const real *avel, const real *mass, const real *idiag);
 void orc_world_add_spheres(orc_world *w, int n, const real *pos, const real *quat,
                            const real *lvel, const real *avel, const real *mass,
                            const real *idiag, const real *radius);

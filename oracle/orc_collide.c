@@ -183,6 +183,37 @@ static int collide_sphere_box(const real *sp, real radius, const real *bp, const
     return 1;
 }
 
+/* ---- convex - plane [ODE-recall dCollideConvexPlane, convex.cpp]: walk the hull's points in array order; every point
+ *      on or below the plane becomes a contact (position = the point, normal = the plane's, depth = distance below)
+ *      until maxc are taken; the walk stops early once maxc contacts exist AND points on both sides have been seen;
+ *      the result counts only if the hull has points on both sides (or on the plane). */
+static int collide_convex_plane(const orc_world *w, const real *pos, const real *Rm, const real *pl, int maxc,
+                                orc_contactgeom *c)
+{
+    enum { LTEQ_ZERO = 1, GTEQ_ZERO = 2, BOTH_SIGNS = 3 };
+    int contacts = 0, totalsign = 0;
+    for (int i = 0; i < w->hull_n; i++) {
+        real v2[3];
+        orc_mul0_331(v2, Rm, w->hull + 3 * i);
+        v2[0] += pos[0]; v2[1] += pos[1]; v2[2] += pos[2];
+        int sign = GTEQ_ZERO;
+        real distance2 = orc_dot3(pl, v2) - pl[3];
+        if (distance2 <= 0) {
+            sign = distance2 != 0 ? LTEQ_ZERO : BOTH_SIGNS;
+            if (contacts != maxc) {
+                orc_contactgeom *t = &c[contacts];
+                t->normal[0] = pl[0]; t->normal[1] = pl[1]; t->normal[2] = pl[2];
+                t->pos[0] = v2[0]; t->pos[1] = v2[1]; t->pos[2] = v2[2];
+                t->depth = -distance2;
+                contacts++;
+            }
+        }
+        totalsign |= sign;
+        if (contacts == maxc && totalsign == BOTH_SIGNS) break;
+    }
+    return totalsign == BOTH_SIGNS ? contacts : 0;
+}
+
 /* ---- dCollide dispatch (main.c:678) --------------------------------------- */
 static int collide_ordered(orc_world *w, const orc_geom *a, const orc_geom *b, int maxc,
                            orc_contactgeom *out, int *handled)
@@ -200,6 +231,12 @@ static int collide_ordered(orc_world *w, const orc_geom *a, const orc_geom *b, i
         return collide_sphere_box(pa, a->side[0], pb, Rb, b->side, out);
     if (a->type == ORC_GEOM_BOX && b->type == ORC_GEOM_BOX)
         return orc_collide_box_box(pa, Ra, a->side, pb, Rb, b->side, maxc, out);
+    if (a->type == ORC_GEOM_CONVEX && b->type == ORC_GEOM_PLANE)
+        return collide_convex_plane(w, pa, Ra, b->plane, maxc, out);
+    /* convex against box / sphere / convex: no contacts.  [ODE-recall] dCollideConvexBox is an empty stub that
+       returns 0; ODE's convex-sphere and convex-convex colliders are not restated (nothing on this path uses them). */
+    if (a->type == ORC_GEOM_CONVEX && b->type != ORC_GEOM_PLANE)
+        return 0;
     *handled = 0;
     return 0;
 }
@@ -299,13 +336,27 @@ void orc_collide_all(orc_world *w)
         pairs = (int *)realloc(pairs, 2 * cap * sizeof(int)); } \
         pairs[2 * np] = (A) < (B) ? (A) : (B); pairs[2 * np + 1] = (A) < (B) ? (B) : (A); np++; } while (0)
 
-    /* finite AABBs: box = centre +- sum_j |R_ij| side_j / 2; sphere = centre +- r */
+    /* finite AABBs: box = centre +- sum_j |R_ij| side_j / 2; sphere = centre +- r; convex = bounds of its
+       transformed points [ODE-recall dxConvex::computeAABB] */
     for (int g = 0; g < ng; g++) {
         const orc_geom *ge = &w->geoms[g];
         if (ge->type == ORC_GEOM_PLANE) continue;
         const real *p = orc_geom_pos(w, ge), *Rm = orc_geom_R(w, ge);
         aabb_t *a = &bb[nbb++];
         a->g = g;
+        if (ge->type == ORC_GEOM_CONVEX) {
+            for (int i = 0; i < 3; i++) { a->lo[i] = ORC_INF; a->hi[i] = -ORC_INF; }
+            for (int k = 0; k < w->hull_n; k++) {
+                real v[3];
+                orc_mul0_331(v, Rm, w->hull + 3 * k);
+                for (int i = 0; i < 3; i++) {
+                    real c = v[i] + p[i];
+                    if (c < a->lo[i]) a->lo[i] = c;
+                    if (c > a->hi[i]) a->hi[i] = c;
+                }
+            }
+            continue;
+        }
         for (int i = 0; i < 3; i++) {
             real r = (ge->type == ORC_GEOM_SPHERE)
                          ? ge->side[0]

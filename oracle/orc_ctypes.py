@@ -92,6 +92,9 @@ class Oracle:
         sig("orc_world_body_count", C.c_int, P)
         sig("orc_world_add_boxes", None, P, C.c_int, P, P, P, P, P, P, P)
         sig("orc_world_add_spheres", None, P, C.c_int, P, P, P, P, P, P, P)
+        sig("orc_world_set_hull", None, P, C.c_int, P)
+        sig("orc_geom_create_convex", C.c_int, P)
+        sig("orc_world_add_convex", None, P, C.c_int, P, P, P, P, P, P)
         sig("orc_world_get_state", None, P, P, P, P, P)
         sig("orc_world_run", C.c_double, P, real, C.c_int)
         sig("orc_pack_transform", None, RP, RP, RP)
@@ -149,6 +152,16 @@ class World:
         n = len(pos)
         self.lib.orc_world_add_spheres(self.w, n, self._p(pos), self._p(quat), self._p(lvel),
                                        self._p(avel), self._p(mass), self._p(idiag), self._p(radius))
+        self._keep.clear()
+
+    def set_hull(self, points):
+        pts = np.ascontiguousarray(points, dtype=self.o.dtype)
+        self.lib.orc_world_set_hull(self.w, len(pts), pts.ctypes.data_as(C.c_void_p))
+
+    def add_convex(self, pos, quat, lvel, avel, mass, idiag):
+        n = len(pos)
+        self.lib.orc_world_add_convex(self.w, n, self._p(pos), self._p(quat), self._p(lvel),
+                                      self._p(avel), self._p(mass), self._p(idiag))
         self._keep.clear()
 
     def add_plane(self, a, b, c, d):

@@ -51,6 +51,8 @@ struct orc_world {
     orc_geom *geoms;  int ng, cap_g;
     orc_joint *joints; int nj, cap_j;
 
+    real *hull; int hull_n;   /* body-frame points of the hull every ORC_GEOM_CONVEX geom uses */
+
     int last_contacts;
     int last_body_pairs;      /* finite-AABB pairs that reached the near callback in the last tick */
     double last_residual;

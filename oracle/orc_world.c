@@ -38,7 +38,7 @@ orc_world *orc_world_create(void)
 void orc_world_destroy(orc_world *w)
 {
     if (!w) return;
-    free(w->bodies); free(w->geoms); free(w->joints);
+    free(w->bodies); free(w->geoms); free(w->joints); free(w->hull);
     free(w);
 }
 
@@ -163,6 +163,19 @@ int orc_geom_create_sphere(orc_world *w, real radius)
     return g;
 }
 
+void orc_world_set_hull(orc_world *w, int n, const real *points)
+{
+    free(w->hull);
+    w->hull = (real *)malloc((size_t)(n > 0 ? n : 1) * 3 * sizeof(real));
+    memcpy(w->hull, points, (size_t)n * 3 * sizeof(real));
+    w->hull_n = n;
+}
+
+int orc_geom_create_convex(orc_world *w)
+{
+    return geom_new(w, ORC_GEOM_CONVEX);
+}
+
 int orc_geom_create_plane(orc_world *w, real a, real b, real c, real d)
 {
     /* [ODE-recall] dCreatePlane normalises (a,b,c,d) by |(a,b,c)| */
@@ -222,6 +235,7 @@ static void add_bulk(orc_world *w, int type, int n, const real *pos, const real 
         }
         int g = (type == ORC_GEOM_BOX)
                     ? orc_geom_create_box(w, dims[3 * i], dims[3 * i + 1], dims[3 * i + 2])
+                    : (type == ORC_GEOM_CONVEX) ? orc_geom_create_convex(w)
                     : orc_geom_create_sphere(w, dims[i]);
         /* AddBody: category CMASK_OBJ=2, collide CMASK_OBJ|CMASK_MAP=3  (main.c:181,724-725) */
         orc_geom_set_category_bits(w, g, 2u);
@@ -234,6 +248,10 @@ void orc_world_add_boxes(orc_world *w, int n, const real *pos, const real *quat,
                          const real *lvel, const real *avel, const real *mass,
                          const real *idiag, const real *sides)
 { add_bulk(w, ORC_GEOM_BOX, n, pos, quat, lvel, avel, mass, idiag, sides); }
+
+void orc_world_add_convex(orc_world *w, int n, const real *pos, const real *quat,
+                          const real *lvel, const real *avel, const real *mass, const real *idiag)
+{ add_bulk(w, ORC_GEOM_CONVEX, n, pos, quat, lvel, avel, mass, idiag, NULL); }
 
 void orc_world_add_spheres(orc_world *w, int n, const real *pos, const real *quat,
                            const real *lvel, const real *avel, const real *mass,

@@ -13,6 +13,6 @@ The directory name contains a hyphen, so load it with
 """
 from . import _lib          # noqa: F401
 from .batch import BatchWorld, DMX_F32, DMX_F64   # noqa: F401
-from . import rand, scenes, shard  # noqa: F401
+from . import rand, scenes, shard, hull, batch  # noqa: F401
 
 __all__ = ["BatchWorld", "DMX_F32", "DMX_F64", "rand", "scenes", "shard"]

@@ -22,7 +22,7 @@ BATCH_SYMBOLS = [
     "dmxBatchGetStream", "dmxBatchSetBodyCollisions", "dmxBatchCollisionStats",
     "dmxBatchScatterBodiesOnStream", "dmxBatchSetBoundaryPack",
     "dmxBatchChunkBegin", "dmxBatchChunkTick", "dmxBatchCheckZonesOnStream", "dmxBatchChunkEnd",
-    "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream",
+    "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream", "dmxBatchSetConvexHull",
 ]
 
 _lib = None
@@ -97,5 +97,6 @@ def load():
     sig("dmxBatchChunkRollback", I, P)
     sig("dmxBatchExactTick", I, P, D)
     sig("dmxBatchRefreshGhostsOnStream", I, P, P, L, L, P, L, P, I)
+    sig("dmxBatchSetConvexHull", I, P, C.c_int32, P, C.POINTER(D))
     _lib = lib
     return lib

@@ -96,6 +96,14 @@ class BatchWorld:
         t = np.ascontiguousarray(types, dtype=np.uint8)
         _check(self.lib.dmxBatchUploadGeomType(self.h, t.ctypes.data, first, t.shape[0]), "dmxBatchUploadGeomType")
 
+    def set_convex_hull(self, points):
+        """Body-frame points of the hull every GEOM_CONVEX body uses; returns the hull's bounding radius (upload it as
+        sides[:, 0] of the convex bodies)."""
+        p = np.ascontiguousarray(points, dtype=np.float64)
+        r = C.c_double()
+        _check(self.lib.dmxBatchSetConvexHull(self.h, p.shape[0], p.ctypes.data, C.byref(r)), "dmxBatchSetConvexHull")
+        return r.value
+
     def load_scene(self, scene):
         """Upload a scenes.Scene (the batch form of the AddBody loop, main.c:695-733)."""
         self.upload(POS, scene.pos)
@@ -104,6 +112,8 @@ class BatchWorld:
         self.upload(AVEL, scene.avel)
         self.upload(MASS, scene.mass)
         self.upload(INERTIA, scene.inertia)
+        if getattr(scene, "hull_points", None) is not None:
+            self.set_convex_hull(scene.hull_points)
         self.upload(SIDES, scene.sides)
         self.upload_geom_type(scene.gtype)
         if scene.plane is not None:

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <cmath>
 #include <vector>
 
 #include "dmx_batch_priv.hpp"
@@ -115,7 +116,7 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
     for (dmxBatch::DevBuf *d : { &b->jd_int, &b->jd_real, &b->jd_rows, &b->jd_rowjb, &b->jd_bscr, &b->jd_local })
         if (d->p) (void)hipFree(d->p);
     for (dmxBatch::DevBuf *d : { &b->bp_count, &b->bp_items, &b->bp_flags, &b->bp_pairs, &b->bp_inpair, &b->bp_snapshot, &b->bp_idx, &b->bp_gather,
-                                &b->np_pos, &b->np_normal, &b->np_depth, &b->np_count, &b->np_pairs })
+                                &b->np_pos, &b->np_normal, &b->np_depth, &b->np_count, &b->np_pairs, &b->hull, &b->cbuf, &b->ccount })
         if (d->p) (void)hipFree(d->p);
     if (b->bp_flags_host) (void)hipHostFree(b->bp_flags_host);
     if (b->jh_int) (void)hipHostFree(b->jh_int);
@@ -276,6 +277,7 @@ template <class T> static int step_t(dmxBatch *b, double h, int nsteps, int64_t 
 {
     StepParams<T> P = dmx_make_params<T>(b, h);
     if (first != 0) P.pack_out = nullptr;      // the boundary pack is defined on whole-slab launches only
+    if (P.cbuf != nullptr) { P.cbuf += (size_t)first * CONVEX_MAXC * 4; P.ccount += first; }   // per-body contact slots follow the range
     for (int s = 0; s < nsteps; s++) {
         (void)reset_diag;   // every wave overwrites its own slot each tick: nothing to clear
         HIP_TRY(launch_step<T>((T *)b->slab + slab_ix(0, first), b->gtype + first, b->stride, count, P, b->ext_pending,
@@ -302,6 +304,35 @@ extern "C" int dmxBatchSetBodyCollisions(dmxBatchID b, int enable)
 {
     if (!b) return DMX_EINVAL;
     b->bp_enabled = enable ? 1 : 0;
+    b->bp_valid = false;
+    return DMX_OK;
+}
+
+// ---- convex bodies ------------------------------------------------------------------------------
+extern "C" int dmxBatchSetConvexHull(dmxBatchID b, int32_t n_points, const double *points_xyz, double *radius_out)
+{
+    if (!b || n_points < 4 || !points_xyz) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    int rc;
+    if ((rc = dmx_ensure_dev(b->hull, (size_t)n_points * 3 * b->rsize)) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->cbuf, (size_t)b->stride * CONVEX_MAXC * 4 * b->rsize)) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->ccount, (size_t)b->stride * sizeof(int))) != DMX_OK) return rc;
+    double r2 = 0;
+    for (int32_t i = 0; i < n_points; i++) {
+        const double *p = points_xyz + 3 * (size_t)i;
+        r2 = std::max(r2, p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    }
+    if (radius_out) *radius_out = std::sqrt(r2);
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->precision == DMX_F32) {
+        std::vector<float> f((size_t)n_points * 3);
+        for (size_t i = 0; i < f.size(); i++) f[i] = (float)points_xyz[i];
+        HIP_TRY(hipMemcpy(b->hull.p, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY(hipMemcpy(b->hull.p, points_xyz, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemset(b->ccount.p, 0, (size_t)b->stride * sizeof(int)));
+    b->hull_n = n_points;
     b->bp_valid = false;
     return DMX_OK;
 }

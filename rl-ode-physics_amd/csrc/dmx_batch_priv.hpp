@@ -73,6 +73,9 @@ struct dmxBatch {
     int bp_max_pairs = 0;
     std::vector<double> h_sides;               // host mirror of DMX_SIDES (exact values of the batch precision)
     std::vector<uint8_t> h_gtype;
+    // convex bodies: the shared hull's body-frame points, and the per-tick plane contacts of every convex body
+    DevBuf hull, cbuf, ccount;
+    int hull_n = 0;
     int64_t stat_rollbacks = 0;
     int64_t stat_fast_ticks = 0, stat_careful_ticks = 0, stat_rebuilds = 0, stat_pair_ticks = 0;
     unsigned long long last_pairs = 0;
@@ -130,6 +133,8 @@ template <class T> inline StepParams<T> dmx_make_params(dmxBatch *b, double h)
     P.bp_flags = nullptr;
     P.skip = nullptr;
     P.pack_out = (T *)b->pack_out; P.pack_lo = b->pack_lo; P.pack_hi = b->pack_hi;
+    P.hull = (const T *)b->hull.p; P.hull_n = b->hull_n;
+    P.cbuf = (T *)b->cbuf.p; P.ccount = (int *)b->ccount.p;
     return P;
 }
 

@@ -23,7 +23,7 @@ __device__ __forceinline__ uint32_t cell_hash(int ix, int iz, uint32_t mask)
 template <class T> __device__ __forceinline__ T bound_radius(int gt, const T *S, int64_t stride, int64_t i)
 {
     const T sx = S[slab_ix(C_SIDES + 0, i)];
-    if (gt == GEOM_SPHERE) return sx;
+    if (gt == GEOM_SPHERE || gt == GEOM_CONVEX) return sx;       // convex: hull bounding radius
     const T sy = S[slab_ix(C_SIDES + 1, i)], sz = S[slab_ix(C_SIDES + 2, i)];
     return T(0.5) * tsqrt<T>(sx * sx + sy * sy + sz * sz);
 }
@@ -85,7 +85,7 @@ template <class T> __device__ __forceinline__ void body_aabb(const T *S, const u
 {
     const T p[3] = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
     T r[3];
-    if (gtype[i] == GEOM_SPHERE) {
+    if (gtype[i] == GEOM_SPHERE || gtype[i] == GEOM_CONVEX) {      // convex: the bounding sphere's box (conservative)
         r[0] = r[1] = r[2] = S[slab_ix(C_SIDES + 0, i)];
     } else {
         const Q4<T> q = { S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)],

@@ -52,7 +52,7 @@ int ensure_buffers(dmxBatch *b)
         double r = 0;
         for (int64_t i = 0; i < b->n; i++) {
             const double *s = &b->h_sides[(size_t)3 * i];
-            const double ri = b->h_gtype[(size_t)i] == GEOM_SPHERE ? s[0]
+            const double ri = (b->h_gtype[(size_t)i] == GEOM_SPHERE || b->h_gtype[(size_t)i] == GEOM_CONVEX) ? s[0]
                             : b->h_gtype[(size_t)i] == GEOM_BOX ? 0.5 * std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]) : 0.0;
             r = std::max(r, ri);
         }
@@ -140,7 +140,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
         if ((rc = grow_buckets(b)) != DMX_OK) return rc;
         return careful_tick<T>(b, h);
     }
-    const uint32_t np = b->bp_flags_host[BPF_NPAIRS];
+    uint32_t np = b->bp_flags_host[BPF_NPAIRS];
     b->last_pairs = np;
     b->stat_careful_ticks++;
     if (np == 0) {
@@ -157,8 +157,19 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     std::vector<int32_t> pr((size_t)2 * np);
     HIP_TRY(hipMemcpyAsync(pr.data(), b->bp_pairs.p, pr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
-    std::vector<std::pair<int32_t, int32_t>> pairs(np);
-    for (uint32_t k = 0; k < np; k++) pairs[k] = { pr[2 * k], pr[2 * k + 1] };
+    std::vector<std::pair<int32_t, int32_t>> pairs;
+    pairs.reserve(np);
+    for (uint32_t k = 0; k < np; k++) {
+        // a convex body has no collider against another body (ODE's dCollideConvexBox is an empty stub; convex-convex and
+        // convex-sphere are not built): such a pair yields no contact, so neither body is "involved" on its account
+        if (b->h_gtype[(size_t)pr[2 * k]] == GEOM_CONVEX || b->h_gtype[(size_t)pr[2 * k + 1]] == GEOM_CONVEX) continue;
+        pairs.push_back({ pr[2 * k], pr[2 * k + 1] });
+    }
+    np = (uint32_t)pairs.size();
+    if (np == 0) {
+        b->last_mixed = false;
+        return fused_tick<T>(b, h, false, nullptr);
+    }
     std::sort(pairs.begin(), pairs.end());
     for (auto &p : pairs)
         if (p.first >= b->n_active || p.second >= b->n_active) {

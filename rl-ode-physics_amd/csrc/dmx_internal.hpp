@@ -40,7 +40,9 @@ __host__ __device__ __forceinline__ int64_t slab_ix(int c, int64_t i)
     return (i >> SLAB_TILE_LOG2) * (int64_t)(C_COUNT * SLAB_TILE) + (int64_t)c * SLAB_TILE + (i & (SLAB_TILE - 1));
 }
 
-enum : int { GEOM_NONE = 0, GEOM_SPHERE = 1, GEOM_BOX = 2 };
+// GEOM_CONVEX: the batch's one convex hull (StepParams::hull); its bounding radius sits in sides[0] like a sphere's
+enum : int { GEOM_NONE = 0, GEOM_SPHERE = 1, GEOM_BOX = 2, GEOM_CONVEX = 3 };
+constexpr int CONVEX_MAXC = 8;      // contact slots per convex body per tick (the reference's MAX_CONTACTS, main.c:675)
 enum : int { SURF_BOUNCE = 0x004, SURF_SOFT_ERP = 0x008, SURF_SOFT_CFM = 0x010 };
 // per-slot body flags (uint8 array)
 enum : int { BF_ALIVE = 1, BF_KINEMATIC = 2, BF_NOGRAVITY = 4, BF_NOGYRO = 8 };
@@ -88,6 +90,10 @@ template <class T> struct StepParams {
     // boundary-row pack for the multi-GPU exchange (null = off): bodies i < pack_lo and i >= pack_hi also write
     // their new 13-real state to pack_out[slot*13 ..], slot = i (lower row) or pack_lo + i - pack_hi (upper row)
     T *pack_out; int64_t pack_lo, pack_hi;
+    // convex bodies: the shared hull (hull_n body-frame points, 3 reals each) and the tick's ground-plane contacts of
+    // every convex body, written by np_convex_plane and read by step_plane: cbuf[i][k] = (x, y, z, depth), ccount[i]
+    const T *hull; int hull_n;
+    T *cbuf; int *ccount;
 };
 
 // hashed (x,z)-column grid of the body-body broadphase
@@ -124,6 +130,9 @@ hipError_t launch_bp_pairs(const T *S, const uint8_t *gtype, int64_t stride, int
 template <class T>
 hipError_t launch_np_plane(const T *S, const uint8_t *gtype, int64_t stride, const int32_t *bodies, int nb,
                            const StepParams<T> &P, T *gpos, T *gnormal, T *gdepth, int32_t *count, hipStream_t st);
+// ground-plane contacts of the convex bodies among [0, n): one wavefront per body walks the hull (dCollideConvexPlane)
+template <class T>
+hipError_t launch_np_convex_plane(const T *S, const uint8_t *gtype, int64_t n, const StepParams<T> &P, hipStream_t st);
 template <class T>
 hipError_t launch_np_pairs(const T *S, const uint8_t *gtype, int64_t stride, const int32_t *pairs, int np, int maxc,
                            int base_slot, T *gpos, T *gnormal, T *gdepth, int32_t *count, hipStream_t st);

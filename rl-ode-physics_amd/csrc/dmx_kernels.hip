@@ -172,10 +172,9 @@ template <class T> __device__ __forceinline__ T wave_sum(T x)
 // SOR-PGS sweeps -> velocity update -> integrate.  One lane per body; rows live in registers.
 // Algorithmic traffic per body-step: 13 + 4 + 3 (sides) read, 13 written = 33 reals.
 // ---------------------------------------------------------------------------------------------
-constexpr int MAXC = 4;          // box-plane yields at most 4 contacts
-constexpr int MAXR = 3 * MAXC;   // rows per body
-
-template <class T, bool EXT, int MINW>
+// NC = contact slots per body: 4 (box-plane yields at most 4 contacts) or CONVEX_MAXC when the batch has convex bodies,
+// whose plane contacts np_convex_plane left in P.cbuf.
+template <class T, bool EXT, int MINW, int NC>
 __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const uint8_t *__restrict__ gtype,
                                                   int64_t stride, int64_t n, StepParams<T> P,
                                                   StepDiag *__restrict__ diag)
@@ -216,12 +215,20 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
         }
 
         // ---- narrowphase (dCollide) --------------------------------------------------------
+        constexpr int MAXC = NC, MAXR = 3 * NC;
         V3<T> cp[MAXC];
         T cd[MAXC];
         int nc = 0;
         if (P.plane_on) {
             if (gt == GEOM_BOX) nc = box_plane(x, R, side, P.pn, P.pd, P.max_contacts, cp, cd);
             else if (gt == GEOM_SPHERE) nc = sphere_plane(x, side[0], P.pn, P.pd, cp, cd);
+            else if (NC >= CONVEX_MAXC && gt == GEOM_CONVEX) {
+                nc = P.ccount[i];
+                const T *cb = P.cbuf + (size_t)i * CONVEX_MAXC * 4;
+#pragma unroll
+                for (int k = 0; k < MAXC; k++)
+                    if (k < nc) { cp[k] = { cb[4 * k], cb[4 * k + 1], cb[4 * k + 2] }; cd[k] = cb[4 * k + 3]; }
+            }
         }
         my_contacts = nc;
 
@@ -547,9 +554,18 @@ hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, co
         const unsigned grid = blocks_for(n, 256);
 #define DMX_LAUNCH_PLANE(MW)                                                                                           \
     do {                                                                                                                   \
-        if (ext) hipLaunchKernelGGL((step_plane<T, true, MW>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag);  \
-        else     hipLaunchKernelGGL((step_plane<T, false, MW>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag); \
+        if (convex) {                                                                                                      \
+            if (ext) hipLaunchKernelGGL((step_plane<T, true, 1, CONVEX_MAXC>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag);  \
+            else     hipLaunchKernelGGL((step_plane<T, false, 1, CONVEX_MAXC>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag); \
+        } else if (ext) hipLaunchKernelGGL((step_plane<T, true, MW, 4>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag);  \
+        else     hipLaunchKernelGGL((step_plane<T, false, MW, 4>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag); \
     } while (0)
+        // convex bodies: their plane contacts first (one wavefront per body), then the fused step with 8 contact slots
+        const bool convex = P.hull_n > 0 && P.cbuf != nullptr;
+        if (convex) {
+            const hipError_t e = launch_np_convex_plane<T>(S, gtype, n, P, st);
+            if (e != hipSuccess) return e;
+        }
         switch (P.min_waves) {
         case 1: DMX_LAUNCH_PLANE(1); break;
         case 2: DMX_LAUNCH_PLANE(2); break;

@@ -13,7 +13,7 @@ import numpy as np
 
 from .rand import Rand
 
-GEOM_SPHERE, GEOM_BOX = 1, 2
+GEOM_SPHERE, GEOM_BOX, GEOM_CONVEX = 1, 2, 3
 PITCH = 2.5
 DRAWS_PER_BODY = 7
 
@@ -29,6 +29,7 @@ class Scene:
     sides: np.ndarray     # n x 3 (box side lengths; sphere: radius in column 0)
     gtype: np.ndarray     # n uint8
     plane: Optional[Tuple[float, float, float, float]]
+    hull_points: Optional[np.ndarray] = None    # body-frame points of the hull the GEOM_CONVEX bodies share
 
     @property
     def n(self):
@@ -37,11 +38,13 @@ class Scene:
     def astype(self, dtype):
         f = lambda a: np.ascontiguousarray(a, dtype=dtype)
         return Scene(f(self.pos), f(self.quat), f(self.lvel), f(self.avel), f(self.mass),
-                     f(self.inertia), f(self.sides), self.gtype, self.plane)
+                     f(self.inertia), f(self.sides), self.gtype, self.plane,
+                     None if self.hull_points is None else f(self.hull_points))
 
     def slice(self, lo, hi):
         return Scene(self.pos[lo:hi], self.quat[lo:hi], self.lvel[lo:hi], self.avel[lo:hi],
-                     self.mass[lo:hi], self.inertia[lo:hi], self.sides[lo:hi], self.gtype[lo:hi], self.plane)
+                     self.mass[lo:hi], self.inertia[lo:hi], self.sides[lo:hi], self.gtype[lo:hi], self.plane,
+                     self.hull_points)
 
 
 def box_grid(nx, nz, *, seed=1, y_range=(20.0, 50.0), spin=True, box_mass=False, plane=True,
@@ -94,6 +97,41 @@ def config2(n_side=1024, box_mass=False):
 def config3(n_side=512):
     """262 144 boxes dropping onto the ground plane from y in [1,3] (BASELINE configs[2])."""
     return box_grid(n_side, n_side, seed=1, y_range=(1.0, 3.0), spin=False, plane=True)
+
+
+HULL_PITCH = 3.0      # grid pitch of the hull scenes: the 0.01-scale teapot hull is 2.13 m across its bounding sphere
+
+
+def hull_grid(hull, nx, nz, *, seed=1, y_range=(1.5, 3.5), spin=False, density=1.0, plane=True, tilt=0.0):
+    """nx x nz copies of one convex hull (a hull.Hull) over the ground plane (BASELINE configs[4]).
+
+    Every body starts upright (the hull's input-frame orientation) unless tilt > 0, which turns body i about a
+    drawn horizontal axis by a drawn angle in [0, tilt]; heights and spin are drawn like box_grid's."""
+    n = nx * nz
+    r = Rand(seed)
+    d = r.next(n * DRAWS_PER_BODY).astype(np.float64).reshape(n, DRAWS_PER_BODY) / float(0xFFFFFFFF)
+    y = y_range[0] + d[:, 3] * (y_range[1] - y_range[0])
+    omega = (-1.0 + d[:, 4:7] * 2.0) if spin else np.zeros((n, 3))
+    col = np.tile(np.arange(nx, dtype=np.float64), nz)
+    row = np.repeat(np.arange(nz, dtype=np.float64), nx)
+    pos = np.stack([(col - (nx - 1) / 2.0) * HULL_PITCH, y, (row - (nz - 1) / 2.0) * HULL_PITCH], axis=1)
+    q0 = hull.upright_quaternion()
+    quat = np.tile(q0, (n, 1))
+    if tilt > 0:
+        ang = d[:, 0] * tilt
+        phi = d[:, 1] * 2.0 * np.pi
+        ax = np.stack([np.cos(phi), np.zeros(n), np.sin(phi)], axis=1)
+        qt = np.concatenate([np.cos(ang / 2)[:, None], ax * np.sin(ang / 2)[:, None]], axis=1)
+        w1, x1, y1, z1 = qt.T
+        w2, x2, y2, z2 = q0
+        quat = np.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                         w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], axis=1)
+    mass = np.full((n, 1), density * hull.volume)
+    inertia = np.tile(density * hull.inertia, (n, 1))
+    sides = np.zeros((n, 3))
+    sides[:, 0] = hull.radius                     # the broadphase reads a convex body's bounding radius here
+    return Scene(pos, quat, np.zeros((n, 3)), omega, mass, inertia, sides, np.full(n, GEOM_CONVEX, np.uint8),
+                 (0.0, 1.0, 0.0, 0.0) if plane else None, hull.points.copy())
 
 
 def config4(n_side=1024, slabs=8):

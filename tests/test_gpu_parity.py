@@ -39,9 +39,21 @@ def _oracle_build(orc, scene, gyro=None, spheres=False, setup=None):
         setup(orc, ow)
     if scene.plane is not None:
         ow.add_plane(*scene.plane)
+    if scene.hull_points is not None:
+        ow.set_hull(scene.hull_points)
+    convex = scene.gtype == pkg.scenes.GEOM_CONVEX
     if spheres:
         ow.add_spheres(scene.pos, scene.quat, scene.lvel, scene.avel, scene.mass[:, 0], scene.inertia,
                        scene.sides[:, 0])
+    elif convex.any():
+        # boxes first, hulls behind them (the scenes that mix the two are laid out that way)
+        nb = int(np.argmax(convex)) if not convex.all() else 0
+        assert not convex[:nb].any() and convex[nb:].all()
+        if nb:
+            ow.add_boxes(scene.pos[:nb], scene.quat[:nb], scene.lvel[:nb], scene.avel[:nb], scene.mass[:nb, 0],
+                         scene.inertia[:nb], scene.sides[:nb])
+        ow.add_convex(scene.pos[nb:], scene.quat[nb:], scene.lvel[nb:], scene.avel[nb:], scene.mass[nb:, 0],
+                      scene.inertia[nb:])
     else:
         ow.add_boxes(scene.pos, scene.quat, scene.lvel, scene.avel, scene.mass[:, 0], scene.inertia, scene.sides)
     return ow
@@ -639,3 +651,44 @@ def test_two_ranks_share_the_gpu_and_match_the_unsharded_oracle(speed):
     else:
         # quiet chunks exchange once, at their end; a chunk that ends in an exact replay exchanges every tick
         assert got[0][1]["fast_ticks"] >= 64 and got[0][2] == got[1][2] < steps // 2
+
+
+# ----------------------------------------------------------------- convex hulls (BASELINE configs[4])
+def _teapot_hull():
+    import os
+    from __graft_entry__ import ROOT
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "teapot_hull.npz"))
+    return pkg.hull.build(gold["points"], 0.01)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_teapot_hulls_dropping_on_the_plane_match_oracle(dtype):
+    """64 teapot hulls (1 265 points each), tilted and spinning, dropped on the ground plane: np_convex_plane (one
+    wavefront per hull) + the 8-slot fused step against the oracle's sequential dCollideConvexPlane + QuickStep."""
+    hull = _teapot_hull()
+    scene = pkg.scenes.hull_grid(hull, 8, 8, seed=4, y_range=(0.8, 2.5), spin=True, tilt=0.6).astype(dtype)
+    steps = 240
+    w = _gpu_run(scene, dtype, steps)
+    ow = _oracle_run(_orc(dtype), scene, steps, allow_pairs=True)
+    _compare(w.state(), ow.state())
+    assert w.last_contact_count() == ow.n_contacts() > 0
+    y = w.state()[0][:, 1]
+    # the hulls are held by the plane (dCollideConvexPlane keeps the FIRST eight penetrating points in array order, so a
+    # tipped hull can be propped on one side and sag on the other -- ODE's behaviour, reproduced by oracle and kernel alike)
+    assert 0.3 < np.median(y) < 0.7 and np.all(y > -0.5) and np.all(y < 1.5)
+
+
+def test_boxes_and_hulls_share_a_batch():
+    hull = _teapot_hull()
+    hs = pkg.scenes.hull_grid(hull, 8, 4, seed=6, y_range=(0.8, 2.0), spin=True, tilt=0.3)
+    bs = pkg.scenes.box_grid(8, 4, seed=7, y_range=(0.8, 2.0), spin=True, box_mass=True, plane=True)
+    bs.pos[:, 2] -= 20.0                                        # the boxes' rows well clear of the hulls' rows
+    cat = lambda a, b: np.concatenate([a, b])
+    scene = pkg.scenes.Scene(cat(bs.pos, hs.pos), cat(bs.quat, hs.quat), cat(bs.lvel, hs.lvel), cat(bs.avel, hs.avel),
+                             cat(bs.mass, hs.mass), cat(bs.inertia, hs.inertia), cat(bs.sides, hs.sides),
+                             cat(bs.gtype, hs.gtype), bs.plane, hs.hull_points).astype("float64")
+    steps = 200
+    w = _gpu_run(scene, "float64", steps)
+    ow = _oracle_run(_orc("float64"), scene, steps, allow_pairs=True)
+    _compare(w.state(), ow.state())
+    assert w.last_contact_count() == ow.n_contacts() > 0
