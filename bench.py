@@ -23,7 +23,8 @@ sys.path.insert(0, ROOT)
 
 H = 1.0 / 60.0
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-BYTES_PER_BODY_STEP = {"free": 30, "plane": 33}   # reals; SURVEY.md 8(d)
+BYTES_PER_BODY_STEP = {"free": 30, "plane": 33,    # reals; SURVEY.md 8(d)
+                       "convex": 33 + 2 * 33}          # + the 8 x 4 + 1 contact slots np_convex_plane writes and the step reads back
 
 
 def parse():
@@ -31,7 +32,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3], help="BASELINE.json configs[] index + 1")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5], help="BASELINE.json configs[] index + 1")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--side", type=int, default=0, help="grid side (bodies = side^2 per GPU); 0 = config default")
     ap.add_argument("--exchange", default="boundary", choices=["boundary", "none"])
@@ -66,7 +67,11 @@ def cpu_baseline(pkg, scene, dtype, kind, budget_s):
     ow = orc.world()
     if scene.plane is not None:
         ow.add_plane(*scene.plane)
-    ow.add_boxes(scene.pos, scene.quat, scene.lvel, scene.avel, scene.mass[:, 0], scene.inertia, scene.sides)
+    if scene.hull_points is not None:
+        ow.set_hull(scene.hull_points)
+        ow.add_convex(scene.pos, scene.quat, scene.lvel, scene.avel, scene.mass[:, 0], scene.inertia)
+    else:
+        ow.add_boxes(scene.pos, scene.quat, scene.lvel, scene.avel, scene.mass[:, 0], scene.inertia, scene.sides)
     t = ow.run(H, 2)                                   # probe
     steps = int(max(2, min(2000, budget_s / max(t / 2, 1e-9))))
     t = ow.run(H, steps)
@@ -89,7 +94,8 @@ def cpu_baseline_all_cores(scene, dtype, kind, budget_s):
             sl = slice(c * per, (c + 1) * per)
             path = os.path.join(tmp, f"slice{c}.npz")
             np.savez(path, pos=scene.pos[sl], quat=scene.quat[sl], lvel=scene.lvel[sl], avel=scene.avel[sl],
-                     mass=scene.mass[sl, 0], inertia=scene.inertia[sl], sides=scene.sides[sl], plane=plane)
+                     mass=scene.mass[sl, 0], inertia=scene.inertia[sl], sides=scene.sides[sl], plane=plane,
+                     hull=scene.hull_points if scene.hull_points is not None else np.zeros((0, 3)))
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), path, dtype,
                                            str(budget_s)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
         rate = 0.0
@@ -146,6 +152,14 @@ def main():
         workload = f"configs[1]: {side * side} free-falling boxes per GPU, no contacts, dt=1/60"
         # every rank draws its own slab with its own seed; slabs are disjoint islands (configs[3] layout)
         scene = pkg.scenes.box_grid(side, side, seed=1 + rank, spin=True, plane=False).astype(dtype)
+    elif a.config == 5:
+        side = a.side or 128
+        kind = "convex"
+        workload = (f"configs[4]: {side * side} convex hulls of res/teapot.obj (1 265 points, scale 0.01) per GPU on the "
+                    f"ground plane, convex-plane contacts (<= 8 per hull), 20 SOR iterations, dt=1/60")
+        gold = np.load(os.path.join(ROOT, "tests", "golden", "teapot_hull.npz"))     # the hull's vertices (data fixture)
+        hull = pkg.hull.build(gold["points"], 0.01)
+        scene = pkg.scenes.hull_grid(hull, side, side, seed=1 + rank, y_range=(0.6, 1.6), spin=False, tilt=0.2).astype(dtype)
     else:
         side = a.side or 512
         kind = "plane"
@@ -154,7 +168,7 @@ def main():
 
     # configs[3] layout: rank r's slab sits r slab-depths (+ 10 m) further along z, so the slabs are disjoint islands and
     # a neighbour's boundary row (this rank's ghosts) lies >= 10 m beyond this rank's own last row
-    scene.pos[:, 2] += rank * (side * pkg.scenes.PITCH + 10.0)
+    scene.pos[:, 2] += rank * (side * (pkg.scenes.HULL_PITCH if kind == "convex" else pkg.scenes.PITCH) + 10.0)
     layout = pkg.shard.SlabLayout(side, side)
     exchanging = use_dist and a.exchange == "boundary"
     w = pkg.BatchWorld(layout.n_total if exchanging else scene.n, dtype=dtype, device=local_rank)
@@ -185,7 +199,7 @@ def main():
     def run(nsteps):
         stepper.run(H, nsteps)
 
-    if a.config == 3:
+    if a.config in (3, 5):
         run(120)                            # let the boxes land: timed steps are all in contact
     run(a.warmup)
     graphed = False
@@ -238,12 +252,14 @@ def main():
                    "collide": ("body-body pairs: none by assertion (check off)" if a.no_body_collisions else
                                f"body-body pairs proven absent per tick by broadphase safe zones ({stats['fast_ticks']} fast ticks, "
                                f"{stats['careful_ticks']} exact-search ticks, {stats['rebuilds']} zone rebuilds, {stats['pair_ticks']} ticks with pairs)")
-                              + ("; ground plane fused into the step kernel" if kind == "plane" else ""),
+                              + ("; ground plane fused into the step kernel" if kind == "plane" else "")
+                              + ("; convex-plane narrowphase: one wavefront per hull, then the fused step with 8 contact slots" if kind == "convex" else ""),
                    "integrator": "QuickStep semantics: gravity + implicit gyroscopic torque + semi-implicit Euler + "
-                                 "quaternion renormalise" + ("; box-plane contacts, 20 SOR sweeps" if kind == "plane" else "")},
+                                 "quaternion renormalise" + ("; box-plane contacts, 20 SOR sweeps" if kind == "plane" else "")
+                                 + ("; convex-plane contacts, 20 SOR sweeps" if kind == "convex" else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kind, a.dtype, scene.n),
-                     "kernel": "integrate_free" if kind == "free" else "step_plane",
+                     "kernel": {"free": "integrate_free", "plane": "step_plane", "convex": "np_convex_plane + step_plane<8>"}[kind],
                      "kernel_us": kernel_s * 1e6,
                      "algorithmic_bytes_per_body_step": BYTES_PER_BODY_STEP[kind] * rsize},
     }

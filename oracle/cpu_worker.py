@@ -17,7 +17,11 @@ def main():
     ow = orc.world()
     if d["plane"].size == 4:
         ow.add_plane(*[float(v) for v in d["plane"]])
-    ow.add_boxes(d["pos"], d["quat"], d["lvel"], d["avel"], d["mass"], d["inertia"], d["sides"])
+    if "hull" in d and len(d["hull"]):
+        ow.set_hull(d["hull"])
+        ow.add_convex(d["pos"], d["quat"], d["lvel"], d["avel"], d["mass"], d["inertia"])
+    else:
+        ow.add_boxes(d["pos"], d["quat"], d["lvel"], d["avel"], d["mass"], d["inertia"], d["sides"])
     h = 1.0 / 60.0
     t = ow.run(h, 2)
     steps = int(max(2, min(2000, budget / max(t / 2, 1e-9))))

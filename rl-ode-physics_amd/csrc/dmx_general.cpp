@@ -52,7 +52,7 @@ int ensure_buffers(dmxBatch *b)
         double r = 0;
         for (int64_t i = 0; i < b->n; i++) {
             const double *s = &b->h_sides[(size_t)3 * i];
-            const double ri = (b->h_gtype[(size_t)i] == GEOM_SPHERE || b->h_gtype[(size_t)i] == GEOM_CONVEX) ? s[0]
+            const double ri = b->h_gtype[(size_t)i] == GEOM_SPHERE ? s[0]     // convex bodies are not in the broadphase
                             : b->h_gtype[(size_t)i] == GEOM_BOX ? 0.5 * std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]) : 0.0;
             r = std::max(r, ri);
         }

@@ -9,3 +9,8 @@ python3 scripts/pmc_traffic.py free f32 1048576 integrate_free $O/c2_fetch $O/c2
 cat $O/c2/*/*kernel_stats.csv | cut -c1-200
 cat $O/c3/*/*kernel_stats.csv | cut -c1-200
 tail -1 $O/c2.log | cut -c1-400
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -- python3 $R/bench.py --config 5 --steps 200 --warmup 20 --no-cpu-baseline > $O/c5.log 2>&1
+cd $R
+cat "$(ls -t $O/c5/*/*kernel_stats.csv | head -1)" | cut -c1-200
+tail -1 $O/c5.log | cut -c1-600
