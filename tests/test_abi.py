@@ -27,6 +27,16 @@ def test_library_loads_and_exports_batch_abi():
     assert b"gfx950" in lib.dmxVersion()
 
 
+def test_every_header_symbol_is_exported():
+    lib = pkg._lib.load()
+    headers = sorted(h for h in os.listdir(os.path.join(ROOT, "include")) if h.endswith(".h"))
+    assert headers == ["dmx_batch.h", "dmx_hull.h"]
+    assert _declared("dmx_hull.h") == ["dmxHullBuild", "dmxObjReadVertices"]
+    for h in headers:
+        for n in _declared(h):
+            assert hasattr(lib, n), f"{n} declared in include/{h} but not exported"
+
+
 def test_no_cpu_fallback_without_device():
     """On a box without a GPU the product refuses to run instead of falling back."""
     lib = pkg._lib.load()
