@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 ranks all on cuda:0 with the collectives staged through gloo: a functional rehearsal of the "
                          "multi-GPU loop on a one-GPU box, not a measurement")
+    ap.add_argument("--fused-ticks", type=int, default=32,
+                    help="also time the contact-free scene with this many ticks per launch (extra 'fused' object; 1 = skip)")
     ap.add_argument("--force-exchange", action="store_true", help="run the exchange path even with one rank (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gyro", type=int, default=2, choices=[0, 1, 2], help="0 off, 1 explicit, 2 implicit (ODE default)")
@@ -263,6 +265,22 @@ def main():
                      "kernel_us": kernel_s * 1e6,
                      "algorithmic_bytes_per_body_step": BYTES_PER_BODY_STEP[kind] * rsize},
     }
+    if kind == "free" and stepper.exchange is None and a.fused_ticks > 1:
+        # the same scene and step count with several ticks per launch (state in registers between ticks; results are
+        # bit-identical, tests/test_gpu_parity.py).  Reported beside the headline, which stays one launch per tick.
+        w.set_ticks_per_launch(a.fused_ticks)
+        run(a.warmup)
+        fence()
+        t0 = time.perf_counter()
+        run(a.steps)
+        fence()
+        dtf = time.perf_counter() - t0
+        w.set_ticks_per_launch(1)
+        out["fused"] = {"ticks_per_launch": a.fused_ticks, "value": total_bodies * a.steps / dtf, "unit": "body-steps/s",
+                        "ms_per_step": dtf * 1e3 / a.steps,
+                        "algorithmic_GBps": alg_bytes * a.steps / dtf / 1e9,
+                        "note": "one read + one write of the state per launch instead of per tick: past the per-tick HBM "
+                                "roofline, bounded by VALU issue"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, scene, dtype, kind, a.cpu_seconds)
         allc = cpu_baseline_all_cores(scene, dtype, kind, min(6.0, a.cpu_seconds))

@@ -131,6 +131,10 @@ int dmxBatchStepTimed(dmxBatchID b, double h, int nsteps, float *ms);
  * stats: [0] ticks in fast mode, [1] ticks in exact mode, [2] safe-zone rebuilds, [3] ticks that had body
  * pairs, [4] body pairs in the last tick, [5] crowded bodies at the last rebuild. */
 int dmxBatchSetBodyCollisions(dmxBatchID b, int enable);
+/* Contact-free ticks (no ground plane) may be taken `ticks` at a time inside one kernel launch, the bodies' state held
+ * in registers between them: same arithmetic per tick, same results bit for bit, one read and one write of the state
+ * per launch instead of per tick.  Default 1 (one launch per tick); 1..64. */
+int dmxBatchSetTicksPerLaunch(dmxBatchID b, int ticks);
 int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6]);
 
 /* ---- the collision-checked tick loop in pieces.  dmxBatchStep(b, h, n) with body collisions enabled runs, inside
@@ -155,6 +159,8 @@ int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6]);
  *                a ghost slot */
 int dmxBatchChunkBegin(dmxBatchID b, int *exact_only, int *ballistic);
 int dmxBatchChunkTick(dmxBatchID b, double h, int check);
+/* n ticks of a ballistic chunk: the test at the run's first / last tick only, as asked */
+int dmxBatchChunkTicks(dmxBatchID b, double h, int nticks, int check_first, int check_last);
 int dmxBatchCheckZonesOnStream(dmxBatchID b, void *hip_stream, int64_t first, int64_t count);
 int dmxBatchRefreshGhostsOnStream(dmxBatchID b, void *hip_stream, int64_t first, int64_t count_lo, const void *src_lo,
                                   int64_t count_hi, const void *src_hi, int check);

@@ -22,7 +22,7 @@ BATCH_SYMBOLS = [
     "dmxBatchGetStream", "dmxBatchSetBodyCollisions", "dmxBatchCollisionStats",
     "dmxBatchScatterBodiesOnStream", "dmxBatchSetBoundaryPack",
     "dmxBatchChunkBegin", "dmxBatchChunkTick", "dmxBatchCheckZonesOnStream", "dmxBatchChunkEnd",
-    "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream", "dmxBatchSetConvexHull",
+    "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream", "dmxBatchSetConvexHull", "dmxBatchChunkTicks", "dmxBatchSetTicksPerLaunch",
 ]
 
 _lib = None
@@ -98,5 +98,7 @@ def load():
     sig("dmxBatchExactTick", I, P, D)
     sig("dmxBatchRefreshGhostsOnStream", I, P, P, L, L, P, L, P, I)
     sig("dmxBatchSetConvexHull", I, P, C.c_int32, P, C.POINTER(D))
+    sig("dmxBatchChunkTicks", I, P, D, I, I, I)
+    sig("dmxBatchSetTicksPerLaunch", I, P, I)
     _lib = lib
     return lib

@@ -151,6 +151,12 @@ class BatchWorld:
     def chunk_tick(self, h, check=True):
         _check(self.lib.dmxBatchChunkTick(self.h, h, int(check)), "dmxBatchChunkTick")
 
+    def chunk_ticks(self, h, nticks, check_first=True, check_last=True):
+        _check(self.lib.dmxBatchChunkTicks(self.h, h, nticks, int(check_first), int(check_last)), "dmxBatchChunkTicks")
+
+    def set_ticks_per_launch(self, ticks):
+        _check(self.lib.dmxBatchSetTicksPerLaunch(self.h, ticks), "dmxBatchSetTicksPerLaunch")
+
     def check_zones_on(self, stream_handle, first, count):
         _check(self.lib.dmxBatchCheckZonesOnStream(self.h, stream_handle, first, count), "dmxBatchCheckZonesOnStream")
 

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -278,10 +279,16 @@ template <class T> static int step_t(dmxBatch *b, double h, int nsteps, int64_t 
     StepParams<T> P = dmx_make_params<T>(b, h);
     if (first != 0) P.pack_out = nullptr;      // the boundary pack is defined on whole-slab launches only
     if (P.cbuf != nullptr) { P.cbuf += (size_t)first * CONVEX_MAXC * 4; P.ccount += first; }   // per-body contact slots follow the range
-    for (int s = 0; s < nsteps; s++) {
+    // contact-free ticks go ticks_per_launch at a time (state in registers between ticks); the first tick alone when
+    // external force accumulators are pending (they act once)
+    const int per = (b->plane_on || first != 0) ? 1 : std::max(1, b->ticks_per_launch);
+    for (int s = 0; s < nsteps;) {
         (void)reset_diag;   // every wave overwrites its own slot each tick: nothing to clear
-        HIP_TRY(launch_step<T>((T *)b->slab + slab_ix(0, first), b->gtype + first, b->stride, count, P, b->ext_pending,
+        const bool ext = b->ext_pending && s == 0;
+        P.ticks = ext ? 1 : std::min(per, nsteps - s);
+        HIP_TRY(launch_step<T>((T *)b->slab + slab_ix(0, first), b->gtype + first, b->stride, count, P, ext,
                                b->diag + first / 64, b->stream));
+        s += P.ticks;
     }
     b->stepped_with_plane = b->plane_on != 0;
     b->last_islands = false;
@@ -349,6 +356,18 @@ extern "C" int dmxBatchChunkTick(dmxBatchID b, double h, int check)
     if (!b || !(h > 0)) return DMX_EINVAL;
     HIP_TRY(hipSetDevice(b->device));
     return dmx_chunk_tick(b, h, check);
+}
+extern "C" int dmxBatchChunkTicks(dmxBatchID b, double h, int nticks, int check_first, int check_last)
+{
+    if (!b || !(h > 0) || nticks < 0) return DMX_EINVAL;
+    HIP_TRY(hipSetDevice(b->device));
+    return dmx_chunk_ticks(b, h, nticks, check_first, check_last);
+}
+extern "C" int dmxBatchSetTicksPerLaunch(dmxBatchID b, int ticks)
+{
+    if (!b || ticks < 1 || ticks > 64) return DMX_EINVAL;
+    b->ticks_per_launch = ticks;
+    return DMX_OK;
 }
 extern "C" int dmxBatchCheckZonesOnStream(dmxBatchID b, void *hip_stream, int64_t first, int64_t count)
 {

@@ -51,6 +51,7 @@ struct dmxBatch {
     double mu = __builtin_huge_val(), bounce = 0.2, bounce_vel = 0.1;   // main.c:685-687
     int max_contacts = 8;                               // main.c:675
     bool ext_pending = false;
+    int ticks_per_launch = 1;        // contact-free ticks fused into one integrate_free launch (dmxBatchSetTicksPerLaunch)
     int min_waves = 0, tune = 0;     // DMX_MIN_WAVES / DMX_TUNE launch-tuning overrides (see StepParams)
     int vec = 0;                     // DMX_VEC launch-tuning override (bodies per lane), 0 = 16 B per lane
     bool stepped_with_plane = false;
@@ -93,6 +94,7 @@ int dmx_step_collide(dmxBatch *b, double h, int nsteps);
 // the collision-checked loop in pieces (dmx_general.cpp)
 int dmx_chunk_begin(dmxBatch *b, int *exact_only, int *ballistic);
 int dmx_chunk_tick(dmxBatch *b, double h, int check);
+int dmx_chunk_ticks(dmxBatch *b, double h, int n, int check_first, int check_last);
 int dmx_check_zones(dmxBatch *b, hipStream_t st, int64_t first, int64_t count);
 int dmx_chunk_end(dmxBatch *b, int *violated, int *warn);
 int dmx_chunk_commit(dmxBatch *b, int ticks, int refresh_zones);
@@ -130,6 +132,7 @@ template <class T> inline StepParams<T> dmx_make_params(dmxBatch *b, double h)
     P.min_waves = b->min_waves;
     P.tune = b->tune;
     P.bp_check = 0;          // set by the collision-aware tick (dmx_general.cpp)
+    P.ticks = 1;
     P.bp_flags = nullptr;
     P.skip = nullptr;
     P.pack_out = (T *)b->pack_out; P.pack_lo = b->pack_lo; P.pack_hi = b->pack_hi;

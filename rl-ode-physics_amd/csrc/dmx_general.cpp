@@ -119,11 +119,34 @@ template <class T> int build_safe_zones(dmxBatch *b)
 template <class T> int fused_tick(dmxBatch *b, double h, bool check, const uint8_t *skip)
 {
     StepParams<T> P = dmx_make_params<T>(b, h);
-    P.bp_check = check ? 1 : 0;
+    P.bp_check = check ? BPC_ALL : 0;
     P.bp_flags = (uint32_t *)b->bp_flags.p;
     P.skip = skip;
     HIP_TRY(launch_step<T>((T *)b->slab, b->gtype, b->stride, b->n_active, P, b->ext_pending, b->diag, b->stream));
     b->ext_pending = false;
+    return DMX_OK;
+}
+
+// n ticks of the fast path.  ends_only: the safe-zone test is needed at the run's first (check_first) and last
+// (check_last) tick only -- ballistic chunks; otherwise at every tick.  Contact-free scenes take them
+// ticks_per_launch at a time inside one integrate_free launch (state in registers between ticks).
+template <class T> int fused_run(dmxBatch *b, double h, int n, bool ends_only, bool check_first, bool check_last)
+{
+    int rc;
+    const int per = (b->plane_on || b->ext_pending) ? 1 : std::max(1, b->ticks_per_launch);
+    for (int s = 0; s < n; s += per) {
+        const int kk = std::min(per, n - s);
+        if (kk == 1) {
+            const bool check = !ends_only || (s == 0 && check_first) || (s == n - 1 && check_last);
+            if ((rc = fused_tick<T>(b, h, check, nullptr)) != DMX_OK) return rc;
+            continue;
+        }
+        StepParams<T> P = dmx_make_params<T>(b, h);
+        P.ticks = kk;
+        P.bp_check = !ends_only ? BPC_ALL : ((s == 0 && check_first ? BPC_FIRST : 0) | (s + kk == n && check_last ? BPC_LAST : 0));
+        P.bp_flags = (uint32_t *)b->bp_flags.p;
+        HIP_TRY(launch_step<T>((T *)b->slab, b->gtype, b->stride, b->n_active, P, false, b->diag, b->stream));
+    }
     return DMX_OK;
 }
 
@@ -265,8 +288,7 @@ template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
             // straight line during the chunk, and a disc is convex, so a body inside its zone at the chunk's first and
             // last tick is inside it at every tick between -- two checks per chunk prove all of them.
             const bool ballistic = !b->plane_on && b->g[0] == 0.0 && b->g[2] == 0.0;
-            for (int s = 0; s < k; s++)
-                if ((rc = fused_tick<T>(b, h, !ballistic || s == 0 || s == k - 1, nullptr)) != DMX_OK) return rc;
+            if ((rc = fused_run<T>(b, h, k, ballistic, true, true)) != DMX_OK) return rc;
             if ((rc = read_flags(b)) != DMX_OK) return rc;
             if (!b->bp_flags_host[BPF_VIOLATION]) {
                 b->stat_fast_ticks += k;
@@ -341,6 +363,18 @@ int dmx_chunk_tick(dmxBatch *b, double h, int check)
 {
     if (!b->bp_flags.p) return DMX_EINVAL;          // no chunk begun
     const int rc = b->precision == DMX_F32 ? fused_tick<float>(b, h, check != 0, nullptr) : fused_tick<double>(b, h, check != 0, nullptr);
+    b->stepped_with_plane = b->plane_on != 0;
+    b->last_islands = false;
+    b->last_mixed = false;
+    b->last_pairs = 0;
+    return rc;
+}
+
+int dmx_chunk_ticks(dmxBatch *b, double h, int n, int check_first, int check_last)
+{
+    if (!b->bp_flags.p) return DMX_EINVAL;          // no chunk begun
+    const int rc = b->precision == DMX_F32 ? fused_run<float>(b, h, n, true, check_first != 0, check_last != 0)
+                                           : fused_run<double>(b, h, n, true, check_first != 0, check_last != 0);
     b->stepped_with_plane = b->plane_on != 0;
     b->last_islands = false;
     b->last_mixed = false;

@@ -84,7 +84,8 @@ template <class T> struct StepParams {
     int vec;            // launch tuning: bodies per lane in integrate_free (0 = 16 B per lane)
     int min_waves;      // launch tuning (env DMX_MIN_WAVES): waves per SIMD the register allocator must leave room for, 0 = default
     int tune;           // launch tuning (env DMX_TUNE): experiment bits, 0 = default
-    int bp_check;       // 1: test every body against its broadphase safe zone (pre-step position)
+    int bp_check;       // safe-zone test of every body's pre-step position (BPC_* bits; any bit = "this tick" for one-tick kernels)
+    int ticks;          // integrate_free: ticks taken by one launch with the state held in registers (>= 1)
     uint32_t *bp_flags; // device flags (BPF_*), written when a body has left its safe zone
     const uint8_t *skip; // per-body: 1 = stepped by the island path this tick, leave untouched (may be null)
     // boundary-row pack for the multi-GPU exchange (null = off): bodies i < pack_lo and i >= pack_hi also write
@@ -96,6 +97,8 @@ template <class T> struct StepParams {
     T *cbuf; int *ccount;
 };
 
+// StepParams::bp_check for a launch of `ticks` ticks: test at every tick, or only at the launch's first / last tick
+enum : int { BPC_ALL = 1, BPC_FIRST = 2, BPC_LAST = 4 };
 // hashed (x,z)-column grid of the body-body broadphase
 enum : int { BPF_OVERFLOW = 0, BPF_CROWDED = 1, BPF_NPAIRS = 2, BPF_VIOLATION = 3, BPF_WARN = 4, BPF_COUNT = 5 };
 template <class T> struct GridParams {

@@ -100,10 +100,11 @@ __device__ __forceinline__ void free_body_step(V3<T> &x, Q4<T> &q, V3<T> &v, V3<
 // integrate_free: contact-free tick (BASELINE config 2/4).  Algorithmic traffic per body-step:
 // read 13 state + 4 constant reals, write 13 state reals = 30 reals (120 B f32 / 240 B f64).
 // ---------------------------------------------------------------------------------------------
-template <class T, int V, bool EXT, int MINW>
+template <class T, int V, bool EXT, int MINW, bool MULTI>
 __global__ __launch_bounds__(256, MINW) void integrate_free(T *__restrict__ S, int64_t stride, int64_t nvec,
                                                       StepParams<T> P)
 {
+    const int nticks = MULTI ? P.ticks : 1;         // MULTI = false: the one-tick kernel, no loop
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nvec;
          t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = t * V;
@@ -111,41 +112,47 @@ __global__ __launch_bounds__(256, MINW) void integrate_free(T *__restrict__ S, i
         Pack<T, V> c[C_SIDES];
 #pragma unroll
         for (int k = 0; k < C_SIDES; k++) c[k] = ldv<T, V>(S, stride, k, i);
+        Pack<T, V> bx, bz, bs;
         if (P.bp_check) {
-            // dSpaceCollide for body-body pairs, by proof: a body inside its safe zone cannot touch any other
-            const Pack<T, V> bx = ldv<T, V>(S, stride, C_BPX, i), bz = ldv<T, V>(S, stride, C_BPZ, i),
-                             bs = ldv<T, V>(S, stride, C_BPSAFE, i);
-            int zs = 0;
-#pragma unroll
-            for (int b = 0; b < V; b++) {
-                const int z = zone_state(c[C_POS].v[b] - bx.v[b], c[C_POS + 2].v[b] - bz.v[b], bs.v[b]);
-                zs = z > zs ? z : zs;
-            }
-            report_zone(zs, P.bp_flags);
+            bx = ldv<T, V>(S, stride, C_BPX, i); bz = ldv<T, V>(S, stride, C_BPZ, i); bs = ldv<T, V>(S, stride, C_BPSAFE, i);
         }
         Pack<T, V> f[6];
         if (EXT) {
 #pragma unroll
             for (int k = 0; k < 6; k++) f[k] = ldv<T, V>(S, stride, C_FORCE + k, i);
         }
+        // P.ticks ticks with the state in registers: one read and one write of the state per launch, not per tick
+        for (int s = 0; s < nticks; s++) {
+            if (P.bp_check && ((P.bp_check & BPC_ALL) || (s == 0 && (P.bp_check & BPC_FIRST)) ||
+                               (s == nticks - 1 && (P.bp_check & BPC_LAST)))) {
+                // dSpaceCollide for body-body pairs, by proof: a body inside its safe zone cannot touch any other
+                int zs = 0;
 #pragma unroll
-        for (int b = 0; b < V; b++) {
-            V3<T> x = { c[C_POS].v[b], c[C_POS + 1].v[b], c[C_POS + 2].v[b] };
-            Q4<T> q = { c[C_QUAT].v[b], c[C_QUAT + 1].v[b], c[C_QUAT + 2].v[b], c[C_QUAT + 3].v[b] };
-            V3<T> v = { c[C_LVEL].v[b], c[C_LVEL + 1].v[b], c[C_LVEL + 2].v[b] };
-            V3<T> w = { c[C_AVEL].v[b], c[C_AVEL + 1].v[b], c[C_AVEL + 2].v[b] };
-            const V3<T> Ib = { c[C_INERTIA].v[b], c[C_INERTIA + 1].v[b], c[C_INERTIA + 2].v[b] };
-            V3<T> facc = { T(0), T(0), T(0) }, tacc = { T(0), T(0), T(0) };
-            if (EXT) {
-                facc = { f[0].v[b], f[1].v[b], f[2].v[b] };
-                tacc = { f[3].v[b], f[4].v[b], f[5].v[b] };
+                for (int b = 0; b < V; b++) {
+                    const int z = zone_state(c[C_POS].v[b] - bx.v[b], c[C_POS + 2].v[b] - bz.v[b], bs.v[b]);
+                    zs = z > zs ? z : zs;
+                }
+                report_zone(zs, P.bp_flags);
             }
-            free_body_step(x, q, v, w, c[C_MASS].v[b], Ib, facc, tacc, P.g, P.h, P.gyro);
-            pack_boundary(P, i + b, x, q, v, w);
-            c[C_POS].v[b] = x.x; c[C_POS + 1].v[b] = x.y; c[C_POS + 2].v[b] = x.z;
-            c[C_QUAT].v[b] = q.w; c[C_QUAT + 1].v[b] = q.x; c[C_QUAT + 2].v[b] = q.y; c[C_QUAT + 3].v[b] = q.z;
-            c[C_LVEL].v[b] = v.x; c[C_LVEL + 1].v[b] = v.y; c[C_LVEL + 2].v[b] = v.z;
-            c[C_AVEL].v[b] = w.x; c[C_AVEL + 1].v[b] = w.y; c[C_AVEL + 2].v[b] = w.z;
+#pragma unroll
+            for (int b = 0; b < V; b++) {
+                V3<T> x = { c[C_POS].v[b], c[C_POS + 1].v[b], c[C_POS + 2].v[b] };
+                Q4<T> q = { c[C_QUAT].v[b], c[C_QUAT + 1].v[b], c[C_QUAT + 2].v[b], c[C_QUAT + 3].v[b] };
+                V3<T> v = { c[C_LVEL].v[b], c[C_LVEL + 1].v[b], c[C_LVEL + 2].v[b] };
+                V3<T> w = { c[C_AVEL].v[b], c[C_AVEL + 1].v[b], c[C_AVEL + 2].v[b] };
+                const V3<T> Ib = { c[C_INERTIA].v[b], c[C_INERTIA + 1].v[b], c[C_INERTIA + 2].v[b] };
+                V3<T> facc = { T(0), T(0), T(0) }, tacc = { T(0), T(0), T(0) };
+                if (EXT && s == 0) {                       // the accumulators act in the first tick and are cleared by it
+                    facc = { f[0].v[b], f[1].v[b], f[2].v[b] };
+                    tacc = { f[3].v[b], f[4].v[b], f[5].v[b] };
+                }
+                free_body_step(x, q, v, w, c[C_MASS].v[b], Ib, facc, tacc, P.g, P.h, P.gyro);
+                if (s == nticks - 1) pack_boundary(P, i + b, x, q, v, w);
+                c[C_POS].v[b] = x.x; c[C_POS + 1].v[b] = x.y; c[C_POS + 2].v[b] = x.z;
+                c[C_QUAT].v[b] = q.w; c[C_QUAT + 1].v[b] = q.x; c[C_QUAT + 2].v[b] = q.y; c[C_QUAT + 3].v[b] = q.z;
+                c[C_LVEL].v[b] = v.x; c[C_LVEL + 1].v[b] = v.y; c[C_LVEL + 2].v[b] = v.z;
+                c[C_AVEL].v[b] = w.x; c[C_AVEL + 1].v[b] = w.y; c[C_AVEL + 2].v[b] = w.z;
+            }
         }
 #pragma unroll
         for (int k = 0; k < C_MASS; k++) stv<T, V>(S, stride, k, i, c[k]);
@@ -542,8 +549,9 @@ hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, co
         const unsigned grid = blocks_for(nvec, 256);
 #define DMX_LAUNCH_FREE(VV, MW)                                                                                      \
     do {                                                                                                             \
-        if (ext) hipLaunchKernelGGL((integrate_free<T, VV, true, MW>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P);  \
-        else     hipLaunchKernelGGL((integrate_free<T, VV, false, MW>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P); \
+        if (P.ticks > 1) hipLaunchKernelGGL((integrate_free<T, VV, false, MW, true>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P);   \
+        else if (ext) hipLaunchKernelGGL((integrate_free<T, VV, true, MW, false>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P);  \
+        else     hipLaunchKernelGGL((integrate_free<T, VV, false, MW, false>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P); \
     } while (0)
         const int mw = P.min_waves;   // launch tuning: minimum waves per SIMD the register allocator must leave room for
         if (V == 1) { if (mw == 8) DMX_LAUNCH_FREE(1, 8); else if (mw == 6) DMX_LAUNCH_FREE(1, 6); else DMX_LAUNCH_FREE(1, 1); }

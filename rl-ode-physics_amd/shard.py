@@ -359,8 +359,8 @@ class ShardedStepper:
         if ballistic and not self.exchange_every_tick:
             if self.exchange.fused:
                 self.exchange.ops.disarm_pack()
-            for s in range(k - 1):
-                self.w.chunk_tick(h, s == 0)
+            if k > 1:
+                self.w.chunk_ticks(h, k - 1, True, False)      # the library fuses them ticks_per_launch at a time
             self.tick(h, check=True)
             return
         g = self.graph_steps if (self.graph is not None and self.ballistic_graph == ballistic) else 0

@@ -692,3 +692,49 @@ def test_boxes_and_hulls_share_a_batch():
     ow = _oracle_run(_orc("float64"), scene, steps, allow_pairs=True)
     _compare(w.state(), ow.state())
     assert w.last_contact_count() == ow.n_contacts() > 0
+
+
+# ----------------------------------------------------------------- several ticks per launch
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("ticks", [2, 5, 8])
+def test_ticks_per_launch_changes_nothing_but_the_launch_count(dtype, ticks):
+    """dmxBatchSetTicksPerLaunch: contact-free ticks fused into one integrate_free launch give the bits of one launch per
+    tick -- with the collision proof riding along (chunks of 32+, not multiples of `ticks`) and without it."""
+    scene = pkg.scenes.box_grid(40, 25, seed=17, spin=True, box_mass=True, plane=False).astype(dtype)
+    steps = 77
+    ref = _gpu_run(scene, dtype, steps)
+    for collide in (True, False):
+        w = _gpu_run(scene, dtype, steps, setup=lambda w: (w.set_ticks_per_launch(ticks), w.set_body_collisions(collide)))
+        _compare(w.state(), ref.state())
+        if collide:
+            assert w.collision_stats()["fast_ticks"] == steps
+    ow = _oracle_run(_orc(dtype), scene, steps)
+    _compare(ref.state(), ow.state())
+
+
+def test_fused_ticks_still_catch_midair_collisions():
+    scene = pkg.scenes.box_grid(16, 16, seed=13, y_range=(10.0, 12.0), spin=True, box_mass=True, plane=False).astype("float64")
+    rng = np.random.default_rng(5)
+    scene.lvel[:, 0] = rng.uniform(-3.0, 3.0, scene.n)
+    scene.lvel[:, 2] = rng.uniform(-3.0, 3.0, scene.n)
+    w = _gpu_run(scene, "float64", 150, setup=lambda w: w.set_ticks_per_launch(8))
+    ow = _oracle_run(_orc("float64"), scene, 150, allow_pairs=True)
+    _compare(w.state(), ow.state())
+    assert w.collision_stats()["pair_ticks"] > 0
+
+
+def test_fused_ticks_apply_external_force_once():
+    scene = pkg.scenes.box_grid(8, 8, seed=2, spin=True, plane=False).astype("float64")
+    f = np.zeros((scene.n, 3)); f[:, 0] = 3.0
+    outs = []
+    for ticks in (1, 6):
+        w = pkg.BatchWorld(scene.n, dtype="float64")
+        w.load_scene(scene)
+        w.set_body_collisions(False)
+        w.set_ticks_per_launch(ticks)
+        w.upload(pkg.batch.FORCE, f)
+        w.step(H, 13)
+        w.synchronize()
+        outs.append(w.state())
+    _compare(outs[1], outs[0])
+    assert np.allclose(outs[0][2][:, 0], 3.0 * H)          # one tick's worth of impulse (m = 1), whatever the fusion

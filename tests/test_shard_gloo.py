@@ -152,6 +152,10 @@ class HostWorld:
             self.flag = True
         self.t += 1
 
+    def chunk_ticks(self, h, n, check_first=True, check_last=True):
+        for s in range(n):
+            self.chunk_tick(h, (s == 0 and check_first) or (s == n - 1 and check_last))
+
     def chunk_end(self):
         return self.flag, self.warn
 
