@@ -53,7 +53,10 @@ enum {
     DMX_TORQUE = 8,   /* k=3  dBodyAddTorque accumulator                                  */
     DMX_QUAT_RAW = 9, /* k=4  like DMX_QUAT but stored as given (DMX_QUAT normalises on upload,
                               as dBodySetQuaternion does); for state that came from the device */
-    DMX_NFIELDS = 10
+    DMX_STATE = 10,   /* k=13 pos3 quat4 lvel3 avel3 in one piece (the row layout of GatherBodies and of the boundary
+                              pack): the whole read-back of main.c:221-237 in one transfer; the quaternion is stored
+                              as given, like DMX_QUAT_RAW */
+    DMX_NFIELDS = 11
 };
 
 /* geometry class per body (uint8 array) */

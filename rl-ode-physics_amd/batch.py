@@ -12,7 +12,8 @@ from . import _lib
 
 DMX_F32, DMX_F64 = 0, 1
 POS, QUAT, LVEL, AVEL, MASS, INERTIA, SIDES, FORCE, TORQUE = range(9)
-_K = {POS: 3, QUAT: 4, LVEL: 3, AVEL: 3, MASS: 1, INERTIA: 3, SIDES: 3, FORCE: 3, TORQUE: 3}
+QUAT_RAW, STATE = 9, 10      # quaternion stored as given; pos3 quat4 lvel3 avel3 in one piece
+_K = {POS: 3, QUAT: 4, LVEL: 3, AVEL: 3, MASS: 1, INERTIA: 3, SIDES: 3, FORCE: 3, TORQUE: 3, QUAT_RAW: 4, STATE: 13}
 GEOM_NONE, GEOM_SPHERE, GEOM_BOX = 0, 1, 2
 GYRO_OFF, GYRO_EXPLICIT, GYRO_IMPLICIT = 0, 1, 2
 CONTACT_BOUNCE = 0x004

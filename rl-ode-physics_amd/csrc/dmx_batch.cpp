@@ -14,8 +14,9 @@
 
 #include "dmx_batch_priv.hpp"
 
-static const int k_field_comp0[DMX_NFIELDS] = { C_POS, C_QUAT, C_LVEL, C_AVEL, C_MASS, C_INERTIA, C_SIDES, C_FORCE, C_TORQUE, C_QUAT };
-static const int k_field_k[DMX_NFIELDS] = { 3, 4, 3, 3, 1, 3, 3, 3, 3, 4 };
+static const int k_field_comp0[DMX_NFIELDS] = { C_POS, C_QUAT, C_LVEL, C_AVEL, C_MASS, C_INERTIA, C_SIDES, C_FORCE, C_TORQUE, C_QUAT, C_POS };
+static const int k_field_k[DMX_NFIELDS] = { 3, 4, 3, 3, 1, 3, 3, 3, 3, 4, C_MASS };
+static_assert(C_POS == 0 && C_QUAT == 3 && C_LVEL == 7 && C_AVEL == 10 && C_MASS == 13, "DMX_STATE is components 0..12");
 
 extern "C" const char *dmxVersion(void) { return "libode_mi355 0.1 (gfx950)"; }
 
@@ -192,7 +193,7 @@ static int upload_t(dmxBatch *b, int field, const void *host, int64_t first, int
         for (int64_t i = 0; i < count * 3; i++) b->h_sides[(size_t)(3 * first + i)] = (double)p[i];
         b->bp_rmax = 0;
     }
-    if (field == DMX_POS || field == DMX_SIDES) b->bp_valid = false;     // poses / extents changed under the safe zones
+    if (field == DMX_POS || field == DMX_SIDES || field == DMX_STATE) b->bp_valid = false;     // poses / extents changed under the safe zones
     return DMX_OK;
 }
 

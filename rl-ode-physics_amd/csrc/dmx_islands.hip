@@ -9,7 +9,8 @@
 //                       the sweep follows a level schedule (row r's level = 1 + the latest level of an earlier row
 //                       sharing a body with r): rows of one level touch disjoint bodies, so updating them
 //                       concurrently gives exactly the sequential result; one barrier per level.
-// Rows and per-body scratch live in HBM/L2.  Single bodies resting on the ground plane never come here: they take
+// Rows and per-body scratch live in HBM/L2; solve_island_wg keeps the constraint-force accumulators in LDS during the
+// sweeps and prefetches each lane's next row across the level barrier.  Single bodies resting on the ground plane never come here: they take
 // the fused register-resident path (step_plane).
 #include <hip/hip_runtime.h>
 #include "dmx_internal.hpp"
@@ -215,6 +216,46 @@ __device__ __forceinline__ T row_sor(T *rows, const int *jb, T *bs, int i)
     return tabs(delta);
 }
 
+// ---- the same row update with the row in registers and the bodies' constraint-force accumulators in LDS
+//      (solve_island_wg): identical arithmetic, identical bits ---------------------------------------------------
+template <class T> struct RowRegs { T J[12], iMJ[12], rhs, ad, lo, hi, lam; int l1, l2, row; };
+
+template <class T>
+__device__ __forceinline__ void row_load(const T *rows, const int *jb, int i, RowRegs<T> &r)
+{
+    const T *row = rows + (size_t)i * RW_COUNT;
+#pragma unroll
+    for (int j = 0; j < 12; j++) { r.J[j] = row[RW_J + j]; r.iMJ[j] = row[RW_IMJ + j]; }
+    r.rhs = row[RW_RHS]; r.ad = row[RW_AD]; r.lo = row[RW_LO]; r.hi = row[RW_HI]; r.lam = row[RW_LAM];
+    r.l1 = jb[2 * i]; r.l2 = jb[2 * i + 1];
+    r.row = i;
+}
+
+template <class T>
+__device__ __forceinline__ T row_sor_lds(T *rows, RowRegs<T> &r, T *fc)
+{
+    T *fc1 = fc + 6 * r.l1;
+    T *fc2 = r.l2 >= 0 ? fc + 6 * r.l2 : nullptr;
+    const T *J = r.J;
+    const T old = r.lam;
+    T delta = fma_(-old, r.ad, r.rhs);
+    delta -= fma_(fc1[5], J[5], fma_(fc1[4], J[4], fma_(fc1[3], J[3], fma_(fc1[2], J[2], fma_(fc1[1], J[1], fc1[0] * J[0])))));
+    if (fc2)
+        delta -= fma_(fc2[5], J[11], fma_(fc2[4], J[10], fma_(fc2[3], J[9], fma_(fc2[2], J[8], fma_(fc2[1], J[7], fc2[0] * J[6])))));
+    const T nl = old + delta;
+    if (nl < r.lo) { delta = r.lo - old; r.lam = r.lo; }
+    else if (nl > r.hi) { delta = r.hi - old; r.lam = r.hi; }
+    else r.lam = nl;
+    rows[(size_t)r.row * RW_COUNT + RW_LAM] = r.lam;
+#pragma unroll
+    for (int j = 0; j < 6; j++) fc1[j] = fma_(delta, r.iMJ[j], fc1[j]);
+    if (fc2) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) fc2[j] = fma_(delta, r.iMJ[6 + j], fc2[j]);
+    }
+    return tabs(delta);
+}
+
 // ---- body k: v += h cforce ; v += h M^-1 f ; integrate ; clear accumulators -------------------------------------
 template <class T>
 __device__ __forceinline__ void finish_body(T *S, const uint8_t *bflags, int64_t stride, const T *b, int s, bool has_rows, T h)
@@ -288,6 +329,7 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
 
 // ================================================================================ one workgroup per large island
 constexpr int WG = 256;
+constexpr int FC_LDS_BYTES = 48 * 1024;     // islands of up to 2048 (f32) / 1024 (f64) bodies keep their accumulators in LDS
 
 template <class T>
 __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const uint8_t *__restrict__ bflags,
@@ -317,15 +359,54 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
     __syncthreads();
 
     double resid = 0.0;
-    for (int it = 0; it < P.iters; it++) {
-        const bool last = (it == P.iters - 1);
-        for (int lv = 0; lv < nlev; lv++) {
-            const int a = lev_off[lv], e = lev_off[lv + 1];
-            for (int t = a + tid; t < e; t += WG) {
-                const T d = row_sor(rows, jb, bs, I.lev_rows[t]);
+    // LDS staging: the only data one level hands to the next is the bodies' constraint-force accumulators (6 reals per
+    // body); they live in LDS for the sweeps.  A row's own data does not depend on other rows, so each lane fetches its
+    // row of the NEXT level before it works on this one: between two barriers only LDS traffic and arithmetic remain.
+    __shared__ T fc_lds[FC_LDS_BYTES / sizeof(T)];
+    const bool use_lds = (size_t)nb * 6 * sizeof(T) <= (size_t)FC_LDS_BYTES && nlev > 0;    // workgroup-uniform
+    if (use_lds) {
+        for (int k = tid; k < nb; k += WG)
+            for (int j = 0; j < 6; j++) fc_lds[6 * k + j] = bs[(size_t)k * BW_COUNT + BW_FC + j];
+        __syncthreads();
+        const int total = nlev * P.iters;
+        auto first_row = [&](int lv) { const int t = lev_off[lv] + tid; return t < lev_off[lv + 1] ? I.lev_rows[t] : -1; };
+        RowRegs<T> cur, nxt;
+        int rn = total > 0 ? first_row(0) : -1;
+        if (rn >= 0) row_load(rows, jb, rn, nxt);
+        for (int g = 0, lv = 0; g < total; g++, lv = (lv + 1 == nlev ? 0 : lv + 1)) {
+            const bool last = g >= total - nlev;
+            const int rc = rn;
+            cur = nxt;
+            if (g + 1 < total) {
+                rn = first_row(lv + 1 == nlev ? 0 : lv + 1);
+                if (rn >= 0) row_load(rows, jb, rn, nxt);
+            }
+            if (rc >= 0) {
+                const T d = row_sor_lds(rows, cur, fc_lds);
+                if (last) resid += (double)d;
+                if (rn == rc) nxt.lam = cur.lam;              // one-level schedule: the prefetch predates this update
+            }
+            for (int t = lev_off[lv] + tid + WG; t < lev_off[lv + 1]; t += WG) {       // levels wider than the workgroup
+                RowRegs<T> x;
+                row_load(rows, jb, I.lev_rows[t], x);
+                const T d = row_sor_lds(rows, x, fc_lds);
                 if (last) resid += (double)d;
             }
             __syncthreads();                                  // the next level reads the fc this one wrote
+        }
+        for (int k = tid; k < nb; k += WG)                     // back for finish_body (same lane, same bodies)
+            for (int j = 0; j < 6; j++) bs[(size_t)k * BW_COUNT + BW_FC + j] = fc_lds[6 * k + j];
+    } else {
+        for (int it = 0; it < P.iters; it++) {
+            const bool last = (it == P.iters - 1);
+            for (int lv = 0; lv < nlev; lv++) {
+                const int a = lev_off[lv], e = lev_off[lv + 1];
+                for (int t = a + tid; t < e; t += WG) {
+                    const T d = row_sor(rows, jb, bs, I.lev_rows[t]);
+                    if (last) resid += (double)d;
+                }
+                __syncthreads();                              // the next level reads the fc this one wrote
+            }
         }
     }
     for (int k = tid; k < nb; k += WG) finish_body(S, bflags, stride, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], m > 0, h);

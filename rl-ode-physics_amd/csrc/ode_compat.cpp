@@ -122,17 +122,17 @@ struct dxWorld {
     void to_host()
     {
         if (!dev_newer) return;
-        const struct { int field, k; size_t off; } f[4] = {
-            { DMX_POS, 3, offsetof(dxBody, pos) }, { DMX_QUAT, 4, offsetof(dxBody, q) },
-            { DMX_LVEL, 3, offsetof(dxBody, lvel) }, { DMX_AVEL, 3, offsetof(dxBody, avel) } };
-        for (const auto &fi : f) {
-            buf.resize((size_t)cap * fi.k);
-            DMX_MUST(dmxBatchDownload(batch, fi.field, buf.data(), 0, cap));
-            for (int s = 0; s < cap; s++) {
-                if (!slots[(size_t)s]) continue;
-                dReal *dst = (dReal *)((char *)slots[(size_t)s] + fi.off);
-                for (int k = 0; k < fi.k; k++) dst[k] = buf[(size_t)s * fi.k + k];
-            }
+        // one transfer for the whole read-back (13 reals per slot: pos3 quat4 lvel3 avel3), up to the highest live slot
+        int hi = 0;
+        for (int s = 0; s < cap; s++) if (slots[(size_t)s]) hi = s + 1;
+        buf.resize((size_t)hi * 13);
+        if (hi > 0) DMX_MUST(dmxBatchDownload(batch, DMX_STATE, buf.data(), 0, hi));
+        for (int s = 0; s < hi; s++) {
+            dxBody *b = slots[(size_t)s];
+            if (!b) continue;
+            const dReal *r = &buf[(size_t)s * 13];
+            for (int k = 0; k < 3; k++) { b->pos[k] = r[k]; b->lvel[k] = r[7 + k]; b->avel[k] = r[10 + k]; }
+            for (int k = 0; k < 4; k++) b->q[k] = r[3 + k];
         }
         for (dxBody *b : slots) {
             if (!b) continue;
@@ -151,14 +151,12 @@ struct dxWorld {
             buf.assign((size_t)cap * k, 0);
             for (int s = 0; s < cap; s++) {
                 const dxBody *b = slots[(size_t)s];
-                for (int j = 0; j < k; j++) buf[(size_t)s * k + j] = b ? get(b, j) : (dReal)(field == DMX_QUAT_RAW ? (j == 0) : (field == DMX_MASS || field == DMX_INERTIA));
+                for (int j = 0; j < k; j++) buf[(size_t)s * k + j] = b ? get(b, j) : (dReal)(field == DMX_STATE ? (j == 3) : (field == DMX_MASS || field == DMX_INERTIA));   // empty slot: unit quaternion, unit mass
             }
             DMX_MUST(dmxBatchUpload(batch, field, buf.data(), 0, cap));
         };
-        up(DMX_POS, 3, [](const dxBody *b, int j) { return b->pos[j]; });
-        up(DMX_QUAT_RAW, 4, [](const dxBody *b, int j) { return b->q[j]; });   // already normalised: store as is
-        up(DMX_LVEL, 3, [](const dxBody *b, int j) { return b->lvel[j]; });
-        up(DMX_AVEL, 3, [](const dxBody *b, int j) { return b->avel[j]; });
+        // pos3 quat4 lvel3 avel3 in one transfer; the quaternion is already normalised and is stored as is
+        up(DMX_STATE, 13, [](const dxBody *b, int j) { return j < 3 ? b->pos[j] : j < 7 ? b->q[j - 3] : j < 10 ? b->lvel[j - 7] : b->avel[j - 10]; });
         up(DMX_MASS, 1, [](const dxBody *b, int) { return b->mass.mass; });
         up(DMX_INERTIA, 3, [](const dxBody *b, int j) { return b->mass.I[5 * j]; });
         up(DMX_FORCE, 3, [](const dxBody *b, int j) { return b->facc[j]; });

@@ -277,6 +277,18 @@ def test_upload_download_roundtrip_and_partial_ranges():
     assert np.allclose(np.linalg.norm(w.download(B.QUAT), axis=1), 1.0, atol=1e-6)
 
 
+def test_state_field_is_the_four_fields_in_one_transfer():
+    scene = pkg.scenes.box_grid(9, 7, seed=8, spin=True, plane=False).astype("float32")
+    w = _gpu_run(scene, "float32", 11)
+    st = w.download(pkg.batch.STATE)
+    assert st.shape == (scene.n, 13)
+    assert np.array_equal(st, np.concatenate(w.state(), axis=1))
+    assert np.array_equal(w.download(pkg.batch.STATE, 5, 20), st[5:25])
+    w2 = pkg.BatchWorld(scene.n, dtype="float32")
+    w2.upload(pkg.batch.STATE, st)                      # stored as given (no renormalisation of the quaternion)
+    assert np.array_equal(np.concatenate(w2.state(), axis=1), st)
+
+
 def test_external_force_is_applied_once_and_cleared():
     B = pkg.batch
     w = pkg.BatchWorld(300, dtype="float64", gravity=(0, 0, 0))
