@@ -14,11 +14,11 @@ namespace {
 
 // islands with at least this many rows get a workgroup and a level schedule (DMX_BIG_ISLAND_ROWS overrides, for tests).
 // One lane walking an island pays a dependent L2 round trip per row and sweep, so anything beyond a body or two is
-// better off with a workgroup: 500-body reference scene 5.2 / 3.3 / 2.4 / 1.7 / 1.3 ms per tick at 384 / 128 / 64 / 32 /
-// 16 rows (profiles/r01_big_island_threshold.txt).
+// better off with a workgroup: 500-body reference scene 5.2 / 3.3 / 2.4 / 1.7 / 1.3 / 1.1 / 0.8 ms per tick at 384 / 128 /
+// 64 / 32 / 16 / 8 / 4 rows (profiles/r01_big_island_threshold.txt).
 int big_island_rows()
 {
-    static const int v = [] { const char *e = getenv("DMX_BIG_ISLAND_ROWS"); return e ? atoi(e) : 16; }();
+    static const int v = [] { const char *e = getenv("DMX_BIG_ISLAND_ROWS"); return e ? atoi(e) : 4; }();
     return v;
 }
 

@@ -160,7 +160,7 @@ def test_reference_scene_through_ode_api_matches_oracle(tmp_path, single):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("big_rows", ["12", "96", "1000000"])
+@pytest.mark.parametrize("big_rows", ["1", "96", "1000000"])
 def test_large_islands_take_the_workgroup_kernel_with_identical_bits(tmp_path, big_rows):
     """A pile in the reference's pen (floor + walls): its island is solved by solve_island_wg under a level
     schedule; the result must equal the sequential sweep of the oracle bit for bit."""
