@@ -76,7 +76,6 @@ extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int dev
     b->cfm = precision == DMX_F32 ? 1e-5 : 1e-10;      // dWorldCreate default per precision [ODE]
     if (const char *v = getenv("DMX_VEC")) b->vec = atoi(v);
     if (const char *v = getenv("DMX_MIN_WAVES")) b->min_waves = atoi(v);
-    if (const char *v = getenv("DMX_TUNE")) b->tune = atoi(v);
     int rc = DMX_OK;
     do {
         if (hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = DMX_EHIP; break; }

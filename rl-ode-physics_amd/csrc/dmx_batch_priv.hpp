@@ -52,8 +52,8 @@ struct dmxBatch {
     int max_contacts = 8;                               // main.c:675
     bool ext_pending = false;
     int ticks_per_launch = 1;        // contact-free ticks fused into one integrate_free launch (dmxBatchSetTicksPerLaunch)
-    int min_waves = 0, tune = 0;     // DMX_MIN_WAVES / DMX_TUNE launch-tuning overrides (see StepParams)
-    int vec = 0;                     // DMX_VEC launch-tuning override (bodies per lane), 0 = 16 B per lane
+    int min_waves = 0;               // DMX_MIN_WAVES launch-tuning override (see StepParams)
+    int vec = 0;                     // DMX_VEC launch-tuning override (bodies per lane in integrate_free), 0 = default (1)
     bool stepped_with_plane = false;
     // general island path (explicit contact joints)
     uint8_t *bflags = nullptr;                 // device, per-slot BF_* flags
@@ -130,7 +130,6 @@ template <class T> inline StepParams<T> dmx_make_params(dmxBatch *b, double h)
     P.max_contacts = b->max_contacts;
     P.vec = b->vec;
     P.min_waves = b->min_waves;
-    P.tune = b->tune;
     P.bp_check = 0;          // set by the collision-aware tick (dmx_general.cpp)
     P.ticks = 1;
     P.bp_flags = nullptr;

@@ -81,9 +81,8 @@ template <class T> struct StepParams {
     V3<T> pn; T pd;     // plane n.x = d
     int surf_mode; T mu, bounce, bounce_vel;   // contact surface (NearCallback, main.c:684-687)
     int max_contacts;
-    int vec;            // launch tuning: bodies per lane in integrate_free (0 = 16 B per lane)
+    int vec;            // launch tuning (env DMX_VEC): bodies per lane in integrate_free (0 = default, one)
     int min_waves;      // launch tuning (env DMX_MIN_WAVES): waves per SIMD the register allocator must leave room for, 0 = default
-    int tune;           // launch tuning (env DMX_TUNE): experiment bits, 0 = default
     int bp_check;       // safe-zone test of every body's pre-step position (BPC_* bits; any bit = "this tick" for one-tick kernels)
     int ticks;          // integrate_free: ticks taken by one launch with the state held in registers (>= 1)
     uint32_t *bp_flags; // device flags (BPF_*), written when a body has left its safe zone

@@ -259,11 +259,11 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
             T Ad[MAXR], rhs[MAXR], adcfm[MAXR], lam[MAXR];
             // row limits are implied by the row kind: normal rows [0, inf), friction rows [-mu, mu]
             const T lo_f = -P.mu, hi_f = P.mu, hi_n = Limits<T>::inf();
-            V3<T> Ja[MAXR], iMa[MAXR];
+            V3<T> Ja[MAXR], iMa[MAXR], Jl[MAXR];      // Jl = the row's linear Jacobian (its direction) times Ad, as J *= Ad leaves it
 #pragma unroll
             for (int r = 0; r < MAXR; r++) {      // rows of absent contacts stay zero
                 Ad[r] = rhs[r] = adcfm[r] = lam[r] = T(0);
-                Ja[r] = { T(0), T(0), T(0) }; iMa[r] = { T(0), T(0), T(0) };
+                Ja[r] = { T(0), T(0), T(0) }; iMa[r] = { T(0), T(0), T(0) }; Jl[r] = { T(0), T(0), T(0) };
             }
 #pragma unroll
             for (int k = 0; k < MAXC; k++) {
@@ -298,6 +298,7 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
                             const T ad = P.sor_w / (s2 + cfm);
                             Ad[r] = ad;
                             Ja[r] = { ja.x * ad, ja.y * ad, ja.z * ad };
+                            Jl[r] = { dir[dnum].x * ad, dir[dnum].y * ad, dir[dnum].z * ad };
                             iMa[r] = ima;
                             rhs[r] = b * ad;
                             adcfm[r] = ad * cfm;
@@ -330,9 +331,8 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
                             if (dnum < rpc) {
                                 const T old = lam[r];
                                 T delta = fma_(-old, adcfm[r], rhs[r]);
-                                const T ad = Ad[r];
                                 delta -= fma_(fa.z, Ja[r].z, fma_(fa.y, Ja[r].y, fma_(fa.x, Ja[r].x,
-                                         fma_(fl.z, dir[dnum].z * ad, fma_(fl.y, dir[dnum].y * ad, fl.x * (dir[dnum].x * ad))))));
+                                         fma_(fl.z, Jl[r].z, fma_(fl.y, Jl[r].y, fl.x * Jl[r].x)))));
                                 const T nl = old + delta;
                                 T nlam = nl;
                                 if (dnum == 0 || !decltype(FAST)::value) {
