@@ -16,6 +16,7 @@
 #ifndef DMX_ODE_H
 #define DMX_ODE_H
 
+#include <stddef.h>
 #include "common.h"
 
 #ifdef __cplusplus
@@ -175,6 +176,13 @@ void dRtoQ(const dMatrix3 R, dQuaternion q);
  * (main.c:221-237 + GetTransformMat main.c:602-622): fills out[i*16 .. i*16+15]
  * (column-major 4x4) for bodies[i], i < n, in one device pass + one copy. */
 int dmxWorldSnapshotTransforms(dWorldID, const dBodyID *bodies, int n, dReal *out);
+/* The same over the reference's own arrays, in place of the loop main.c:221-237:
+ *   dmxWorldSnapshotBodyStates(world, &bodies[0].body, sizeof(Body), MAX_BODIES,
+ *                              bodyStates[0].transform, sizeof(BodyState));
+ * handles that are 0 (empty slots and static geoms, main.c:228) are skipped, their states left as they are.
+ * Returns the number of transforms written, -1 on error. */
+int dmxWorldSnapshotBodyStates(dWorldID, const void *first_body, size_t body_stride, int n,
+                               void *first_transform, size_t state_stride);
 
 #ifdef __cplusplus
 }

@@ -623,3 +623,27 @@ extern "C" int dmxWorldSnapshotTransforms(dWorldID w, const dBodyID *bodies, int
     }
     return 1;
 }
+
+// The whole of main.c:221-237 in one call: walks the caller's array of body handles (stride body_stride bytes, as in
+// `Body bodies[MAX_BODIES]`, body.h:20-24) and writes each live body's column-major 4x4 into the caller's array of
+// states (stride state_stride bytes, as in `BodyState bodyStates[MAX_BODIES]`, body.h:26-31).  Entries whose handle is
+// 0 (empty slots, static geoms: main.c:228) are left untouched.  Returns the number of transforms written, -1 on error.
+extern "C" int dmxWorldSnapshotBodyStates(dWorldID w, const void *first_body, size_t body_stride, int n,
+                                          void *first_transform, size_t state_stride)
+{
+    if (!w || !first_body || !first_transform || n < 0 || body_stride < sizeof(dBodyID) || state_stride < 16 * sizeof(dReal))
+        return -1;
+    w->to_device();
+    w->buf.resize((size_t)w->cap * 16);
+    DMX_MUST(dmxBatchDownloadTransforms(w->batch, w->buf.data(), 0, w->cap));
+    int written = 0;
+    for (int i = 0; i < n; i++) {
+        dBodyID b;
+        memcpy(&b, (const char *)first_body + (size_t)i * body_stride, sizeof b);
+        if (!b) continue;
+        if (b->world != w) return -1;
+        memcpy((char *)first_transform + (size_t)i * state_stride, w->buf.data() + (size_t)b->slot * 16, 16 * sizeof(dReal));
+        written++;
+    }
+    return written;
+}

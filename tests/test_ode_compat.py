@@ -210,6 +210,7 @@ def _ode(single=False):
         ("dBodyGetRotation", C.POINTER(real), [P]), ("dBodySetKinematic", None, [P]), ("dBodyAddForce", None, [P, real, real, real]),
         ("dBodySetAngularVel", None, [P, real, real, real]),
         ("dmxWorldSnapshotTransforms", C.c_int, [P, C.POINTER(P), C.c_int, C.POINTER(real)]),
+        ("dmxWorldSnapshotBodyStates", C.c_int, [P, P, C.c_size_t, C.c_int, P, C.c_size_t]),
     ]:
         f = getattr(lib, name); f.restype = res; f.argtypes = args
     return lib, real
@@ -243,6 +244,21 @@ def test_ode_api_forces_kinematic_slot_reuse_and_snapshot():
     R, p = lib.dBodyGetRotation(a), lib.dBodyGetPosition(a)
     assert list(out[:16]) == [R[0], R[4], R[8], 0, R[1], R[5], R[9], 0, R[2], R[6], R[10], 0, p[0], p[1], p[2], 1]
     assert out[16 + 12] == lib.dBodyGetPosition(k)[0]
+    # the same over arrays laid out like the reference's Body[] / BodyState[] (body.h:20-31): strided handles, strided
+    # states, a null handle (static geom / empty slot) skipped and its state left alone
+    class Body(C.Structure):
+        _fields_ = [("body", C.c_void_p), ("geom", C.c_void_p), ("type", C.c_int)]
+
+    class BodyState(C.Structure):
+        _fields_ = [("type", C.c_int), ("transform", real * 16), ("size", C.c_float * 3), ("col", C.c_ubyte * 4)]
+    bodies = (Body * 3)(Body(a, None, 2), Body(None, None, 2), Body(k, None, 1))
+    states = (BodyState * 3)()
+    states[1].transform[5] = 42.0
+    off = BodyState.transform.offset
+    assert lib.dmxWorldSnapshotBodyStates(w, C.addressof(bodies), C.sizeof(Body), 3,
+                                          C.addressof(states) + off, C.sizeof(BodyState)) == 2
+    assert list(states[0].transform) == list(out[:16]) and list(states[2].transform) == list(out[16:32])
+    assert states[1].transform[5] == 42.0 and states[0].type == 0
     # destroy + create reuses the slot; the new body starts from ODE's defaults
     lib.dBodyDestroy(a)
     n = lib.dBodyCreate(w)
