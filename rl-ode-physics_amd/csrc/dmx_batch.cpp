@@ -76,6 +76,7 @@ extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int dev
     b->cfm = precision == DMX_F32 ? 1e-5 : 1e-10;      // dWorldCreate default per precision [ODE]
     if (const char *v = getenv("DMX_VEC")) b->vec = atoi(v);
     if (const char *v = getenv("DMX_MIN_WAVES")) b->min_waves = atoi(v);
+    b->prof_on = getenv("DMX_HOST_PROFILE") != nullptr;
     int rc = DMX_OK;
     do {
         if (hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = DMX_EHIP; break; }
@@ -111,6 +112,13 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
     if (!b) return DMX_EINVAL;
     (void)hipSetDevice(b->device);
     if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
+    if (b->prof_on) {
+        static const char *names[12] = { "pair search + flag read", "pair list D2H + sort", "narrowphase + counts D2H", "joint list",
+                                         "joints: canonical + union-find", "joints: level schedules", "joints: staging fill",
+                                         "joints: upload + launch", "fused kernel for the rest", "", "", "" };
+        fprintf(stderr, "libode_mi355 host profile (exact ticks: %lld):\n", (long long)b->stat_careful_ticks);
+        for (int k = 0; k < 9; k++) fprintf(stderr, "  %-32s %9.3f ms total\n", names[k], b->prof[k] * 1e3);
+    }
     if (b->slab) (void)hipFree(b->slab);
     if (b->gtype) (void)hipFree(b->gtype);
     if (b->bflags) (void)hipFree(b->bflags);

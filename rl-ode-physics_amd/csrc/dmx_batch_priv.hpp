@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <chrono>
 #include <vector>
 
 #include "../../include/dmx_batch.h"
@@ -51,6 +52,14 @@ struct dmxBatch {
     double mu = __builtin_huge_val(), bounce = 0.2, bounce_vel = 0.1;   // main.c:685-687
     int max_contacts = 8;                               // main.c:675
     bool ext_pending = false;
+    // host scratch of the island grouping, persistent between ticks (dmx_joints.cpp) and of the exact tick (dmx_general.cpp)
+    std::vector<int> sc_parent, sc_island, sc_last, sc_slots;
+    std::vector<int32_t> sc_last_count;         // counting-sort scratch of the pair ordering
+    std::vector<uint8_t> sc_include;            // per slot: 1 while the body is in this tick's island subset
+    const int32_t *sc_include_list = nullptr;   // that subset as an ascending list (set around dmx_step_joints by the exact tick)
+    int64_t sc_include_count = 0;
+    // host-side phase timers of the exact tick (seconds), printed at destroy when DMX_HOST_PROFILE is set
+    double prof[12] = { 0 }; bool prof_on = false;
     int ticks_per_launch = 1;        // contact-free ticks fused into one integrate_free launch (dmxBatchSetTicksPerLaunch)
     int min_waves = 0;               // DMX_MIN_WAVES launch-tuning override (see StepParams)
     int vec = 0;                     // DMX_VEC launch-tuning override (bodies per lane in integrate_free), 0 = default (1)
@@ -85,6 +94,11 @@ struct dmxBatch {
 };
 
 int dmx_ensure_dev(dmxBatch::DevBuf &d, size_t bytes);
+struct DmxPhase {          // adds the scope's wall time to b->prof[k]
+    dmxBatch *b; int k; std::chrono::steady_clock::time_point t0;
+    DmxPhase(dmxBatch *bb, int kk) : b(bb), k(kk) { if (b->prof_on) t0 = std::chrono::steady_clock::now(); }
+    ~DmxPhase() { if (b->prof_on) b->prof[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 // contact geometry that already lives on the device (device narrowphase): joint k's pos/normal/depth are entry src[k]
 struct DevGeometry { const void *pos, *normal, *depth; const int32_t *src; };
 int dmx_step_joints(dmxBatch *b, double h, int64_t n_joints, const dmxContactJoint *joints, const uint8_t *include,

@@ -14,6 +14,7 @@
 // Both modes give the same bits as the sequential CPU oracle.
 #include <string.h>
 #include <algorithm>
+#include <memory>
 #include <cmath>
 
 #include "dmx_batch_priv.hpp"
@@ -116,6 +117,26 @@ template <class T> int build_safe_zones(dmxBatch *b)
     return DMX_OK;
 }
 
+// canonical pair order (ascending first body, then second).  Many pairs: counting sort on the first body over the
+// batch's slots, then each body's short run of partners; few: a comparison sort.
+void sort_pairs(std::vector<std::pair<int32_t, int32_t>> &pairs, int64_t n, std::vector<int32_t> &count)
+{
+    const size_t np = pairs.size();
+    if ((int64_t)np * 16 < n) { std::sort(pairs.begin(), pairs.end()); return; }
+    count.assign((size_t)n + 1, 0);
+    for (auto &p : pairs) count[(size_t)p.first + 1]++;
+    for (int64_t i = 0; i < n; i++) count[(size_t)i + 1] += count[(size_t)i];
+    std::vector<std::pair<int32_t, int32_t>> out(np);
+    {
+        std::vector<int32_t> fill(count.begin(), count.end() - 1);
+        for (auto &p : pairs) out[(size_t)fill[(size_t)p.first]++] = p;
+    }
+    for (int64_t i = 0; i < n; i++)
+        if (count[(size_t)i + 1] - count[(size_t)i] > 1)
+            std::sort(out.begin() + count[(size_t)i], out.begin() + count[(size_t)i + 1]);
+    pairs.swap(out);
+}
+
 template <class T> int fused_tick(dmxBatch *b, double h, bool check, const uint8_t *skip)
 {
     StepParams<T> P = dmx_make_params<T>(b, h);
@@ -154,6 +175,7 @@ template <class T> int fused_run(dmxBatch *b, double h, int n, bool ends_only, b
 template <class T> int careful_tick(dmxBatch *b, double h)
 {
     int rc;
+    std::unique_ptr<DmxPhase> ph(new DmxPhase(b, 0));
     if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
     HIP_TRY(hipMemsetAsync(b->bp_inpair.p, 0, (size_t)b->stride, b->stream));
     HIP_TRY(launch_bp_pairs<T>((const T *)b->slab, b->gtype, b->stride, b->n_active, grid_of<T>(b),
@@ -177,6 +199,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     b->stat_pair_ticks++;
 
     // ---- pairs and the bodies in them, canonical order (ascending i, then j) ---------------------------
+    ph.reset(new DmxPhase(b, 1));
     std::vector<int32_t> pr((size_t)2 * np);
     HIP_TRY(hipMemcpyAsync(pr.data(), b->bp_pairs.p, pr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -193,20 +216,35 @@ template <class T> int careful_tick(dmxBatch *b, double h)
         b->last_mixed = false;
         return fused_tick<T>(b, h, false, nullptr);
     }
-    std::sort(pairs.begin(), pairs.end());
+    sort_pairs(pairs, b->n, b->sc_last_count);
     for (auto &p : pairs)
         if (p.first >= b->n_active || p.second >= b->n_active) {
             fprintf(stderr, "libode_mi355: bodies %d and %d touch across two ranks' slabs; an island spanning ranks has to be "
                             "migrated to one owner first\n", p.first, p.second);
             return DMX_ECROSS;
         }
+    // the bodies in pairs, ascending: marks in a per-slot byte array that persists between ticks (all zero outside one)
+    std::vector<uint8_t> &include = b->sc_include;
+    if ((int64_t)include.size() != b->n) include.assign((size_t)b->n, 0);
     std::vector<int32_t> inv;
     inv.reserve((size_t)2 * np);
-    for (auto &p : pairs) { inv.push_back(p.first); inv.push_back(p.second); }
-    std::sort(inv.begin(), inv.end());
-    inv.erase(std::unique(inv.begin(), inv.end()), inv.end());
+    for (auto &p : pairs) {
+        if (!include[(size_t)p.first]) { include[(size_t)p.first] = 1; inv.push_back(p.first); }
+        if (!include[(size_t)p.second]) { include[(size_t)p.second] = 1; inv.push_back(p.second); }
+    }
+    if ((int64_t)inv.size() * 16 > b->n) {       // many: read them back off the marks in slot order
+        inv.clear();
+        for (int64_t s = 0; s < b->n; s++) if (include[(size_t)s]) inv.push_back((int32_t)s);
+    } else {
+        std::sort(inv.begin(), inv.end());
+    }
     const int64_t ninv = (int64_t)inv.size();
+    struct Unmark {                              // the marks go back to zero however this tick ends
+        std::vector<uint8_t> &m; const std::vector<int32_t> &ids;
+        ~Unmark() { for (int32_t id : ids) m[(size_t)id] = 0; }
+    } unmark{ include, inv };
 
+    ph.reset(new DmxPhase(b, 2));
     // ---- device narrowphase: ground-plane contacts of those bodies (4 slots each), then the pairs' contacts
     //      (8 slots each); only the integer counts come back to the host --------------------------------------
     const int base = 4 * (int)ninv;
@@ -231,10 +269,9 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     HIP_TRY(hipMemcpyAsync(cnt.data(), cnt_dev, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
 
+    ph.reset(new DmxPhase(b, 3));
     // ---- the tick's contact joints for those bodies, in creation order: ground-plane contacts by body, then
     //      body pairs (what NearCallback would have created, main.c:674-693).  Geometry is referenced by slot. ----
-    std::vector<uint8_t> include((size_t)b->n, 0);
-    for (int32_t id : inv) include[(size_t)id] = 1;
     std::vector<dmxContactJoint> joints;
     std::vector<int32_t> src;
     auto push = [&](int32_t slot, int32_t b1, int32_t b2) {
@@ -252,8 +289,14 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     const DevGeometry geo = { b->np_pos.p, b->np_normal.p, b->np_depth.p, src.data() };
 
     // ---- islands of the bodies in pairs on the device; everyone else through the fused kernel -------------
-    if ((rc = dmx_step_joints(b, h, (int64_t)joints.size(), joints.data(), include.data(), &geo)) != DMX_OK) return rc;
+    ph.reset();
+    b->sc_include_list = inv.data(); b->sc_include_count = ninv;
+    rc = dmx_step_joints(b, h, (int64_t)joints.size(), joints.data(), include.data(), &geo);
+    b->sc_include_list = nullptr; b->sc_include_count = 0;
+    if (rc != DMX_OK) return rc;
+    ph.reset(new DmxPhase(b, 8));
     if ((rc = fused_tick<T>(b, h, false, (const uint8_t *)b->bp_inpair.p)) != DMX_OK) return rc;
+    ph.reset();
     b->last_islands = false;
     b->last_mixed = true;
     b->stepped_with_plane = true;

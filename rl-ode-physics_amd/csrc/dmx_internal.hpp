@@ -69,6 +69,9 @@ template <class T> struct IslandSet {
     // island index and level count; lev_rows = island-relative row indices grouped by level; crow = first row of a contact
     const int *big; int n_big; const int *big_list; const int *lev_count; const int *lev_off; const int *lev_rows;
     const int *crow;
+    // launch shape of solve_island_wg: bodies of the largest such island (its accumulators go to LDS when they fit) and
+    // the widest level of any schedule (64 lanes per island are enough when no level is wider)
+    int big_max_bodies, big_max_width;
 };
 
 template <class T> struct StepParams {

@@ -328,13 +328,12 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
 }
 
 // ================================================================================ one workgroup per large island
-constexpr int WG = 256;
 constexpr int FC_LDS_BYTES = 48 * 1024;     // islands of up to 2048 (f32) / 1024 (f64) bodies keep their accumulators in LDS
 
-template <class T>
+template <class T, int WG>
 __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const uint8_t *__restrict__ bflags,
                                                       int64_t stride, IslandSet<T> I, StepParams<T> P,
-                                                      StepDiag *__restrict__ diag)
+                                                      StepDiag *__restrict__ diag, int lds_bodies)
 {
     const int isl = I.big_list[blockIdx.x];
     const int tid = threadIdx.x;
@@ -362,8 +361,11 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
     // LDS staging: the only data one level hands to the next is the bodies' constraint-force accumulators (6 reals per
     // body); they live in LDS for the sweeps.  A row's own data does not depend on other rows, so each lane fetches its
     // row of the NEXT level before it works on this one: between two barriers only LDS traffic and arithmetic remain.
-    __shared__ T fc_lds[FC_LDS_BYTES / sizeof(T)];
-    const bool use_lds = (size_t)nb * 6 * sizeof(T) <= (size_t)FC_LDS_BYTES && nlev > 0;    // workgroup-uniform
+    // dynamic LDS, sized by the launch for the largest island in it (small islands must not reserve 48 KB each: that
+    // would cap a CU at three of them)
+    extern __shared__ __align__(16) unsigned char fc_raw[];
+    T *fc_lds = reinterpret_cast<T *>(fc_raw);
+    const bool use_lds = nb <= lds_bodies && nlev > 0;    // workgroup-uniform
     if (use_lds) {
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) fc_lds[6 * k + j] = bs[(size_t)k * BW_COUNT + BW_FC + j];
@@ -427,8 +429,15 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
         const unsigned grid = (unsigned)((I.n_islands + 63) / 64);
         hipLaunchKernelGGL((solve_islands<T>), dim3(grid), dim3(64), 0, st, S, bflags, stride, I, P, diag);
     }
-    if (I.n_big > 0)
-        hipLaunchKernelGGL((solve_island_wg<T>), dim3((unsigned)I.n_big), dim3(WG), 0, st, S, bflags, stride, I, P, diag);
+    if (I.n_big > 0) {
+        const size_t want = (size_t)I.big_max_bodies * 6 * sizeof(T);
+        const int lds_bodies = want <= (size_t)FC_LDS_BYTES ? I.big_max_bodies : 0;     // 0: accumulators stay in HBM/L2
+        const size_t lds = (size_t)lds_bodies * 6 * sizeof(T);
+        if (I.big_max_width <= 64)      // no level has more than 64 rows: one wavefront per island, barriers cost nothing
+            hipLaunchKernelGGL((solve_island_wg<T, 64>), dim3((unsigned)I.n_big), dim3(64), lds, st, S, bflags, stride, I, P, diag, lds_bodies);
+        else
+            hipLaunchKernelGGL((solve_island_wg<T, 256>), dim3((unsigned)I.n_big), dim3(256), lds, st, S, bflags, stride, I, P, diag, lds_bodies);
+    }
     return hipGetLastError();
 }
 

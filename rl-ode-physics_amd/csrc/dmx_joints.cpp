@@ -6,6 +6,7 @@
 // (islands by lowest slot, bodies ascending, joints in creation order), copy the arrays to the device and
 // launch solve_islands.  All arithmetic of the step runs on the GPU.
 #include <string.h>
+#include <memory>
 #include <numeric>
 
 #include "dmx_batch_priv.hpp"
@@ -22,9 +23,11 @@ int big_island_rows()
     return v;
 }
 
+// union-find over body slots on a parent array that persists between ticks (identity outside a tick: only the entries
+// a tick touched are put back, so a tick costs O(bodies involved), not O(bodies of the batch))
 struct UnionFind {
-    std::vector<int> p;
-    explicit UnionFind(size_t n) : p(n) { std::iota(p.begin(), p.end(), 0); }
+    std::vector<int> &p;
+    explicit UnionFind(std::vector<int> &parent) : p(parent) {}
     int find(int x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
     void unite(int a, int b) { a = find(a); b = find(b); if (a != b) { if (a < b) p[b] = a; else p[a] = b; } }
 };
@@ -44,10 +47,17 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
                                      const uint8_t *include, const DevGeometry *geo)
 {
     const int n = (int)b->n;
+    // per-slot scratch that persists between ticks: parent = identity, island = -1, last = -1 outside a tick
+    if ((int)b->sc_parent.size() != n) {
+        b->sc_parent.resize((size_t)n); std::iota(b->sc_parent.begin(), b->sc_parent.end(), 0);
+        b->sc_island.assign((size_t)n, -1);
+        b->sc_last.assign((size_t)n, -1);
+    }
     // previous tick's async copies read the pinned staging buffers: drain before refilling
     HIP_TRY(hipStreamSynchronize(b->stream));
 
     // ---- canonical joints: body1 is a live dynamic slot, normal points into it -----------------------
+    std::unique_ptr<DmxPhase> ph(new DmxPhase(b, 4));
     struct CJ { int b1, b2; const dmxContactJoint *j; bool rev; };
     std::vector<CJ> cj;
     cj.reserve((size_t)nj_in);
@@ -64,20 +74,26 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     }
     const int nc = (int)cj.size();
 
+    // ---- the bodies this tick steps, ascending: the caller's subset (`include`, with its list) or every live slot ----
+    std::vector<int> &slots = b->sc_slots;
+    slots.clear();
+    if (include && b->sc_include_list) slots.assign(b->sc_include_list, b->sc_include_list + b->sc_include_count);
+    else for (int s = 0; s < n; s++) if (live(s)) slots.push_back(s);
+    const int nlive = (int)slots.size();
+
     // ---- islands ----------------------------------------------------------------------------------------
-    UnionFind uf((size_t)n);
+    UnionFind uf(b->sc_parent);
     for (const CJ &c : cj) if (c.b2 >= 0) uf.unite(c.b1, c.b2);
-    std::vector<int> island_of((size_t)n, -1);
-    int ni = 0, nlive = 0;
-    for (int s = 0; s < n; s++) {
-        if (!live(s)) continue;
-        nlive++;
+    std::vector<int> &island_of = b->sc_island;
+    int ni = 0;
+    for (int s : slots) {
         const int r = uf.find(s);             // roots are the lowest slot of their component
         if (r == s) island_of[(size_t)s] = ni++;
     }
-    for (int s = 0; s < n; s++)
-        if (live(s) && island_of[(size_t)s] < 0) island_of[(size_t)s] = island_of[(size_t)uf.find(s)];
+    for (int s : slots)
+        if (island_of[(size_t)s] < 0) island_of[(size_t)s] = island_of[(size_t)uf.find(s)];
 
+    ph.reset(new DmxPhase(b, 5));
     // ---- which islands are large enough for a workgroup, and their level schedules (integers only) ------------
     // contacts are not yet in island order here; gather per-island contact lists in creation order first
     std::vector<int> con_start((size_t)ni + 1, 0);
@@ -90,8 +106,12 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     }
     std::vector<int> crow_h((size_t)nc, 0);           // island-relative first row of each (sorted) contact
     std::vector<int> big_h((size_t)ni, -1), big_list_h, lev_count_h, lev_off_h, lev_rows_h;
+    int big_max_bodies = 0, big_max_width = 0;
+    std::vector<int> island_bodies((size_t)ni, 0);
+    for (int s : slots) island_bodies[(size_t)island_of[(size_t)s]]++;
     {
-        std::vector<int> last((size_t)n, -1);         // per slot: level of the latest row touching the body
+        std::vector<int> &last = b->sc_last;          // per slot: level of the latest row touching the body
+        std::vector<int> lvl, cnt, f;                 // reused from island to island
         for (int i = 0; i < ni; i++) {
             int m = 0;
             for (int d = con_start[(size_t)i]; d < con_start[(size_t)i + 1]; d++) {
@@ -100,7 +120,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
             }
             if (m < big_island_rows()) continue;
             // row r's level = 1 + the latest level of an earlier row sharing a body with it
-            std::vector<int> lvl((size_t)m);
+            lvl.resize((size_t)m);
             int nlev = 0, r = 0;
             for (int d = con_start[(size_t)i]; d < con_start[(size_t)i + 1]; d++) {
                 const CJ &c = cj[(size_t)con_sorted[(size_t)d]];
@@ -120,20 +140,23 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
                 last[(size_t)c.b1] = -1;
                 if (c.b2 >= 0) last[(size_t)c.b2] = -1;
             }
+            big_max_bodies = std::max(big_max_bodies, island_bodies[(size_t)i]);
             big_h[(size_t)i] = (int)lev_off_h.size();
             big_list_h.push_back(i);
             lev_count_h.push_back(nlev);
             const int base = (int)lev_rows_h.size();
-            std::vector<int> cnt((size_t)nlev + 1, 0);
+            cnt.assign((size_t)nlev + 1, 0);
             for (int q = 0; q < m; q++) cnt[(size_t)lvl[(size_t)q] + 1]++;
+            for (int q = 1; q <= nlev; q++) big_max_width = std::max(big_max_width, cnt[(size_t)q]);
             for (int q = 0; q < nlev; q++) cnt[(size_t)q + 1] += cnt[(size_t)q];
             for (int q = 0; q <= nlev; q++) lev_off_h.push_back(base + cnt[(size_t)q]);
             lev_rows_h.resize((size_t)base + m);
-            std::vector<int> f(cnt.begin(), cnt.end() - 1);
+            f.assign(cnt.begin(), cnt.end() - 1);
             for (int q = 0; q < m; q++) lev_rows_h[(size_t)base + f[(size_t)lvl[(size_t)q]]++] = q;
         }
     }
     const int n_big = (int)big_list_h.size();
+    ph.reset(new DmxPhase(b, 6));
 
     // int staging: body_off[ni+1] bodies[nlive] con_off[ni+1] row_off[ni+1] cb1[nc] cb2[nc] cmode[nc] csrc[nc] crow[nc]
     //              big[ni] big_list[n_big] lev_count[n_big] lev_off[..] lev_rows[..]
@@ -161,13 +184,13 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     // counting sort of bodies and joints by island (stable: ascending slots / creation order)
     memset(body_off, 0, (size_t)(ni + 1) * sizeof(int));
     memset(con_off, 0, (size_t)(ni + 1) * sizeof(int));
-    for (int s = 0; s < n; s++) if (island_of[(size_t)s] >= 0) body_off[island_of[(size_t)s] + 1]++;
+    for (int s : slots) body_off[island_of[(size_t)s] + 1]++;
     for (const CJ &c : cj) con_off[island_of[(size_t)c.b1] + 1]++;
     for (int i = 0; i < ni; i++) { body_off[i + 1] += body_off[i]; con_off[i + 1] += con_off[i]; }
     for (int i = 0; i <= ni; i++) row_off[i] = 3 * con_off[i];
     {
         std::vector<int> fill(body_off, body_off + ni);
-        for (int s = 0; s < n; s++) if (island_of[(size_t)s] >= 0) bodies[fill[(size_t)island_of[(size_t)s]]++] = s;
+        for (int s : slots) bodies[fill[(size_t)island_of[(size_t)s]]++] = s;
         std::vector<int> cfill(con_off, con_off + ni);
         for (const CJ &c : cj) {
             const int d = cfill[(size_t)island_of[(size_t)c.b1]]++;
@@ -184,7 +207,10 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
         }
     }
 
+    for (int s : slots) { b->sc_parent[(size_t)s] = s; island_of[(size_t)s] = -1; }     // scratch back to its idle state
+
     // ---- device buffers -----------------------------------------------------------------------------------
+    ph.reset(new DmxPhase(b, 7));
     const size_t nrows = (size_t)3 * nc;
     if ((rc = dmx_ensure_dev(b->jd_int, n_int * sizeof(int) + 64)) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->jd_real, n_real * sizeof(T) + 64)) != DMX_OK) return rc;
@@ -205,6 +231,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     I.crow = I.cmode + 2 * (size_t)nc;
     I.big = I.crow + nc; I.n_big = n_big; I.big_list = I.big + ni; I.lev_count = I.big_list + n_big;
     I.lev_off = I.lev_count + n_big; I.lev_rows = I.lev_off + lev_off_h.size();
+    I.big_max_bodies = big_max_bodies; I.big_max_width = big_max_width;
     I.gpos = geo ? (const T *)geo->pos : nullptr; I.gnormal = geo ? (const T *)geo->normal : nullptr;
     I.gdepth = geo ? (const T *)geo->depth : nullptr;
     I.cpos = dr; I.cnormal = dr + 3 * (size_t)nc; I.cdepth = I.cnormal + 3 * (size_t)nc; I.cmu = I.cdepth + nc;
