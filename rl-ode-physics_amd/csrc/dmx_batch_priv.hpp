@@ -5,7 +5,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <algorithm>
 #include <chrono>
+#include <functional>
+#include <thread>
 #include <vector>
 
 #include "../../include/dmx_batch.h"
@@ -55,6 +58,8 @@ struct dmxBatch {
     // host scratch of the island grouping, persistent between ticks (dmx_joints.cpp) and of the exact tick (dmx_general.cpp)
     std::vector<int> sc_parent, sc_island, sc_last, sc_slots;
     std::vector<int32_t> sc_last_count;         // counting-sort scratch of the pair ordering
+    std::vector<dmxContactJoint> sc_joints;     // the exact tick's joint list and, per joint, its narrowphase slot
+    std::vector<int32_t> sc_src;
     std::vector<uint8_t> sc_include;            // per slot: 1 while the body is in this tick's island subset
     const int32_t *sc_include_list = nullptr;   // that subset as an ascending list (set around dmx_step_joints by the exact tick)
     int64_t sc_include_count = 0;
@@ -94,6 +99,26 @@ struct dmxBatch {
 };
 
 int dmx_ensure_dev(dmxBatch::DevBuf &d, size_t bytes);
+// f(begin, end, thread) over contiguous chunks of [0, n) on up to DMX_HOST_THREADS (default: the host's cores, at most 16)
+// threads of a persistent pool (dmx_host_pool.cpp); runs inline when n is below two grains.  The chunks must touch
+// disjoint data.
+namespace dmx { void host_pool_run(int nt, const std::function<void(int)> &f); }
+template <class F> inline void dmx_parallel_for(int64_t n, int64_t grain, F f)
+{
+    static const int max_threads = [] {
+        const char *e = getenv("DMX_HOST_THREADS");
+        int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        return t < 1 ? 1 : (t > 16 ? 16 : t);
+    }();
+    const int nt = (int)std::min<int64_t>(max_threads, n / (grain > 0 ? grain : 1));
+    if (nt <= 1) { if (n > 0) f((int64_t)0, n, 0); return; }
+    const int64_t per = (n + nt - 1) / nt;
+    dmx::host_pool_run(nt, [&](int t) {
+        const int64_t lo = t * per, hi = std::min(n, lo + per);
+        if (lo < hi) f(lo, hi, t);
+    });
+}
+
 struct DmxPhase {          // adds the scope's wall time to b->prof[k]
     dmxBatch *b; int k; std::chrono::steady_clock::time_point t0;
     DmxPhase(dmxBatch *bb, int kk) : b(bb), k(kk) { if (b->prof_on) t0 = std::chrono::steady_clock::now(); }

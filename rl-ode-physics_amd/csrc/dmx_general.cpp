@@ -272,26 +272,37 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     ph.reset(new DmxPhase(b, 3));
     // ---- the tick's contact joints for those bodies, in creation order: ground-plane contacts by body, then
     //      body pairs (what NearCallback would have created, main.c:674-693).  Geometry is referenced by slot. ----
-    std::vector<dmxContactJoint> joints;
-    std::vector<int32_t> src;
-    auto push = [&](int32_t slot, int32_t b1, int32_t b2) {
-        dmxContactJoint j;
+    // offsets first (prefix sums of the counts), then the joints are written in parallel
+    std::vector<int64_t> joff((size_t)ninv + np + 1, 0);
+    for (size_t k = 0; k < cnt.size(); k++) joff[k + 1] = joff[k] + cnt[k];
+    const int64_t njoints = joff.back();
+    std::vector<dmxContactJoint> &joints = b->sc_joints;      // kept at its high-water size: no per-tick zero fill
+    std::vector<int32_t> &src = b->sc_src;
+    if ((int64_t)joints.size() < njoints) { joints.resize((size_t)njoints); src.resize((size_t)njoints); }
+    auto put = [&](int64_t at, int32_t slot, int32_t b1, int32_t b2) {
+        dmxContactJoint &j = joints[(size_t)at];
         memset(&j, 0, sizeof(j));
         j.body1 = b1; j.body2 = b2;
         j.mode = b->surf_mode; j.mu = b->mu; j.bounce = b->bounce; j.bounce_vel = b->bounce_vel;
-        joints.push_back(j);
-        src.push_back(slot);
+        src[(size_t)at] = slot;
     };
-    for (int64_t k = 0; k < ninv; k++)
-        for (int c = 0; c < cnt[(size_t)k]; c++) push(4 * (int32_t)k + c, inv[(size_t)k], -1);
-    for (uint32_t p = 0; p < np; p++)
-        for (int c = 0; c < cnt[(size_t)ninv + p]; c++) push(base + 8 * (int32_t)p + c, pairs[p].first, pairs[p].second);
+    dmx_parallel_for(ninv + (int64_t)np, 4096, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t k = lo; k < hi; k++) {
+            if (k < ninv) {
+                for (int c = 0; c < cnt[(size_t)k]; c++) put(joff[(size_t)k] + c, 4 * (int32_t)k + c, inv[(size_t)k], -1);
+            } else {
+                const int64_t p = k - ninv;
+                for (int c = 0; c < cnt[(size_t)k]; c++)
+                    put(joff[(size_t)k] + c, base + 8 * (int32_t)p + c, pairs[(size_t)p].first, pairs[(size_t)p].second);
+            }
+        }
+    });
     const DevGeometry geo = { b->np_pos.p, b->np_normal.p, b->np_depth.p, src.data() };
 
     // ---- islands of the bodies in pairs on the device; everyone else through the fused kernel -------------
     ph.reset();
     b->sc_include_list = inv.data(); b->sc_include_count = ninv;
-    rc = dmx_step_joints(b, h, (int64_t)joints.size(), joints.data(), include.data(), &geo);
+    rc = dmx_step_joints(b, h, njoints, joints.data(), include.data(), &geo);
     b->sc_include_list = nullptr; b->sc_include_count = 0;
     if (rc != DMX_OK) return rc;
     ph.reset(new DmxPhase(b, 8));

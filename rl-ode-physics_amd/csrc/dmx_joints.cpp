@@ -110,49 +110,85 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     std::vector<int> island_bodies((size_t)ni, 0);
     for (int s : slots) island_bodies[(size_t)island_of[(size_t)s]]++;
     {
-        std::vector<int> &last = b->sc_last;          // per slot: level of the latest row touching the body
-        std::vector<int> lvl, cnt, f;                 // reused from island to island
-        for (int i = 0; i < ni; i++) {
-            int m = 0;
-            for (int d = con_start[(size_t)i]; d < con_start[(size_t)i + 1]; d++) {
-                crow_h[(size_t)d] = m;
-                m += cj[(size_t)con_sorted[(size_t)d]].j->mu > 0 ? 3 : 1;
-            }
-            if (m < big_island_rows()) continue;
-            // row r's level = 1 + the latest level of an earlier row sharing a body with it
-            lvl.resize((size_t)m);
-            int nlev = 0, r = 0;
-            for (int d = con_start[(size_t)i]; d < con_start[(size_t)i + 1]; d++) {
-                const CJ &c = cj[(size_t)con_sorted[(size_t)d]];
-                const int rpc = c.j->mu > 0 ? 3 : 1;
-                for (int q = 0; q < rpc; q++, r++) {
-                    int lv = last[(size_t)c.b1];
-                    if (c.b2 >= 0 && last[(size_t)c.b2] > lv) lv = last[(size_t)c.b2];
-                    lv += 1;
-                    lvl[(size_t)r] = lv;
-                    last[(size_t)c.b1] = lv;
-                    if (c.b2 >= 0) last[(size_t)c.b2] = lv;
-                    if (lv + 1 > nlev) nlev = lv + 1;
+        // Islands are independent, so every per-island pass below is spread over the host's cores (dmx_parallel_for).
+        // (1) rows per island and each contact's first row
+        std::vector<int> m_of((size_t)ni, 0);
+        dmx_parallel_for(ni, 512, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t i = lo; i < hi; i++) {
+                int m = 0;
+                for (int d = con_start[(size_t)i]; d < con_start[(size_t)i + 1]; d++) {
+                    crow_h[(size_t)d] = m;
+                    m += cj[(size_t)con_sorted[(size_t)d]].j->mu > 0 ? 3 : 1;
                 }
+                m_of[(size_t)i] = m;
             }
-            for (int d = con_start[(size_t)i]; d < con_start[(size_t)i + 1]; d++) {      // reset for the next island
-                const CJ &c = cj[(size_t)con_sorted[(size_t)d]];
-                last[(size_t)c.b1] = -1;
-                if (c.b2 >= 0) last[(size_t)c.b2] = -1;
-            }
-            big_max_bodies = std::max(big_max_bodies, island_bodies[(size_t)i]);
-            big_h[(size_t)i] = (int)lev_off_h.size();
+        });
+        // (2) the islands that get a workgroup, and where their rows sit in the flat arrays
+        std::vector<int> row_base;
+        int rows_total = 0;
+        for (int i = 0; i < ni; i++) {
+            if (m_of[(size_t)i] < big_island_rows()) continue;
             big_list_h.push_back(i);
-            lev_count_h.push_back(nlev);
-            const int base = (int)lev_rows_h.size();
-            cnt.assign((size_t)nlev + 1, 0);
-            for (int q = 0; q < m; q++) cnt[(size_t)lvl[(size_t)q] + 1]++;
-            for (int q = 1; q <= nlev; q++) big_max_width = std::max(big_max_width, cnt[(size_t)q]);
-            for (int q = 0; q < nlev; q++) cnt[(size_t)q + 1] += cnt[(size_t)q];
-            for (int q = 0; q <= nlev; q++) lev_off_h.push_back(base + cnt[(size_t)q]);
-            lev_rows_h.resize((size_t)base + m);
-            f.assign(cnt.begin(), cnt.end() - 1);
-            for (int q = 0; q < m; q++) lev_rows_h[(size_t)base + f[(size_t)lvl[(size_t)q]]++] = q;
+            row_base.push_back(rows_total);
+            rows_total += m_of[(size_t)i];
+            big_max_bodies = std::max(big_max_bodies, island_bodies[(size_t)i]);
+        }
+        const int nbig = (int)big_list_h.size();
+        // (3) row r's level = 1 + the latest level of an earlier row sharing a body with it (creation order)
+        std::vector<int> lvl((size_t)rows_total);
+        lev_count_h.assign((size_t)nbig, 0);
+        std::vector<int> &last = b->sc_last;          // per slot: level of the latest row touching the body; islands own disjoint slots
+        dmx_parallel_for(nbig, 64, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t k = lo; k < hi; k++) {
+                const int i = big_list_h[(size_t)k];
+                int *lv_out = lvl.data() + row_base[(size_t)k];
+                int nlev = 0, r = 0;
+                for (int d = con_start[(size_t)i]; d < con_start[(size_t)i + 1]; d++) {
+                    const CJ &c = cj[(size_t)con_sorted[(size_t)d]];
+                    const int rpc = c.j->mu > 0 ? 3 : 1;
+                    for (int q = 0; q < rpc; q++, r++) {
+                        int lv = last[(size_t)c.b1];
+                        if (c.b2 >= 0 && last[(size_t)c.b2] > lv) lv = last[(size_t)c.b2];
+                        lv += 1;
+                        lv_out[r] = lv;
+                        last[(size_t)c.b1] = lv;
+                        if (c.b2 >= 0) last[(size_t)c.b2] = lv;
+                        if (lv + 1 > nlev) nlev = lv + 1;
+                    }
+                }
+                for (int d = con_start[(size_t)i]; d < con_start[(size_t)i + 1]; d++) {      // back to the idle state
+                    const CJ &c = cj[(size_t)con_sorted[(size_t)d]];
+                    last[(size_t)c.b1] = -1;
+                    if (c.b2 >= 0) last[(size_t)c.b2] = -1;
+                }
+                lev_count_h[(size_t)k] = nlev;
+            }
+        });
+        // (4) offsets of every island's level table, then (5) its rows grouped by level (counting sort)
+        std::vector<int> off_base((size_t)nbig + 1, 0);
+        for (int k = 0; k < nbig; k++) off_base[(size_t)k + 1] = off_base[(size_t)k] + lev_count_h[(size_t)k] + 1;
+        lev_off_h.assign((size_t)off_base[(size_t)nbig], 0);
+        lev_rows_h.assign((size_t)rows_total, 0);
+        std::vector<int> width_of((size_t)nbig, 0);
+        dmx_parallel_for(nbig, 64, [&](int64_t lo, int64_t hi, int) {
+            std::vector<int> fill;
+            for (int64_t k = lo; k < hi; k++) {
+                const int i = big_list_h[(size_t)k], m = m_of[(size_t)i], nlev = lev_count_h[(size_t)k], base = row_base[(size_t)k];
+                int *off = lev_off_h.data() + off_base[(size_t)k];          // [nlev + 1], absolute positions in lev_rows
+                const int *lv = lvl.data() + base;
+                for (int q = 0; q < m; q++) off[lv[q] + 1]++;
+                int w = 0;
+                for (int q = 1; q <= nlev; q++) w = std::max(w, off[q]);
+                width_of[(size_t)k] = w;
+                off[0] = base;
+                for (int q = 0; q < nlev; q++) off[q + 1] += off[q];
+                fill.assign(off, off + nlev);
+                for (int q = 0; q < m; q++) lev_rows_h[(size_t)fill[(size_t)lv[q]]++] = q;
+            }
+        });
+        for (int k = 0; k < nbig; k++) {
+            big_h[(size_t)big_list_h[(size_t)k]] = off_base[(size_t)k];
+            big_max_width = std::max(big_max_width, width_of[(size_t)k]);
         }
     }
     const int n_big = (int)big_list_h.size();
@@ -191,20 +227,22 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     {
         std::vector<int> fill(body_off, body_off + ni);
         for (int s : slots) bodies[fill[(size_t)island_of[(size_t)s]]++] = s;
-        std::vector<int> cfill(con_off, con_off + ni);
-        for (const CJ &c : cj) {
-            const int d = cfill[(size_t)island_of[(size_t)c.b1]]++;
-            const dmxContactJoint &j = *c.j;
-            cb1[d] = c.b1; cb2[d] = c.b2; cmode[d] = j.mode;
-            csrc[d] = geo ? geo->src[(size_t)(c.j - joints)] : 0;
-            for (int k = 0; k < 3; k++) {
-                cpos[3 * (size_t)d + k] = (T)j.pos[k];
-                const T nk = (T)j.normal[k];
-                cnormal[3 * (size_t)d + k] = c.rev ? -nk : nk;
+        // contact d of the island-ordered arrays is joint con_sorted[d] (stable counting sort above): fill in parallel
+        dmx_parallel_for(nc, 8192, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t d = lo; d < hi; d++) {
+                const CJ &c = cj[(size_t)con_sorted[(size_t)d]];
+                const dmxContactJoint &j = *c.j;
+                cb1[d] = c.b1; cb2[d] = c.b2; cmode[d] = j.mode;
+                csrc[d] = geo ? geo->src[(size_t)(c.j - joints)] : 0;
+                for (int k = 0; k < 3; k++) {
+                    cpos[3 * (size_t)d + k] = (T)j.pos[k];
+                    const T nk = (T)j.normal[k];
+                    cnormal[3 * (size_t)d + k] = c.rev ? -nk : nk;
+                }
+                cdepth[d] = (T)j.depth; cmu[d] = (T)j.mu; cbounce[d] = (T)j.bounce; cbv[d] = (T)j.bounce_vel;
+                cserp[d] = (T)j.soft_erp; cscfm[d] = (T)j.soft_cfm;
             }
-            cdepth[d] = (T)j.depth; cmu[d] = (T)j.mu; cbounce[d] = (T)j.bounce; cbv[d] = (T)j.bounce_vel;
-            cserp[d] = (T)j.soft_erp; cscfm[d] = (T)j.soft_cfm;
-        }
+        });
     }
 
     for (int s : slots) { b->sc_parent[(size_t)s] = s; island_of[(size_t)s] = -1; }     // scratch back to its idle state
