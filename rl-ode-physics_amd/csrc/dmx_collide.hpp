@@ -232,9 +232,56 @@ template <class T> DMX_HD int intersect_rect_quad(const T h[2], const T p[8], T 
 
 }  // namespace detail
 
+// cullPoints [ODE-recall, box.cpp]: of the n clipped 2-D points keep m, point i0 (the deepest) first, the others
+// chosen nearest to m evenly spaced directions about the polygon's centroid.
+DMX_HD float  tatan2(float y, float x)   { return ::atan2f(y, x); }
+DMX_HD double tatan2(double y, double x) { return ::atan2(y, x); }
+template <class T> DMX_HD void cull_points(int n, const T p[], int m, int i0, int iret[])
+{
+    T a, cx, cy, q;
+    if (n == 1) { cx = p[0]; cy = p[1]; }
+    else if (n == 2) { cx = T(0.5) * (p[0] + p[2]); cy = T(0.5) * (p[1] + p[3]); }
+    else {
+        a = 0; cx = 0; cy = 0;
+        for (int i = 0; i < n - 1; i++) {
+            q = p[i * 2] * p[i * 2 + 3] - p[i * 2 + 2] * p[i * 2 + 1];
+            a += q;
+            cx += q * (p[i * 2] + p[i * 2 + 2]);
+            cy += q * (p[i * 2 + 1] + p[i * 2 + 3]);
+        }
+        q = p[n * 2 - 2] * p[1] - p[0] * p[n * 2 - 1];
+        a = T(1.0) / (T(3.0) * (a + q));
+        cx = a * (cx + q * (p[n * 2 - 2] + p[0]));
+        cy = a * (cy + q * (p[n * 2 - 1] + p[1]));
+    }
+    T A[8];
+    for (int i = 0; i < n; i++) A[i] = tatan2(p[i * 2 + 1] - cy, p[i * 2] - cx);
+    int avail[8];
+    for (int i = 0; i < n; i++) avail[i] = 1;
+    avail[i0] = 0;
+    iret[0] = i0;
+    int w = 1;
+    const T pi = T(3.14159265358979323846);
+    for (int j = 1; j < m; j++) {
+        a = (T)((T)j * (2 * pi / m) + A[i0]);
+        if (a > pi) a -= 2 * pi;
+        T maxdiff = T(1e9), diff;
+        iret[w] = i0;
+        for (int i = 0; i < n; i++) {
+            if (avail[i]) {
+                diff = tabs(A[i] - a);
+                if (diff > pi) diff = 2 * pi - diff;
+                if (diff < maxdiff) { maxdiff = diff; iret[w] = i; }
+            }
+        }
+        avail[iret[w]] = 0;
+        w++;
+    }
+}
+
 // Returns the contact count; contacts' normal = -(box1 -> box2 separating axis).  maxc >= 8 returns every
-// clipped point (the reference asks for 8, main.c:675); smaller maxc keeps the first maxc in clip order after
-// the deepest one (angular culling of surplus points is not implemented on this path).
+// clipped point (the reference asks for 8, main.c:675); with a smaller maxc the surplus points are culled as ODE does
+// (cullPoints: the deepest one, then the ones nearest to evenly spaced directions about the centroid).
 template <class T>
 DMX_HD int box_box(const V3<T> &p1, const M3<T> &R1, const T side1[3], const V3<T> &p2, const M3<T> &R2,
                    const T side2[3], int maxc_in, ContactPoint<T> *out)
@@ -376,7 +423,11 @@ DMX_HD int box_box(const V3<T> &p1, const M3<T> &R1, const T side1[3], const V3<
         point[cnum] = { center.x + k1 * rb1.x + k2 * rb2.x, center.y + k1 * rb1.y + k2 * rb2.y,
                         center.z + k1 * rb1.z + k2 * rb2.z };
         dep[cnum] = Sa[codeN] - dot(normal2, point[cnum]);
-        if (dep[cnum] >= 0) cnum++;
+        if (dep[cnum] >= 0) {
+            ret[cnum * 2] = ret[j * 2];              // keep the 2-D point with its contact: cull_points reads them
+            ret[cnum * 2 + 1] = ret[j * 2 + 1];
+            cnum++;
+        }
     }
     if (cnum < 1) return 0;
 
@@ -394,19 +445,18 @@ DMX_HD int box_box(const V3<T> &p1, const M3<T> &R1, const T side1[3], const V3<
         }
         return cnum;
     }
-    // fewer contacts wanted than found: deepest first, then clip order
+    // fewer contacts wanted than found: the deepest point, then cullPoints' angular selection
     int i1 = 0;
     T maxdepth = dep[0];
     for (int i = 1; i < cnum; i++) if (dep[i] > maxdepth) { maxdepth = dep[i]; i1 = i; }
-    int w = 0;
-    out[w].pos = { point[i1].x + pa.x, point[i1].y + pa.y, point[i1].z + pa.z };
-    out[w].depth = dep[i1]; out[w].normal = cn; w++;
-    for (int j = 0; j < cnum && w < maxc; j++) {
-        if (j == i1) continue;
-        out[w].pos = { point[j].x + pa.x, point[j].y + pa.y, point[j].z + pa.z };
-        out[w].depth = dep[j]; out[w].normal = cn; w++;
+    int iret[8];
+    cull_points<T>(cnum, ret, maxc, i1, iret);
+    for (int j = 0; j < maxc; j++) {
+        const int k = iret[j];
+        out[j].pos = { point[k].x + pa.x, point[k].y + pa.y, point[k].z + pa.z };
+        out[j].depth = dep[k]; out[j].normal = cn;
     }
-    return w;
+    return maxc;
 }
 
 }  // namespace dmx
