@@ -185,6 +185,26 @@ def test_plane_scene_through_ode_api_matches_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_random_spawns_through_ode_api_match_oracle(tmp_path, seed):
+    """The reference's spawner (main.c:502-521) with other seeds, counts, drop heights and step sizes, in the reference's
+    pen or on a plane, both precisions: poses after the run are the oracle's, bit for bit."""
+    rng = np.random.default_rng(500 + seed)
+    single = bool(seed % 2)
+    n = int(rng.integers(8, 160))
+    use_plane = bool(rng.random() < 0.4)
+    statics = [] if use_plane else pkg.scenes.reference_map()
+    bodies = pkg.scenes.reference_spawn(n, seed=100 + seed, y_range=(1.2, float(rng.uniform(4.0, 25.0))))
+    dt = 1.0 / float(rng.choice([60.0, 120.0]))
+    steps = int(rng.integers(120, 320))
+    exe = _build_harness(str(tmp_path), single)
+    got = _run_harness(exe, _scene_text(dt, steps, use_plane, statics, bodies))
+    ref, ow = _oracle_poses("float32" if single else "float64", dt, steps, use_plane, statics, bodies)
+    assert np.all(np.isfinite(ref))
+    assert np.array_equal(got.astype(ref.dtype), ref), (seed, n, use_plane, dt, steps, np.abs(got - ref).max())
+
+
+@pytest.mark.gpu
 def test_growth_beyond_512_bodies(tmp_path):
     """More bodies than MAX_BODIES (inc/body.h:6): the world's device batch doubles transparently."""
     bodies = pkg.scenes.reference_spawn(700, seed=5, y_range=(2.0, 400.0))
