@@ -301,10 +301,12 @@ template <class T> int careful_tick(dmxBatch *b, double h)
 
     // ---- islands of the bodies in pairs on the device; everyone else through the fused kernel -------------
     ph.reset();
+    const bool ext = b->ext_pending;            // the island step consumes the accumulators of ITS bodies only ...
     b->sc_include_list = inv.data(); b->sc_include_count = ninv;
     rc = dmx_step_joints(b, h, njoints, joints.data(), include.data(), &geo);
     b->sc_include_list = nullptr; b->sc_include_count = 0;
     if (rc != DMX_OK) return rc;
+    b->ext_pending = ext;                       // ... everyone else's are still pending for the fused kernel below
     ph.reset(new DmxPhase(b, 8));
     if ((rc = fused_tick<T>(b, h, false, (const uint8_t *)b->bp_inpair.p)) != DMX_OK) return rc;
     ph.reset();

@@ -101,3 +101,73 @@ def test_random_scene_matches_oracle(seed):
         assert np.array_equal(a, r), (f"seed {seed} {dtype} {name}: max abs diff {np.max(np.abs(a - r))} "
                                       f"at body {int(np.argmax(np.abs(a - r).max(axis=1)))} of {scene.n} (boxes/spheres {nb}); {p}")
     assert w.last_contact_count() == ow.n_contacts()
+
+
+# ----------------------------------------------------------------- random sequences of API calls
+@pytest.mark.parametrize("seed", range(32))
+def test_random_call_sequences_match_oracle(seed):
+    """A random walk over the batch API between steps -- forces and torques on some bodies, bodies teleported or given
+    new velocities, ticks-per-launch changed -- mirrored call for call on the oracle; the state
+    is compared bit for bit after every step.  Exercises the bookkeeping around the kernels: pending accumulators, stale
+    safe zones, chunk lengths, fused launches."""
+    from oracle.orc_ctypes import Oracle
+    rng = np.random.default_rng(7000 + seed)
+    dtype = "float64" if seed % 2 == 0 else "float32"
+    plane = seed % 3 != 0
+    nx, nz = int(rng.integers(6, 14)), int(rng.integers(6, 14))
+    scene = pkg.scenes.box_grid(nx, nz, seed=50 + seed, y_range=(0.8, 8.0), spin=True, box_mass=bool(seed % 4 == 1),
+                                plane=plane).astype(dtype)
+    n = scene.n
+    w = pkg.BatchWorld(n, dtype=dtype)
+    w.load_scene(scene)
+    orc = Oracle(dtype)
+    lib = orc.lib
+    ow = orc.world()
+    if plane:
+        ow.add_plane(*scene.plane)
+    ow.add_boxes(scene.pos, scene.quat, scene.lvel, scene.avel, scene.mass[:, 0], scene.inertia, scene.sides)
+    rt = orc.dtype.type
+
+    def check(tag):
+        w.synchronize()
+        for name, a, r in zip(("pos", "quat", "lvel", "avel"), w.state(), ow.state()):
+            assert np.array_equal(a, r), f"seed {seed} after {tag}: {name} differs by {np.max(np.abs(a - r))}"
+
+    log = []
+    for op_i in range(int(rng.integers(10, 18))):
+        op = int(rng.integers(0, 5))            # 4 = just step
+        if op == 0:                                   # forces / torques on a few bodies, consumed by the next tick
+            ids = rng.choice(n, size=int(rng.integers(1, 6)), replace=False)
+            f = np.zeros((n, 3), orc.dtype); t = np.zeros((n, 3), orc.dtype)
+            f[ids] = rng.uniform(-20, 20, (len(ids), 3)); t[ids] = rng.uniform(-2, 2, (len(ids), 3))
+            w.upload(pkg.batch.FORCE, f); w.upload(pkg.batch.TORQUE, t)
+            for i in ids:
+                lib.orc_body_add_force(ow.w, int(i), rt(f[i, 0]), rt(f[i, 1]), rt(f[i, 2]))
+                lib.orc_body_add_torque(ow.w, int(i), rt(t[i, 0]), rt(t[i, 1]), rt(t[i, 2]))
+            log.append(f"force{list(ids)}")
+        elif op == 1:                                 # teleport some bodies sideways / upwards (zones go stale)
+            pos = w.download(pkg.batch.POS)
+            ids = rng.choice(n, size=int(rng.integers(1, 4)), replace=False)
+            pos[ids] += rng.uniform(-0.3, 0.3, (len(ids), 3)).astype(orc.dtype) + np.array([0, 0.5, 0], orc.dtype)
+            w.upload(pkg.batch.POS, pos)
+            for i in ids:
+                lib.orc_body_set_position(ow.w, int(i), rt(pos[i, 0]), rt(pos[i, 1]), rt(pos[i, 2]))
+            log.append(f"teleport{list(ids)}")
+        elif op == 2:                                 # new velocities, some of them sideways
+            v = w.download(pkg.batch.LVEL)
+            ids = rng.choice(n, size=int(rng.integers(1, 6)), replace=False)
+            v[ids] = rng.uniform(-2, 2, (len(ids), 3)).astype(orc.dtype)
+            w.upload(pkg.batch.LVEL, v)
+            for i in ids:
+                lib.orc_body_set_linear_vel(ow.w, int(i), rt(v[i, 0]), rt(v[i, 1]), rt(v[i, 2]))
+            log.append(f"vel{list(ids)}")
+        elif op == 3:
+            k = int(rng.choice([1, 2, 5, 8, 32]))
+            w.set_ticks_per_launch(k)
+            log.append(f"tpl{k}")
+        steps = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 70]))
+        w.step(H, steps)
+        ow.run(H, steps)
+        log.append(f"step{steps}")
+        check(" ".join(log[-6:]))
+    w.close()
