@@ -59,8 +59,9 @@ static double rd(void)
 
 int main(void)
 {
-    int steps, use_plane, n_static, n_body, i, k, s;
-    double dt;
+    int steps, use_plane, n_static, n_body, i, k, s, up_front, every, readback, created;
+    double dt, sink = 0;
+    struct spawn { int type; dReal size[3], pos[3]; dMatrix3 rm; } *spawn;
     dBodyID *bodies;
     dGeomID *geoms;
 
@@ -90,25 +91,42 @@ int main(void)
     n_body = (int)rd();
     bodies = (dBodyID *)calloc((size_t)n_body + 1, sizeof(dBodyID));
     geoms = (dGeomID *)calloc((size_t)n_body + 1, sizeof(dGeomID));
+    spawn = (struct spawn *)calloc((size_t)n_body + 1, sizeof(struct spawn));
     for (i = 0; i < n_body; i++) {
-        int type = (int)rd();
-        dReal sx = (dReal)rd(), sy = (dReal)rd(), sz = (dReal)rd();
-        dReal px = (dReal)rd(), py = (dReal)rd(), pz = (dReal)rd();
-        dMatrix3 rm;
-        for (k = 0; k < 12; k++) rm[k] = (dReal)rd();
-        bodies[i] = dBodyCreate(world);
-        dBodySetPosition(bodies[i], px, py, pz);
-        dBodySetRotation(bodies[i], rm);
-        geoms[i] = (type == 1) ? dCreateSphere(space, sx) : dCreateBox(space, sx, sy, sz);
-        dGeomSetCategoryBits(geoms[i], CMASK_OBJ);
-        dGeomSetCollideBits(geoms[i], CMASK_OBJ | CMASK_MAP);
-        dGeomSetBody(geoms[i], bodies[i]);
+        spawn[i].type = (int)rd();
+        for (k = 0; k < 3; k++) spawn[i].size[k] = (dReal)rd();
+        for (k = 0; k < 3; k++) spawn[i].pos[k] = (dReal)rd();
+        for (k = 0; k < 12; k++) spawn[i].rm[k] = (dReal)rd();
     }
-
-    for (s = 0; s < steps; s++) {
+    /* HARNESS_SPAWN="m k": the first m bodies exist from the start, then one more every k ticks (the reference spawns
+     * between ticks on a key press, main.c:502-521); HARNESS_READBACK=r: poses of the live bodies are read every r
+     * ticks (the 60 Hz broadcast loop, main.c:221-237).  Unset: everything up front, poses read at the end only. */
+    up_front = n_body; every = 0; readback = 0;
+    if (getenv("HARNESS_SPAWN") && sscanf(getenv("HARNESS_SPAWN"), "%d %d", &up_front, &every) != 2) { up_front = n_body; every = 0; }
+    if (getenv("HARNESS_READBACK")) readback = atoi(getenv("HARNESS_READBACK"));
+    created = 0;
+    for (s = 0; s <= steps; s++) {
+        while (created < n_body && (created < up_front || s == steps || (every > 0 && s >= (created - up_front + 1) * every))) {
+            i = created++;
+            bodies[i] = dBodyCreate(world);
+            dBodySetPosition(bodies[i], spawn[i].pos[0], spawn[i].pos[1], spawn[i].pos[2]);
+            dBodySetRotation(bodies[i], spawn[i].rm);
+            geoms[i] = (spawn[i].type == 1) ? dCreateSphere(space, spawn[i].size[0])
+                                            : dCreateBox(space, spawn[i].size[0], spawn[i].size[1], spawn[i].size[2]);
+            dGeomSetCategoryBits(geoms[i], CMASK_OBJ);
+            dGeomSetCollideBits(geoms[i], CMASK_OBJ | CMASK_MAP);
+            dGeomSetBody(geoms[i], bodies[i]);
+        }
+        if (s == steps) break;
         dSpaceCollide(space, NULL, near_callback);
         dWorldStep(world, (dReal)dt);
         dJointGroupEmpty(contactGroup);
+        if (readback > 0 && (s + 1) % readback == 0)
+            for (i = 0; i < created; i++) {
+                dReal t[16];
+                pack_transform(t, dBodyGetPosition(bodies[i]), dBodyGetRotation(bodies[i]));
+                sink += (double)t[13];
+            }
     }
 
     for (i = 0; i < n_body; i++) {
@@ -124,6 +142,6 @@ int main(void)
     dJointGroupDestroy(contactGroup);
     dWorldDestroy(world);
     dCloseODE();
-    free(bodies); free(geoms);
-    return 0;
+    free(bodies); free(geoms); free(spawn);
+    return sink == 12345.678 ? 1 : 0;
 }

@@ -36,7 +36,7 @@ def _scene_text(dt, steps, use_plane, statics, bodies):
     return "\n".join(lines) + "\n"
 
 
-def _oracle_poses(dtype, dt, steps, use_plane, statics, bodies):
+def _oracle_poses(dtype, dt, steps, use_plane, statics, bodies, up_front=None, every=0):
     from oracle.orc_ctypes import Oracle
     import ctypes as C
     orc = Oracle(dtype)
@@ -51,7 +51,8 @@ def _oracle_poses(dtype, dt, steps, use_plane, statics, bodies):
         lib.orc_geom_set_rotation(ow.w, g, rp)
         lib.orc_geom_set_category_bits(ow.w, g, 0xFFFFFFFE)      # the double SetCategoryBits of main.c:751-752
     ident = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0]
-    for kind, size, pos in bodies:
+
+    def create(kind, size, pos):
         b = lib.orc_body_create(ow.w)
         lib.orc_body_set_position(ow.w, b, *pos)
         _, rp = orc.arr(ident)
@@ -60,7 +61,17 @@ def _oracle_poses(dtype, dt, steps, use_plane, statics, bodies):
         lib.orc_geom_set_category_bits(ow.w, g, 2)
         lib.orc_geom_set_collide_bits(ow.w, g, 3)
         lib.orc_geom_set_body(ow.w, g, b)
-    ow.run(dt, steps)
+
+    # bodies spawn as the harness spawns them (HARNESS_SPAWN): `up_front` at the start, then one every `every` ticks
+    up_front = len(bodies) if up_front is None else up_front
+    created = 0
+    for s in range(steps + 1):
+        while created < len(bodies) and (created < up_front or s == steps
+                                         or (every > 0 and s >= (created - up_front + 1) * every)):
+            create(*bodies[created])
+            created += 1
+        if s < steps:
+            ow.run(dt, 1)
     out = np.zeros((len(bodies), 16), orc.dtype)
     RP = C.POINTER(orc.real)
     for i in range(len(bodies)):
@@ -202,6 +213,27 @@ def test_random_spawns_through_ode_api_match_oracle(tmp_path, seed):
     ref, ow = _oracle_poses("float32" if single else "float64", dt, steps, use_plane, statics, bodies)
     assert np.all(np.isfinite(ref))
     assert np.array_equal(got.astype(ref.dtype), ref), (seed, n, use_plane, dt, steps, np.abs(got - ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_bodies_spawned_between_ticks_and_poses_read_every_frame(tmp_path, seed):
+    """The reference's run-time pattern: bodies are added between ticks (key M, main.c:502-521) and every live body's
+    pose is read each broadcast frame (main.c:221-237) -- host mirrors and device state change hands every tick."""
+    rng = np.random.default_rng(900 + seed)
+    single = bool(seed % 2)
+    n = int(rng.integers(20, 90))
+    up_front, every = int(rng.integers(0, 8)), int(rng.integers(1, 5))
+    steps = (n - up_front) * every + int(rng.integers(5, 60))
+    use_plane = bool(seed % 3 == 0)
+    statics = [] if use_plane else pkg.scenes.reference_map()
+    bodies = pkg.scenes.reference_spawn(n, seed=300 + seed, y_range=(1.2, 6.0))
+    dt = 1.0 / 120.0
+    exe = _build_harness(str(tmp_path), single)
+    got = _run_harness(exe, _scene_text(dt, steps, use_plane, statics, bodies),
+                       env={"HARNESS_SPAWN": f"{up_front} {every}", "HARNESS_READBACK": str(int(rng.integers(1, 4)))})
+    ref, ow = _oracle_poses("float32" if single else "float64", dt, steps, use_plane, statics, bodies, up_front, every)
+    assert np.array_equal(got.astype(ref.dtype), ref), (seed, n, up_front, every, steps, np.abs(got - ref).max())
 
 
 @pytest.mark.gpu
