@@ -21,9 +21,9 @@ def _scene(seed):
     nb = n - nh
     spread = rng.uniform(1.5, 5.0)                    # metres: tight clusters collide at once, loose ones later
     pos = np.stack([rng.uniform(-spread, spread, n), rng.uniform(0.8, 6.0, n), rng.uniform(-spread, spread, n)], axis=1)
-    if nh:
-        pos[nb:, 0] += 40.0                           # hulls have no collider against other bodies: park them aside
-        pos[nb:, 0] += np.arange(nh) * 3.0
+    if nh and seed % 6 != 0:
+        pos[nb:, 0] += 40.0                           # hulls have no collider against other bodies: usually parked aside,
+        pos[nb:, 0] += np.arange(nh) * 3.0            # every other time left in the cluster (they pass through the others)
     axis = rng.normal(size=(n, 3)); axis /= np.linalg.norm(axis, axis=1)[:, None]
     ang = rng.uniform(0, np.pi, n)
     quat = np.concatenate([np.cos(ang / 2)[:, None], axis * np.sin(ang / 2)[:, None]], axis=1)

@@ -613,7 +613,7 @@ def _two_rank_scene(p, nx, rows, speed):
     return scene
 
 
-@pytest.mark.parametrize("speed", [0.1, 3.0])
+@pytest.mark.parametrize("speed", [0.1, 1.0, 3.0])
 def test_two_ranks_share_the_gpu_and_match_the_unsharded_oracle(speed):
     """Two processes, one slab each, one GPU: the whole N>1 loop (geometry sharing, boundary pack, ghost refresh and
     ghost zone checks, collective rollback, exact replay with per-tick exchange) against the oracle stepping the full
@@ -657,10 +657,11 @@ def test_two_ranks_share_the_gpu_and_match_the_unsharded_oracle(speed):
         src = (L.lower if r == 0 else L.upper) + other * L.n
         _compare([a[ghost] for a in state], [a[src] for a in ref])
         assert stats["fast_ticks"] + stats["careful_ticks"] >= steps
+    assert got[0][2] == got[1][2]                          # both ranks issued the same number of exchanges
     if speed > 1.0:
         assert pairs > 0 and got[0][1]["pair_ticks"] + got[1][1]["pair_ticks"] > 0
-        assert got[0][2] == got[1][2] > 4                  # rolled-back chunks replay with an exchange every tick
-    else:
+        assert got[0][2] > 4                               # rolled-back chunks replay with an exchange every tick
+    elif speed < 0.5:
         # quiet chunks exchange once, at their end; a chunk that ends in an exact replay exchanges every tick
         assert got[0][1]["fast_ticks"] >= 64 and got[0][2] == got[1][2] < steps // 2
 
