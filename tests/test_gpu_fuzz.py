@@ -209,3 +209,31 @@ def test_random_call_sequences_match_oracle(seed, one_rank_group):
         import torch
         torch.cuda.set_stream(torch.cuda.default_stream())
     w.close()
+
+
+@pytest.mark.parametrize("dtype,ticks", [("float32", 8), ("float64", 32)])
+def test_sixteen_thousand_drifting_bodies_with_rollbacks(dtype, ticks):
+    """Free flight at a size where chunks grow long (up to 256 ticks, fused launches) while bodies drift sideways into
+    their neighbours: violations inside long chunks, rollbacks, zone rebuilds and exact ticks with hundreds of pairs."""
+    from oracle.orc_ctypes import Oracle
+    scene = pkg.scenes.box_grid(128, 128, seed=77, y_range=(20.0, 26.0), spin=True, box_mass=True, plane=False).astype(dtype)
+    rng = np.random.default_rng(9)
+    scene.lvel[:, 0] = rng.uniform(-0.25, 0.25, scene.n).astype(scene.lvel.dtype)
+    scene.lvel[:, 2] = rng.uniform(-0.25, 0.25, scene.n).astype(scene.lvel.dtype)
+    steps = 400
+    w = pkg.BatchWorld(scene.n, dtype=dtype)
+    w.set_ticks_per_launch(ticks)
+    w.load_scene(scene)
+    w.step(H, steps)
+    w.synchronize()
+    orc = Oracle(dtype)
+    ow = orc.world()
+    ow.add_boxes(scene.pos, scene.quat, scene.lvel, scene.avel, scene.mass[:, 0], scene.inertia, scene.sides)
+    pairs = 0
+    for _ in range(steps):
+        ow.tick(H)
+        pairs += ow.n_body_pairs()
+    for name, a, r in zip(("pos", "quat", "lvel", "avel"), w.state(), ow.state()):
+        assert np.array_equal(a, r), f"{name}: max abs diff {np.max(np.abs(a - r))}"
+    st = w.collision_stats()
+    assert pairs > 100 and st["pair_ticks"] > 0 and st["fast_ticks"] > 0
