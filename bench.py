@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 ranks all on cuda:0 with the collectives staged through gloo: a functional rehearsal of the "
                          "multi-GPU loop on a one-GPU box, not a measurement")
+    ap.add_argument("--ticks-per-launch", type=int, default=1,
+                    help="contact-free ticks fused into one launch for the HEADLINE run (default 1 = one launch per tick; "
+                         "the roofline object then counts one launch's ticks, so frac can exceed 1: temporal reuse)")
     ap.add_argument("--fused-ticks", type=int, default=32,
                     help="also time the contact-free scene with this many ticks per launch (extra 'fused' object; 1 = skip)")
     ap.add_argument("--force-exchange", action="store_true", help="run the exchange path even with one rank (debug)")
@@ -178,6 +181,8 @@ def main():
     if exchanging:
         w.set_active_count(scene.n)         # the slots behind are ghosts of the neighbours' boundary rows
     w.set_gyro_mode(a.gyro)
+    if a.ticks_per_launch > 1:
+        w.set_ticks_per_launch(a.ticks_per_launch)
     collide = not a.no_body_collisions
     if not collide:
         w.set_body_collisions(False)
@@ -236,8 +241,9 @@ def main():
     stats = w.collision_stats()
     total_bodies = scene.n * world
     value = total_bodies * a.steps / dt
-    kernel_s = dev_ms * 1e-3 / a.steps                       # average launch duration, HIP events on the launch stream
-    alg_bytes = BYTES_PER_BODY_STEP[kind] * rsize * scene.n  # per launch (one GPU)
+    tpl = a.ticks_per_launch if (kind == "free" and a.ticks_per_launch > 1) else 1
+    kernel_s = dev_ms * 1e-3 / a.steps * tpl                 # average launch duration, HIP events on the launch stream
+    alg_bytes = BYTES_PER_BODY_STEP[kind] * rsize * scene.n * tpl   # per launch (one GPU): a launch takes tpl ticks
     achieved = alg_bytes / kernel_s / 1e9
     out = {
         "metric": "body-steps/sec at 1M rigid bodies, dt=1/60",
@@ -263,9 +269,10 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kind, a.dtype, scene.n),
                      "kernel": {"free": "integrate_free", "plane": "step_plane", "convex": "np_convex_plane + step_plane<8>"}[kind],
                      "kernel_us": kernel_s * 1e6,
-                     "algorithmic_bytes_per_body_step": BYTES_PER_BODY_STEP[kind] * rsize},
+                     "algorithmic_bytes_per_body_step": BYTES_PER_BODY_STEP[kind] * rsize,
+                     "ticks_per_launch": tpl},
     }
-    if kind == "free" and stepper.exchange is None and a.fused_ticks > 1:
+    if kind == "free" and stepper.exchange is None and a.fused_ticks > 1 and tpl == 1:
         # the same scene and step count with several ticks per launch (state in registers between ticks; results are
         # bit-identical, tests/test_gpu_parity.py).  Reported beside the headline, which stays one launch per tick.
         w.set_ticks_per_launch(a.fused_ticks)
