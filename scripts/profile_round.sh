@@ -14,3 +14,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -- python3 $R/benc
 cd $R
 cat "$(ls -t $O/c5/*/*kernel_stats.csv | head -1)" | cut -c1-200
 tail -1 $O/c5.log | cut -c1-600
+cd /tmp
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c3_fetch -- python3 $R/bench.py --config 3 --steps 40 --warmup 8 --no-cpu-baseline > $O/c3_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c3_write -- python3 $R/bench.py --config 3 --steps 40 --warmup 8 --no-cpu-baseline > $O/c3_write.log 2>&1
+cd $R
+python3 scripts/pmc_traffic.py plane f32 262144 step_plane $O/c3_fetch $O/c3_write $O/hbm_pmc_plane_f32_262144.json
