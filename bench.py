@@ -80,9 +80,12 @@ def cpu_baseline(pkg, scene, dtype, kind, budget_s):
     t = ow.run(H, 2)                                   # probe
     steps = int(max(2, min(2000, budget_s / max(t / 2, 1e-9))))
     t = ow.run(H, steps)
+    import ctypes.util
+    have_ode = ctypes.util.find_library("ode") is not None      # say whether genuine ODE is on this host (it is never faked)
     return {"value": scene.n * steps / t, "unit": "body-steps/s", "cores": 1, "kind": "port",
             "sample": f"{scene.n} bodies x {steps} steps of the same scene ({kind}), oracle/ C restatement "
-                      f"-O2 single thread, {t:.1f} s"}
+                      f"-O2 single thread, {t:.1f} s",
+            "system_libode": have_ode}
 
 
 def cpu_baseline_all_cores(scene, dtype, kind, budget_s):
