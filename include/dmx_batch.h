@@ -10,7 +10,7 @@
  * entry point below names the reference call (file:line) whose per-object
  * loop it replaces.  Plain C, plain pointers and sizes, no framework types.
  *
- * All state lives in HBM as structure-of-arrays; `real` is float (DMX_F32,
+ * All state lives in HBM in one tiled slab (tiles of 64 bodies, see dmxBatchDevicePtr); `real` is float (DMX_F32,
  * ODE dSINGLE) or double (DMX_F64, ODE dDOUBLE) per batch.  Host arrays are
  * array-of-structs, row-major n x k, in the batch's precision.
  *
