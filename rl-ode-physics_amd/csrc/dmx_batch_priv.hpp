@@ -40,7 +40,7 @@ struct dmxBatch {
     size_t n_diag = 0;
     bool last_islands = false;       // which diagnostics the last tick wrote
     StepDiag *diag_host = nullptr;   // pinned
-    void *stage = nullptr;           // device staging for AoS <-> SoA
+    void *stage = nullptr;           // device staging between host-order rows and the tiled slab
     size_t stage_bytes = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void scatter_bodies(T *__restrict__ S, int64_t
     S[slab_ix(c, idx[b])] = in[t];
 }
 
-// AoS (n x k) <-> SoA component arrays, used by upload/download through a staging buffer
+// host-order rows (n x k, array of structs) <-> the slab's component tiles, used by upload/download through a staging buffer
 template <class T>
 __global__ __launch_bounds__(256) void aos_to_soa(T *__restrict__ S, int64_t stride, int comp0, int k,
                                                   int64_t first, int64_t count, const T *__restrict__ aos)
