@@ -15,8 +15,13 @@
 
 namespace dmx {
 
-__device__ __forceinline__ uint32_t cell_hash(int ix, int iz, uint32_t mask)
+// Cell (ix, iz) -> bucket.  Torus form: entry (iz mod rows) * 2^xbits + (ix mod 2^xbits), so a wavefront of bodies
+// adjacent in space looks up adjacent entries (a handful of cache lines instead of one per lookup); cells a whole
+// torus period apart share a bucket, which callers tell apart by the bodies' true cells.  Scenes far longer than
+// wide wrap too often for that; they use the scrambled form (xbits = 0).
+__device__ __forceinline__ uint32_t cell_hash(int ix, int iz, uint32_t mask, int xbits)
 {
+    if (xbits > 0) return ((((uint32_t)iz) << xbits) | ((uint32_t)ix & ((1u << xbits) - 1u))) & mask;
     return ((uint32_t)ix * 73856093u ^ (uint32_t)iz * 19349663u) & mask;
 }
 
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(256) void bp_insert(T *__restrict__ S, const uint8_
     S[slab_ix(C_BPR, i)] = bound_radius<T>(gtype[i], S, stride, i);      // neighbours read this instead of 3 sides + sqrt
     const int ix = (int)floor((double)(S[slab_ix(C_POS + 0, i)] * G.inv_cell));
     const int iz = (int)floor((double)(S[slab_ix(C_POS + 2, i)] * G.inv_cell));
-    const uint32_t h = cell_hash(ix, iz, G.mask);
+    const uint32_t h = cell_hash(ix, iz, G.mask, G.xbits);
     const uint32_t slot = atomicAdd(&G.count[h], 1u);
     if (slot < (uint32_t)G.cap) G.items[(size_t)h * G.cap + slot] = (int32_t)i;
     else atomicOr(&G.flags[BPF_OVERFLOW], 1u);
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uin
         T gap = G.cell - ri - G.r_max;
         for (int dz = -1; dz <= 1; dz++)
             for (int dx = -1; dx <= 1; dx++) {
-                const uint32_t h = cell_hash(ix + dx, iz + dz, G.mask);
+                const uint32_t h = cell_hash(ix + dx, iz + dz, G.mask, G.xbits);
                 uint32_t cnt = G.count[h];
                 if (cnt > (uint32_t)G.cap) cnt = (uint32_t)G.cap;
                 for (uint32_t s = 0; s < cnt; s++) {
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256) void bp_pairs(const T *__restrict__ S, const u
     const int iz = (int)floor((double)(S[slab_ix(C_POS + 2, i)] * G.inv_cell));
     for (int dz = -1; dz <= 1; dz++)
         for (int dx = -1; dx <= 1; dx++) {
-            const uint32_t h = cell_hash(ix + dx, iz + dz, G.mask);
+            const uint32_t h = cell_hash(ix + dx, iz + dz, G.mask, G.xbits);
             uint32_t cnt = G.count[h];
             if (cnt > (uint32_t)G.cap) cnt = (uint32_t)G.cap;
             for (uint32_t s = 0; s < cnt; s++) {

@@ -33,6 +33,7 @@ template <class T> GridParams<T> grid_of(dmxBatch *b)
     G.cell = (T)(2.0 * kSkin * b->bp_rmax);
     G.inv_cell = T(1) / G.cell;
     G.mask = b->bp_mask;
+    G.xbits = b->bp_xbits > 0 ? b->bp_xbits : 0;
     G.cap = b->bp_cap;
     G.count = (uint32_t *)b->bp_count.p;
     G.items = (int32_t *)b->bp_items.p;
@@ -64,6 +65,9 @@ int ensure_buffers(dmxBatch *b)
         while ((int64_t)h < 2 * b->n) h <<= 1;
         b->bp_mask = h - 1;
         b->bp_cap = kBucketCap;
+        int bits = 0;
+        while ((1u << bits) < h) bits++;
+        b->bp_xbits = (bits + 1) / 2;          // a square torus to start with; see grow_buckets
         b->bp_max_pairs = (int)std::min<int64_t>(4 * b->n + 1024, 1 << 24);
     }
     int rc;
@@ -81,6 +85,10 @@ int ensure_buffers(dmxBatch *b)
 // stacked bodies share an (x,z) column: double the bucket capacity when one overflows
 int grow_buckets(dmxBatch *b)
 {
+    if (b->bp_xbits > 0) {                      // the torus wraps this scene onto itself too often: scramble instead
+        b->bp_xbits = 0;
+        return DMX_OK;
+    }
     if (b->bp_cap >= 1024) {
         fprintf(stderr, "libode_mi355: broadphase bucket overflow (> %d bodies in one (x,z) column)\n", b->bp_cap);
         return DMX_ECAPACITY;

@@ -106,6 +106,8 @@ enum : int { BPF_OVERFLOW = 0, BPF_CROWDED = 1, BPF_NPAIRS = 2, BPF_VIOLATION = 
 template <class T> struct GridParams {
     T cell, inv_cell, r_max;
     uint32_t mask;         // table size - 1 (power of two)
+    int xbits;             // > 0: the table is a 2-D torus of 2^xbits columns per row (neighbouring cells are neighbouring
+                           // entries: coalesced lookups); 0: scrambled hash (scenes too elongated for the torus)
     int cap;               // bodies per bucket
     uint32_t *count;       // [mask+1]
     int32_t *items;        // [(mask+1) * cap]
