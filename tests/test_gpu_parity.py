@@ -751,3 +751,13 @@ def test_fused_ticks_apply_external_force_once():
         outs.append(w.state())
     _compare(outs[1], outs[0])
     assert np.allclose(outs[0][2][:, 0], 3.0 * H)          # one tick's worth of impulse (m = 1), whatever the fusion
+
+
+def test_elongated_scene_falls_back_to_the_scrambled_broadphase_table():
+    """4 096 bodies in one row: the torus-addressed broadphase table would wrap the row onto itself dozens of times
+    (bucket overflow), so the batch switches to the scrambled hash; results and the fast path are unaffected."""
+    scene = pkg.scenes.box_grid(4096, 1, seed=31, spin=True, plane=False).astype("float32")
+    w = _gpu_run(scene, "float32", 64)
+    ow = _oracle_run(_orc("float32"), scene, 64)
+    _compare(w.state(), ow.state())
+    assert w.collision_stats()["fast_ticks"] == 64
