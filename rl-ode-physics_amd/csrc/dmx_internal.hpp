@@ -72,6 +72,7 @@ template <class T> struct IslandSet {
     // launch shape of solve_island_wg: bodies of the largest such island (its accumulators go to LDS when they fit) and
     // the widest level of any schedule (64 lanes per island are enough when no level is wider)
     int big_max_bodies, big_max_width;
+    const int *row_level;  // level of every scheduled row, laid out like lev_rows (an island's rows start at its lev_off[0])
 };
 
 template <class T> struct StepParams {

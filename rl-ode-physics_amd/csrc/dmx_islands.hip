@@ -231,7 +231,7 @@ __device__ __forceinline__ void row_load(const T *rows, const int *jb, int i, Ro
     r.row = i;
 }
 
-template <class T>
+template <class T, bool STORE_LAM = true>
 __device__ __forceinline__ T row_sor_lds(T *rows, RowRegs<T> &r, T *fc)
 {
     T *fc1 = fc + 6 * r.l1;
@@ -246,7 +246,7 @@ __device__ __forceinline__ T row_sor_lds(T *rows, RowRegs<T> &r, T *fc)
     if (nl < r.lo) { delta = r.lo - old; r.lam = r.lo; }
     else if (nl > r.hi) { delta = r.hi - old; r.lam = r.hi; }
     else r.lam = nl;
-    rows[(size_t)r.row * RW_COUNT + RW_LAM] = r.lam;
+    if (STORE_LAM) rows[(size_t)r.row * RW_COUNT + RW_LAM] = r.lam;
 #pragma unroll
     for (int j = 0; j < 6; j++) fc1[j] = fma_(delta, r.iMJ[j], fc1[j]);
     if (fc2) {
@@ -366,7 +366,41 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
     extern __shared__ __align__(16) unsigned char fc_raw[];
     T *fc_lds = reinterpret_cast<T *>(fc_raw);
     const bool use_lds = nb <= lds_bodies && nlev > 0;    // workgroup-uniform
-    if (use_lds) {
+    constexpr int RPL = 4;      // rows a lane can own in registers (wavefront-per-island form)
+    if (WG == 64 && use_lds && m <= 64 * RPL) {
+        // Small island, one wavefront: every row is OWNED by a lane for the whole solve (row r by lane r mod 64) and stays
+        // in that lane's registers; a level step is "lanes whose row is in this level update it".  Nothing is fetched
+        // between two barriers but the bodies' accumulators in LDS.
+        for (int k = tid; k < nb; k += WG)
+            for (int j = 0; j < 6; j++) fc_lds[6 * k + j] = bs[(size_t)k * BW_COUNT + BW_FC + j];
+        RowRegs<T> mine[RPL];
+        int my_level[RPL];
+        const int *row_level = I.row_level + lev_off[0];
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+            const int r = tid + 64 * j;
+            my_level[j] = -1;
+            if (r < m) { row_load(rows, jb, r, mine[j]); my_level[j] = row_level[r]; }
+        }
+        __syncthreads();
+        for (int it = 0; it < P.iters; it++) {
+            const bool last = (it == P.iters - 1);
+            for (int lv = 0; lv < nlev; lv++) {
+#pragma unroll
+                for (int j = 0; j < RPL; j++)
+                    if (my_level[j] == lv) {
+                        const T d = row_sor_lds<T, false>(rows, mine[j], fc_lds);
+                        if (last) resid += (double)d;
+                    }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RPL; j++)
+            if (my_level[j] >= 0) rows[(size_t)mine[j].row * RW_COUNT + RW_LAM] = mine[j].lam;
+        for (int k = tid; k < nb; k += WG)
+            for (int j = 0; j < 6; j++) bs[(size_t)k * BW_COUNT + BW_FC + j] = fc_lds[6 * k + j];
+    } else if (use_lds) {
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) fc_lds[6 * k + j] = bs[(size_t)k * BW_COUNT + BW_FC + j];
         __syncthreads();

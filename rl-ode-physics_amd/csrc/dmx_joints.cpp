@@ -105,7 +105,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
         for (int k = 0; k < nc; k++) con_sorted[(size_t)f[(size_t)island_of[(size_t)cj[(size_t)k].b1]]++] = k;
     }
     std::vector<int> crow_h((size_t)nc, 0);           // island-relative first row of each (sorted) contact
-    std::vector<int> big_h((size_t)ni, -1), big_list_h, lev_count_h, lev_off_h, lev_rows_h;
+    std::vector<int> big_h((size_t)ni, -1), big_list_h, lev_count_h, lev_off_h, lev_rows_h, lvl_all;
     int big_max_bodies = 0, big_max_width = 0;
     std::vector<int> island_bodies((size_t)ni, 0);
     for (int s : slots) island_bodies[(size_t)island_of[(size_t)s]]++;
@@ -135,7 +135,8 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
         }
         const int nbig = (int)big_list_h.size();
         // (3) row r's level = 1 + the latest level of an earlier row sharing a body with it (creation order)
-        std::vector<int> lvl((size_t)rows_total);
+        std::vector<int> &lvl = lvl_all;                // row -> level, laid out like lev_rows (island k's rows from row_base[k])
+        lvl.assign((size_t)rows_total, 0);
         lev_count_h.assign((size_t)nbig, 0);
         std::vector<int> &last = b->sc_last;          // per slot: level of the latest row touching the body; islands own disjoint slots
         dmx_parallel_for(nbig, 64, [&](int64_t lo, int64_t hi, int) {
@@ -197,7 +198,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     // int staging: body_off[ni+1] bodies[nlive] con_off[ni+1] row_off[ni+1] cb1[nc] cb2[nc] cmode[nc] csrc[nc] crow[nc]
     //              big[ni] big_list[n_big] lev_count[n_big] lev_off[..] lev_rows[..]
     const size_t n_int = (size_t)3 * (ni + 1) + (size_t)nlive + (size_t)5 * nc + (size_t)ni + (size_t)2 * n_big +
-                         lev_off_h.size() + lev_rows_h.size();
+                         lev_off_h.size() + 2 * lev_rows_h.size();      // ... lev_rows[..] row_level[..]
     // real staging: cpos[3nc] cnormal[3nc] cdepth cmu cbounce cbounce_vel csoft_erp csoft_cfm [nc each]
     const size_t n_real = (size_t)12 * nc;
     int rc;
@@ -213,7 +214,10 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     if (ni) memcpy(big, big_h.data(), (size_t)ni * sizeof(int));
     if (n_big) { memcpy(big_list, big_list_h.data(), (size_t)n_big * sizeof(int)); memcpy(lev_count, lev_count_h.data(), (size_t)n_big * sizeof(int)); }
     if (!lev_off_h.empty()) memcpy(lev_off, lev_off_h.data(), lev_off_h.size() * sizeof(int));
-    if (!lev_rows_h.empty()) memcpy(lev_rows, lev_rows_h.data(), lev_rows_h.size() * sizeof(int));
+    if (!lev_rows_h.empty()) {
+        memcpy(lev_rows, lev_rows_h.data(), lev_rows_h.size() * sizeof(int));
+        memcpy(lev_rows + lev_rows_h.size(), lvl_all.data(), lev_rows_h.size() * sizeof(int));      // row_level, same layout
+    }
     T *cpos = hr, *cnormal = cpos + 3 * (size_t)nc, *cdepth = cnormal + 3 * (size_t)nc, *cmu = cdepth + nc,
       *cbounce = cmu + nc, *cbv = cbounce + nc, *cserp = cbv + nc, *cscfm = cserp + nc;
 
@@ -270,6 +274,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     I.big = I.crow + nc; I.n_big = n_big; I.big_list = I.big + ni; I.lev_count = I.big_list + n_big;
     I.lev_off = I.lev_count + n_big; I.lev_rows = I.lev_off + lev_off_h.size();
     I.big_max_bodies = big_max_bodies; I.big_max_width = big_max_width;
+    I.row_level = I.lev_rows + lev_rows_h.size();
     I.gpos = geo ? (const T *)geo->pos : nullptr; I.gnormal = geo ? (const T *)geo->normal : nullptr;
     I.gdepth = geo ? (const T *)geo->depth : nullptr;
     I.cpos = dr; I.cnormal = dr + 3 * (size_t)nc; I.cdepth = I.cnormal + 3 * (size_t)nc; I.cmu = I.cdepth + nc;
