@@ -9,6 +9,7 @@
 #include <chrono>
 #include <functional>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/dmx_batch.h"
@@ -25,6 +26,9 @@
     } while (0)
 
 using namespace dmx;
+
+// a contact joint in canonical form: body1 a live dynamic slot, normal into it (dmx_joints.cpp)
+struct DmxCanonicalJoint { int b1, b2; const dmxContactJoint *j; bool rev; };
 
 struct dmxBatch {
     int64_t n = 0, stride = 0;
@@ -58,6 +62,11 @@ struct dmxBatch {
     // host scratch of the island grouping, persistent between ticks (dmx_joints.cpp) and of the exact tick (dmx_general.cpp)
     std::vector<int> sc_parent, sc_island, sc_last, sc_slots;
     std::vector<int32_t> sc_last_count;         // counting-sort scratch of the pair ordering
+    std::vector<int> sc_iv[16];                 // work arrays of the island grouping (dmx_joints.cpp)
+    std::vector<int32_t> sc_i32[4];             // ... and of the exact tick (dmx_general.cpp)
+    std::vector<std::pair<int32_t, int32_t>> sc_pairs, sc_pairs2;
+    std::vector<int64_t> sc_joff;
+    std::vector<DmxCanonicalJoint> sc_cj;
     std::vector<dmxContactJoint> sc_joints;     // the exact tick's joint list and, per joint, its narrowphase slot
     std::vector<int32_t> sc_src;
     std::vector<uint8_t> sc_include;            // per slot: 1 while the body is in this tick's island subset

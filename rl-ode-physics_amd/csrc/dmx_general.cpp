@@ -127,16 +127,17 @@ template <class T> int build_safe_zones(dmxBatch *b)
 
 // canonical pair order (ascending first body, then second).  Many pairs: counting sort on the first body over the
 // batch's slots, then each body's short run of partners; few: a comparison sort.
-void sort_pairs(std::vector<std::pair<int32_t, int32_t>> &pairs, int64_t n, std::vector<int32_t> &count)
+void sort_pairs(std::vector<std::pair<int32_t, int32_t>> &pairs, int64_t n, std::vector<int32_t> &count,
+                std::vector<std::pair<int32_t, int32_t>> &out, std::vector<int32_t> &fill)
 {
     const size_t np = pairs.size();
     if ((int64_t)np * 16 < n) { std::sort(pairs.begin(), pairs.end()); return; }
     count.assign((size_t)n + 1, 0);
     for (auto &p : pairs) count[(size_t)p.first + 1]++;
     for (int64_t i = 0; i < n; i++) count[(size_t)i + 1] += count[(size_t)i];
-    std::vector<std::pair<int32_t, int32_t>> out(np);
+    out.resize(np);
     {
-        std::vector<int32_t> fill(count.begin(), count.end() - 1);
+        fill.assign(count.begin(), count.end() - 1);
         for (auto &p : pairs) out[(size_t)fill[(size_t)p.first]++] = p;
     }
     for (int64_t i = 0; i < n; i++)
@@ -208,10 +209,12 @@ template <class T> int careful_tick(dmxBatch *b, double h)
 
     // ---- pairs and the bodies in them, canonical order (ascending i, then j) ---------------------------
     ph.reset(new DmxPhase(b, 1));
-    std::vector<int32_t> pr((size_t)2 * np);
+    std::vector<int32_t> &pr = b->sc_i32[1];       // (work arrays are members of the batch, reused from tick to tick)
+    pr.resize((size_t)2 * np);
     HIP_TRY(hipMemcpyAsync(pr.data(), b->bp_pairs.p, pr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
-    std::vector<std::pair<int32_t, int32_t>> pairs;
+    std::vector<std::pair<int32_t, int32_t>> &pairs = b->sc_pairs;
+    pairs.clear();
     pairs.reserve(np);
     for (uint32_t k = 0; k < np; k++) {
         // a convex body has no collider against another body (ODE's dCollideConvexBox is an empty stub; convex-convex and
@@ -224,7 +227,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
         b->last_mixed = false;
         return fused_tick<T>(b, h, false, nullptr);
     }
-    sort_pairs(pairs, b->n, b->sc_last_count);
+    sort_pairs(pairs, b->n, b->sc_last_count, b->sc_pairs2, b->sc_i32[0]);
     for (auto &p : pairs)
         if (p.first >= b->n_active || p.second >= b->n_active) {
             fprintf(stderr, "libode_mi355: bodies %d and %d touch across two ranks' slabs; an island spanning ranks has to be "
@@ -234,7 +237,8 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     // the bodies in pairs, ascending: marks in a per-slot byte array that persists between ticks (all zero outside one)
     std::vector<uint8_t> &include = b->sc_include;
     if ((int64_t)include.size() != b->n) include.assign((size_t)b->n, 0);
-    std::vector<int32_t> inv;
+    std::vector<int32_t> &inv = b->sc_i32[2];
+    inv.clear();
     inv.reserve((size_t)2 * np);
     for (auto &p : pairs) {
         if (!include[(size_t)p.first]) { include[(size_t)p.first] = 1; inv.push_back(p.first); }
@@ -273,7 +277,8 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     HIP_TRY(launch_np_pairs<T>((const T *)b->slab, b->gtype, b->stride, (const int32_t *)b->np_pairs.p, (int)np,
                                b->max_contacts, base, (T *)b->np_pos.p, (T *)b->np_normal.p, (T *)b->np_depth.p,
                                cnt_dev + ninv, b->stream));
-    std::vector<int32_t> cnt((size_t)ninv + np);
+    std::vector<int32_t> &cnt = b->sc_i32[3];
+    cnt.resize((size_t)ninv + np);
     HIP_TRY(hipMemcpyAsync(cnt.data(), cnt_dev, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
 
@@ -281,7 +286,8 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     // ---- the tick's contact joints for those bodies, in creation order: ground-plane contacts by body, then
     //      body pairs (what NearCallback would have created, main.c:674-693).  Geometry is referenced by slot. ----
     // offsets first (prefix sums of the counts), then the joints are written in parallel
-    std::vector<int64_t> joff((size_t)ninv + np + 1, 0);
+    std::vector<int64_t> &joff = b->sc_joff;
+    joff.assign((size_t)ninv + np + 1, 0);
     for (size_t k = 0; k < cnt.size(); k++) joff[k + 1] = joff[k] + cnt[k];
     const int64_t njoints = joff.back();
     std::vector<dmxContactJoint> &joints = b->sc_joints;      // kept at its high-water size: no per-tick zero fill

@@ -58,8 +58,11 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
 
     // ---- canonical joints: body1 is a live dynamic slot, normal points into it -----------------------
     std::unique_ptr<DmxPhase> ph(new DmxPhase(b, 4));
-    struct CJ { int b1, b2; const dmxContactJoint *j; bool rev; };
-    std::vector<CJ> cj;
+    // (all per-tick work arrays below are members of the batch, reused from tick to tick: tens of MB of fresh
+    // allocations per tick would be handed back to the OS and page-faulted in again every time)
+    typedef DmxCanonicalJoint CJ;
+    std::vector<CJ> &cj = b->sc_cj;
+    cj.clear();
     cj.reserve((size_t)nj_in);
     // `include` (optional) restricts the tick to a subset of bodies: the rest is stepped by the fused kernels
     auto live = [&](int s) { return s >= 0 && s < n && (b->h_bflags[(size_t)s] & BF_ALIVE) && (!include || include[s]); };
@@ -96,23 +99,31 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     ph.reset(new DmxPhase(b, 5));
     // ---- which islands are large enough for a workgroup, and their level schedules (integers only) ------------
     // contacts are not yet in island order here; gather per-island contact lists in creation order first
-    std::vector<int> con_start((size_t)ni + 1, 0);
+    std::vector<int> &con_start = b->sc_iv[0];
+    con_start.assign((size_t)ni + 1, 0);
     for (const CJ &c : cj) con_start[(size_t)island_of[(size_t)c.b1] + 1]++;
     for (int i = 0; i < ni; i++) con_start[(size_t)i + 1] += con_start[(size_t)i];
-    std::vector<int> con_sorted((size_t)nc);          // cj indices grouped by island, creation order inside
+    std::vector<int> &con_sorted = b->sc_iv[1];          // cj indices grouped by island, creation order inside
+    con_sorted.resize((size_t)nc);
     {
-        std::vector<int> f(con_start.begin(), con_start.end() - 1);
+        std::vector<int> &f = b->sc_iv[15];
+        f.assign(con_start.begin(), con_start.end() - 1);
         for (int k = 0; k < nc; k++) con_sorted[(size_t)f[(size_t)island_of[(size_t)cj[(size_t)k].b1]]++] = k;
     }
-    std::vector<int> crow_h((size_t)nc, 0);           // island-relative first row of each (sorted) contact
-    std::vector<int> big_h((size_t)ni, -1), big_list_h, lev_count_h, lev_off_h, lev_rows_h, lvl_all;
+    std::vector<int> &crow_h = b->sc_iv[2];           // island-relative first row of each (sorted) contact
+    crow_h.assign((size_t)nc, 0);
+    std::vector<int> &big_h = b->sc_iv[3], &big_list_h = b->sc_iv[4], &lev_count_h = b->sc_iv[5], &lev_off_h = b->sc_iv[6],
+                     &lev_rows_h = b->sc_iv[7], &lvl_all = b->sc_iv[8];
+    big_h.assign((size_t)ni, -1); big_list_h.clear(); lev_count_h.clear(); lev_off_h.clear(); lev_rows_h.clear(); lvl_all.clear();
     int big_max_bodies = 0, big_max_width = 0;
-    std::vector<int> island_bodies((size_t)ni, 0);
+    std::vector<int> &island_bodies = b->sc_iv[9];
+    island_bodies.assign((size_t)ni, 0);
     for (int s : slots) island_bodies[(size_t)island_of[(size_t)s]]++;
     {
         // Islands are independent, so every per-island pass below is spread over the host's cores (dmx_parallel_for).
         // (1) rows per island and each contact's first row
-        std::vector<int> m_of((size_t)ni, 0);
+        std::vector<int> &m_of = b->sc_iv[10];
+        m_of.assign((size_t)ni, 0);
         dmx_parallel_for(ni, 512, [&](int64_t lo, int64_t hi, int) {
             for (int64_t i = lo; i < hi; i++) {
                 int m = 0;
@@ -124,7 +135,8 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
             }
         });
         // (2) the islands that get a workgroup, and where their rows sit in the flat arrays
-        std::vector<int> row_base;
+        std::vector<int> &row_base = b->sc_iv[11];
+        row_base.clear();
         int rows_total = 0;
         for (int i = 0; i < ni; i++) {
             if (m_of[(size_t)i] < big_island_rows()) continue;
@@ -166,11 +178,13 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
             }
         });
         // (4) offsets of every island's level table, then (5) its rows grouped by level (counting sort)
-        std::vector<int> off_base((size_t)nbig + 1, 0);
+        std::vector<int> &off_base = b->sc_iv[12];
+        off_base.assign((size_t)nbig + 1, 0);
         for (int k = 0; k < nbig; k++) off_base[(size_t)k + 1] = off_base[(size_t)k] + lev_count_h[(size_t)k] + 1;
         lev_off_h.assign((size_t)off_base[(size_t)nbig], 0);
         lev_rows_h.assign((size_t)rows_total, 0);
-        std::vector<int> width_of((size_t)nbig, 0);
+        std::vector<int> &width_of = b->sc_iv[13];
+        width_of.assign((size_t)nbig, 0);
         dmx_parallel_for(nbig, 64, [&](int64_t lo, int64_t hi, int) {
             std::vector<int> fill;
             for (int64_t k = lo; k < hi; k++) {
@@ -229,7 +243,8 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     for (int i = 0; i < ni; i++) { body_off[i + 1] += body_off[i]; con_off[i + 1] += con_off[i]; }
     for (int i = 0; i <= ni; i++) row_off[i] = 3 * con_off[i];
     {
-        std::vector<int> fill(body_off, body_off + ni);
+        std::vector<int> &fill = b->sc_iv[14];
+        fill.assign(body_off, body_off + ni);
         for (int s : slots) bodies[fill[(size_t)island_of[(size_t)s]]++] = s;
         // contact d of the island-ordered arrays is joint con_sorted[d] (stable counting sort above): fill in parallel
         dmx_parallel_for(nc, 8192, [&](int64_t lo, int64_t hi, int) {
