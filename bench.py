@@ -124,6 +124,11 @@ def cpu_baseline_all_cores(scene, dtype, kind, budget_s):
 
 def main():
     a = parse()
+    # stdout carries exactly one line, the JSON: native libraries print banners there (RCCL's version block at
+    # communicator set-up), so fd 1 points at stderr until the result is ready
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -296,6 +301,9 @@ def main():
         allc = cpu_baseline_all_cores(scene, dtype, kind, min(6.0, a.cpu_seconds))
         if allc is not None:
             out["cpu_baseline_all_cores"] = allc
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    os.close(json_fd)
     if rank == 0:
         print(json.dumps(out), flush=True)
     w.close()
