@@ -32,7 +32,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5], help="BASELINE.json configs[] index + 1")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configs[] index + 1 (4 = configs[3]: the configs[1] scene, one 1 Mi-body slab per GPU, i.e. what --gpus N runs; the same as 2)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--side", type=int, default=0, help="grid side (bodies = side^2 per GPU); 0 = config default")
     ap.add_argument("--exchange", default="boundary", choices=["boundary", "none"])
@@ -159,10 +160,11 @@ def main():
 
     dtype = "float32" if a.dtype == "f32" else "float64"
     rsize = np.dtype(dtype).itemsize
-    if a.config == 2:
+    if a.config in (2, 4):
         side = a.side or 1024
         kind = "free"
-        workload = f"configs[1]: {side * side} free-falling boxes per GPU, no contacts, dt=1/60"
+        workload = (f"configs[1]: {side * side} free-falling boxes per GPU, no contacts, dt=1/60"
+                    + (f" (configs[3] layout: {world} disjoint slabs 10 m apart, one per GPU)" if world > 1 or a.config == 4 else ""))
         # every rank draws its own slab with its own seed; slabs are disjoint islands (configs[3] layout)
         scene = pkg.scenes.box_grid(side, side, seed=1 + rank, spin=True, plane=False).astype(dtype)
     elif a.config == 5:
