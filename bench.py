@@ -156,7 +156,9 @@ def main():
         if a.rehearse_on_one_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            import datetime
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(minutes=5))      # a wedged collective fails the run instead of hanging it
 
     dtype = "float32" if a.dtype == "f32" else "float64"
     rsize = np.dtype(dtype).itemsize
