@@ -5,16 +5,18 @@ GPUs as whole islands, one process per GPU.  For the grid scenes rank r owns one
 stacked along z.  The only data a neighbour ever needs is the state of the bodies next to the shared slab
 face (the ones a body-body broadphase on the neighbour can reach): the slab's first and last row.
 
-Every tick each rank
-  1. steps its slab; the step kernel also writes the new 13-real state of the two boundary rows, packed,
+An exchanging tick
+  1. steps the slab; the step kernel also writes the new 13-real state of the two boundary rows, packed,
      into the send buffer                                     (dmxBatchSetBoundaryPack, batch stream)
   2. (hosts without the fused pack, e.g. the CPU test double, gather the rows explicitly)
   3. all-gathers the packed rows over RCCL / xGMI              (torch.distributed, side stream)
-  4. writes its neighbours' rows into its ghost slots          (dmxBatchScatterBodiesOnStream, side stream)
+  4. writes its neighbours' rows into its ghost slots and tests them against their safe zones, in one launch
+                                                               (dmxBatchRefreshGhostsOnStream, side stream)
 Steps 3-4 of tick k run on the side stream while the batch stream already integrates tick k+1: ghost slots
-([n_active, n) of the batch) are never read or written by the step kernels, and the pack of tick k+1 waits for
-exchange k-1 to have drained the (double-buffered) send buffer.  Consumers of ghost state (broadphase rebuild / pair
-search) wait for the in-flight exchange first (`drain()`).
+([n_active, n) of the batch) are never read or written by the step kernels, and a tick's pack waits for the exchange
+that last read its send buffer (a ring of buffers).  Consumers of ghost state (broadphase rebuild / pair search) wait
+for the in-flight exchange first (`drain()`).  Which ticks exchange: every tick, except inside a ballistic chunk of
+the collision-checked loop, where only the chunk's last tick does (see ShardedStepper._fast_ticks).
 
 For slabs farther apart than a broadphase cell (BASELINE configs[3], >= 10 m) the boundary set is empty and
 `exchange="none"` skips steps 2-4.
