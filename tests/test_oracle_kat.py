@@ -318,3 +318,85 @@ def test_grid_and_sweep_broadphase_agree(orc64):
     assert pa == pb > 0
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+# ---------------------------------------------------------------- body-body colliders (closed forms)
+def _pair_contacts(orc, w, g1, g2, maxc=8):
+    cg = (orc.ContactGeom * 16)()
+    n = orc.lib.orc_collide(w.w, g1, g2, maxc, cg)
+    return [(np.array(cg[i].pos[:]), np.array(cg[i].normal[:]), cg[i].depth) for i in range(n)]
+
+
+def test_kat6_sphere_sphere(orc64):
+    # centres 0.7 apart along a slanted axis, radii 0.5 and 0.3: one contact, depth 0.1, normal from sphere 2 to sphere 1
+    axis = np.array([2.0, 1.0, -2.0]) / 3.0
+    p1, p2 = np.array([1.0, 2.0, 3.0]), np.array([1.0, 2.0, 3.0]) - 0.7 * axis
+    w = orc64.world()
+    w.add_spheres([p1, p2], None, None, None, None, None, [0.5, 0.3])
+    c = _pair_contacts(orc64, w, 0, 1)
+    assert len(c) == 1
+    p, n, d = c[0]
+    assert np.allclose(n, axis, atol=1e-15) and abs(d - 0.1) < 1e-15
+    # the contact point lies on the line of centres, inside the overlap lens
+    t = np.dot(p - p2, axis)
+    assert np.allclose(p, p2 + t * axis, atol=1e-15) and 0.2 - 1e-12 <= t <= 0.3 + 1e-12
+    # apart: nothing; swapped: the normal flips
+    w2 = orc64.world()
+    w2.add_spheres([p1, p1 - 0.81 * axis], None, None, None, None, None, [0.5, 0.3])
+    assert _pair_contacts(orc64, w2, 0, 1) == []
+    assert np.allclose(_pair_contacts(orc64, w, 1, 0)[0][1], -axis, atol=1e-15)
+
+
+def test_kat6_sphere_on_a_box_face(orc64):
+    # sphere r = 0.4 whose centre sits 0.35 above the top face of a 2 x 1 x 2 box: depth 0.05, normal +y (into the sphere)
+    w = orc64.world()
+    w.add_spheres([(0.3, 0.85, -0.2)], None, None, None, None, None, [0.4])
+    w.add_boxes([(0.0, 0.0, 0.0)], None, None, None, None, None, [(2.0, 1.0, 2.0)])
+    c = _pair_contacts(orc64, w, 0, 1)
+    assert len(c) == 1
+    p, n, d = c[0]
+    assert np.allclose(n, [0, 1, 0], atol=1e-15) and abs(d - 0.05) < 1e-15
+    assert np.allclose(p[[0, 2]], [0.3, -0.2], atol=1e-15) and 0.45 - 1e-12 <= p[1] <= 0.5 + 1e-12
+    # beyond reach: nothing
+    w2 = orc64.world()
+    w2.add_spheres([(0.3, 0.95, -0.2)], None, None, None, None, None, [0.4])
+    w2.add_boxes([(0.0, 0.0, 0.0)], None, None, None, None, None, [(2.0, 1.0, 2.0)])
+    assert _pair_contacts(orc64, w2, 0, 1) == []
+
+
+def test_kat6_box_box_face_contact(orc64):
+    # two unit cubes, the second shifted 0.9 along x and a little in y, z: the faces overlap by 0.1 -> four contacts at
+    # the corners of the common face region, each 0.1 deep, normal along x pointing into box 1
+    w = orc64.world()
+    w.add_boxes([(0.0, 0.0, 0.0), (0.9, 0.2, -0.1)], None, None, None, None, None, [(1.0, 1.0, 1.0), (1.0, 1.0, 1.0)])
+    c = _pair_contacts(orc64, w, 0, 1)
+    assert len(c) == 4
+    for p, n, d in c:
+        assert np.allclose(n, [-1, 0, 0], atol=1e-15) and abs(d - 0.1) < 1e-12
+    yz = sorted((round(float(p[1]), 9), round(float(p[2]), 9)) for p, _, _ in c)
+    assert yz == [(-0.3, -0.5), (-0.3, 0.4), (0.5, -0.5), (0.5, 0.4)]       # y in [-0.3, 0.5], z in [-0.5, 0.4]
+    # fewer contacts asked than found: the deepest comes first and max_contacts is honoured (ODE's cullPoints)
+    c2 = _pair_contacts(orc64, w, 0, 1, maxc=2)
+    assert len(c2) == 2 and all(abs(d - 0.1) < 1e-12 for _, _, d in c2)
+    # separated by a hair: nothing
+    w2 = orc64.world()
+    w2.add_boxes([(0.0, 0.0, 0.0), (1.0001, 0.2, -0.1)], None, None, None, None, None, [(1.0, 1.0, 1.0), (1.0, 1.0, 1.0)])
+    assert _pair_contacts(orc64, w2, 0, 1) == []
+
+
+def test_kat6_box_box_edge_edge(orc64):
+    # cube 1 axis-aligned; cube 2 turned 45 degrees about x and about z-offset so one of its edges crosses an edge of
+    # cube 1: a single edge-edge contact whose normal is perpendicular to both edges
+    a = math.pi / 4
+    qx = np.array([math.cos(a / 2), math.sin(a / 2), 0, 0])           # cube 2's edge along x sticks down like a roof ridge
+    w = orc64.world()
+    # cube 1 turned 45 degrees about z: its top is a ridge along z.  Ridge heights: sqrt(0.5) each.
+    qz = np.array([math.cos(a / 2), 0, 0, math.sin(a / 2)])
+    gap = 2 * math.sqrt(0.5) - 0.05                                  # ridges overlap by 0.05
+    w.add_boxes([(0.0, 0.0, 0.0), (0.0, gap, 0.0)], [tuple(qz), tuple(qx)], None, None, None, None,
+                [(1.0, 1.0, 1.0), (1.0, 1.0, 1.0)])
+    c = _pair_contacts(orc64, w, 0, 1)
+    assert len(c) == 1
+    p, n, d = c[0]
+    assert np.allclose(np.abs(n), [0, 1, 0], atol=1e-12) and abs(d - 0.05) < 1e-12
+    assert abs(p[0]) < 1e-12 and abs(p[2]) < 1e-12                   # where the two ridges cross
