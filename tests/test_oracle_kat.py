@@ -400,3 +400,39 @@ def test_kat6_box_box_edge_edge(orc64):
     p, n, d = c[0]
     assert np.allclose(np.abs(n), [0, 1, 0], atol=1e-12) and abs(d - 0.05) < 1e-12
     assert abs(p[0]) < 1e-12 and abs(p[2]) < 1e-12                   # where the two ridges cross
+
+
+# ---------------------------------------------------------------- friction rows (closed forms)
+def _sliding_sphere(orc, mu, vx=1.0, radius=0.5):
+    w = orc.world(gravity=(0, 0, 0))
+    orc.lib.orc_world_set_surface(w.w, 0, mu, 0.0, 0.0)          # no bounce
+    w.add_plane(0, 1, 0, 0)
+    w.add_spheres([(0.0, radius, 0.0)], None, [(vx, 0.0, 0.0)], None, None, None, [radius])   # touching, depth 0
+    return w
+
+
+def test_kat7_unbounded_friction_brings_the_contact_point_to_rest(orc64):
+    """mu = dInfinity (the reference's surface, main.c:687): the two friction rows are equality constraints on the
+    contact point's tangential velocity.  Sphere m = I = 1 (dBodyCreate's default), R = 0.5, sliding at 1 m/s: the
+    impulse J = -v / (1/m + R^2/I) = -0.8 leaves v = 0.2, w_z = -0.4 (rolling without slipping), rows decoupled."""
+    w = _sliding_sphere(orc64, float("inf"))
+    w.tick(H)
+    _, _, lvel, avel = w.state()
+    assert abs(lvel[0, 0] - 0.2) < 1e-8 and abs(avel[0, 2] + 0.4) < 1e-8
+    assert abs(lvel[0, 0] + avel[0, 2] * 0.5) < 1e-8                 # contact point at rest: v_x + w_z R = 0
+    assert abs(lvel[0, 1]) < 1e-9 and abs(lvel[0, 2]) < 1e-12 and abs(avel[0, 0]) < 1e-12
+
+
+def test_kat7_bounded_friction_clamps_at_mu(orc64):
+    """finite mu without dContactApprox1: |lambda_friction| <= mu as a FORCE bound [ODE-recall contact getInfo2], so one
+    tick removes at most mu*h of momentum: v = 1 - mu*h/m, w_z = -R*mu*h/I."""
+    mu = 0.3
+    w = _sliding_sphere(orc64, mu)
+    w.tick(H)
+    _, _, lvel, avel = w.state()
+    assert abs(lvel[0, 0] - (1.0 - mu * H)) < 1e-12 and abs(avel[0, 2] + 0.5 * mu * H) < 1e-12
+    # mu = 0: a single (normal) row, the sphere keeps sliding
+    w0 = _sliding_sphere(orc64, 0.0)
+    w0.tick(H)
+    _, _, lvel, avel = w0.state()
+    assert lvel[0, 0] == 1.0 and np.all(avel[0] == 0)
