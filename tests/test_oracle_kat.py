@@ -436,3 +436,27 @@ def test_kat7_bounded_friction_clamps_at_mu(orc64):
     w0.tick(H)
     _, _, lvel, avel = w0.state()
     assert lvel[0, 0] == 1.0 and np.all(avel[0] == 0)
+
+
+# ---------------------------------------------------------------- two dynamic bodies: equal and opposite impulses
+def test_kat8_head_on_spheres_conserve_momentum_and_separate_at_the_row_velocity(orc64):
+    """Two unit-mass spheres (r = 0.5) overlapping by 0.1, closing head-on at 1 m/s each, no gravity, mu = 0, bounce 0.5:
+    the row's target separation speed is max(erp * depth / h, bounce * closing speed) = max(1.2, 1.0) = 1.2, split evenly;
+    linear momentum is conserved to rounding; a glancing hit with friction also conserves it."""
+    w = orc64.world(gravity=(0, 0, 0))
+    orc64.lib.orc_world_set_surface(w.w, oc.CONTACT_BOUNCE, 0.0, 0.5, 0.1)
+    w.add_spheres([(-0.45, 0.0, 0.0), (0.45, 0.0, 0.0)], None, [(1.0, 0.0, 0.0), (-1.0, 0.0, 0.0)], None, None, None, [0.5, 0.5])
+    w.tick(H)
+    assert w.n_contacts() == 1
+    _, _, lvel, avel = w.state()
+    assert abs(lvel[0, 0] + 0.6) < 1e-7 and abs(lvel[1, 0] - 0.6) < 1e-7
+    assert abs(lvel[0, 0] + lvel[1, 0]) < 1e-14 and np.all(avel == 0)
+    # glancing, unequal masses, infinite friction: total momentum m1 v1 + m2 v2 is what it was
+    w = orc64.world(gravity=(0, 0, 0))
+    m = np.array([2.0, 0.5])
+    v = np.array([[0.8, 0.1, 0.0], [-1.0, 0.3, 0.2]])
+    w.add_spheres([(-0.4, 0.1, 0.0), (0.4, -0.2, 0.1)], None, v, None, m, [(0.2, 0.2, 0.2), (0.05, 0.05, 0.05)], [0.5, 0.5])
+    w.tick(H)
+    assert w.n_contacts() == 1
+    _, _, lvel, _ = w.state()
+    assert np.allclose((m[:, None] * lvel).sum(axis=0), (m[:, None] * v).sum(axis=0), rtol=0, atol=1e-13)
