@@ -120,6 +120,21 @@ class BatchWorld:
         if scene.plane is not None:
             self.set_plane(*scene.plane, enable=True)
 
+    # -- checkpoint / resume ---------------------------------------------------------------------------------
+    def checkpoint(self):
+        """Everything a later `restore` needs to continue bit for bit: the 13-real state, the accumulators and the
+        per-body constants (the reference keeps no resumable state -- its 60 Hz snapshot holds poses only, SURVEY
+        section 5 -- so this is new surface, built on Download)."""
+        self.synchronize()
+        return {"state": self.download(STATE), "force": self.download(FORCE), "torque": self.download(TORQUE),
+                "mass": self.download(MASS), "inertia": self.download(INERTIA), "sides": self.download(SIDES)}
+
+    def restore(self, ckpt):
+        self.upload(MASS, ckpt["mass"]); self.upload(INERTIA, ckpt["inertia"]); self.upload(SIDES, ckpt["sides"])
+        self.upload(STATE, ckpt["state"])                    # stored as given: no renormalisation of the quaternions
+        if np.any(ckpt["force"]) or np.any(ckpt["torque"]):
+            self.upload(FORCE, ckpt["force"]); self.upload(TORQUE, ckpt["torque"])
+
     def state(self):
         return (self.download(POS), self.download(QUAT), self.download(LVEL), self.download(AVEL))
 
