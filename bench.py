@@ -4,7 +4,9 @@ One "step" = one tick (collide -> QuickStep -> clear contacts, main.c:211-215)
 over the whole batch of synthetic bodies.  At N=1 the workload is BASELINE.json
 configs[1]: 1 048 576 free-falling boxes, no contacts, dt = 1/60.  With N>1
 every rank owns one such slab of disjoint islands (weak scaling) and exchanges
-the state of its slab-boundary bodies with an RCCL all-gather every step.
+the state of its slab-boundary bodies with an RCCL all-gather -- at the end of
+every collision-proof chunk for these ballistic scenes, every tick otherwise
+or with --exchange-every-tick.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description),
 including `roofline` (HBM, algorithmic bytes / measured kernel time) and
@@ -20,6 +22,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's driver only does dmabuf IPC (RCCL across processes)
 
 H = 1.0 / 60.0
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
