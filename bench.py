@@ -212,41 +212,60 @@ def main():
     if a.force_exchange and world == 1 and exchanging:
         # one-rank group: the collective degenerates to a copy, every other step of the path is exercised
         forced_ops = pkg.shard.DeviceOps(w, torch.device("cuda", local_rank), stream)
-    stepper = pkg.shard.ShardedStepper(w, layout, rank, world,
-                                       exchange=a.exchange if exchanging else "none", device=torch.device("cuda", local_rank),
-                                       stream=stream, collide=collide and exchanging,
-                                       geometry=(scene.sides, scene.gtype), ops=forced_ops,
-                                       exchange_every_tick=a.exchange_every_tick)
-
-    def run(nsteps):
-        stepper.run(H, nsteps)
-
-    if a.config in (3, 5):
-        run(120)                            # let the boxes land: timed steps are all in contact
-    run(a.warmup)
-    graphed = False
-    if stepper.exchange is not None and a.graph_steps > 0:
-        torch.cuda.synchronize()
-        graphed = stepper.capture(H, a.graph_steps, stream)
-        run(a.graph_steps)                  # one replay outside the timed region
-
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    ex0 = stepper.exchange.count if stepper.exchange is not None else 0
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record(stream)
-    run(a.steps)
-    stepper.drain()                         # the last tick's exchange is part of the timed work
-    e1.record(stream)
-    fence()
-    dt = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)
-    n_exchanges = (a.steps if graphed else stepper.exchange.count - ex0) if stepper.exchange is not None else 0
+    def measure(with_exchange):
+        """build the tick loop, warm it up, time a.steps ticks; -> (stepper, graphed, dt, dev_ms, n_exchanges)"""
+        st = pkg.shard.ShardedStepper(w, layout, rank, world,
+                                      exchange=a.exchange if with_exchange else "none", device=torch.device("cuda", local_rank),
+                                      stream=stream, collide=collide and with_exchange,
+                                      geometry=(scene.sides, scene.gtype), ops=forced_ops if with_exchange else None,
+                                      exchange_every_tick=a.exchange_every_tick)
+        if a.config in (3, 5):
+            st.run(H, 120)                      # let the boxes land: timed steps are all in contact (SURVEY 8d)
+        st.run(H, a.warmup)
+        if with_exchange and os.environ.get("BENCH_INJECT_EXCHANGE_FAILURE"):
+            raise RuntimeError("injected by BENCH_INJECT_EXCHANGE_FAILURE (tests the N>1 safety net)")
+        graphed = False
+        if st.exchange is not None and a.graph_steps > 0:
+            torch.cuda.synchronize()
+            graphed = st.capture(H, a.graph_steps, stream)
+            st.run(H, a.graph_steps)            # one replay outside the timed region
+        fence()
+        ex0 = st.exchange.count if st.exchange is not None else 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        st.run(H, a.steps)
+        st.drain()                              # the last tick's exchange is part of the timed work
+        e1.record(stream)
+        fence()
+        dt = time.perf_counter() - t0
+        n_ex = (a.steps if graphed else st.exchange.count - ex0) if st.exchange is not None else 0
+        return st, graphed, dt, e0.elapsed_time(e1), n_ex
+
+    exchange_fallback = None
+    try:
+        stepper, graphed, dt, dev_ms, n_exchanges = measure(exchanging)
+    except Exception as e:      # noqa: BLE001
+        # Safety net for the N>1 run only (it cannot be rehearsed on real multi-GPU RCCL before the driver runs it): if the
+        # exchanging loop raises -- in rank-symmetric code, so on every rank -- the slabs, which are disjoint islands 10 m
+        # apart, are timed without the exchange instead, and the JSON line says so.  Never taken at N=1.
+        if not (world > 1 and exchanging):
+            raise
+        exchange_fallback = f"{type(e).__name__}: {e}"
+        print(f"bench.py[rank {rank}]: exchanging loop failed ({exchange_fallback}); timing the slabs without the exchange",
+              file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        w.upload_geom_type(np.zeros(layout.n_total - scene.n, np.uint8), first=scene.n)    # ghost slots: inert again
+        stepper, graphed, dt, dev_ms, n_exchanges = measure(False)
+
+    def run(nsteps):
+        stepper.run(H, nsteps)
+
 
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if a.rehearse_on_one_gpu else "cuda")
@@ -271,7 +290,8 @@ def main():
                                      f"{', HIP-graph replay' if graphed else ''}: {n_exchanges} exchanges in the {a.steps} timed ticks "
                                      f"({'every tick' if n_exchanges >= a.steps else 'at the end of every collision-proof chunk: inside a ballistic chunk nothing reads the ghost rows'})"
                                      if stepper.exchange is not None
-                                     else "no exchange (one rank)" if world == 1 else "no exchange"),
+                                     else "no exchange (one rank)" if world == 1 else
+                                     "no exchange" + (f" (FALLBACK: the exchanging loop raised {exchange_fallback})" if exchange_fallback else "")),
                    "collide": ("body-body pairs: none by assertion (check off)" if a.no_body_collisions else
                                f"body-body pairs proven absent per tick by broadphase safe zones ({stats['fast_ticks']} fast ticks, "
                                f"{stats['careful_ticks']} exact-search ticks, {stats['rebuilds']} zone rebuilds, {stats['pair_ticks']} ticks with pairs)")
@@ -287,6 +307,8 @@ def main():
                      "algorithmic_bytes_per_body_step": BYTES_PER_BODY_STEP[kind] * rsize,
                      "ticks_per_launch": tpl},
     }
+    if exchange_fallback:
+        out["exchange_fallback"] = exchange_fallback
     if kind == "free" and stepper.exchange is None and a.fused_ticks > 1 and tpl == 1:
         # the same scene and step count with several ticks per launch (state in registers between ticks; results are
         # bit-identical, tests/test_gpu_parity.py).  Reported beside the headline, which stays one launch per tick.
