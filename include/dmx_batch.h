@@ -101,7 +101,9 @@ int dmxBatchSetConvexHull(dmxBatchID b, int32_t n_points, const double *points_x
 /* device address of component c of a field for body 0.  The slab is tiled: bodies are stored in tiles of
  * DMX_SLAB_TILE; inside a tile each of the DMX_SLAB_COMPONENTS components holds DMX_SLAB_TILE consecutive
  * reals, so body i's value sits (i / DMX_SLAB_TILE) * DMX_SLAB_COMPONENTS * DMX_SLAB_TILE + i % DMX_SLAB_TILE
- * reals after the returned address.  dmxBatchStride = bodies the slab is allocated for (a multiple of 256). */
+ * reals after the returned address.  dmxBatchStride = bodies the slab is allocated for (a multiple of 256).
+ * The batch keeps TWO slabs of this layout and the state alternates between them (see dmxBatchSetSnapshotMode): the
+ * address is that of the slab holding the current state and is valid until the next step / chunk call. */
 #define DMX_SLAB_TILE       64
 #define DMX_SLAB_COMPONENTS 30
 void *dmxBatchDevicePtr(dmxBatchID b, int field, int component);
@@ -134,6 +136,13 @@ int dmxBatchStepTimed(dmxBatchID b, double h, int nsteps, float *ms);
  * stats: [0] ticks in fast mode, [1] ticks in exact mode, [2] safe-zone rebuilds, [3] ticks that had body
  * pairs, [4] body pairs in the last tick, [5] crowded bodies at the last rebuild. */
 int dmxBatchSetBodyCollisions(dmxBatchID b, int enable);
+/* How a collision-proof chunk keeps its start state for a rollback.
+ * DMX_SNAPSHOT_PINGPONG (default): the batch owns two slabs; the chunk's first launch reads one and writes the new state
+ * to the other, later launches run in place there, a rollback swaps back -- no copy, no extra HBM traffic.
+ * DMX_SNAPSHOT_COPY: the 13 state components are copied aside at the chunk's start and the state never changes slab --
+ * for callers that replay captured HIP graphs of ticks, which bake the slab's address in.  Not inside a chunk. */
+enum { DMX_SNAPSHOT_PINGPONG = 0, DMX_SNAPSHOT_COPY = 1 };
+int dmxBatchSetSnapshotMode(dmxBatchID b, int mode);
 /* Contact-free ticks (no ground plane) may be taken `ticks` at a time inside one kernel launch, the bodies' state held
  * in registers between them: same arithmetic per tick, same results bit for bit, one read and one write of the state
  * per launch instead of per tick.  Default 1 (one launch per tick); 1..64. */
@@ -144,7 +153,8 @@ int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6]);
  * the library: [zones, snapshot] -> k checked ticks -> one flag read -> commit, or roll back and replay exactly.  A
  * caller that has work of its own between ticks -- the multi-GPU boundary exchange, which refreshes the ghost slots
  * [active count, body count) every tick -- drives the same steps itself:
- *   ChunkBegin   rebuild stale safe zones (ghost slots included), snapshot the state, clear the violation flag;
+ *   ChunkBegin   rebuild stale safe zones (ghost slots included), arm the rollback snapshot (dmxBatchSetSnapshotMode),
+ *                clear the violation flag;
  *                *exact_only = 1 when the fast path may not be used (crowded bodies, pending external forces),
  *                *ballistic = 1 when bodies move on straight horizontal lines, so checking the chunk's first
  *                and last tick proves the ticks between

@@ -23,6 +23,7 @@ BATCH_SYMBOLS = [
     "dmxBatchScatterBodiesOnStream", "dmxBatchSetBoundaryPack",
     "dmxBatchChunkBegin", "dmxBatchChunkTick", "dmxBatchCheckZonesOnStream", "dmxBatchChunkEnd",
     "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream", "dmxBatchSetConvexHull", "dmxBatchChunkTicks", "dmxBatchSetTicksPerLaunch",
+    "dmxBatchSetSnapshotMode",
 ]
 
 _lib = None
@@ -100,5 +101,6 @@ def load():
     sig("dmxBatchSetConvexHull", I, P, C.c_int32, P, C.POINTER(D))
     sig("dmxBatchChunkTicks", I, P, D, I, I, I)
     sig("dmxBatchSetTicksPerLaunch", I, P, I)
+    sig("dmxBatchSetSnapshotMode", I, P, I)
     _lib = lib
     return lib

@@ -17,6 +17,7 @@ _K = {POS: 3, QUAT: 4, LVEL: 3, AVEL: 3, MASS: 1, INERTIA: 3, SIDES: 3, FORCE: 3
 GEOM_NONE, GEOM_SPHERE, GEOM_BOX = 0, 1, 2
 GYRO_OFF, GYRO_EXPLICIT, GYRO_IMPLICIT = 0, 1, 2
 CONTACT_BOUNCE = 0x004
+SNAPSHOT_PINGPONG, SNAPSHOT_COPY = 0, 1
 
 
 class DmxError(RuntimeError):
@@ -169,6 +170,10 @@ class BatchWorld:
 
     def chunk_ticks(self, h, nticks, check_first=True, check_last=True):
         _check(self.lib.dmxBatchChunkTicks(self.h, h, nticks, int(check_first), int(check_last)), "dmxBatchChunkTicks")
+
+    def set_snapshot_mode(self, mode):
+        """SNAPSHOT_PINGPONG (default) / SNAPSHOT_COPY: how a chunk keeps its start state (include/dmx_batch.h)"""
+        _check(self.lib.dmxBatchSetSnapshotMode(self.h, mode), "dmxBatchSetSnapshotMode")
 
     def set_ticks_per_launch(self, ticks):
         _check(self.lib.dmxBatchSetTicksPerLaunch(self.h, ticks), "dmxBatchSetTicksPerLaunch")

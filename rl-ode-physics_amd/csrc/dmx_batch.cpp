@@ -14,6 +14,13 @@
 
 #include "dmx_batch_priv.hpp"
 
+// a chunk dmxBatchStep left open is closed (flag read, rollback + replay if need be) before anything observes or changes the batch
+#define SETTLE(b)                                  \
+    do {                                           \
+        const int rc_settle_ = dmx_settle(b);      \
+        if (rc_settle_ != DMX_OK) return rc_settle_; \
+    } while (0)
+
 static const int k_field_comp0[DMX_NFIELDS] = { C_POS, C_QUAT, C_LVEL, C_AVEL, C_MASS, C_INERTIA, C_SIDES, C_FORCE, C_TORQUE, C_QUAT, C_POS };
 static const int k_field_k[DMX_NFIELDS] = { 3, 4, 3, 3, 1, 3, 3, 3, 3, 4, C_MASS };
 static_assert(C_POS == 0 && C_QUAT == 3 && C_LVEL == 7 && C_AVEL == 10 && C_MASS == 13, "DMX_STATE is components 0..12");
@@ -43,10 +50,12 @@ static_assert(DMX_SLAB_TILE == SLAB_TILE && DMX_SLAB_COMPONENTS == C_COUNT, "inc
 template <class T> static int fill_defaults(dmxBatch *b)
 {
     // every slot, pad included: mass 1, inertia 1 (dBodyCreate default), q = identity
-    HIP_TRY(hipMemsetAsync(b->slab, 0, (size_t)C_COUNT * b->stride * sizeof(T), b->stream));
     const int ones[] = { C_QUAT, C_MASS, C_INERTIA, C_INERTIA + 1, C_INERTIA + 2 };
-    for (int c : ones)
-        HIP_TRY(launch_fill_component<T>((T *)b->slab, c, T(1), b->stride, b->stream));
+    for (void *slab : { b->slab, b->slab_alt }) {
+        HIP_TRY(hipMemsetAsync(slab, 0, (size_t)C_COUNT * b->stride * sizeof(T), b->stream));
+        for (int c : ones)
+            HIP_TRY(launch_fill_component<T>((T *)slab, c, T(1), b->stride, b->stream));
+    }
     HIP_TRY(hipMemsetAsync(b->gtype, 0, (size_t)b->stride, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return DMX_OK;
@@ -77,12 +86,14 @@ extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int dev
     if (const char *v = getenv("DMX_VEC")) b->vec = atoi(v);
     if (const char *v = getenv("DMX_MIN_WAVES")) b->min_waves = atoi(v);
     b->prof_on = getenv("DMX_HOST_PROFILE") != nullptr;
+    if (const char *v = getenv("DMX_LAZY_CHUNKS")) b->lazy_chunks = atoi(v) != 0;
     int rc = DMX_OK;
     do {
         if (hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = DMX_EHIP; break; }
         b->stream = b->own_stream;
         if (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) { rc = DMX_EHIP; break; }
         if (hipMalloc(&b->slab, (size_t)C_COUNT * b->stride * b->rsize) != hipSuccess) { rc = DMX_ENOMEM; break; }
+        if (hipMalloc(&b->slab_alt, (size_t)C_COUNT * b->stride * b->rsize) != hipSuccess) { rc = DMX_ENOMEM; break; }
         if (hipMalloc((void **)&b->gtype, (size_t)b->stride) != hipSuccess) { rc = DMX_ENOMEM; break; }
         if (hipMalloc((void **)&b->bflags, (size_t)b->stride) != hipSuccess) { rc = DMX_ENOMEM; break; }
         b->h_bflags.assign((size_t)b->stride, 0);
@@ -111,6 +122,7 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
 {
     if (!b) return DMX_EINVAL;
     (void)hipSetDevice(b->device);
+    (void)dmx_settle(b);
     if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
     if (b->prof_on) {
         static const char *names[12] = { "pair search + flag read", "pair list D2H + sort", "narrowphase + counts D2H", "joint list",
@@ -120,6 +132,7 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
         for (int k = 0; k < 9; k++) fprintf(stderr, "  %-32s %9.3f ms total\n", names[k], b->prof[k] * 1e3);
     }
     if (b->slab) (void)hipFree(b->slab);
+    if (b->slab_alt) (void)hipFree(b->slab_alt);
     if (b->gtype) (void)hipFree(b->gtype);
     if (b->bflags) (void)hipFree(b->bflags);
     for (dmxBatch::DevBuf *d : { &b->jd_int, &b->jd_real, &b->jd_rows, &b->jd_rowjb, &b->jd_bscr, &b->jd_local })
@@ -146,25 +159,27 @@ extern "C" int dmxBatchPrecision(dmxBatchID b) { return b ? b->precision : DMX_E
 extern "C" int64_t dmxBatchStride(dmxBatchID b) { return b ? b->stride : DMX_EINVAL; }
 
 extern "C" int dmxBatchSetGravity(dmxBatchID b, double x, double y, double z)
-{ if (!b) return DMX_EINVAL; b->g[0] = x; b->g[1] = y; b->g[2] = z; return DMX_OK; }
-extern "C" int dmxBatchSetERP(dmxBatchID b, double erp) { if (!b) return DMX_EINVAL; b->erp = erp; return DMX_OK; }
-extern "C" int dmxBatchSetCFM(dmxBatchID b, double cfm) { if (!b) return DMX_EINVAL; b->cfm = cfm; return DMX_OK; }
+{ if (!b) return DMX_EINVAL; SETTLE(b); b->g[0] = x; b->g[1] = y; b->g[2] = z; return DMX_OK; }
+extern "C" int dmxBatchSetERP(dmxBatchID b, double erp) { if (!b) return DMX_EINVAL; SETTLE(b); b->erp = erp; return DMX_OK; }
+extern "C" int dmxBatchSetCFM(dmxBatchID b, double cfm) { if (!b) return DMX_EINVAL; SETTLE(b); b->cfm = cfm; return DMX_OK; }
 extern "C" int dmxBatchSetQuickStep(dmxBatchID b, int iters, double w)
-{ if (!b || iters < 0) return DMX_EINVAL; b->iters = iters; b->sor_w = w; return DMX_OK; }
+{ if (!b || iters < 0) return DMX_EINVAL; SETTLE(b); b->iters = iters; b->sor_w = w; return DMX_OK; }
 extern "C" int dmxBatchSetGyroMode(dmxBatchID b, int mode)
-{ if (!b || mode < 0 || mode > 2) return DMX_EINVAL; b->gyro = mode; return DMX_OK; }
+{ if (!b || mode < 0 || mode > 2) return DMX_EINVAL; SETTLE(b); b->gyro = mode; return DMX_OK; }
 extern "C" int dmxBatchSetSurface(dmxBatchID b, int mode, double mu, double bounce, double bounce_vel)
 {
     if (!b) return DMX_EINVAL;
+    SETTLE(b);
     b->surf_mode = mode; b->mu = mu < 0 ? 0 : mu; b->bounce = bounce; b->bounce_vel = bounce_vel;
     return DMX_OK;
 }
 extern "C" int dmxBatchSetMaxContacts(dmxBatchID b, int m)
-{ if (!b || m < 1) return DMX_EINVAL; b->max_contacts = m; return DMX_OK; }
+{ if (!b || m < 1) return DMX_EINVAL; SETTLE(b); b->max_contacts = m; return DMX_OK; }
 
 extern "C" int dmxBatchSetPlane(dmxBatchID b, double a, double bb, double c, double d, int enable)
 {
     if (!b) return DMX_EINVAL;
+    SETTLE(b);
     b->plane[0] = a; b->plane[1] = bb; b->plane[2] = c; b->plane[3] = d;
     b->plane_on = enable ? 1 : 0;
     return DMX_OK;
@@ -193,6 +208,9 @@ static int upload_t(dmxBatch *b, int field, const void *host, int64_t first, int
     HIP_TRY(hipMemcpyAsync(b->stage, src, bytes, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(launch_aos_to_soa<T>((T *)b->slab, b->stride, k_field_comp0[field], k, first, count,
                                  (const T *)b->stage, b->stream));
+    if (field == DMX_MASS || field == DMX_INERTIA || field == DMX_SIDES)       // constants live in both slabs
+        HIP_TRY(launch_aos_to_soa<T>((T *)b->slab_alt, b->stride, k_field_comp0[field], k, first, count,
+                                     (const T *)b->stage, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));   // host buffer (and tmp) may be released on return
     if (field == DMX_FORCE || field == DMX_TORQUE) b->ext_pending = true;
     if (field == DMX_SIDES) {
@@ -226,6 +244,7 @@ static bool range_ok(dmxBatch *b, int field, const void *p, int64_t first, int64
 extern "C" int dmxBatchUpload(dmxBatchID b, int field, const void *host, int64_t first, int64_t count)
 {
     if (!range_ok(b, field, host, first, count)) return DMX_EINVAL;
+    SETTLE(b);
     if (count == 0) return DMX_OK;
     HIP_TRY(hipSetDevice(b->device));
     return b->precision == DMX_F32 ? upload_t<float>(b, field, host, first, count)
@@ -235,6 +254,7 @@ extern "C" int dmxBatchUpload(dmxBatchID b, int field, const void *host, int64_t
 extern "C" int dmxBatchDownload(dmxBatchID b, int field, void *host, int64_t first, int64_t count)
 {
     if (!range_ok(b, field, host, first, count)) return DMX_EINVAL;
+    SETTLE(b);
     if (count == 0) return DMX_OK;
     HIP_TRY(hipSetDevice(b->device));
     return b->precision == DMX_F32 ? download_t<float>(b, field, host, first, count)
@@ -244,6 +264,7 @@ extern "C" int dmxBatchDownload(dmxBatchID b, int field, void *host, int64_t fir
 extern "C" int dmxBatchUploadGeomType(dmxBatchID b, const uint8_t *types, int64_t first, int64_t count)
 {
     if (!b || !types || first < 0 || count < 0 || first + count > b->n) return DMX_EINVAL;
+    SETTLE(b);
     if (count == 0) return DMX_OK;
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemcpyAsync(b->gtype + first, types, (size_t)count, hipMemcpyHostToDevice, b->stream));
@@ -256,6 +277,7 @@ extern "C" int dmxBatchUploadGeomType(dmxBatchID b, const uint8_t *types, int64_
 extern "C" int dmxBatchUploadBodyFlags(dmxBatchID b, const uint8_t *flags, int64_t first, int64_t count)
 {
     if (!b || !flags || first < 0 || count < 0 || first + count > b->n) return DMX_EINVAL;
+    SETTLE(b);
     if (count == 0) return DMX_OK;
     HIP_TRY(hipSetDevice(b->device));
     for (int64_t i = 0; i < count; i++) b->h_bflags[(size_t)(first + i)] = flags[i];
@@ -278,6 +300,7 @@ int dmx_ensure_dev(dmxBatch::DevBuf &d, size_t bytes)
 extern "C" void *dmxBatchDevicePtr(dmxBatchID b, int field, int component)
 {
     if (!b || field < 0 || field >= DMX_NFIELDS || component < 0 || component >= k_field_k[field]) return nullptr;
+    if (dmx_settle(b) != DMX_OK) return nullptr;
     return (char *)b->slab + (size_t)slab_ix(k_field_comp0[field] + component, 0) * b->rsize;
 }
 
@@ -294,8 +317,8 @@ template <class T> static int step_t(dmxBatch *b, double h, int nsteps, int64_t 
         (void)reset_diag;   // every wave overwrites its own slot each tick: nothing to clear
         const bool ext = b->ext_pending && s == 0;
         P.ticks = ext ? 1 : std::min(per, nsteps - s);
-        HIP_TRY(launch_step<T>((T *)b->slab + slab_ix(0, first), b->gtype + first, b->stride, count, P, ext,
-                               b->diag + first / 64, b->stream));
+        T *S = (T *)b->slab + slab_ix(0, first);
+        HIP_TRY(launch_step<T>(S, S, b->gtype + first, b->stride, count, P, ext, b->diag + first / 64, b->stream));
         s += P.ticks;
     }
     b->stepped_with_plane = b->plane_on != 0;
@@ -308,6 +331,7 @@ extern "C" int dmxBatchStep(dmxBatchID b, double h, int nsteps)
     if (!b || !(h > 0) || nsteps < 0) return DMX_EINVAL;
     HIP_TRY(hipSetDevice(b->device));
     if (b->bp_enabled) return dmx_step_collide(b, h, nsteps);
+    SETTLE(b);
     int rc = b->precision == DMX_F32 ? step_t<float>(b, h, nsteps, 0, b->n_active, true)
                                      : step_t<double>(b, h, nsteps, 0, b->n_active, true);
     b->ext_pending = false;   // the step cleared the accumulators
@@ -315,9 +339,20 @@ extern "C" int dmxBatchStep(dmxBatchID b, double h, int nsteps)
     return rc;
 }
 
+extern "C" int dmxBatchSetSnapshotMode(dmxBatchID b, int mode)
+{
+    if (!b || (mode != DMX_SNAPSHOT_PINGPONG && mode != DMX_SNAPSHOT_COPY)) return DMX_EINVAL;
+    SETTLE(b);
+    if (b->flipped) return DMX_EINVAL;          // not inside a chunk that has already advanced
+    b->flip_armed = false;
+    b->snapshot_mode = mode;
+    return DMX_OK;
+}
+
 extern "C" int dmxBatchSetBodyCollisions(dmxBatchID b, int enable)
 {
     if (!b) return DMX_EINVAL;
+    SETTLE(b);
     b->bp_enabled = enable ? 1 : 0;
     b->bp_valid = false;
     return DMX_OK;
@@ -327,6 +362,7 @@ extern "C" int dmxBatchSetBodyCollisions(dmxBatchID b, int enable)
 extern "C" int dmxBatchSetConvexHull(dmxBatchID b, int32_t n_points, const double *points_xyz, double *radius_out)
 {
     if (!b || n_points < 4 || !points_xyz) return DMX_EINVAL;
+    SETTLE(b);
     HIP_TRY(hipSetDevice(b->device));
     int rc;
     if ((rc = dmx_ensure_dev(b->hull, (size_t)n_points * 3 * b->rsize)) != DMX_OK) return rc;
@@ -356,6 +392,7 @@ extern "C" int dmxBatchSetConvexHull(dmxBatchID b, int32_t n_points, const doubl
 extern "C" int dmxBatchChunkBegin(dmxBatchID b, int *exact_only, int *ballistic)
 {
     if (!b || !exact_only || !ballistic) return DMX_EINVAL;
+    SETTLE(b);
     HIP_TRY(hipSetDevice(b->device));
     return dmx_chunk_begin(b, exact_only, ballistic);
 }
@@ -374,12 +411,14 @@ extern "C" int dmxBatchChunkTicks(dmxBatchID b, double h, int nticks, int check_
 extern "C" int dmxBatchSetTicksPerLaunch(dmxBatchID b, int ticks)
 {
     if (!b || ticks < 1 || ticks > 64) return DMX_EINVAL;
+    SETTLE(b);
     b->ticks_per_launch = ticks;
     return DMX_OK;
 }
 extern "C" int dmxBatchCheckZonesOnStream(dmxBatchID b, void *hip_stream, int64_t first, int64_t count)
 {
     if (!b || first < 0 || count < 0 || first + count > b->n) return DMX_EINVAL;
+    SETTLE(b);
     HIP_TRY(hipSetDevice(b->device));
     return dmx_check_zones(b, (hipStream_t)hip_stream, first, count);
 }
@@ -387,6 +426,7 @@ extern "C" int dmxBatchRefreshGhostsOnStream(dmxBatchID b, void *hip_stream, int
                                             const void *src_lo, int64_t count_hi, const void *src_hi, int check)
 {
     if (!b || first < b->n_active || count_lo < 0 || count_hi < 0 || first + count_lo + count_hi > b->n) return DMX_EINVAL;
+    SETTLE(b);
     if (check && !b->bp_flags.p) return DMX_EINVAL;          // no chunk begun: there are no zones to test against
     HIP_TRY(hipSetDevice(b->device));
     uint32_t *flags = (uint32_t *)b->bp_flags.p;
@@ -418,6 +458,7 @@ extern "C" int dmxBatchChunkRollback(dmxBatchID b)
 extern "C" int dmxBatchExactTick(dmxBatchID b, double h)
 {
     if (!b || !(h > 0)) return DMX_EINVAL;
+    SETTLE(b);
     HIP_TRY(hipSetDevice(b->device));
     return dmx_exact_tick(b, h);
 }
@@ -425,6 +466,7 @@ extern "C" int dmxBatchExactTick(dmxBatchID b, double h)
 extern "C" int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6])
 {
     if (!b || !out) return DMX_EINVAL;
+    SETTLE(b);
     out[0] = b->stat_fast_ticks; out[1] = b->stat_careful_ticks; out[2] = b->stat_rebuilds;
     out[3] = b->stat_pair_ticks; out[4] = (int64_t)b->last_pairs; out[5] = (int64_t)b->bp_crowded;
     return DMX_OK;
@@ -433,6 +475,7 @@ extern "C" int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6])
 extern "C" int dmxBatchSetBoundaryPack(dmxBatchID b, void *out_dev, int64_t lo_count, int64_t hi_first)
 {
     if (!b || lo_count < 0 || hi_first < lo_count || hi_first > b->n_active) return DMX_EINVAL;
+    SETTLE(b);
     b->pack_out = out_dev; b->pack_lo = lo_count; b->pack_hi = hi_first;
     return DMX_OK;
 }
@@ -440,6 +483,7 @@ extern "C" int dmxBatchSetBoundaryPack(dmxBatchID b, void *out_dev, int64_t lo_c
 extern "C" int dmxBatchSetActiveCount(dmxBatchID b, int64_t n_active)
 {
     if (!b || n_active < 0 || n_active > b->n) return DMX_EINVAL;
+    SETTLE(b);
     if (n_active != b->n && n_active % 4 != 0) return DMX_EINVAL;   // the last 16 B pack must not reach into ghost slots
     b->n_active = n_active;
     return DMX_OK;
@@ -448,6 +492,7 @@ extern "C" int dmxBatchSetActiveCount(dmxBatchID b, int64_t n_active)
 extern "C" int dmxBatchStepRange(dmxBatchID b, double h, int64_t first, int64_t count, int reset_diag)
 {
     if (!b || !(h > 0) || first < 0 || count < 0 || first + count > b->n_active) return DMX_EINVAL;
+    SETTLE(b);
     // lanes own 16 B packs of consecutive bodies: ranges must start on a pack and end on one (or at the end)
     const int64_t pack = 16 / (int64_t)b->rsize;
     if (first % pack != 0 || (count % pack != 0 && first + count != b->n_active)) return DMX_EINVAL;
@@ -461,6 +506,7 @@ extern "C" int dmxBatchStepRange(dmxBatchID b, double h, int64_t first, int64_t 
 extern "C" int dmxBatchSynchronize(dmxBatchID b)
 {
     if (!b) return DMX_EINVAL;
+    SETTLE(b);
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return DMX_OK;
@@ -469,6 +515,7 @@ extern "C" int dmxBatchSynchronize(dmxBatchID b)
 extern "C" int dmxBatchSetStream(dmxBatchID b, void *hip_stream)
 {
     if (!b) return DMX_EINVAL;
+    SETTLE(b);
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
     b->stream = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
@@ -521,6 +568,7 @@ static int fetch_diag(dmxBatch *b, unsigned long long *contacts, double *residua
 extern "C" int dmxBatchLastContactCount(dmxBatchID b, int64_t *n)
 {
     if (!b || !n) return DMX_EINVAL;
+    SETTLE(b);
     if (!b->stepped_with_plane) { *n = 0; return DMX_OK; }
     unsigned long long c; double r;
     int rc = fetch_diag(b, &c, &r);
@@ -532,6 +580,7 @@ extern "C" int dmxBatchLastContactCount(dmxBatchID b, int64_t *n)
 extern "C" int dmxBatchLastResidual(dmxBatchID b, double *res)
 {
     if (!b || !res) return DMX_EINVAL;
+    SETTLE(b);
     if (!b->stepped_with_plane) { *res = 0; return DMX_OK; }
     unsigned long long c; double r;
     int rc = fetch_diag(b, &c, &r);
@@ -544,6 +593,7 @@ extern "C" int dmxBatchLastResidual(dmxBatchID b, double *res)
 extern "C" int dmxBatchPackTransforms(dmxBatchID b, void *out_dev, int64_t first, int64_t count)
 {
     if (!b || !out_dev || first < 0 || count < 0 || first + count > b->n) return DMX_EINVAL;
+    SETTLE(b);
     HIP_TRY(hipSetDevice(b->device));
     if (b->precision == DMX_F32)
         HIP_TRY(launch_pack_transforms<float>((const float *)b->slab, b->stride, first, count, (float *)out_dev, b->stream));
@@ -571,6 +621,7 @@ extern "C" int dmxBatchDownloadTransforms(dmxBatchID b, void *out_host, int64_t 
 extern "C" int dmxBatchGatherBodies(dmxBatchID b, const int32_t *idx_dev, int64_t count, void *out_dev)
 {
     if (!b || count < 0 || (count > 0 && (!idx_dev || !out_dev))) return DMX_EINVAL;
+    SETTLE(b);
     HIP_TRY(hipSetDevice(b->device));
     if (b->precision == DMX_F32)
         HIP_TRY(launch_gather<float>((const float *)b->slab, b->stride, idx_dev, count, (float *)out_dev, b->stream));
@@ -582,6 +633,7 @@ extern "C" int dmxBatchGatherBodies(dmxBatchID b, const int32_t *idx_dev, int64_
 static int scatter_on(dmxBatch *b, const int32_t *idx_dev, int64_t count, const void *in_dev, hipStream_t st)
 {
     if (!b || count < 0 || (count > 0 && (!idx_dev || !in_dev))) return DMX_EINVAL;
+    SETTLE(b);
     b->bp_valid = false;
     HIP_TRY(hipSetDevice(b->device));
     if (b->precision == DMX_F32)

@@ -37,7 +37,24 @@ struct dmxBatch {
     int precision = DMX_F32;
     int device = 0;
     size_t rsize = 4;
-    void *slab = nullptr;            // C_COUNT x stride reals
+    void *slab = nullptr;            // C_COUNT x stride reals: the CURRENT slab (state, constants, zones)
+    // Second slab of the same layout.  Constants and zones are kept identical in both (every writer of those
+    // components writes both); the state lives in `slab`.  The first launch of a collision-proof chunk reads `slab`
+    // and writes the new state to `slab_alt`, then the two swap roles: the chunk's start state stays behind,
+    // untouched, as the rollback snapshot (rollback = swap back) at no copy and no extra traffic.
+    void *slab_alt = nullptr;
+    bool flip_armed = false;         // the next fast launch starts a chunk: write out of place and swap
+    bool flipped = false;            // this chunk has swapped: its snapshot is `slab_alt`
+    int snapshot_mode = DMX_SNAPSHOT_PINGPONG;
+    int snap_kind = 0;               // how the chunk in flight keeps its start state (dmx_general.cpp: SNAP_*)
+    // a collision-proof chunk left open by dmxBatchStep (dmx_general.cpp "lazy chunks"): its calls so far, to replay
+    // them after a rollback; closed by dmx_settle
+    struct OpenChunk {
+        bool open = false, ballistic = false, last_checked = false;
+        int ticks = 0, budget = 0;
+        std::vector<std::pair<double, int>> segs;       // (h, ticks) per Step call, in order
+    } oc;
+    bool lazy_chunks = true;         // DMX_LAZY_CHUNKS=0 reads every chunk's flag before dmxBatchStep returns
     uint8_t *gtype = nullptr;        // stride bytes
     StepDiag *diag = nullptr;        // device, one slot per wave of the fused step
     StepDiag *diag_isl = nullptr;    // device, island path (atomics)
@@ -139,6 +156,9 @@ int dmx_step_joints(dmxBatch *b, double h, int64_t n_joints, const dmxContactJoi
                     const DevGeometry *geo);
 // body-body collision handling of the batch tick (dmx_general.cpp)
 int dmx_step_collide(dmxBatch *b, double h, int nsteps);
+// close the chunk dmxBatchStep may have left open (flag read; rollback + replay on a violation).  Every entry point that
+// observes or changes the batch calls this first.
+int dmx_settle(dmxBatch *b);
 // the collision-checked loop in pieces (dmx_general.cpp)
 int dmx_chunk_begin(dmxBatch *b, int *exact_only, int *ballistic);
 int dmx_chunk_tick(dmxBatch *b, double h, int check);

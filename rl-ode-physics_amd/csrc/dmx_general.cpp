@@ -77,7 +77,6 @@ int ensure_buffers(dmxBatch *b)
     if ((rc = dmx_ensure_dev(b->bp_flags, 64)) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->bp_pairs, (size_t)b->bp_max_pairs * 2 * sizeof(int32_t))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->bp_inpair, (size_t)b->stride)) != DMX_OK) return rc;
-    if ((rc = dmx_ensure_dev(b->bp_snapshot, (size_t)C_MASS * b->stride * b->rsize)) != DMX_OK) return rc;
     if (!b->bp_flags_host) HIP_TRY(hipHostMalloc((void **)&b->bp_flags_host, 64));
     return DMX_OK;
 }
@@ -120,6 +119,8 @@ template <class T> int build_safe_zones(dmxBatch *b)
         return build_safe_zones<T>(b);
     }
     b->bp_crowded = b->bp_flags_host[BPF_CROWDED];
+    // zones (and the bounding radii bp_insert refreshed) are constants of the ticks to come: both slabs hold them
+    HIP_TRY(launch_copy_components<T>((const T *)b->slab, (T *)b->slab_alt, C_BPX, C_COUNT - C_BPX, 0, b->n, b->stream));
     b->bp_valid = true;
     b->stat_rebuilds++;
     return DMX_OK;
@@ -146,13 +147,77 @@ void sort_pairs(std::vector<std::pair<int32_t, int32_t>> &pairs, int64_t n, std:
     pairs.swap(out);
 }
 
+// ---- the chunk's rollback snapshot ------------------------------------------------------------------------
+// Ping-pong (default): nothing is copied.  The chunk's first fast launch reads the current slab and writes the new
+// state to the other one, the slabs swap roles, later launches run in place; the start state stays behind untouched
+// and a rollback swaps back.  Copy mode (callers that replay captured HIP graphs, which bake the slab address in):
+// the 13 state components are copied aside at the chunk's start.
+enum : int { SNAP_NONE = 0, SNAP_PINGPONG = 1, SNAP_COPY = 2 };
+
+template <class T> int snapshot_by_copy(dmxBatch *b)
+{
+    int rc;
+    if ((rc = dmx_ensure_dev(b->bp_snapshot, (size_t)C_MASS * b->stride * b->rsize)) != DMX_OK) return rc;
+    HIP_TRY(launch_copy_state<T>((T *)b->slab, (T *)b->bp_snapshot.p, b->stride, true, b->stream));
+    b->flip_armed = false; b->flipped = false;
+    b->snap_kind = SNAP_COPY;
+    return DMX_OK;
+}
+
+template <class T> int snapshot_begin(dmxBatch *b)
+{
+    if (b->snapshot_mode == DMX_SNAPSHOT_COPY) return snapshot_by_copy<T>(b);
+    b->flip_armed = true; b->flipped = false;
+    b->snap_kind = SNAP_NONE;                   // becomes SNAP_PINGPONG at the first fast launch
+    return DMX_OK;
+}
+
+template <class T> int snapshot_restore(dmxBatch *b)
+{
+    if (b->snap_kind == SNAP_COPY)
+        HIP_TRY(launch_copy_state<T>((T *)b->slab, (T *)b->bp_snapshot.p, b->stride, false, b->stream));
+    else if (b->snap_kind == SNAP_PINGPONG)
+        std::swap(b->slab, b->slab_alt);        // the untouched start state (ghost slots included) is current again
+    b->flip_armed = false; b->flipped = false;
+    b->snap_kind = SNAP_NONE;
+    return DMX_OK;
+}
+
+inline void snapshot_drop(dmxBatch *b) { b->flip_armed = false; b->flipped = false; b->snap_kind = SNAP_NONE; }
+
+// one launch of the fused kernels over the active bodies; starts the chunk's ping-pong when one is armed
+template <class T> int launch_fast(dmxBatch *b, const StepParams<T> &P, bool ext)
+{
+    T *S = (T *)b->slab, *So = S;
+    if (b->flip_armed) {
+        if (ext || P.skip != nullptr) {
+            // this launch clears accumulators / skips bodies in its input slab: it cannot leave that slab behind
+            // as the snapshot.  Take the snapshot by copy for this chunk.
+            int rc = snapshot_by_copy<T>(b);
+            if (rc != DMX_OK) return rc;
+        } else {
+            So = (T *)b->slab_alt;
+        }
+    }
+    HIP_TRY(launch_step<T>(S, So, b->gtype, b->stride, b->n_active, P, ext, b->diag, b->stream));
+    if (So != S) {
+        // ghost slots [n_active, n) are not stepped: their state follows by copy (a few boundary rows)
+        HIP_TRY(launch_copy_components<T>(S, So, 0, C_MASS, b->n_active, b->n - b->n_active, b->stream));
+        std::swap(b->slab, b->slab_alt);
+        b->flip_armed = false; b->flipped = true;
+        b->snap_kind = SNAP_PINGPONG;
+    }
+    return DMX_OK;
+}
+
 template <class T> int fused_tick(dmxBatch *b, double h, bool check, const uint8_t *skip)
 {
     StepParams<T> P = dmx_make_params<T>(b, h);
     P.bp_check = check ? BPC_ALL : 0;
     P.bp_flags = (uint32_t *)b->bp_flags.p;
     P.skip = skip;
-    HIP_TRY(launch_step<T>((T *)b->slab, b->gtype, b->stride, b->n_active, P, b->ext_pending, b->diag, b->stream));
+    int rc = launch_fast<T>(b, P, b->ext_pending);
+    if (rc != DMX_OK) return rc;
     b->ext_pending = false;
     return DMX_OK;
 }
@@ -175,7 +240,7 @@ template <class T> int fused_run(dmxBatch *b, double h, int n, bool ends_only, b
         P.ticks = kk;
         P.bp_check = !ends_only ? BPC_ALL : ((s == 0 && check_first ? BPC_FIRST : 0) | (s + kk == n && check_last ? BPC_LAST : 0));
         P.bp_flags = (uint32_t *)b->bp_flags.p;
-        HIP_TRY(launch_step<T>((T *)b->slab, b->gtype, b->stride, b->n_active, P, false, b->diag, b->stream));
+        if ((rc = launch_fast<T>(b, P, false)) != DMX_OK) return rc;
     }
     return DMX_OK;
 }
@@ -184,6 +249,7 @@ template <class T> int fused_run(dmxBatch *b, double h, int n, bool ends_only, b
 template <class T> int careful_tick(dmxBatch *b, double h)
 {
     int rc;
+    snapshot_drop(b);           // exact ticks run in place and are never rolled back
     std::unique_ptr<DmxPhase> ph(new DmxPhase(b, 0));
     if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
     HIP_TRY(hipMemsetAsync(b->bp_inpair.p, 0, (size_t)b->stride, b->stream));
@@ -330,7 +396,9 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     return DMX_OK;
 }
 
-template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
+// The collision-checked loop, synchronous form: every chunk's flag is read (one stream synchronisation) before the
+// call returns.  The lazy form below defers that read; this one is what it falls back to after a violation.
+template <class T> int step_sync_t(dmxBatch *b, double h, int nsteps)
 {
     int rc;
     int remaining = nsteps;
@@ -352,7 +420,7 @@ template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
         // left its zone the chunk is rolled back; the first retry only refreshes the zones (a body that has
         // drifted since the last build usually fits again), the second replays the chunk exactly.
         for (int attempt = 0; !careful; attempt++) {
-            HIP_TRY(launch_copy_state<T>((T *)b->slab, (T *)b->bp_snapshot.p, b->stride, true, b->stream));
+            if ((rc = snapshot_begin<T>(b)) != DMX_OK) return rc;
             HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, 2 * sizeof(uint32_t), b->stream));
             // Without a ground plane and with gravity along y nothing acts horizontally: every body's (x,z) moves on a
             // straight line during the chunk, and a disc is convex, so a body inside its zone at the chunk's first and
@@ -361,6 +429,7 @@ template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
             if ((rc = fused_run<T>(b, h, k, ballistic, true, true)) != DMX_OK) return rc;
             if ((rc = read_flags(b)) != DMX_OK) return rc;
             if (!b->bp_flags_host[BPF_VIOLATION]) {
+                snapshot_drop(b);
                 b->stat_fast_ticks += k;
                 b->last_pairs = 0;
                 b->last_mixed = false;
@@ -368,7 +437,7 @@ template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
                 else if (k == b->bp_chunk) b->bp_chunk = std::min(2 * b->bp_chunk, kChunkMax);   // quiet scene: snapshot and read the flag less often
                 break;
             }
-            HIP_TRY(launch_copy_state<T>((T *)b->slab, (T *)b->bp_snapshot.p, b->stride, false, b->stream));
+            if ((rc = snapshot_restore<T>(b)) != DMX_OK) return rc;
             b->stat_rollbacks++;
             b->bp_chunk = kChunk;
             k = std::min(k, kChunk);            // the retry (and an exact replay, if it comes to that) covers a short chunk
@@ -390,6 +459,79 @@ template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
     return DMX_OK;
 }
 
+// ---- lazy chunks ----------------------------------------------------------------------------------------------
+// dmxBatchStep returns without reading the chunk's violation flag: the chunk stays OPEN across calls (the reference's
+// loop issues a tick or two per frame, main.c:211) and is closed -- one zone test of the current poses for a ballistic
+// chunk, one flag read -- when it reaches its length or when anything observes or changes the batch (every other entry
+// point settles it first).  A violation found at the close rolls the whole chunk back to its snapshot and replays its
+// calls through the synchronous loop above, so what a caller can observe is unchanged; a clean scene never waits for
+// the host inside a run of Step calls.
+template <class T> int close_chunk_t(dmxBatch *b)
+{
+    int rc;
+    dmxBatch::OpenChunk &oc = b->oc;
+    if (!oc.open) return DMX_OK;
+    oc.open = false;
+    if (oc.ballistic && !oc.last_checked)
+        // the poses after the chunk's last tick inside their zones (and the first tick's before it: tested in that
+        // launch) prove every tick between: each body's (x,z) moved on a straight line and a disc is convex
+        HIP_TRY(launch_check_zones<T>((const T *)b->slab, 0, b->n_active, (uint32_t *)b->bp_flags.p, b->stream));
+    if ((rc = read_flags(b)) != DMX_OK) return rc;
+    if (!b->bp_flags_host[BPF_VIOLATION]) {
+        snapshot_drop(b);
+        b->stat_fast_ticks += oc.ticks;
+        b->last_pairs = 0;
+        b->last_mixed = false;
+        if (b->bp_flags_host[BPF_WARN]) b->bp_valid = false;
+        else if (oc.ticks >= b->bp_chunk) b->bp_chunk = std::min(2 * b->bp_chunk, kChunkMax);
+        oc.segs.clear();
+        return DMX_OK;
+    }
+    if ((rc = snapshot_restore<T>(b)) != DMX_OK) return rc;
+    b->stat_rollbacks++;
+    b->bp_chunk = kChunk;
+    b->bp_valid = false;                 // fresh zones first: a body that has drifted since the last build usually fits again
+    std::vector<std::pair<double, int>> segs;
+    segs.swap(oc.segs);
+    for (auto &sg : segs)
+        if ((rc = step_sync_t<T>(b, sg.first, sg.second)) != DMX_OK) return rc;
+    return DMX_OK;
+}
+
+template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
+{
+    int rc;
+    dmxBatch::OpenChunk &oc = b->oc;
+    int remaining = nsteps;
+    while (remaining > 0) {
+        if (!oc.open) {
+            if (b->ext_pending || !b->lazy_chunks) return step_sync_t<T>(b, h, remaining);
+            if (!b->bp_valid && (rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
+            if (b->bp_crowded > 0) return step_sync_t<T>(b, h, remaining);
+            if (b->bp_chunk < kChunk) b->bp_chunk = kChunk;
+            if ((rc = snapshot_begin<T>(b)) != DMX_OK) return rc;
+            HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, 2 * sizeof(uint32_t), b->stream));
+            oc.open = true; oc.ticks = 0; oc.budget = b->bp_chunk; oc.last_checked = false;
+            oc.ballistic = !b->plane_on && b->g[0] == 0.0 && b->g[2] == 0.0;
+            oc.segs.clear();
+        }
+        const int k = std::min(remaining, oc.budget - oc.ticks);
+        const bool closes = oc.ticks + k >= oc.budget;         // the chunk's last tick is in this run: test it there
+        if ((rc = fused_run<T>(b, h, k, oc.ballistic, oc.ticks == 0, closes)) != DMX_OK) return rc;
+        oc.last_checked = closes;
+        b->stepped_with_plane = b->plane_on != 0;
+        b->last_islands = false;
+        b->last_mixed = false;
+        b->last_pairs = 0;
+        if (!oc.segs.empty() && oc.segs.back().first == h) oc.segs.back().second += k;
+        else oc.segs.push_back({ h, k });
+        oc.ticks += k;
+        remaining -= k;
+        if (closes && (rc = close_chunk_t<T>(b)) != DMX_OK) return rc;      // (a replay after a violation sets them anew)
+    }
+    return DMX_OK;
+}
+
 // ---- the same loop in pieces, for a caller that interleaves its own per-tick work (shard.py's exchange) ----
 template <class T> int chunk_begin_t(dmxBatch *b, int *exact_only, int *ballistic)
 {
@@ -398,14 +540,15 @@ template <class T> int chunk_begin_t(dmxBatch *b, int *exact_only, int *ballisti
     if (!b->bp_valid && (rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
     *exact_only = (b->bp_crowded > 0 || b->ext_pending) ? 1 : 0;
     *ballistic = (!b->plane_on && b->g[0] == 0.0 && b->g[2] == 0.0) ? 1 : 0;
-    HIP_TRY(launch_copy_state<T>((T *)b->slab, (T *)b->bp_snapshot.p, b->stride, true, b->stream));
+    if ((rc = snapshot_begin<T>(b)) != DMX_OK) return rc;
     HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, 2 * sizeof(uint32_t), b->stream));
     return DMX_OK;
 }
 
 template <class T> int chunk_rollback_t(dmxBatch *b)
 {
-    HIP_TRY(launch_copy_state<T>((T *)b->slab, (T *)b->bp_snapshot.p, b->stride, false, b->stream));
+    int rc;
+    if ((rc = snapshot_restore<T>(b)) != DMX_OK) return rc;
     b->stat_rollbacks++;
     b->bp_valid = false;
     return DMX_OK;
@@ -418,6 +561,13 @@ template <class T> int check_zones_t(dmxBatch *b, hipStream_t st, int64_t first,
 }
 
 }  // namespace
+
+int dmx_settle(dmxBatch *b)
+{
+    if (!b->oc.open) return DMX_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    return b->precision == DMX_F32 ? close_chunk_t<float>(b) : close_chunk_t<double>(b);
+}
 
 int dmx_step_collide(dmxBatch *b, double h, int nsteps)
 {
@@ -470,6 +620,7 @@ int dmx_chunk_end(dmxBatch *b, int *violated, int *warn)
 
 int dmx_chunk_commit(dmxBatch *b, int ticks, int refresh_zones)
 {
+    snapshot_drop(b);
     b->stat_fast_ticks += ticks;
     if (refresh_zones) b->bp_valid = false;
     return DMX_OK;
@@ -477,7 +628,7 @@ int dmx_chunk_commit(dmxBatch *b, int ticks, int refresh_zones)
 
 int dmx_chunk_rollback(dmxBatch *b)
 {
-    if (!b->bp_snapshot.p) return DMX_EINVAL;
+    if (!b->bp_flags.p) return DMX_EINVAL;           // no chunk begun
     return b->precision == DMX_F32 ? chunk_rollback_t<float>(b) : chunk_rollback_t<double>(b);
 }
 

@@ -120,8 +120,11 @@ struct StepDiag {
     double residual;
 };
 
+// S: the slab the tick reads (state, constants, zones); So: the slab the new state is written to -- S itself for an
+// in-place tick, or the batch's other slab (constants and zones are kept identical in both), which leaves S's state
+// behind untouched: the zero-cost snapshot of a collision-proof chunk (dmx_general.cpp)
 template <class T>
-hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, const StepParams<T> &P, bool ext,
+hipError_t launch_step(T *S, T *So, const uint8_t *gtype, int64_t stride, int64_t n, const StepParams<T> &P, bool ext,
                        StepDiag *diag, hipStream_t st);
 template <class T>
 hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
@@ -163,6 +166,9 @@ hipError_t launch_fill_component(T *S, int c, T value, int64_t n, hipStream_t st
 // rollback snapshot of the 13 state components of bodies [0, n_bodies): save = slab -> packed, else packed -> slab
 template <class T>
 hipError_t launch_copy_state(T *S, T *packed, int64_t n_bodies, bool save, hipStream_t st);
+// components [c0, c0+k) of bodies [first, first+count) from one slab to the other (same layout)
+template <class T>
+hipError_t launch_copy_components(const T *from, T *to, int c0, int k, int64_t first, int64_t count, hipStream_t st);
 template <class T>
 hipError_t launch_aos_to_soa(T *S, int64_t stride, int comp0, int k, int64_t first, int64_t count, const T *aos,
                              hipStream_t st);

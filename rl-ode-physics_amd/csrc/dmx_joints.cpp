@@ -318,5 +318,6 @@ extern "C" int dmxBatchStepJoints(dmxBatchID b, double h, int64_t n_joints, cons
 {
     if (!b || !(h > 0) || n_joints < 0 || (n_joints > 0 && !joints)) return DMX_EINVAL;
     HIP_TRY(hipSetDevice(b->device));
+    { const int rc = dmx_settle(b); if (rc != DMX_OK) return rc; }
     return dmx_step_joints(b, h, n_joints, joints, nullptr, nullptr);
 }

@@ -101,9 +101,11 @@ __device__ __forceinline__ void free_body_step(V3<T> &x, Q4<T> &q, V3<T> &v, V3<
 // read 13 state + 4 constant reals, write 13 state reals = 30 reals (120 B f32 / 240 B f64).
 // ---------------------------------------------------------------------------------------------
 template <class T, int V, bool EXT, int MINW, bool MULTI>
-__global__ __launch_bounds__(256, MINW) void integrate_free(T *__restrict__ S, int64_t stride, int64_t nvec,
+__global__ __launch_bounds__(256, MINW) void integrate_free(T *S, T *So, int64_t stride, int64_t nvec,
                                                       StepParams<T> P)
 {
+    // So = where the new state goes: S itself (in place) or the batch's other slab (the first launch of a
+    // collision-proof chunk, which thereby leaves the chunk's start state behind as the rollback snapshot)
     const int nticks = MULTI ? P.ticks : 1;         // MULTI = false: the one-tick kernel, no loop
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nvec;
          t += (int64_t)gridDim.x * blockDim.x) {
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256, MINW) void integrate_free(T *__restrict__ S, i
             }
         }
 #pragma unroll
-        for (int k = 0; k < C_MASS; k++) stv<T, V>(S, stride, k, i, c[k]);
+        for (int k = 0; k < C_MASS; k++) stv<T, V>(So, stride, k, i, c[k]);
         if (EXT) {
             Pack<T, V> z;
 #pragma unroll
@@ -182,7 +184,7 @@ template <class T> __device__ __forceinline__ T wave_sum(T x)
 // NC = contact slots per body: 4 (box-plane yields at most 4 contacts) or CONVEX_MAXC when the batch has convex bodies,
 // whose plane contacts np_convex_plane left in P.cbuf.
 template <class T, bool EXT, int MINW, int NC>
-__global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const uint8_t *__restrict__ gtype,
+__global__ __launch_bounds__(256, MINW) void step_plane(T *S, T *So, const uint8_t *__restrict__ gtype,
                                                   int64_t stride, int64_t n, StepParams<T> P,
                                                   StepDiag *__restrict__ diag)
 {
@@ -382,11 +384,11 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *__restrict__ S, const
         integrate_quat(q, w, h);
         pack_boundary(P, i, x, q, v, w);
 
-        S[slab_ix(C_POS + 0, i)] = x.x; S[slab_ix(C_POS + 1, i)] = x.y; S[slab_ix(C_POS + 2, i)] = x.z;
-        S[slab_ix(C_QUAT + 0, i)] = q.w; S[slab_ix(C_QUAT + 1, i)] = q.x;
-        S[slab_ix(C_QUAT + 2, i)] = q.y; S[slab_ix(C_QUAT + 3, i)] = q.z;
-        S[slab_ix(C_LVEL + 0, i)] = v.x; S[slab_ix(C_LVEL + 1, i)] = v.y; S[slab_ix(C_LVEL + 2, i)] = v.z;
-        S[slab_ix(C_AVEL + 0, i)] = w.x; S[slab_ix(C_AVEL + 1, i)] = w.y; S[slab_ix(C_AVEL + 2, i)] = w.z;
+        So[slab_ix(C_POS + 0, i)] = x.x; So[slab_ix(C_POS + 1, i)] = x.y; So[slab_ix(C_POS + 2, i)] = x.z;
+        So[slab_ix(C_QUAT + 0, i)] = q.w; So[slab_ix(C_QUAT + 1, i)] = q.x;
+        So[slab_ix(C_QUAT + 2, i)] = q.y; So[slab_ix(C_QUAT + 3, i)] = q.z;
+        So[slab_ix(C_LVEL + 0, i)] = v.x; So[slab_ix(C_LVEL + 1, i)] = v.y; So[slab_ix(C_LVEL + 2, i)] = v.z;
+        So[slab_ix(C_AVEL + 0, i)] = w.x; So[slab_ix(C_AVEL + 1, i)] = w.y; So[slab_ix(C_AVEL + 2, i)] = w.z;
         if (EXT) {
 #pragma unroll
             for (int k = 0; k < 6; k++) S[slab_ix(C_FORCE + k, i)] = T(0);
@@ -484,6 +486,18 @@ __global__ __launch_bounds__(256) void copy_state(T *__restrict__ S, T *__restri
     else      S[s] = packed[t];
 }
 
+// components [c0, c0+k) of bodies [first, first+count), slab to slab (the batch keeps two slabs of one layout)
+template <class T>
+__global__ __launch_bounds__(256) void copy_components(const T *__restrict__ from, T *__restrict__ to, int c0, int k,
+                                                       int64_t first, int64_t count)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= count * k) return;
+    const int c = (int)(t / count);
+    const int64_t ix = slab_ix(c0 + c, first + (t - (int64_t)c * count));
+    to[ix] = from[ix];
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void gather_bodies(const T *__restrict__ S, int64_t stride,
                                                      const int32_t *__restrict__ idx, int64_t count,
@@ -535,7 +549,7 @@ __global__ __launch_bounds__(256) void soa_to_aos(const T *__restrict__ S, int64
 static inline unsigned blocks_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 template <class T>
-hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, const StepParams<T> &P, bool ext,
+hipError_t launch_step(T *S, T *So, const uint8_t *gtype, int64_t stride, int64_t n, const StepParams<T> &P, bool ext,
                        StepDiag *diag, hipStream_t st)
 {
     if (!P.plane_on) {
@@ -549,9 +563,9 @@ hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, co
         const unsigned grid = blocks_for(nvec, 256);
 #define DMX_LAUNCH_FREE(VV, MW)                                                                                      \
     do {                                                                                                             \
-        if (P.ticks > 1) hipLaunchKernelGGL((integrate_free<T, VV, false, MW, true>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P);   \
-        else if (ext) hipLaunchKernelGGL((integrate_free<T, VV, true, MW, false>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P);  \
-        else     hipLaunchKernelGGL((integrate_free<T, VV, false, MW, false>), dim3(grid), dim3(256), 0, st, S, stride, nvec, P); \
+        if (P.ticks > 1) hipLaunchKernelGGL((integrate_free<T, VV, false, MW, true>), dim3(grid), dim3(256), 0, st, S, So, stride, nvec, P);   \
+        else if (ext) hipLaunchKernelGGL((integrate_free<T, VV, true, MW, false>), dim3(grid), dim3(256), 0, st, S, So, stride, nvec, P);  \
+        else     hipLaunchKernelGGL((integrate_free<T, VV, false, MW, false>), dim3(grid), dim3(256), 0, st, S, So, stride, nvec, P); \
     } while (0)
         const int mw = P.min_waves;   // launch tuning: minimum waves per SIMD the register allocator must leave room for
         if (V == 1) { if (mw == 8) DMX_LAUNCH_FREE(1, 8); else if (mw == 6) DMX_LAUNCH_FREE(1, 6); else DMX_LAUNCH_FREE(1, 1); }
@@ -563,10 +577,10 @@ hipError_t launch_step(T *S, const uint8_t *gtype, int64_t stride, int64_t n, co
 #define DMX_LAUNCH_PLANE(MW)                                                                                           \
     do {                                                                                                                   \
         if (convex) {                                                                                                      \
-            if (ext) hipLaunchKernelGGL((step_plane<T, true, 1, CONVEX_MAXC>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag);  \
-            else     hipLaunchKernelGGL((step_plane<T, false, 1, CONVEX_MAXC>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag); \
-        } else if (ext) hipLaunchKernelGGL((step_plane<T, true, MW, 4>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag);  \
-        else     hipLaunchKernelGGL((step_plane<T, false, MW, 4>), dim3(grid), dim3(256), 0, st, S, gtype, stride, n, P, diag); \
+            if (ext) hipLaunchKernelGGL((step_plane<T, true, 1, CONVEX_MAXC>), dim3(grid), dim3(256), 0, st, S, So, gtype, stride, n, P, diag);  \
+            else     hipLaunchKernelGGL((step_plane<T, false, 1, CONVEX_MAXC>), dim3(grid), dim3(256), 0, st, S, So, gtype, stride, n, P, diag); \
+        } else if (ext) hipLaunchKernelGGL((step_plane<T, true, MW, 4>), dim3(grid), dim3(256), 0, st, S, So, gtype, stride, n, P, diag);  \
+        else     hipLaunchKernelGGL((step_plane<T, false, MW, 4>), dim3(grid), dim3(256), 0, st, S, So, gtype, stride, n, P, diag); \
     } while (0)
         // convex bodies: their plane contacts first (one wavefront per body), then the fused step with 8 contact slots
         const bool convex = P.hull_n > 0 && P.cbuf != nullptr;
@@ -626,6 +640,14 @@ hipError_t launch_copy_state(T *S, T *packed, int64_t n_bodies, bool save, hipSt
 }
 
 template <class T>
+hipError_t launch_copy_components(const T *from, T *to, int c0, int k, int64_t first, int64_t count, hipStream_t st)
+{
+    if (count <= 0 || k <= 0) return hipSuccess;
+    hipLaunchKernelGGL((copy_components<T>), dim3(blocks_for(count * k, 256)), dim3(256), 0, st, from, to, c0, k, first, count);
+    return hipGetLastError();
+}
+
+template <class T>
 hipError_t launch_gather(const T *S, int64_t stride, const int32_t *idx, int64_t count, T *out, hipStream_t st)
 {
     if (count <= 0) return hipSuccess;
@@ -657,7 +679,7 @@ hipError_t launch_soa_to_aos(const T *S, int64_t stride, int comp0, int k, int64
 }
 
 #define DMX_INSTANTIATE(T)                                                                                         \
-    template hipError_t launch_step<T>(T *, const uint8_t *, int64_t, int64_t, const StepParams<T> &, bool,        \
+    template hipError_t launch_step<T>(T *, T *, const uint8_t *, int64_t, int64_t, const StepParams<T> &, bool,   \
                                        StepDiag *, hipStream_t);                                                   \
     template hipError_t launch_pack_transforms<T>(const T *, int64_t, int64_t, int64_t, T *, hipStream_t);         \
     template hipError_t launch_gather<T>(const T *, int64_t, const int32_t *, int64_t, T *, hipStream_t);          \
@@ -666,6 +688,7 @@ hipError_t launch_soa_to_aos(const T *S, int64_t stride, int comp0, int k, int64
     template hipError_t launch_soa_to_aos<T>(const T *, int64_t, int, int, int64_t, int64_t, T *, hipStream_t);     \
     template hipError_t launch_fill_component<T>(T *, int, T, int64_t, hipStream_t);                                \
     template hipError_t launch_copy_state<T>(T *, T *, int64_t, bool, hipStream_t);                                 \
+    template hipError_t launch_copy_components<T>(const T *, T *, int, int, int64_t, int64_t, hipStream_t);         \
     template hipError_t launch_check_zones<T>(const T *, int64_t, int64_t, uint32_t *, hipStream_t);               \
     template hipError_t launch_refresh_ghosts<T>(T *, int64_t, int64_t, const T *, int64_t, const T *, int, uint32_t *, hipStream_t);
 DMX_INSTANTIATE(float)

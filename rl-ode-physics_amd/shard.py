@@ -134,6 +134,11 @@ class DeviceOps:
         """safe-zone test of the freshly written ghost slots, behind the scatter on the side stream"""
         self.w.check_zones_on(self.side.cuda_stream, first, count)
 
+    def check_active(self, first, count):
+        """safe-zone test of the rank's own bodies as they stand, on the batch's stream (a lazily kept chunk that is
+        closed before it reaches its length: its last tick did not carry the test)"""
+        self.w.check_zones_on(self.main.cuda_stream, first, count)
+
     def any_rank(self, flags, group=None):
         """element-wise logical OR of a few host flags over the ranks (one small all-reduce)"""
         flags = [bool(f) for f in flags]
@@ -279,8 +284,12 @@ class ShardedStepper:
     CHUNK_MIN, CHUNK_MAX = 32, 256
 
     def __init__(self, world_batch, layout, rank, world_size, exchange="boundary", device=None, stream=None,
-                 collide=False, geometry=None, ops=None, group=None, exchange_every_tick=False):
+                 collide=False, geometry=None, ops=None, group=None, exchange_every_tick=False, lazy=False):
         self.w, self.L = world_batch, layout
+        # lazy: ballistic chunks stay open across run() calls (a caller that issues a few ticks per call does not pay a
+        # chunk's exchange, flag read and flag all-reduce per call); settle() closes the open chunk
+        self.lazy = bool(lazy)
+        self._open = None
         self.exchange = None
         if (world_size > 1 and exchange == "boundary") or ops is not None:
             ops = ops if ops is not None else DeviceOps(world_batch, device, stream)
@@ -332,13 +341,11 @@ class ShardedStepper:
         if self.exchange is None:
             self.w.step(h, nsteps)          # the C loop: no per-tick host work
             return
+        if self.collide and self.lazy and self.graph is None and not self.exchange_every_tick:
+            self._run_lazy(h, nsteps)
+            return
         if self.collide:
-            remaining = nsteps
-            while remaining > 0:
-                k = self.chunk
-                if self.graph is not None:
-                    k = max(1, k // self.graph_steps) * self.graph_steps + 1      # whole replays + the tested last tick
-                remaining -= self._chunk(h, min(remaining, k))
+            self._run_chunks(h, nsteps)
             return
         if self.graph is not None:
             reps, nsteps = divmod(nsteps, self.graph_steps)
@@ -346,6 +353,91 @@ class ShardedStepper:
                 self._replay()
         for _ in range(nsteps):
             self.tick(h)
+
+    def _run_chunks(self, h, nsteps, begun=None):
+        """the collision-checked loop, one closed chunk after another; `begun` = (exact_only, ballistic) of a chunk the
+        caller has already begun (and OR-ed over the ranks)"""
+        remaining = nsteps
+        while remaining > 0:
+            k = self.chunk
+            if self.graph is not None:
+                k = max(1, k // self.graph_steps) * self.graph_steps + 1      # whole replays + the tested last tick
+            remaining -= self._chunk(h, min(remaining, k), begun)
+            begun = None
+
+    # -- lazily closed ballistic chunks ----------------------------------------------------------------------
+    def _begin(self):
+        """begin a chunk on every rank; -> (exact_only, ballistic), OR-ed / AND-ed over the ranks"""
+        ex = self.exchange
+        ex.drain()                           # zones, snapshot and flag reset see the last exchange's ghost rows
+        exact_only, ballistic = self.w.chunk_begin()
+        # every decision that shapes the loop (path, chunk length, exchange cadence) is taken on flags OR-ed over the
+        # ranks, so all ranks issue the same sequence of collectives
+        exact_only, not_ballistic = ex.ops.any_rank([exact_only, not ballistic], ex.group)
+        return exact_only, not not_ballistic
+
+    def _run_lazy(self, h, nsteps):
+        ex, w = self.exchange, self.w
+        remaining = nsteps
+        while remaining > 0:
+            if self._open is None:
+                exact_only, ballistic = self._begin()
+                if exact_only or not ballistic:
+                    # crowded bodies, pending forces or bent paths somewhere: this stretch goes chunk by chunk
+                    k = min(remaining, self.chunk)
+                    self._run_chunks(h, k, begun=(exact_only, ballistic))
+                    remaining -= k
+                    continue
+                self._open = {"ticks": 0, "budget": self.chunk, "segs": [], "checked": False}
+            oc = self._open
+            k = min(remaining, oc["budget"] - oc["ticks"])
+            closes = oc["ticks"] + k >= oc["budget"]
+            first = oc["ticks"] == 0
+            if ex.fused:
+                ex.ops.disarm_pack()
+            if closes:
+                # the chunk's last tick carries the zone test and the chunk's one exchange
+                if k > 1:
+                    w.chunk_ticks(h, k - 1, first, False)
+                self.tick(h, check=True)
+                oc["checked"] = True
+            else:
+                w.chunk_ticks(h, k, first, False)
+            if oc["segs"] and oc["segs"][-1][0] == h:
+                oc["segs"][-1][1] += k
+            else:
+                oc["segs"].append([h, k])
+            oc["ticks"] += k
+            remaining -= k
+            if closes:
+                self.settle()
+
+    def settle(self):
+        """Close the chunk run() may have left open: test, exchange, flag read and flag all-reduce; on a violation
+        anywhere every rank rolls back to the chunk's start and replays its calls chunk by chunk."""
+        oc, self._open = self._open, None
+        if oc is None:
+            return
+        ex, w = self.exchange, self.w
+        if not oc["checked"]:
+            # closed before its length: the poses after its last tick inside their zones prove the ticks before
+            # (straight horizontal lines, convex zones); the boundary rows go out by an explicit gather
+            ex.ops.check_active(0, self.L.n)
+            ex.before_step(fused=False)
+            ex.pack(fused=False)
+            ex.exchange(check_ghosts=True)
+        ex.drain()
+        violated, warn_here = w.chunk_end()
+        violated, warn = ex.ops.any_rank([violated, warn_here], ex.group)
+        if not violated:
+            w.chunk_commit(oc["ticks"], refresh_zones=warn_here)
+            if not warn and oc["ticks"] >= self.chunk:
+                self.chunk = min(2 * self.chunk, self.CHUNK_MAX)
+            return
+        w.chunk_rollback()
+        self.chunk = self.CHUNK_MIN
+        for h, k in oc["segs"]:
+            self._run_chunks(h, k)
 
     def _replay(self):
         self.exchange.ops.drain()       # eager exchanges still in flight use the ring too: let them finish first
@@ -373,16 +465,11 @@ class ShardedStepper:
         for s in range(done, k):
             self.tick(h, check=(not ballistic) or s == 0 or s == k - 1)
 
-    def _chunk(self, h, k):
+    def _chunk(self, h, k, begun=None):
         """Run up to k ticks as one chunk; returns the ticks actually advanced."""
         ex, w, ops = self.exchange, self.w, self.exchange.ops
         for attempt in range(3):
-            ex.drain()                           # zones, snapshot and flag reset see the last exchange's ghost rows
-            exact_only, ballistic = w.chunk_begin()
-            # every decision that shapes the loop (path, chunk length, exchange cadence) is taken on flags OR-ed over the
-            # ranks, so all ranks issue the same sequence of collectives
-            exact_only, ballistic_all = ops.any_rank([exact_only, not ballistic], ex.group)
-            ballistic = not ballistic_all
+            exact_only, ballistic = begun if (begun is not None and attempt == 0) else self._begin()
             if exact_only or attempt == 2:
                 break                            # crowded bodies or pending forces somewhere: everyone steps exactly
             self._fast_ticks(h, k, ballistic)
@@ -406,6 +493,14 @@ class ShardedStepper:
         if self.exchange is not None:
             self.exchange.drain()
 
+    def close(self):
+        """settle the open chunk, wait for the exchange, detach the batch from the send buffers"""
+        if self.exchange is not None:
+            self.settle()
+            self.exchange.drain()
+            if self.exchange.fused:
+                self.exchange.ops.disarm_pack()
+
     def capture(self, h, steps_per_graph, stream, ring=2):
         """Capture `steps_per_graph` ticks (kernels, the RCCL all-gather and the stream choreography) into one
         HIP graph so a replay costs one host call; returns False (and stays eager) if capture is not possible.
@@ -415,6 +510,7 @@ class ShardedStepper:
             return False
         ops = self.exchange.ops
         try:
+            self.settle()
             ops.drain()
             torch.cuda.synchronize()
             self.exchange.set_ring(ring)
@@ -423,6 +519,10 @@ class ShardedStepper:
                 _, ballistic = self.w.chunk_begin()        # buffers exist before the capture; nothing is advanced
                 if ballistic and not self.exchange_every_tick:
                     return False                           # one exchange per chunk: nothing worth capturing
+                # a graph bakes the slab's address in: from here on the state must stay in one slab, so chunks keep
+                # their rollback snapshot by copy instead of by ping-pong
+                from .batch import SNAPSHOT_COPY
+                self.w.set_snapshot_mode(SNAPSHOT_COPY)
             torch.cuda.synchronize()
             ops.forget()                               # no event edges from outside the capture
             g = torch.cuda.CUDAGraph()

@@ -788,3 +788,119 @@ def test_checkpoint_and_resume_continue_bit_for_bit():
         w2.step(H, 45); w2.step(H, 45); w2.synchronize()
         _compare(w2.state(), ref)
         w.close(); w2.close()
+
+
+# ----------------------------------------------------------------- ping-pong snapshot, lazily closed chunks
+def _midair_scene(dtype="float64", speed=3.0):
+    scene = pkg.scenes.box_grid(16, 16, seed=13, y_range=(10.0, 12.0), spin=True, box_mass=True, plane=False).astype(dtype)
+    rng = np.random.default_rng(5)
+    scene.lvel[:, 0] = rng.uniform(-speed, speed, scene.n)
+    scene.lvel[:, 2] = rng.uniform(-speed, speed, scene.n)
+    return scene
+
+
+@pytest.mark.parametrize("per_call", [1, 2, 7, 20, 150])
+@pytest.mark.parametrize("speed", [0.1, 3.0])
+def test_step_calls_of_any_length_give_the_oracles_state(per_call, speed):
+    """dmxBatchStep leaves its collision-proof chunk open across calls and validates it later; a violation found then
+    rolls back ticks of EARLIER calls and replays them.  What a caller can observe must not depend on how the ticks
+    were split over calls (the reference issues a tick or two per frame, main.c:211)."""
+    scene = _midair_scene(speed=speed)
+    steps = 150
+    ow = _oracle_build(_orc("float64"), scene)
+    ow.run(H, steps)
+    w = pkg.BatchWorld(scene.n, dtype="float64")
+    w.load_scene(scene)
+    done = 0
+    while done < steps:
+        k = min(per_call, steps - done)
+        w.step(H, k)
+        done += k
+    _compare(w.state(), ow.state())
+    st = w.collision_stats()
+    assert st["fast_ticks"] + st["careful_ticks"] >= steps
+    if speed > 1.0:
+        assert st["pair_ticks"] > 0
+    w.close()
+
+
+def test_observations_between_calls_see_validated_state():
+    """every entry point that reads the batch settles the open chunk first: poses read after each call equal the oracle's"""
+    scene = _midair_scene(speed=3.0)
+    ow = _oracle_build(_orc("float64"), scene)
+    w = pkg.BatchWorld(scene.n, dtype="float64")
+    w.load_scene(scene)
+    for k in range(60):
+        w.step(H, 2)
+        ow.run(H, 2)
+        if k % 5 == 4:
+            assert np.array_equal(w.download(pkg.batch.POS), ow.state()[0]), k
+    _compare(w.state(), ow.state())
+    w.close()
+
+
+@pytest.mark.parametrize("mode", ["pingpong", "copy"])
+def test_snapshot_modes_roll_back_to_the_same_state(mode):
+    scene = _midair_scene(speed=3.0)
+    ow = _oracle_build(_orc("float64"), scene)
+    ow.run(H, 120)
+    w = pkg.BatchWorld(scene.n, dtype="float64")
+    w.set_snapshot_mode(pkg.batch.SNAPSHOT_COPY if mode == "copy" else pkg.batch.SNAPSHOT_PINGPONG)
+    w.load_scene(scene)
+    w.step(H, 120)
+    _compare(w.state(), ow.state())
+    w.close()
+
+
+def test_constants_reach_both_slabs():
+    """the state ping-pongs between two slabs; constants (mass, inertia, extents) and safe zones must be the same in both"""
+    scene = pkg.scenes.box_grid(16, 8, seed=2, spin=True, box_mass=True, plane=False).astype("float32")
+    w = pkg.BatchWorld(scene.n, dtype="float32")
+    w.load_scene(scene)
+    for chunks in range(3):                    # after every closed chunk the state sits in the other slab
+        w.step(H, 32)
+        assert np.array_equal(w.download(pkg.batch.SIDES), scene.sides)
+        assert np.array_equal(w.download(pkg.batch.MASS), scene.mass)
+        assert np.array_equal(w.download(pkg.batch.INERTIA), scene.inertia)
+    heavier = scene.mass * 2
+    w.upload(pkg.batch.MASS, heavier)
+    w.step(H, 32)
+    assert np.array_equal(w.download(pkg.batch.MASS), heavier)
+    w.step(H, 32)
+    assert np.array_equal(w.download(pkg.batch.MASS), heavier)
+    # and the whole run equals the oracle's (mass does not enter free flight with gravity only; inertia does through the gyro term)
+    ow = _oracle_run(_orc("float32"), scene, 160)
+    _compare(w.state(), ow.state())
+    w.close()
+
+
+def test_chunk_api_rollback_restores_own_and_ghost_slots():
+    """ChunkBegin -> ticks -> ChunkRollback through the C ABI: the start state comes back bit for bit, ghost slots included"""
+    scene = pkg.scenes.box_grid(8, 4, seed=3, y_range=(5.0, 6.0), spin=True, plane=False).astype("float32")
+    L = pkg.shard.SlabLayout(8, 4)
+    w = pkg.BatchWorld(L.n_total, dtype="float32")
+    w.load_scene(scene)
+    g = scene.slice(scene.n - 8, scene.n)
+    gpos = g.pos.copy(); gpos[:, 2] += 2.5
+    first = int(L.ghost_hi[0])
+    w.upload(pkg.batch.POS, gpos, first=first)
+    w.upload(pkg.batch.SIDES, g.sides, first=first)
+    w.upload_geom_type(g.gtype, first=first)
+    w.set_active_count(scene.n)
+    before = w.download(pkg.batch.STATE)
+    assert w.chunk_begin() == (False, True)
+    w.chunk_ticks(H, 5, True, True)
+    w.chunk_tick(H, True)
+    moved = w.download(pkg.batch.STATE)
+    assert not np.array_equal(moved[:scene.n], before[:scene.n])
+    assert np.array_equal(moved[scene.n:], before[scene.n:])            # ghost slots follow the state into the other slab
+    assert w.chunk_end() == (False, False)
+    w.chunk_rollback()
+    assert np.array_equal(w.download(pkg.batch.STATE), before)
+    # and a committed chunk keeps going from where it is
+    assert w.chunk_begin() == (False, True)
+    w.chunk_ticks(H, 6, True, True)
+    assert w.chunk_end() == (False, False)
+    w.chunk_commit(6)
+    assert np.array_equal(w.download(pkg.batch.STATE), moved)
+    w.close()

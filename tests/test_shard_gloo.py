@@ -37,6 +37,13 @@ class HostOps:
     def check_ghosts(self, first, count):
         self.ghost_checks = getattr(self, "ghost_checks", 0) + 1
 
+    def check_active(self, first, count):
+        w = getattr(self, "world", None)          # the zone test of the poses as they stand (a chunk closed early)
+        if w is not None:
+            w.log["checked"] += 1
+            if w.violate_at is not None and w.t >= w.violate_at:
+                w.flag = True
+
     def any_rank(self, flags, group=None):
         t = torch.tensor([int(bool(f)) for f in flags], dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -173,7 +180,7 @@ class HostWorld:
         self.log["exact"] += 1
 
 
-def _chunk_worker(rank, world, port, side, rows, ticks, violate, q):
+def _chunk_worker(rank, world, port, side, rows, ticks, violate, q, lazy_calls=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -186,8 +193,17 @@ def _chunk_worker(rank, world, port, side, rows, ticks, violate, q):
         # rank 1 alone sees the warn flag: chunk lengths must still stay in lockstep (they shape the collective sequence)
         w = HostWorld(state, L.n, violate_at=violate[1] if violate and violate[0] == rank else None, warn=(rank == 1))
         ops = HostOps(state)
-        st = shard.ShardedStepper(w, L, rank, world, collide=True, ops=ops)
-        st.run(1.0 / 60, ticks)
+        ops.world = w
+        st = shard.ShardedStepper(w, L, rank, world, collide=True, ops=ops, lazy=lazy_calls > 0)
+        if lazy_calls:
+            done = 0
+            while done < ticks:                  # a caller that issues a few ticks per call
+                k = min(lazy_calls, ticks - done)
+                st.run(1.0 / 60, k)
+                done += k
+            st.close()
+        else:
+            st.run(1.0 / 60, ticks)
         q.put((rank, state.numpy().copy(), dict(w.log), st.chunk, getattr(ops, "ghost_checks", 0)))
     finally:
         dist.destroy_process_group()
@@ -226,6 +242,43 @@ def test_chunked_collision_loop_commits_or_rolls_back_on_every_rank(violate):
     else:
         # rank 1's body is out from tick 40 on: the chunk holding it is rolled back on BOTH ranks, retried once with
         # fresh zones (the double raises the flag again), then replayed exactly; later chunks hit it again
+        assert got[0][1]["rollbacks"] == got[1][1]["rollbacks"] >= 2
+        assert got[0][1]["exact"] == got[1][1]["exact"] >= 32
+        assert got[0][1]["fast"] == got[1][1]["fast"] >= 32
+
+
+@pytest.mark.parametrize("violate", [None, (1, 40)])
+def test_lazily_closed_chunks_span_calls_and_replay_them_after_a_violation(violate):
+    """lazy=True: run() is called with 7 ticks at a time; chunks stay open across the calls (one exchange, one flag
+    read and one flag all-reduce per chunk, not per call) and the last, short chunk is closed by close()."""
+    world, side, rows, ticks = 2, 8, 5, 100
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, world, port, side, rows, ticks, violate, q, 7)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: rest for r, *rest in (q.get(timeout=60) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    L = shard.SlabLayout(side, rows)
+    comp = np.arange(shard.STATE_REALS) / 16.0
+    for r in range(world):
+        st, log, chunk, ghost_checks = got[r]
+        own = 1000.0 * r + np.arange(L.n)[:, None] + comp[None, :] + 0.5 * ticks
+        assert np.array_equal(st[:L.n], own)                       # every tick applied exactly once, rollbacks included
+        other = 1 - r
+        ghost = L.ghost_hi if r == 0 else L.ghost_lo
+        src = L.lower if r == 0 else L.upper
+        assert np.array_equal(st[ghost], 1000.0 * other + src[:, None] + comp[None, :] + 0.5 * ticks)
+        assert log["fast"] + log["exact"] == ticks
+    if violate is None:
+        # chunks of 32, 32, 32 (rank 1 warns: no growth) and the 4 ticks close() settles: 4 begins for 15 calls
+        assert all(got[r][1]["rollbacks"] == 0 and got[r][1]["exact"] == 0 and got[r][1]["begins"] == 4 for r in range(world))
+        # first + last tick of each full chunk, first tick + the standalone test of the short one
+        assert all(got[r][1]["checked"] == 8 for r in range(world))
+    else:
         assert got[0][1]["rollbacks"] == got[1][1]["rollbacks"] >= 2
         assert got[0][1]["exact"] == got[1][1]["exact"] >= 32
         assert got[0][1]["fast"] == got[1][1]["fast"] >= 32
