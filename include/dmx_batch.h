@@ -167,7 +167,8 @@ int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6]);
  *                range untouched; check = 1 also tests the new positions against the slots' zones
  *   ChunkEnd     wait for the batch stream and report the flags; the caller combines them over ranks
  *   ChunkCommit  account `ticks` fast ticks; refresh_zones = 1 schedules a zone rebuild (the warn flag was up)
- *   ChunkRollback  restore the snapshot (zones are rebuilt at the next ChunkBegin)
+ *   ChunkRollback  restore the state the chunk's first tick started from, ghost slots included (zones are rebuilt at the
+ *                next ChunkBegin).  Whatever writes state between ticks (the ghost refresh) does so after that tick
  *   ExactTick    one tick with the exact pair search / narrowphase / island solve; DMX_ECROSS if a pair involves
  *                a ghost slot */
 int dmxBatchChunkBegin(dmxBatchID b, int *exact_only, int *ballistic);

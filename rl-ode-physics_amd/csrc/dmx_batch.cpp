@@ -85,6 +85,8 @@ extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int dev
     b->cfm = precision == DMX_F32 ? 1e-5 : 1e-10;      // dWorldCreate default per precision [ODE]
     if (const char *v = getenv("DMX_VEC")) b->vec = atoi(v);
     if (const char *v = getenv("DMX_MIN_WAVES")) b->min_waves = atoi(v);
+    if (const char *v = getenv("DMX_NT")) b->nt = atoi(v);
+    if (const char *v = getenv("DMX_OOP")) b->oop = atoi(v);
     b->prof_on = getenv("DMX_HOST_PROFILE") != nullptr;
     if (const char *v = getenv("DMX_LAZY_CHUNKS")) b->lazy_chunks = atoi(v) != 0;
     int rc = DMX_OK;
@@ -318,7 +320,13 @@ template <class T> static int step_t(dmxBatch *b, double h, int nsteps, int64_t 
         const bool ext = b->ext_pending && s == 0;
         P.ticks = ext ? 1 : std::min(per, nsteps - s);
         T *S = (T *)b->slab + slab_ix(0, first);
-        HIP_TRY(launch_step<T>(S, S, b->gtype + first, b->stride, count, P, ext, b->diag + first / 64, b->stream));
+        if (b->oop && first == 0 && count == b->n && !ext) {
+            // experiment (DMX_OOP): read one slab, write the other, swap -- every tick
+            HIP_TRY(launch_step<T>(S, (T *)b->slab_alt, b->gtype, b->stride, count, P, false, b->diag, b->stream));
+            std::swap(b->slab, b->slab_alt);
+        } else {
+            HIP_TRY(launch_step<T>(S, S, b->gtype + first, b->stride, count, P, ext, b->diag + first / 64, b->stream));
+        }
         s += P.ticks;
     }
     b->stepped_with_plane = b->plane_on != 0;

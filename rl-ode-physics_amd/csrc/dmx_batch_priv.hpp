@@ -93,6 +93,8 @@ struct dmxBatch {
     double prof[12] = { 0 }; bool prof_on = false;
     int ticks_per_launch = 1;        // contact-free ticks fused into one integrate_free launch (dmxBatchSetTicksPerLaunch)
     int min_waves = 0;               // DMX_MIN_WAVES launch-tuning override (see StepParams)
+    int nt = 0;                      // DMX_NT launch-tuning override (see StepParams)
+    int oop = 0;                     // DMX_OOP=1: the plain (unchecked) loop writes every tick out of place, alternating slabs (experiment)
     int vec = 0;                     // DMX_VEC launch-tuning override (bodies per lane in integrate_free), 0 = default (1)
     bool stepped_with_plane = false;
     // general island path (explicit contact joints)
@@ -198,6 +200,7 @@ template <class T> inline StepParams<T> dmx_make_params(dmxBatch *b, double h)
     P.max_contacts = b->max_contacts;
     P.vec = b->vec;
     P.min_waves = b->min_waves;
+    P.nt = b->nt;
     P.bp_check = 0;          // set by the collision-aware tick (dmx_general.cpp)
     P.ticks = 1;
     P.bp_flags = nullptr;

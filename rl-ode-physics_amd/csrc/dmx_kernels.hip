@@ -34,6 +34,23 @@ __device__ __forceinline__ void stv(T *__restrict__ base, int64_t stride, int co
 {
     *reinterpret_cast<Pack<T, V> *>(base + slab_ix(comp, i)) = p;
 }
+// the same with the non-temporal hint (streamed once: do not keep the line in cache); launch tuning, StepParams::nt
+template <class T, int V>
+__device__ __forceinline__ Pack<T, V> ldv_nt(const T *base, int64_t stride, int comp, int64_t i)
+{
+    Pack<T, V> p;
+    const T *a = base + slab_ix(comp, i);
+#pragma unroll
+    for (int b = 0; b < V; b++) p.v[b] = __builtin_nontemporal_load(a + b);
+    return p;
+}
+template <class T, int V>
+__device__ __forceinline__ void stv_nt(T *base, int64_t stride, int comp, int64_t i, const Pack<T, V> &p)
+{
+    T *a = base + slab_ix(comp, i);
+#pragma unroll
+    for (int b = 0; b < V; b++) __builtin_nontemporal_store(p.v[b], a + b);
+}
 
 // Broadphase safe-zone test of one body (pre-step position): 2 = outside its zone (a body pair may exist),
 // 1 = has used more than a quarter of the radius (zones should be refreshed soon), 0 = well inside.
@@ -112,8 +129,13 @@ __global__ __launch_bounds__(256, MINW) void integrate_free(T *S, T *So, int64_t
         const int64_t i = t * V;
         if (V == 1 && P.skip != nullptr && P.skip[i]) continue;      // this body belongs to the island path this tick
         Pack<T, V> c[C_SIDES];
+        if (P.nt & 2) {
 #pragma unroll
-        for (int k = 0; k < C_SIDES; k++) c[k] = ldv<T, V>(S, stride, k, i);
+            for (int k = 0; k < C_SIDES; k++) c[k] = ldv_nt<T, V>(S, stride, k, i);
+        } else {
+#pragma unroll
+            for (int k = 0; k < C_SIDES; k++) c[k] = ldv<T, V>(S, stride, k, i);
+        }
         Pack<T, V> bx, bz, bs;
         if (P.bp_check) {
             bx = ldv<T, V>(S, stride, C_BPX, i); bz = ldv<T, V>(S, stride, C_BPZ, i); bs = ldv<T, V>(S, stride, C_BPSAFE, i);
@@ -156,8 +178,13 @@ __global__ __launch_bounds__(256, MINW) void integrate_free(T *S, T *So, int64_t
                 c[C_AVEL].v[b] = w.x; c[C_AVEL + 1].v[b] = w.y; c[C_AVEL + 2].v[b] = w.z;
             }
         }
+        if (P.nt & 1) {
 #pragma unroll
-        for (int k = 0; k < C_MASS; k++) stv<T, V>(So, stride, k, i, c[k]);
+            for (int k = 0; k < C_MASS; k++) stv_nt<T, V>(So, stride, k, i, c[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < C_MASS; k++) stv<T, V>(So, stride, k, i, c[k]);
+        }
         if (EXT) {
             Pack<T, V> z;
 #pragma unroll

@@ -529,6 +529,7 @@ def test_ghost_slots_are_checked_and_cross_rank_pairs_are_reported():
     w.check_zones_on(s.cuda_stream, scene.n, 2 * L.side)
     s.synchronize()
     assert w.chunk_end() == (False, False)
+    w.chunk_tick(H, True)                   # the chunk's first tick (from here on a rollback undoes what the exchange writes)
     # a ghost arrives 1 m closer than where its zone was built: outside the zone
     state = np.concatenate([gpos, g.quat, g.lvel, g.avel], axis=1).astype(np.float32)
     state[3, 2] -= 1.0
