@@ -112,6 +112,11 @@ struct dmxBatch {
     uint32_t bp_mask = 0; int bp_cap = 8; int bp_xbits = -1;      // -1: not chosen yet
     DevBuf bp_count, bp_items, bp_flags, bp_pairs, bp_inpair, bp_snapshot, bp_idx, bp_gather;
     DevBuf np_pos, np_normal, np_depth, np_count, np_pairs;   // device narrowphase output of the exact tick
+    // device-resident bookkeeping of the exact tick (dmx_exact.hip): capacity estimates carried from tick to tick, one arena
+    // for the pipeline's arrays, per-body scan arrays, the per-slot level scratch, the pinned read-back record
+    uint32_t ex_cap_pairs = 0, ex_cap_rows = 0;
+    DevBuf ex_arena, ex_body, ex_last;
+    void *ex_counts_host = nullptr;
     uint32_t *bp_flags_host = nullptr;         // pinned
     int bp_max_pairs = 0;
     std::vector<double> h_sides;               // host mirror of DMX_SIDES (exact values of the batch precision)

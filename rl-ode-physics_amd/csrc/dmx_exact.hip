@@ -1,0 +1,467 @@
+// dmx_exact.hip -- the exact (pair-bearing) tick's bookkeeping, on the device.
+//
+// What dSpaceCollide + NearCallback + the island builder of dWorldStep do between them
+// (/root/reference/src/main.c:211-215, 674-693) for the bodies that are in body-body pairs this tick:
+//   body pairs in canonical order (ascending i, then j) -> the bodies involved, ascending -> connected components
+//   (dynamics islands, numbered by their lowest slot) -> narrowphase contacts -> the tick's contact joints in creation
+//   order (ground-plane contacts by body, then pair contacts by pair), grouped by island -> for islands that get a
+//   workgroup, the level schedule of their rows (row level = 1 + latest level of an earlier row sharing a body).
+// Integer / index work over a few arrays: coalesced loads, lock-free union-find (atomicCAS hooking, larger root under
+// smaller), rocPRIM scans and one stable radix sort of (island, entry) keys; no MFMA, nothing to stage in LDS.
+//
+// Sizes live on the device (ExactCounts); every kernel loops over the device-side count with a grid sized from the
+// host's capacity estimate, and arrays are padded up to that capacity with neutral entries, so the host never needs a
+// count to enqueue the pipeline.  It reads ExactCounts back ONCE per tick (capacity check + launch shape of the island
+// solve); a count above its capacity makes the host grow the estimate and run the pipeline again -- nothing has
+// touched the state by then.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "dmx_internal.hpp"
+#include "dmx_math.hpp"
+#include "dmx_collide.hpp"
+#include "dmx_exact.hpp"
+
+namespace dmx {
+
+namespace {
+
+__device__ __forceinline__ uint32_t lo32(uint64_t v) { return (uint32_t)v; }
+__device__ __forceinline__ uint32_t hi32(uint64_t v) { return (uint32_t)(v >> 32); }
+
+__device__ __forceinline__ uint32_t cell_hash_x(int ix, int iz, uint32_t mask, int xbits)
+{
+    if (xbits > 0) return ((((uint32_t)iz) << xbits) | ((uint32_t)ix & ((1u << xbits) - 1u))) & mask;
+    return ((uint32_t)ix * 73856093u ^ (uint32_t)iz * 19349663u) & mask;
+}
+
+template <class T> __device__ __forceinline__ void aabb_of(const T *S, const uint8_t *gtype, int64_t i, T lo[3], T hi[3])
+{
+    const T p[3] = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
+    T r[3];
+    if (gtype[i] == GEOM_SPHERE || gtype[i] == GEOM_CONVEX) {
+        r[0] = r[1] = r[2] = S[slab_ix(C_SIDES + 0, i)];
+    } else {
+        const Q4<T> q = { S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)], S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] };
+        const M3<T> R = quat_to_R(q);
+        const T s[3] = { S[slab_ix(C_SIDES + 0, i)], S[slab_ix(C_SIDES + 1, i)], S[slab_ix(C_SIDES + 2, i)] };
+        for (int a = 0; a < 3; a++)
+            r[a] = T(0.5) * (tabs(R.m[a][0] * s[0]) + tabs(R.m[a][1] * s[1]) + tabs(R.m[a][2] * s[2]));
+    }
+    for (int a = 0; a < 3; a++) { lo[a] = p[a] - r[a]; hi[a] = p[a] + r[a]; }
+}
+
+// Walk the 3x3 columns around body i and call f(j) for every other body whose AABB overlaps i's (each once).
+template <class T, class F>
+__device__ __forceinline__ void for_each_partner(const T *S, const uint8_t *gtype, int64_t i, const GridParams<T> &G, F f)
+{
+    T lo[3], hi[3];
+    aabb_of<T>(S, gtype, i, lo, hi);
+    const int ix = (int)floor((double)(S[slab_ix(C_POS + 0, i)] * G.inv_cell));
+    const int iz = (int)floor((double)(S[slab_ix(C_POS + 2, i)] * G.inv_cell));
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dx = -1; dx <= 1; dx++) {
+            const uint32_t h = cell_hash_x(ix + dx, iz + dz, G.mask, G.xbits);
+            uint32_t cnt = G.count[h];
+            if (cnt > (uint32_t)G.cap) cnt = (uint32_t)G.cap;
+            for (uint32_t s = 0; s < cnt; s++) {
+                const int64_t j = G.items[(size_t)h * G.cap + s];
+                if (j == i) continue;
+                // hashed buckets can mix columns: keep only true 3x3 neighbours so (i,j) is met in one cell only
+                const int jx = (int)floor((double)(S[slab_ix(C_POS + 0, j)] * G.inv_cell));
+                const int jz = (int)floor((double)(S[slab_ix(C_POS + 2, j)] * G.inv_cell));
+                if (jx != ix + dx || jz != iz + dz) continue;
+                T lo2[3], hi2[3];
+                aabb_of<T>(S, gtype, j, lo2, hi2);
+                if (lo2[0] > hi[0] || lo[0] > hi2[0] || lo2[1] > hi[1] || lo[1] > hi2[1] || lo2[2] > hi[2] || lo[2] > hi2[2])
+                    continue;
+                f(j);
+            }
+        }
+}
+
+// ---- 1. per active body: partners above it (the pairs it owns) and whether it is in any pair at all ---------------
+// pc[i] = (owned pairs << 32) | in-any-pair; inpair[i] = in-any-pair (the fused kernel's skip mask).  A partner in a ghost
+// slot means an island spanning two ranks.
+template <class T>
+__global__ __launch_bounds__(256) void ex_pair_count(const T *__restrict__ S, const uint8_t *__restrict__ gtype, int64_t n_active,
+                                                     GridParams<T> G, uint64_t *__restrict__ pc, uint8_t *__restrict__ inpair,
+                                                     ExactCounts *__restrict__ C)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_active) return;
+    uint32_t owned = 0, any = 0;
+    if (gtype[i] != GEOM_NONE && gtype[i] != GEOM_CONVEX) {
+        for_each_partner<T>(S, gtype, i, G, [&](int64_t j) {
+            any = 1;
+            if (j >= n_active) { if (atomicOr(&C->cross, 1u) == 0u) { C->cross_a = (uint32_t)i; C->cross_b = (uint32_t)j; } }
+            else if (j > i) owned++;
+        });
+    }
+    pc[i] = ((uint64_t)owned << 32) | any;
+    inpair[i] = (uint8_t)any;
+}
+
+// ---- 2. pairs in canonical order, the involved bodies ascending, union-find initialised ----------------------------
+// inc = inclusive scan of pc.  Body i owns pairs [hi(exc), hi(exc) + owned) and, if involved, is entry lo(exc) of `inv`.
+template <class T>
+__global__ __launch_bounds__(256) void ex_pair_write(const T *__restrict__ S, const uint8_t *__restrict__ gtype, int64_t n_active,
+                                                     GridParams<T> G, const uint64_t *__restrict__ pc, const uint64_t *__restrict__ inc,
+                                                     int32_t *__restrict__ pairs, int32_t *__restrict__ inv, int32_t *__restrict__ parent,
+                                                     ExactCaps cap, ExactCounts *__restrict__ C)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_active) return;
+    const uint64_t tot = inc[n_active - 1];
+    if (i == 0) {
+        C->npairs = hi32(tot); C->ninv = lo32(tot);
+        if (hi32(tot) > cap.pairs || lo32(tot) > cap.inv) atomicOr(&C->overflow, 1u);
+    }
+    if (hi32(tot) > cap.pairs || lo32(tot) > cap.inv) return;            // the host grows the capacity and runs again
+    const uint64_t mine = pc[i], exc = inc[i] - mine;
+    if (lo32(mine)) {
+        const uint32_t k = lo32(exc);
+        inv[k] = (int32_t)i;
+        parent[k] = (int32_t)k;
+    }
+    const uint32_t owned = hi32(mine);
+    if (owned == 0) return;
+    int32_t *out = pairs + 2 * (size_t)hi32(exc);
+    uint32_t w = 0;
+    for_each_partner<T>(S, gtype, i, G, [&](int64_t j) {
+        if (j > i && j < n_active && w < owned) { out[2 * w] = (int32_t)i; out[2 * w + 1] = (int32_t)j; w++; }
+    });
+    // this thread's own run of partners, ascending (runs are short: insertion sort in place)
+    for (uint32_t a = 1; a < w; a++) {
+        const int32_t v = out[2 * a + 1];
+        uint32_t q = a;
+        while (q > 0 && out[2 * (q - 1) + 1] > v) { out[2 * q + 1] = out[2 * (q - 1) + 1]; q--; }
+        out[2 * q + 1] = v;
+    }
+}
+
+// ---- 3. connected components: lock-free union-find over the involved bodies' indices k (ascending slot order) -------
+__device__ __forceinline__ int uf_find(int32_t *p, int x)
+{
+    for (;;) {
+        const int px = ((volatile int32_t *)p)[x];
+        if (px == x) return x;
+        const int ppx = ((volatile int32_t *)p)[px];
+        if (ppx != px) ((volatile int32_t *)p)[x] = ppx;      // path halving (only ever moves a node closer to its root)
+        x = px;
+    }
+}
+__device__ __forceinline__ void uf_unite(int32_t *p, int a, int b)
+{
+    for (;;) {
+        a = uf_find(p, a); b = uf_find(p, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }           // the larger root goes under the smaller: roots are minima
+        if (atomicCAS(&p[b], b, a) == b) return;
+    }
+}
+__device__ __forceinline__ uint32_t kidx_of(const uint64_t *pc, const uint64_t *inc, int32_t s) { return lo32(inc[s] - pc[s]); }
+
+__global__ __launch_bounds__(256) void ex_unite(const int32_t *__restrict__ pairs, const uint64_t *__restrict__ pc,
+                                                const uint64_t *__restrict__ inc, int32_t *parent, const ExactCounts *__restrict__ C)
+{
+    const uint32_t np = C->overflow ? 0u : C->npairs;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < np; p += gridDim.x * blockDim.x)
+        uf_unite(parent, (int)kidx_of(pc, inc, pairs[2 * p]), (int)kidx_of(pc, inc, pairs[2 * p + 1]));
+}
+
+// root[k]; rf[k] = 1 for roots, 0 elsewhere and for the padding up to the capacity (scanned next: island numbers)
+__global__ __launch_bounds__(256) void ex_flatten(int32_t *parent, int32_t *__restrict__ root, uint32_t *__restrict__ rf,
+                                                  ExactCaps cap, const ExactCounts *__restrict__ C)
+{
+    const uint32_t ninv = C->overflow ? 0u : C->ninv;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < cap.inv; k += gridDim.x * blockDim.x) {
+        uint32_t f = 0;
+        if (k < ninv) { const int r = uf_find(parent, (int)k); root[k] = r; f = (r == (int)k) ? 1u : 0u; }
+        rf[k] = f;
+    }
+}
+
+// ---- 4. narrowphase with device-side counts (same colliders as np_plane / np_pairs) --------------------------------
+template <class T> struct BodyGeomX { V3<T> x; M3<T> R; T side[3]; int gt; };
+template <class T> __device__ __forceinline__ BodyGeomX<T> geom_of(const T *S, const uint8_t *gtype, int64_t i)
+{
+    BodyGeomX<T> g;
+    g.x = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
+    g.R = quat_to_R(Q4<T>{ S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)], S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] });
+    for (int a = 0; a < 3; a++) g.side[a] = S[slab_ix(C_SIDES + a, i)];
+    g.gt = gtype[i];
+    return g;
+}
+template <class T> __device__ __forceinline__ void put_c(T *gpos, T *gnormal, T *gdepth, size_t slot, const V3<T> &p, const V3<T> &n, T d)
+{
+    gpos[3 * slot] = p.x; gpos[3 * slot + 1] = p.y; gpos[3 * slot + 2] = p.z;
+    gnormal[3 * slot] = n.x; gnormal[3 * slot + 1] = n.y; gnormal[3 * slot + 2] = n.z;
+    gdepth[slot] = d;
+}
+
+// entries [0, cap.inv): ground-plane contacts of involved body k (4 slots at 4k); [cap.inv, cap.inv + cap.pairs): contacts
+// of pair p (8 slots at 4 cap.inv + 8p).  cc[e] = contacts of entry e, 0 for the padding.
+template <class T>
+__global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const uint8_t *__restrict__ gtype, const int32_t *__restrict__ inv,
+                                                const int32_t *__restrict__ pairs, StepParams<T> P, ExactCaps cap,
+                                                T *__restrict__ gpos, T *__restrict__ gnormal, T *__restrict__ gdepth,
+                                                uint32_t *__restrict__ cc, const ExactCounts *__restrict__ C)
+{
+    const uint32_t ninv = C->overflow ? 0u : C->ninv, np = C->overflow ? 0u : C->npairs;
+    const uint32_t ne = cap.inv + cap.pairs;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
+        int nc = 0;
+        if (e < cap.inv) {
+            if (e < ninv && P.plane_on) {
+                const BodyGeomX<T> g = geom_of<T>(S, gtype, inv[e]);
+                V3<T> cp[4]; T cd[4];
+                if (g.gt == GEOM_BOX) nc = box_plane(g.x, g.R, g.side, P.pn, P.pd, P.max_contacts, cp, cd);
+                else if (g.gt == GEOM_SPHERE) nc = sphere_plane(g.x, g.side[0], P.pn, P.pd, cp, cd);
+                for (int c = 0; c < nc; c++) put_c(gpos, gnormal, gdepth, (size_t)4 * e + c, cp[c], P.pn, cd[c]);
+            }
+        } else {
+            const uint32_t p = e - cap.inv;
+            if (p < np) {
+                const BodyGeomX<T> A = geom_of<T>(S, gtype, pairs[2 * p]);
+                const BodyGeomX<T> B = geom_of<T>(S, gtype, pairs[2 * p + 1]);
+                ContactPoint<T> c[8];
+                bool flip = false;      // a collider exists only for the swapped class order: swap, then negate the normal
+                const int mc = P.max_contacts > 8 ? 8 : P.max_contacts;
+                if (A.gt == GEOM_BOX && B.gt == GEOM_BOX) nc = box_box(A.x, A.R, A.side, B.x, B.R, B.side, mc, c);
+                else if (A.gt == GEOM_SPHERE && B.gt == GEOM_SPHERE) nc = sphere_sphere(A.x, A.side[0], B.x, B.side[0], c);
+                else if (A.gt == GEOM_SPHERE && B.gt == GEOM_BOX) nc = sphere_box(A.x, A.side[0], B.x, B.R, B.side, c);
+                else if (A.gt == GEOM_BOX && B.gt == GEOM_SPHERE) { nc = sphere_box(B.x, B.side[0], A.x, A.R, A.side, c); flip = true; }
+                if (nc > mc) nc = mc;
+                const size_t base = (size_t)4 * cap.inv + (size_t)8 * p;
+                for (int k = 0; k < nc; k++) {
+                    const V3<T> n = flip ? V3<T>{ -c[k].normal.x, -c[k].normal.y, -c[k].normal.z } : c[k].normal;
+                    put_c(gpos, gnormal, gdepth, base + k, c[k].pos, n, c[k].depth);
+                }
+            }
+        }
+        cc[e] = (uint32_t)nc;
+    }
+}
+
+// ---- 5. sort keys: entry e -> its island (rinc = inclusive scan of the root flags: island of root r = rinc[r] - 1) ---
+__global__ __launch_bounds__(256) void ex_keys(const int32_t *__restrict__ pairs, const uint64_t *__restrict__ pc,
+                                               const uint64_t *__restrict__ inc, const int32_t *__restrict__ root,
+                                               const uint32_t *__restrict__ rinc, ExactCaps cap, uint32_t *__restrict__ keys,
+                                               uint32_t *__restrict__ vals, ExactCounts *C)
+{
+    const uint32_t ninv = C->overflow ? 0u : C->ninv, np = C->overflow ? 0u : C->npairs;
+    const uint32_t ne = cap.inv + cap.pairs;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
+        uint32_t key = cap.inv;                         // padding sorts behind every island
+        if (e < cap.inv) { if (e < ninv) key = rinc[root[e]] - 1u; }
+        else if (e - cap.inv < np) key = rinc[root[kidx_of(pc, inc, pairs[2 * (e - cap.inv)])]] - 1u;
+        keys[e] = key; vals[e] = e;
+        if (e == 0) C->ni = rinc[cap.inv - 1];
+    }
+}
+
+// ---- 6. sorted entries -> (contacts << 32 | is-body-entry), scanned next ------------------------------------------
+__global__ __launch_bounds__(256) void ex_gather(const uint32_t *__restrict__ keys_s, const uint32_t *__restrict__ vals_s,
+                                                 const uint32_t *__restrict__ cc, ExactCaps cap, uint64_t *__restrict__ sc)
+{
+    const uint32_t ne = cap.inv + cap.pairs;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ne; t += gridDim.x * blockDim.x) {
+        uint64_t v = 0;
+        if (keys_s[t] < cap.inv) { const uint32_t e = vals_s[t]; v = ((uint64_t)cc[e] << 32) | (e < cap.inv ? 1u : 0u); }
+        sc[t] = v;
+    }
+}
+
+// ---- 7. island boundaries: first sorted entry of each island gives its offsets ------------------------------------
+__global__ __launch_bounds__(256) void ex_bounds(const uint32_t *__restrict__ keys_s, const uint64_t *__restrict__ sc,
+                                                 const uint64_t *__restrict__ sinc, ExactCaps cap, int *__restrict__ body_off,
+                                                 int *__restrict__ con_off, int *__restrict__ row_off, ExactCounts *C)
+{
+    const uint32_t ne = cap.inv + cap.pairs;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ne; t += gridDim.x * blockDim.x) {
+        const uint32_t key = keys_s[t];
+        if (key < cap.inv && (t == 0 || keys_s[t - 1] != key)) {
+            const uint64_t exc = sinc[t] - sc[t];
+            body_off[key] = (int)lo32(exc); con_off[key] = (int)hi32(exc); row_off[key] = 3 * (int)hi32(exc);
+        }
+        if (t == ne - 1) {
+            const uint64_t tot = sinc[t];
+            const uint32_t ni = C->ni;
+            body_off[ni] = (int)lo32(tot); con_off[ni] = (int)hi32(tot); row_off[ni] = 3 * (int)hi32(tot);
+            C->njoints = hi32(tot);
+        }
+    }
+}
+
+// ---- 8. the island-grouped body list and contact arrays -------------------------------------------------------------
+__global__ __launch_bounds__(256) void ex_fill(const uint32_t *__restrict__ keys_s, const uint32_t *__restrict__ vals_s,
+                                               const uint64_t *__restrict__ sc, const uint64_t *__restrict__ sinc,
+                                               const uint32_t *__restrict__ cc, const int32_t *__restrict__ inv,
+                                               const int32_t *__restrict__ pairs, const int *__restrict__ con_off, ExactCaps cap, int rpc,
+                                               int *__restrict__ bodies, int *__restrict__ cb1, int *__restrict__ cb2,
+                                               int *__restrict__ csrc, int *__restrict__ crow)
+{
+    const uint32_t ne = cap.inv + cap.pairs;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ne; t += gridDim.x * blockDim.x) {
+        const uint32_t key = keys_s[t];
+        if (key >= cap.inv) continue;
+        const uint32_t e = vals_s[t];
+        const uint64_t exc = sinc[t] - sc[t];
+        const int d0 = (int)hi32(exc), c0 = con_off[key];
+        int b1, b2, src0;
+        if (e < cap.inv) { b1 = inv[e]; b2 = -1; src0 = 4 * (int)e; bodies[lo32(exc)] = b1; }
+        else { const uint32_t p = e - cap.inv; b1 = pairs[2 * p]; b2 = pairs[2 * p + 1]; src0 = 4 * (int)cap.inv + 8 * (int)p; }
+        const int nc = (int)cc[e];
+        for (int c = 0; c < nc; c++) {
+            const int d = d0 + c;
+            cb1[d] = b1; cb2[d] = b2; csrc[d] = src0 + c; crow[d] = rpc * (d - c0);
+        }
+    }
+}
+
+// ---- 9. which islands get a workgroup: bg[isl] = (rows << 32 | 1) for those, 0 otherwise and for the padding -------
+__global__ __launch_bounds__(256) void ex_bigflags(const int *__restrict__ con_off, ExactCaps cap, int rpc, int big_rows,
+                                                   uint64_t *__restrict__ bg, const ExactCounts *__restrict__ C)
+{
+    const uint32_t ni = C->overflow ? 0u : C->ni;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap.inv; i += gridDim.x * blockDim.x) {
+        uint64_t v = 0;
+        if (i < ni) { const int m = rpc * (con_off[i + 1] - con_off[i]); if (m >= big_rows) v = ((uint64_t)(uint32_t)m << 32) | 1u; }
+        bg[i] = v;
+    }
+}
+
+// ---- 10. level schedules.  One lane per island; islands own disjoint bodies, so `last` (per slot, -1 when idle) is
+//          private to the lane while it works.  lev_off of island k (big index) lives at row_base + k, nlev + 1 <= rows + 1
+//          entries; lev_rows / row_level at row_base. -----------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ex_levels(const int *__restrict__ con_off, const int *__restrict__ body_off,
+                                                const int *__restrict__ cb1, const int *__restrict__ cb2,
+                                                const uint64_t *__restrict__ bg, const uint64_t *__restrict__ binc, ExactCaps cap, int rpc,
+                                                int *__restrict__ big, int *__restrict__ big_list, int *__restrict__ lev_count,
+                                                int *__restrict__ lev_off, int *__restrict__ lev_rows, int *__restrict__ row_level,
+                                                int *__restrict__ last, ExactCounts *C)
+{
+    const uint32_t ni = C->overflow ? 0u : C->ni;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ni; i += gridDim.x * blockDim.x) {
+        if (i == 0) {
+            const uint64_t tot = binc[cap.inv - 1];
+            C->nbig = lo32(tot); C->big_rows = hi32(tot);
+            if (hi32(tot) > cap.rows) atomicOr(&C->overflow, 2u);
+        }
+        const uint64_t mine = bg[i];
+        if (!lo32(mine)) { big[i] = -1; continue; }
+        const uint64_t exc = binc[i] - mine;
+        const int k = (int)lo32(exc), base = (int)hi32(exc), m = (int)hi32(mine);
+        big[i] = base + k;
+        big_list[k] = (int)i;
+        atomicMax(&C->big_max_bodies, (uint32_t)(body_off[i + 1] - body_off[i]));
+        if ((uint32_t)(base + m) > cap.rows) continue;          // flagged above; the host grows the capacity
+        int *lv_out = row_level + base, *off = lev_off + base + k, *rows_out = lev_rows + base;
+        int nlev = 0, r = 0;
+        for (int d = con_off[i]; d < con_off[i + 1]; d++) {
+            const int b1 = cb1[d], b2 = cb2[d];
+            for (int q = 0; q < rpc; q++, r++) {
+                int lv = last[b1];
+                if (b2 >= 0 && last[b2] > lv) lv = last[b2];
+                lv += 1;
+                lv_out[r] = lv;
+                last[b1] = lv;
+                if (b2 >= 0) last[b2] = lv;
+                if (lv + 1 > nlev) nlev = lv + 1;
+            }
+        }
+        for (int d = con_off[i]; d < con_off[i + 1]; d++) {       // back to the idle state
+            last[cb1[d]] = -1;
+            if (cb2[d] >= 0) last[cb2[d]] = -1;
+        }
+        lev_count[k] = nlev;
+        for (int q = 0; q <= nlev; q++) off[q] = 0;
+        for (int q = 0; q < m; q++) off[lv_out[q] + 1]++;
+        int w = 0;
+        for (int q = 1; q <= nlev; q++) w = off[q] > w ? off[q] : w;
+        atomicMax(&C->big_max_width, (uint32_t)w);
+        off[0] = base;
+        for (int q = 0; q < nlev; q++) off[q + 1] += off[q];
+        // fill: rows of a level in creation order (off[lv] doubles as the fill cursor; restored afterwards)
+        for (int q = 0; q < m; q++) rows_out[off[lv_out[q]]++ - base] = q;
+        for (int q = nlev; q > 0; q--) off[q] = off[q - 1];
+        off[0] = base;
+    }
+}
+
+__global__ void ex_fill_i32(int32_t *p, int32_t v, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+inline unsigned grid_for(size_t n) { size_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
+
+}  // namespace
+
+size_t exact_temp_bytes(const ExactCaps &cap, int64_t n_active)
+{
+    size_t a = 0, b = 0, c = 0, d = 0;
+    const size_t ne = (size_t)cap.inv + cap.pairs;
+    (void)rocprim::inclusive_scan(nullptr, a, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)n_active, rocprim::plus<uint64_t>());
+    (void)rocprim::inclusive_scan(nullptr, b, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)cap.inv, rocprim::plus<uint32_t>());
+    (void)rocprim::inclusive_scan(nullptr, c, (uint64_t *)nullptr, (uint64_t *)nullptr, ne, rocprim::plus<uint64_t>());
+    (void)rocprim::radix_sort_pairs(nullptr, d, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, ne, 0, 32);
+    size_t m = a > b ? a : b;
+    m = m > c ? m : c;
+    m = m > d ? m : d;
+    return m + 256;
+}
+
+hipError_t exact_init_last(int32_t *last, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(ex_fill_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, last, -1, (size_t)n);
+    return hipGetLastError();
+}
+
+#define EX_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+template <class T>
+hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G, const StepParams<T> &P,
+                              const ExactBuffers<T> &B, const ExactCaps &cap, int rpc, int big_rows, hipStream_t st)
+{
+    const size_t ne = (size_t)cap.inv + cap.pairs;
+    size_t tb = B.temp_bytes;
+    EX_TRY(hipMemsetAsync(B.counts, 0, sizeof(ExactCounts), st));
+    hipLaunchKernelGGL((ex_pair_count<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inpair, B.counts);
+    EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.pc, B.inc, (size_t)n_active, rocprim::plus<uint64_t>(), st));
+    hipLaunchKernelGGL((ex_pair_write<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inc,
+                       B.pairs, B.inv, B.parent, cap, B.counts);
+    hipLaunchKernelGGL(ex_unite, dim3(grid_for(cap.pairs)), dim3(256), 0, st, B.pairs, B.pc, B.inc, B.parent, B.counts);
+    hipLaunchKernelGGL(ex_flatten, dim3(grid_for(cap.inv)), dim3(256), 0, st, B.parent, B.root, B.rf, cap, B.counts);
+    tb = B.temp_bytes;
+    EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.rf, B.rinc, (size_t)cap.inv, rocprim::plus<uint32_t>(), st));
+    hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, P, cap,
+                       B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
+    hipLaunchKernelGGL(ex_keys, dim3(grid_for(ne)), dim3(256), 0, st, B.pairs, B.pc, B.inc, B.root, B.rinc, cap, B.keys, B.vals, B.counts);
+    int bits = 1;
+    while ((1u << bits) <= cap.inv && bits < 32) bits++;        // keys are island numbers < cap.inv and the padding key cap.inv
+    tb = B.temp_bytes;
+    EX_TRY(rocprim::radix_sort_pairs(B.temp, tb, B.keys, B.keys_s, B.vals, B.vals_s, ne, 0, (unsigned)bits, st));
+    hipLaunchKernelGGL(ex_gather, dim3(grid_for(ne)), dim3(256), 0, st, B.keys_s, B.vals_s, B.cc, cap, B.sc);
+    tb = B.temp_bytes;
+    EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.sc, B.sinc, ne, rocprim::plus<uint64_t>(), st));
+    hipLaunchKernelGGL(ex_bounds, dim3(grid_for(ne)), dim3(256), 0, st, B.keys_s, B.sc, B.sinc, cap, B.body_off, B.con_off, B.row_off, B.counts);
+    hipLaunchKernelGGL(ex_fill, dim3(grid_for(ne)), dim3(256), 0, st, B.keys_s, B.vals_s, B.sc, B.sinc, B.cc, B.inv, B.pairs, B.con_off, cap, rpc,
+                       B.bodies, B.cb1, B.cb2, B.csrc, B.crow);
+    hipLaunchKernelGGL(ex_bigflags, dim3(grid_for(cap.inv)), dim3(256), 0, st, B.con_off, cap, rpc, big_rows, B.bg, B.counts);
+    tb = B.temp_bytes;
+    EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.bg, B.binc, (size_t)cap.inv, rocprim::plus<uint64_t>(), st));
+    hipLaunchKernelGGL(ex_levels, dim3((unsigned)(((size_t)cap.inv + 63) / 64)), dim3(64), 0, st, B.con_off, B.body_off, B.cb1, B.cb2, B.bg, B.binc,
+                       cap, rpc, B.big, B.big_list, B.lev_count, B.lev_off, B.lev_rows, B.row_level, B.last, B.counts);
+    return hipGetLastError();
+}
+
+template hipError_t launch_exact_group<float>(const float *, const uint8_t *, int64_t, const GridParams<float> &, const StepParams<float> &,
+                                              const ExactBuffers<float> &, const ExactCaps &, int, int, hipStream_t);
+template hipError_t launch_exact_group<double>(const double *, const uint8_t *, int64_t, const GridParams<double> &, const StepParams<double> &,
+                                               const ExactBuffers<double> &, const ExactCaps &, int, int, hipStream_t);
+
+}  // namespace dmx

@@ -1,0 +1,51 @@
+// dmx_exact.hpp -- interface of the device-resident bookkeeping of the exact tick (dmx_exact.hip), used by dmx_general.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dmx_internal.hpp"
+
+namespace dmx {
+
+// capacities the host sized the arrays for (estimates from earlier ticks): body pairs, involved bodies, rows of islands
+// that get a workgroup.  Derived sizes: entries = inv + pairs; contact slots = 4 inv + 8 pairs.
+struct ExactCaps { uint32_t pairs, inv, rows; };
+
+// what the pipeline found, read back by the host once per tick (device struct, 64 B)
+struct ExactCounts {
+    uint32_t npairs, ninv, ni, njoints, nbig, big_rows, big_max_bodies, big_max_width;
+    uint32_t overflow;      // bit 0: pairs / involved bodies above capacity; bit 1: level-schedule rows above capacity
+    uint32_t cross;         // a pair reaches into a ghost slot (an island spanning two ranks); the pair:
+    uint32_t cross_a, cross_b;
+    uint32_t pad[4];
+};
+
+template <class T> struct ExactBuffers {
+    ExactCounts *counts;
+    void *temp; size_t temp_bytes;              // rocPRIM scratch
+    uint64_t *pc, *inc;                         // [n_active] per body: (owned pairs << 32 | involved), and its inclusive scan
+    uint8_t *inpair;                            // [stride] the fused kernel's skip mask
+    int32_t *pairs;                             // [2 pairs]
+    int32_t *inv, *parent, *root;               // [inv]
+    uint32_t *rf, *rinc;                        // [inv] root flags, their inclusive scan
+    T *gpos, *gnormal, *gdepth;                 // [3 / 3 / 1 per contact slot]
+    uint32_t *cc;                               // [entries] contacts per entry
+    uint32_t *keys, *vals, *keys_s, *vals_s;    // [entries]
+    uint64_t *sc, *sinc;                        // [entries]
+    int *body_off, *con_off, *row_off;          // [inv + 1]
+    int *bodies;                                // [inv]
+    int *cb1, *cb2, *csrc, *crow;               // [contact slots]
+    uint64_t *bg, *binc;                        // [inv]
+    int *big, *big_list, *lev_count;            // [inv]
+    int *lev_off;                               // [rows + inv]
+    int *lev_rows, *row_level;                  // [rows]
+    int32_t *last;                              // [stride] per slot, -1 when idle
+};
+
+size_t exact_temp_bytes(const ExactCaps &cap, int64_t n_active);
+hipError_t exact_init_last(int32_t *last, int64_t n, hipStream_t st);
+// the whole pipeline on `st`; the grid G must have been filled (bp_insert) on the same stream before
+template <class T>
+hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G, const StepParams<T> &P,
+                              const ExactBuffers<T> &B, const ExactCaps &cap, int rpc, int big_rows, hipStream_t st);
+
+}  // namespace dmx

@@ -18,6 +18,7 @@
 #include <cmath>
 
 #include "dmx_batch_priv.hpp"
+#include "dmx_exact.hpp"
 
 namespace {
 
@@ -75,7 +76,6 @@ int ensure_buffers(dmxBatch *b)
     if ((rc = dmx_ensure_dev(b->bp_count, tbl * sizeof(uint32_t))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->bp_items, tbl * (size_t)b->bp_cap * sizeof(int32_t))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->bp_flags, 64)) != DMX_OK) return rc;
-    if ((rc = dmx_ensure_dev(b->bp_pairs, (size_t)b->bp_max_pairs * 2 * sizeof(int32_t))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->bp_inpair, (size_t)b->stride)) != DMX_OK) return rc;
     if (!b->bp_flags_host) HIP_TRY(hipHostMalloc((void **)&b->bp_flags_host, 64));
     return DMX_OK;
@@ -245,149 +245,146 @@ template <class T> int fused_run(dmxBatch *b, double h, int n, bool ends_only, b
     return DMX_OK;
 }
 
-// one exact tick: device pair search, then islands for bodies in pairs, fused kernel for the rest
+// ---- one exact tick ---------------------------------------------------------------------------------------------
+// The whole bookkeeping runs on the device (dmx_exact.hip): canonical pair list, involved bodies, islands, narrowphase,
+// joints grouped by island in creation order, level schedules.  The host enqueues the pipeline with capacities
+// estimated from earlier ticks, reads ONE 64-byte record back (counts + overflow flags; the stream synchronisation of
+// the tick), then launches the island solve with the exact shape and the fused kernel for everyone else.
+constexpr int kBigIslandRows = 4;        // islands with at least this many rows get a workgroup (see dmx_joints.cpp)
+
+int big_island_rows_general()
+{
+    static const int v = [] { const char *e = getenv("DMX_BIG_ISLAND_ROWS"); return e ? atoi(e) : kBigIslandRows; }();
+    return v;
+}
+
+template <class T> int ensure_exact_buffers(dmxBatch *b, const ExactCaps &cap, ExactBuffers<T> &B)
+{
+    int rc;
+    const size_t ne = (size_t)cap.inv + cap.pairs, nslots = (size_t)4 * cap.inv + (size_t)8 * cap.pairs;
+    const size_t n = (size_t)b->stride;
+    if ((rc = dmx_ensure_dev(b->ex_body, n * (2 * sizeof(uint64_t)))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->bp_inpair, n)) != DMX_OK) return rc;
+    if (!b->ex_last.p) {
+        if ((rc = dmx_ensure_dev(b->ex_last, n * sizeof(int32_t))) != DMX_OK) return rc;
+        HIP_TRY(exact_init_last((int32_t *)b->ex_last.p, (int64_t)(b->ex_last.bytes / sizeof(int32_t)), b->stream));
+    }
+    const size_t temp = exact_temp_bytes(cap, b->n_active);
+    // one arena, carved up in 256-byte steps
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) / 256 * 256; return at; };
+    const size_t o_counts = take(sizeof(ExactCounts)), o_temp = take(temp), o_pairs = take(2 * (size_t)cap.pairs * 4),
+                 o_inv = take((size_t)cap.inv * 4), o_parent = take((size_t)cap.inv * 4), o_root = take((size_t)cap.inv * 4),
+                 o_rf = take((size_t)cap.inv * 4), o_rinc = take((size_t)cap.inv * 4),
+                 o_gpos = take(nslots * 3 * sizeof(T)), o_gnormal = take(nslots * 3 * sizeof(T)), o_gdepth = take(nslots * sizeof(T)),
+                 o_cc = take(ne * 4), o_keys = take(ne * 4), o_vals = take(ne * 4), o_keys_s = take(ne * 4), o_vals_s = take(ne * 4),
+                 o_sc = take(ne * 8), o_sinc = take(ne * 8),
+                 o_body_off = take(((size_t)cap.inv + 1) * 4), o_con_off = take(((size_t)cap.inv + 1) * 4), o_row_off = take(((size_t)cap.inv + 1) * 4),
+                 o_bodies = take((size_t)cap.inv * 4),
+                 o_cb1 = take(nslots * 4), o_cb2 = take(nslots * 4), o_csrc = take(nslots * 4), o_crow = take(nslots * 4),
+                 o_bg = take((size_t)cap.inv * 8), o_binc = take((size_t)cap.inv * 8),
+                 o_big = take((size_t)cap.inv * 4), o_big_list = take((size_t)cap.inv * 4), o_lev_count = take((size_t)cap.inv * 4),
+                 o_lev_off = take(((size_t)cap.rows + cap.inv + 1) * 4), o_lev_rows = take((size_t)cap.rows * 4), o_row_level = take((size_t)cap.rows * 4);
+    if ((rc = dmx_ensure_dev(b->ex_arena, off)) != DMX_OK) return rc;
+    char *A = (char *)b->ex_arena.p;
+    B.counts = (ExactCounts *)(A + o_counts);
+    B.temp = A + o_temp; B.temp_bytes = temp;
+    B.pc = (uint64_t *)b->ex_body.p; B.inc = B.pc + n;
+    B.inpair = (uint8_t *)b->bp_inpair.p;
+    B.pairs = (int32_t *)(A + o_pairs);
+    B.inv = (int32_t *)(A + o_inv); B.parent = (int32_t *)(A + o_parent); B.root = (int32_t *)(A + o_root);
+    B.rf = (uint32_t *)(A + o_rf); B.rinc = (uint32_t *)(A + o_rinc);
+    B.gpos = (T *)(A + o_gpos); B.gnormal = (T *)(A + o_gnormal); B.gdepth = (T *)(A + o_gdepth);
+    B.cc = (uint32_t *)(A + o_cc);
+    B.keys = (uint32_t *)(A + o_keys); B.vals = (uint32_t *)(A + o_vals); B.keys_s = (uint32_t *)(A + o_keys_s); B.vals_s = (uint32_t *)(A + o_vals_s);
+    B.sc = (uint64_t *)(A + o_sc); B.sinc = (uint64_t *)(A + o_sinc);
+    B.body_off = (int *)(A + o_body_off); B.con_off = (int *)(A + o_con_off); B.row_off = (int *)(A + o_row_off);
+    B.bodies = (int *)(A + o_bodies);
+    B.cb1 = (int *)(A + o_cb1); B.cb2 = (int *)(A + o_cb2); B.csrc = (int *)(A + o_csrc); B.crow = (int *)(A + o_crow);
+    B.bg = (uint64_t *)(A + o_bg); B.binc = (uint64_t *)(A + o_binc);
+    B.big = (int *)(A + o_big); B.big_list = (int *)(A + o_big_list); B.lev_count = (int *)(A + o_lev_count);
+    B.lev_off = (int *)(A + o_lev_off); B.lev_rows = (int *)(A + o_lev_rows); B.row_level = (int *)(A + o_row_level);
+    B.last = (int32_t *)b->ex_last.p;
+    return DMX_OK;
+}
+
 template <class T> int careful_tick(dmxBatch *b, double h)
 {
     int rc;
     snapshot_drop(b);           // exact ticks run in place and are never rolled back
     std::unique_ptr<DmxPhase> ph(new DmxPhase(b, 0));
-    if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
-    HIP_TRY(hipMemsetAsync(b->bp_inpair.p, 0, (size_t)b->stride, b->stream));
-    HIP_TRY(launch_bp_pairs<T>((const T *)b->slab, b->gtype, b->stride, b->n_active, grid_of<T>(b),
-                               (int32_t *)b->bp_pairs.p, b->bp_max_pairs, (uint8_t *)b->bp_inpair.p, b->stream));
-    if ((rc = read_flags(b)) != DMX_OK) return rc;
-    if (b->bp_flags_host[BPF_OVERFLOW]) {          // a column holds more bodies than a bucket: widen and redo the search
-        if ((rc = grow_buckets(b)) != DMX_OK) return rc;
-        return careful_tick<T>(b, h);
+    if (!b->ex_counts_host) HIP_TRY(hipHostMalloc((void **)&b->ex_counts_host, sizeof(ExactCounts)));
+    const StepParams<T> P = dmx_make_params<T>(b, h);
+    const int rpc = b->mu > 0 ? 3 : 1;
+    ExactBuffers<T> B;
+    ExactCounts &C = *(ExactCounts *)b->ex_counts_host;
+    if (b->ex_cap_pairs == 0) { b->ex_cap_pairs = 1024; b->ex_cap_rows = 16384; }
+    for (int attempt = 0;; attempt++) {
+        if (attempt > 40) return DMX_ECAPACITY;
+        ExactCaps cap;
+        cap.pairs = b->ex_cap_pairs;
+        cap.inv = (uint32_t)std::min<int64_t>(2 * (int64_t)cap.pairs, b->n_active);
+        cap.rows = b->ex_cap_rows;
+        if ((rc = ensure_exact_buffers<T>(b, cap, B)) != DMX_OK) return rc;
+        if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
+        HIP_TRY(launch_exact_group<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), P, B, cap, rpc,
+                                      big_island_rows_general(), b->stream));
+        HIP_TRY(hipMemcpyAsync(b->bp_flags_host, b->bp_flags.p, BPF_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(&C, B.counts, sizeof(ExactCounts), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));              // the tick's one wait for the device
+        if (b->bp_flags_host[BPF_OVERFLOW]) {                  // a column holds more bodies than a bucket: widen and search again
+            if ((rc = grow_buckets(b)) != DMX_OK) return rc;
+            continue;
+        }
+        if (C.overflow & 1u) {
+            const uint64_t need = std::max<uint64_t>(C.npairs, (uint64_t)(C.ninv + 1) / 2);
+            b->ex_cap_pairs = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * cap.pairs, need + need / 4 + 64), 1ull << 28);
+            if (need > (1ull << 28)) { fprintf(stderr, "libode_mi355: %llu body pairs exceed the pair capacity\n", (unsigned long long)need); return DMX_ECAPACITY; }
+            continue;
+        }
+        if (C.overflow & 2u) {
+            b->ex_cap_rows = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * cap.rows, (uint64_t)C.big_rows + C.big_rows / 4 + 64), 1ull << 30);
+            continue;
+        }
+        break;
     }
-    uint32_t np = b->bp_flags_host[BPF_NPAIRS];
-    b->last_pairs = np;
+    b->last_pairs = C.npairs;
     b->stat_careful_ticks++;
-    if (np == 0) {
+    if (C.cross) {
+        fprintf(stderr, "libode_mi355: bodies %u and %u touch across two ranks' slabs; an island spanning ranks has to be "
+                        "migrated to one owner first\n", C.cross_a, C.cross_b);
+        return DMX_ECROSS;
+    }
+    if (C.npairs == 0) {
         b->last_mixed = false;
         return fused_tick<T>(b, h, false, nullptr);
-    }
-    if ((int64_t)np > b->bp_max_pairs) {
-        fprintf(stderr, "libode_mi355: %u body pairs exceed the pair buffer (%d)\n", np, b->bp_max_pairs);
-        return DMX_ECAPACITY;
     }
     b->stat_pair_ticks++;
+    // a quiet scene that has turned busy: leave head room so the next ticks do not run the pipeline twice
+    if (2ull * C.npairs > b->ex_cap_pairs) b->ex_cap_pairs = (uint32_t)std::min<uint64_t>(2ull * b->ex_cap_pairs, 1ull << 28);
 
-    // ---- pairs and the bodies in them, canonical order (ascending i, then j) ---------------------------
-    ph.reset(new DmxPhase(b, 1));
-    std::vector<int32_t> &pr = b->sc_i32[1];       // (work arrays are members of the batch, reused from tick to tick)
-    pr.resize((size_t)2 * np);
-    HIP_TRY(hipMemcpyAsync(pr.data(), b->bp_pairs.p, pr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
-    std::vector<std::pair<int32_t, int32_t>> &pairs = b->sc_pairs;
-    pairs.clear();
-    pairs.reserve(np);
-    for (uint32_t k = 0; k < np; k++) {
-        // a convex body has no collider against another body (ODE's dCollideConvexBox is an empty stub; convex-convex and
-        // convex-sphere are not built): such a pair yields no contact, so neither body is "involved" on its account
-        if (b->h_gtype[(size_t)pr[2 * k]] == GEOM_CONVEX || b->h_gtype[(size_t)pr[2 * k + 1]] == GEOM_CONVEX) continue;
-        pairs.push_back({ pr[2 * k], pr[2 * k + 1] });
-    }
-    np = (uint32_t)pairs.size();
-    if (np == 0) {
-        b->last_mixed = false;
-        return fused_tick<T>(b, h, false, nullptr);
-    }
-    sort_pairs(pairs, b->n, b->sc_last_count, b->sc_pairs2, b->sc_i32[0]);
-    for (auto &p : pairs)
-        if (p.first >= b->n_active || p.second >= b->n_active) {
-            fprintf(stderr, "libode_mi355: bodies %d and %d touch across two ranks' slabs; an island spanning ranks has to be "
-                            "migrated to one owner first\n", p.first, p.second);
-            return DMX_ECROSS;
-        }
-    // the bodies in pairs, ascending: marks in a per-slot byte array that persists between ticks (all zero outside one)
-    std::vector<uint8_t> &include = b->sc_include;
-    if ((int64_t)include.size() != b->n) include.assign((size_t)b->n, 0);
-    std::vector<int32_t> &inv = b->sc_i32[2];
-    inv.clear();
-    inv.reserve((size_t)2 * np);
-    for (auto &p : pairs) {
-        if (!include[(size_t)p.first]) { include[(size_t)p.first] = 1; inv.push_back(p.first); }
-        if (!include[(size_t)p.second]) { include[(size_t)p.second] = 1; inv.push_back(p.second); }
-    }
-    if ((int64_t)inv.size() * 16 > b->n) {       // many: read them back off the marks in slot order
-        inv.clear();
-        for (int64_t s = 0; s < b->n; s++) if (include[(size_t)s]) inv.push_back((int32_t)s);
-    } else {
-        std::sort(inv.begin(), inv.end());
-    }
-    const int64_t ninv = (int64_t)inv.size();
-    struct Unmark {                              // the marks go back to zero however this tick ends
-        std::vector<uint8_t> &m; const std::vector<int32_t> &ids;
-        ~Unmark() { for (int32_t id : ids) m[(size_t)id] = 0; }
-    } unmark{ include, inv };
-
-    ph.reset(new DmxPhase(b, 2));
-    // ---- device narrowphase: ground-plane contacts of those bodies (4 slots each), then the pairs' contacts
-    //      (8 slots each); only the integer counts come back to the host --------------------------------------
-    const int base = 4 * (int)ninv;
-    const size_t nslots = (size_t)base + (size_t)8 * np;
-    if ((rc = dmx_ensure_dev(b->bp_idx, (size_t)ninv * sizeof(int32_t))) != DMX_OK) return rc;
-    if ((rc = dmx_ensure_dev(b->np_pairs, (size_t)2 * np * sizeof(int32_t))) != DMX_OK) return rc;
-    if ((rc = dmx_ensure_dev(b->np_pos, nslots * 3 * sizeof(T))) != DMX_OK) return rc;
-    if ((rc = dmx_ensure_dev(b->np_normal, nslots * 3 * sizeof(T))) != DMX_OK) return rc;
-    if ((rc = dmx_ensure_dev(b->np_depth, nslots * sizeof(T))) != DMX_OK) return rc;
-    if ((rc = dmx_ensure_dev(b->np_count, ((size_t)ninv + np) * sizeof(int32_t))) != DMX_OK) return rc;
-    for (uint32_t k = 0; k < np; k++) { pr[2 * k] = pairs[k].first; pr[2 * k + 1] = pairs[k].second; }   // sorted now
-    HIP_TRY(hipMemcpyAsync(b->bp_idx.p, inv.data(), (size_t)ninv * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(hipMemcpyAsync(b->np_pairs.p, pr.data(), pr.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
-    const StepParams<T> P = dmx_make_params<T>(b, h);
-    int32_t *cnt_dev = (int32_t *)b->np_count.p;
-    HIP_TRY(launch_np_plane<T>((const T *)b->slab, b->gtype, b->stride, (const int32_t *)b->bp_idx.p, (int)ninv, P,
-                               (T *)b->np_pos.p, (T *)b->np_normal.p, (T *)b->np_depth.p, cnt_dev, b->stream));
-    HIP_TRY(launch_np_pairs<T>((const T *)b->slab, b->gtype, b->stride, (const int32_t *)b->np_pairs.p, (int)np,
-                               b->max_contacts, base, (T *)b->np_pos.p, (T *)b->np_normal.p, (T *)b->np_depth.p,
-                               cnt_dev + ninv, b->stream));
-    std::vector<int32_t> &cnt = b->sc_i32[3];
-    cnt.resize((size_t)ninv + np);
-    HIP_TRY(hipMemcpyAsync(cnt.data(), cnt_dev, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
-
-    ph.reset(new DmxPhase(b, 3));
-    // ---- the tick's contact joints for those bodies, in creation order: ground-plane contacts by body, then
-    //      body pairs (what NearCallback would have created, main.c:674-693).  Geometry is referenced by slot. ----
-    // offsets first (prefix sums of the counts), then the joints are written in parallel
-    std::vector<int64_t> &joff = b->sc_joff;
-    joff.assign((size_t)ninv + np + 1, 0);
-    for (size_t k = 0; k < cnt.size(); k++) joff[k + 1] = joff[k] + cnt[k];
-    const int64_t njoints = joff.back();
-    std::vector<dmxContactJoint> &joints = b->sc_joints;      // kept at its high-water size: no per-tick zero fill
-    std::vector<int32_t> &src = b->sc_src;
-    if ((int64_t)joints.size() < njoints) { joints.resize((size_t)njoints); src.resize((size_t)njoints); }
-    auto put = [&](int64_t at, int32_t slot, int32_t b1, int32_t b2) {
-        dmxContactJoint &j = joints[(size_t)at];
-        memset(&j, 0, sizeof(j));
-        j.body1 = b1; j.body2 = b2;
-        j.mode = b->surf_mode; j.mu = b->mu; j.bounce = b->bounce; j.bounce_vel = b->bounce_vel;
-        src[(size_t)at] = slot;
-    };
-    dmx_parallel_for(ninv + (int64_t)np, 4096, [&](int64_t lo, int64_t hi, int) {
-        for (int64_t k = lo; k < hi; k++) {
-            if (k < ninv) {
-                for (int c = 0; c < cnt[(size_t)k]; c++) put(joff[(size_t)k] + c, 4 * (int32_t)k + c, inv[(size_t)k], -1);
-            } else {
-                const int64_t p = k - ninv;
-                for (int c = 0; c < cnt[(size_t)k]; c++)
-                    put(joff[(size_t)k] + c, base + 8 * (int32_t)p + c, pairs[(size_t)p].first, pairs[(size_t)p].second);
-            }
-        }
-    });
-    const DevGeometry geo = { b->np_pos.p, b->np_normal.p, b->np_depth.p, src.data() };
-
-    // ---- islands of the bodies in pairs on the device; everyone else through the fused kernel -------------
-    ph.reset();
-    const bool ext = b->ext_pending;            // the island step consumes the accumulators of ITS bodies only ...
-    b->sc_include_list = inv.data(); b->sc_include_count = ninv;
-    rc = dmx_step_joints(b, h, njoints, joints.data(), include.data(), &geo);
-    b->sc_include_list = nullptr; b->sc_include_count = 0;
-    if (rc != DMX_OK) return rc;
-    b->ext_pending = ext;                       // ... everyone else's are still pending for the fused kernel below
+    // ---- islands of the bodies in pairs; everyone else through the fused kernel ------------------------------------
+    ph.reset(new DmxPhase(b, 7));
+    const size_t nrows = (size_t)3 * C.njoints;
+    if ((rc = dmx_ensure_dev(b->jd_rows, (nrows + 1) * 29 * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->jd_rowjb, (nrows + 1) * 2 * sizeof(int))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->jd_bscr, ((size_t)C.ninv + 1) * 28 * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->jd_local, (size_t)b->stride * sizeof(int))) != DMX_OK) return rc;
+    IslandSet<T> I;
+    memset(&I, 0, sizeof(I));
+    I.n_islands = (int)C.ni;
+    I.body_off = B.body_off; I.bodies = B.bodies; I.con_off = B.con_off; I.row_off = B.row_off;
+    I.cb1 = B.cb1; I.cb2 = B.cb2; I.csrc = B.csrc; I.crow = B.crow;
+    I.gpos = B.gpos; I.gnormal = B.gnormal; I.gdepth = B.gdepth;
+    I.big = B.big; I.n_big = (int)C.nbig; I.big_list = B.big_list; I.lev_count = B.lev_count;
+    I.lev_off = B.lev_off; I.lev_rows = B.lev_rows; I.row_level = B.row_level;
+    I.big_max_bodies = (int)C.big_max_bodies; I.big_max_width = (int)C.big_max_width;
+    I.rows = (T *)b->jd_rows.p; I.rowjb = (int *)b->jd_rowjb.p; I.bscr = (T *)b->jd_bscr.p; I.local = (int *)b->jd_local.p;
+    // (cmode / cmu / cbounce ... stay null: every contact carries the batch's surface, NearCallback's policy, main.c:684-687)
+    HIP_TRY(hipMemsetAsync(b->diag_isl, 0, sizeof(StepDiag), b->stream));
+    HIP_TRY(launch_islands<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, b->stream));
     ph.reset(new DmxPhase(b, 8));
+    // the island step consumed the accumulators of ITS bodies only; everyone else's are still pending for the fused kernel
     if ((rc = fused_tick<T>(b, h, false, (const uint8_t *)b->bp_inpair.p)) != DMX_OK) return rc;
     ph.reset();
     b->last_islands = false;

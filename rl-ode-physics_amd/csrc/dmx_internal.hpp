@@ -60,7 +60,7 @@ template <class T> struct IslandSet {
     const int *csrc;       // optional: contact c's geometry lives at index csrc[c] of gpos/gnormal/gdepth (device narrowphase output)
     const T *gpos, *gnormal, *gdepth;
     const int *cb1, *cb2, *cmode;
-    const T *cmu, *cbounce, *cbounce_vel, *csoft_erp, *csoft_cfm;
+    const T *cmu, *cbounce, *cbounce_vel, *csoft_erp, *csoft_cfm;      // all null: every contact carries the batch's surface (StepParams)
     T *rows;               // scratch: 29 reals per row
     int *rowjb;            // scratch: 2 ints per row
     T *bscr;               // scratch: 28 reals per island body

@@ -66,9 +66,10 @@ __device__ __forceinline__ void stage_body(const T *S, const uint8_t *bflags, in
     for (int j = 0; j < 6; j++) b[BW_FC + j] = T(0);
 }
 
-template <class T> __device__ __forceinline__ int contact_rpc(const IslandSet<T> &I, int ci)
+// per-contact surface arrays are optional: without them every contact carries the batch's surface (StepParams)
+template <class T> __device__ __forceinline__ int contact_rpc(const IslandSet<T> &I, const StepParams<T> &P, int ci)
 {
-    return I.cmu[ci] > 0 ? 3 : 1;
+    return (I.cmu != nullptr ? I.cmu[ci] : P.mu) > 0 ? 3 : 1;
 }
 
 // ---- rows of contact ci (normal + 2 friction when mu > 0), written at island-relative row m -----------------
@@ -89,8 +90,9 @@ __device__ __forceinline__ void contact_rows(const T *S, int64_t stride, const I
         const V3<T> x2 = ldS(S, stride, C_POS, s2);
         c2 = { cpos.x - x2.x, cpos.y - x2.y, cpos.z - x2.z };
     }
-    const int mode = I.cmode[ci];
-    T mu = I.cmu[ci];
+    const bool own_surface = I.cmu != nullptr;
+    const int mode = own_surface ? I.cmode[ci] : P.surf_mode;
+    T mu = own_surface ? I.cmu[ci] : P.mu;
     if (mu < 0) mu = 0;
     const int rpc = mu > 0 ? 3 : 1;
     V3<T> dir[3];
@@ -112,17 +114,17 @@ __device__ __forceinline__ void contact_rows(const T *S, int64_t stride, const I
         T cval = T(0), cfm = P.cfm;
         if (dnum == 0) {
             T erp = P.erp;
-            if (mode & SURF_SOFT_ERP) erp = I.csoft_erp[ci];
-            if (mode & SURF_SOFT_CFM) cfm = I.csoft_cfm[ci];
+            if (mode & SURF_SOFT_ERP) erp = own_surface ? I.csoft_erp[ci] : T(0);
+            if (mode & SURF_SOFT_CFM) cfm = own_surface ? I.csoft_cfm[ci] : T(0);
             T depth = ind ? I.gdepth[gi] : I.cdepth[ci];
             if (depth < 0) depth = 0;
             cval = (hinv * erp) * depth;
             if (mode & SURF_BOUNCE) {
                 T outgoing = dot3p(J, ldS(S, stride, C_LVEL, s1)) + dot3p(J + 3, ldS(S, stride, C_AVEL, s1));
                 if (s2 >= 0) outgoing += dot3p(J + 6, ldS(S, stride, C_LVEL, s2)) + dot3p(J + 9, ldS(S, stride, C_AVEL, s2));
-                const T bv = I.cbounce_vel[ci];
+                const T bv = own_surface ? I.cbounce_vel[ci] : P.bounce_vel;
                 if (bv >= 0 && (-outgoing) > bv) {
-                    const T newc = -I.cbounce[ci] * outgoing;
+                    const T newc = -(own_surface ? I.cbounce[ci] : P.bounce) * outgoing;
                     if (newc > cval) cval = newc;
                 }
             }
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
     int m = 0;
     for (int c = 0; c < nc; c++) {
         contact_rows(S, stride, I, P, rows, jb, c0 + c, m, hinv);
-        m += contact_rpc(I, c0 + c);
+        m += contact_rpc(I, P, c0 + c);
     }
     double resid = 0.0;
     if (m > 0) {
