@@ -87,6 +87,17 @@ int dmxBatchSetMaxContacts(dmxBatchID b, int max_contacts);                  /* 
 /* dCreatePlane(space,a,b,c,d): the one static half-space bodies collide with; enable=0 removes it */
 int dmxBatchSetPlane(dmxBatchID b, double a, double bb, double c, double d, int enable);
 
+/* AddBodyMap (main.c:735-761): n static, body-less box geoms -- the reference's floor and walls (main.c:115-121) --
+ * created before every body, as the reference creates them: side lengths (n x 3), positions (n x 3) and rotations
+ * (n x 12: the 3x4 row-major matrix dGeomSetRotation takes, main.c:749), doubles, rounded to the batch's precision.
+ * Every body collides with every static box (the category / collide bits the reference ends up with, main.c:724-725,
+ * 751-752); static boxes do not link dynamics islands and static-static pairs are ignored.  Contacts are dCollide(static
+ * geom, body geom) in creation order: ground plane, static boxes in order, then body pairs.  n = 0 removes them;
+ * at most DMX_MAX_STATIC_BOXES.  Bodies near a static box are stepped by the exact path (pair search, narrowphase, island
+ * solve); the fused kernels keep everyone else and test, per tick, that their bounding spheres stay clear of the boxes. */
+#define DMX_MAX_STATIC_BOXES 64
+int dmxBatchSetStaticBoxes(dmxBatchID b, int32_t n, const double *sides, const double *pos, const double *rot3x4);
+
 /* ---- body data: replaces the AddBody loop (main.c:695-733) and the read-back loop (main.c:221-237) */
 int dmxBatchUpload(dmxBatchID b, int field, const void *host_aos, int64_t first, int64_t count);
 int dmxBatchDownload(dmxBatchID b, int field, void *host_aos, int64_t first, int64_t count);

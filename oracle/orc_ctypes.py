@@ -167,6 +167,17 @@ class World:
     def add_plane(self, a, b, c, d):
         return self.lib.orc_geom_create_plane(self.w, a, b, c, d)
 
+    def add_static_box(self, sides, pos, R12):
+        """AddBodyMap (main.c:735-761): a body-less box geom; category ~CMASK_MAP, collide ~0 (the double
+        SetCategoryBits of main.c:751-752)"""
+        g = self.lib.orc_geom_create_box(self.w, *[float(s) for s in sides])
+        self.lib.orc_geom_set_position(self.w, g, *[float(p) for p in pos])
+        _, rp = self.o.arr(R12)
+        self.lib.orc_geom_set_rotation(self.w, g, rp)
+        self.lib.orc_geom_set_category_bits(self.w, g, 1)
+        self.lib.orc_geom_set_category_bits(self.w, g, 0xFFFFFFFE)
+        return g
+
     def state(self):
         n = self.lib.orc_world_body_count(self.w)
         dt = self.o.dtype

@@ -23,7 +23,7 @@ BATCH_SYMBOLS = [
     "dmxBatchScatterBodiesOnStream", "dmxBatchSetBoundaryPack",
     "dmxBatchChunkBegin", "dmxBatchChunkTick", "dmxBatchCheckZonesOnStream", "dmxBatchChunkEnd",
     "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream", "dmxBatchSetConvexHull", "dmxBatchChunkTicks", "dmxBatchSetTicksPerLaunch",
-    "dmxBatchSetSnapshotMode",
+    "dmxBatchSetSnapshotMode", "dmxBatchSetStaticBoxes",
 ]
 
 _lib = None
@@ -102,5 +102,6 @@ def load():
     sig("dmxBatchChunkTicks", I, P, D, I, I, I)
     sig("dmxBatchSetTicksPerLaunch", I, P, I)
     sig("dmxBatchSetSnapshotMode", I, P, I)
+    sig("dmxBatchSetStaticBoxes", I, P, C.c_int32, P, P, P)
     _lib = lib
     return lib

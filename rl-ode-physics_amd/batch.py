@@ -98,6 +98,15 @@ class BatchWorld:
         t = np.ascontiguousarray(types, dtype=np.uint8)
         _check(self.lib.dmxBatchUploadGeomType(self.h, t.ctypes.data, first, t.shape[0]), "dmxBatchUploadGeomType")
 
+    def set_static_boxes(self, boxes):
+        """AddBodyMap (main.c:735-761): `boxes` = [(sides3, pos3, R12)], the static floor / walls, e.g. scenes.reference_map()"""
+        n = len(boxes)
+        sides = np.ascontiguousarray([b[0] for b in boxes], dtype=np.float64).reshape(n, 3)
+        pos = np.ascontiguousarray([b[1] for b in boxes], dtype=np.float64).reshape(n, 3)
+        rot = np.ascontiguousarray([b[2] for b in boxes], dtype=np.float64).reshape(n, 12)
+        _check(self.lib.dmxBatchSetStaticBoxes(self.h, n, sides.ctypes.data, pos.ctypes.data, rot.ctypes.data),
+               "dmxBatchSetStaticBoxes")
+
     def set_convex_hull(self, points):
         """Body-frame points of the hull every GEOM_CONVEX body uses; returns the hull's bounding radius (upload it as
         sides[:, 0] of the convex bodies)."""

@@ -141,7 +141,7 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
         if (d->p) (void)hipFree(d->p);
     for (dmxBatch::DevBuf *d : { &b->bp_count, &b->bp_items, &b->bp_flags, &b->bp_pairs, &b->bp_inpair, &b->bp_snapshot, &b->bp_idx, &b->bp_gather,
                                 &b->np_pos, &b->np_normal, &b->np_depth, &b->np_count, &b->np_pairs, &b->hull, &b->cbuf, &b->ccount,
-                                &b->ex_arena, &b->ex_body, &b->ex_last })
+                                &b->ex_arena, &b->ex_body, &b->ex_last, &b->ex_aabb, &b->sbox })
         if (d->p) (void)hipFree(d->p);
     if (b->bp_flags_host) (void)hipHostFree(b->bp_flags_host);
     if (b->ex_counts_host) (void)hipHostFree(b->ex_counts_host);
@@ -366,6 +366,44 @@ extern "C" int dmxBatchSetBodyCollisions(dmxBatchID b, int enable)
     b->bp_enabled = enable ? 1 : 0;
     b->bp_valid = false;
     return DMX_OK;
+}
+
+// ---- static box geoms (AddBodyMap, main.c:735-761) -------------------------------------------------
+template <class T> static int set_static_boxes_t(dmxBatch *b, int32_t n, const double *sides, const double *pos, const double *rot)
+{
+    std::vector<T> h((size_t)n * SBOX_REALS, T(0));
+    for (int32_t s = 0; s < n; s++) {
+        T *o = h.data() + (size_t)s * SBOX_REALS;
+        T R[3][3], side[3];
+        for (int a = 0; a < 3; a++) {
+            o[SBOX_POS + a] = (T)pos[3 * s + a];
+            side[a] = o[SBOX_SIDE + a] = (T)sides[3 * s + a];
+            for (int c = 0; c < 3; c++) R[a][c] = o[SBOX_R + 3 * a + c] = (T)rot[12 * s + 4 * a + c];
+        }
+        for (int a = 0; a < 3; a++) {           // the geom's AABB: centre +- sum_j |R_aj| side_j / 2 [ODE dxBox::computeAABB]
+            const T r = T(0.5) * (tabs(R[a][0] * side[0]) + tabs(R[a][1] * side[1]) + tabs(R[a][2] * side[2]));
+            o[SBOX_LO + a] = o[SBOX_POS + a] - r;
+            o[SBOX_HI + a] = o[SBOX_POS + a] + r;
+        }
+    }
+    int rc;
+    if (n > 0) {
+        if ((rc = dmx_ensure_dev(b->sbox, h.size() * sizeof(T))) != DMX_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(b->sbox.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+    }
+    b->n_static = n;
+    b->bp_valid = false;
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchSetStaticBoxes(dmxBatchID b, int32_t n, const double *sides, const double *pos, const double *rot3x4)
+{
+    if (!b || n < 0 || n > DMX_MAX_STATIC_BOXES || (n > 0 && (!sides || !pos || !rot3x4))) return DMX_EINVAL;
+    SETTLE(b);
+    HIP_TRY(hipSetDevice(b->device));
+    return b->precision == DMX_F32 ? set_static_boxes_t<float>(b, n, sides, pos, rot3x4)
+                                   : set_static_boxes_t<double>(b, n, sides, pos, rot3x4);
 }
 
 // ---- convex bodies ------------------------------------------------------------------------------

@@ -115,7 +115,8 @@ struct dmxBatch {
     // device-resident bookkeeping of the exact tick (dmx_exact.hip): capacity estimates carried from tick to tick, one arena
     // for the pipeline's arrays, per-body scan arrays, the per-slot level scratch, the pinned read-back record
     uint32_t ex_cap_pairs = 0, ex_cap_rows = 0;
-    DevBuf ex_arena, ex_body, ex_last;
+    uint32_t ex_prev_pairs = 1;                 // body pairs the last exact tick found
+    DevBuf ex_arena, ex_body, ex_last, ex_aabb;
     void *ex_counts_host = nullptr;
     uint32_t *bp_flags_host = nullptr;         // pinned
     int bp_max_pairs = 0;
@@ -123,6 +124,7 @@ struct dmxBatch {
     std::vector<uint8_t> h_gtype;
     // convex bodies: the shared hull's body-frame points, and the per-tick plane contacts of every convex body
     DevBuf hull, cbuf, ccount;
+    DevBuf sbox; int n_static = 0;             // static box geoms (dmxBatchSetStaticBoxes), SBOX_REALS reals each
     int hull_n = 0;
     int64_t stat_rollbacks = 0;
     int64_t stat_fast_ticks = 0, stat_careful_ticks = 0, stat_rebuilds = 0, stat_pair_ticks = 0;
@@ -211,6 +213,7 @@ template <class T> inline StepParams<T> dmx_make_params(dmxBatch *b, double h)
     P.bp_flags = nullptr;
     P.skip = nullptr;
     P.pack_out = (T *)b->pack_out; P.pack_lo = b->pack_lo; P.pack_hi = b->pack_hi;
+    P.sbox = (const T *)b->sbox.p; P.n_static = b->n_static;
     P.hull = (const T *)b->hull.p; P.hull_n = b->hull_n;
     P.cbuf = (T *)b->cbuf.p; P.ccount = (int *)b->ccount.p;
     return P;

@@ -33,6 +33,24 @@ template <class T> __device__ __forceinline__ T bound_radius(int gt, const T *S,
     return T(0.5) * tsqrt<T>(sx * sx + sy * sy + sz * sz);
 }
 
+template <class T> __device__ __forceinline__ void body_aabb(const T *S, const uint8_t *gtype, int64_t stride,
+                                                             int64_t i, T lo[3], T hi[3])
+{
+    const T p[3] = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
+    T r[3];
+    if (gtype[i] == GEOM_SPHERE || gtype[i] == GEOM_CONVEX) {      // convex: the bounding sphere's box (conservative)
+        r[0] = r[1] = r[2] = S[slab_ix(C_SIDES + 0, i)];
+    } else {
+        const Q4<T> q = { S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)],
+                          S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] };
+        const M3<T> R = quat_to_R(q);
+        const T s[3] = { S[slab_ix(C_SIDES + 0, i)], S[slab_ix(C_SIDES + 1, i)], S[slab_ix(C_SIDES + 2, i)] };
+        for (int a = 0; a < 3; a++)
+            r[a] = T(0.5) * (tabs(R.m[a][0] * s[0]) + tabs(R.m[a][1] * s[1]) + tabs(R.m[a][2] * s[2]));
+    }
+    for (int a = 0; a < 3; a++) { lo[a] = p[a] - r[a]; hi[a] = p[a] + r[a]; }
+}
+
 // bodies [0,n) -> buckets of their (x,z) column
 template <class T>
 __global__ __launch_bounds__(256) void bp_insert(T *__restrict__ S, const uint8_t *__restrict__ gtype,
@@ -43,6 +61,12 @@ __global__ __launch_bounds__(256) void bp_insert(T *__restrict__ S, const uint8_
     // no pair they are part of can ever produce a contact
     if (i >= n || gtype[i] == GEOM_NONE || gtype[i] == GEOM_CONVEX) return;
     S[slab_ix(C_BPR, i)] = bound_radius<T>(gtype[i], S, stride, i);      // neighbours read this instead of 3 sides + sqrt
+    if (G.aabb != nullptr) {                 // the exact pair search tests every candidate's AABB: computed once, here
+        T lo[3], hi[3];
+        body_aabb<T>(S, gtype, stride, i, lo, hi);
+        T *o = G.aabb + 6 * i;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
+    }
     const int ix = (int)floor((double)(S[slab_ix(C_POS + 0, i)] * G.inv_cell));
     const int iz = (int)floor((double)(S[slab_ix(C_POS + 2, i)] * G.inv_cell));
     const uint32_t h = cell_hash(ix, iz, G.mask, G.xbits);
@@ -80,29 +104,18 @@ __global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uin
                 }
             }
         safe = T(0.5) * gap;
-        if (!(safe > 0)) atomicAdd(&G.flags[BPF_CROWDED], 1u);
+        bool near_static = false;            // bounding sphere reaches into a static box's AABB: only the exact path can step it
+        const T y = S[slab_ix(C_POS + 1, i)];
+        for (int s = 0; s < G.n_static; s++) {
+            const T *b = G.sbox + s * SBOX_REALS;
+            if (!(x - ri > b[SBOX_HI + 0] || x + ri < b[SBOX_LO + 0] || y - ri > b[SBOX_HI + 1] || y + ri < b[SBOX_LO + 1] ||
+                  z - ri > b[SBOX_HI + 2] || z + ri < b[SBOX_LO + 2])) near_static = true;
+        }
+        if (!(safe > 0) || near_static) atomicAdd(&G.flags[BPF_CROWDED], 1u);
     }
     S[slab_ix(C_BPX, i)] = x;
     S[slab_ix(C_BPZ, i)] = z;
     S[slab_ix(C_BPSAFE, i)] = safe;
-}
-
-template <class T> __device__ __forceinline__ void body_aabb(const T *S, const uint8_t *gtype, int64_t stride,
-                                                             int64_t i, T lo[3], T hi[3])
-{
-    const T p[3] = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
-    T r[3];
-    if (gtype[i] == GEOM_SPHERE || gtype[i] == GEOM_CONVEX) {      // convex: the bounding sphere's box (conservative)
-        r[0] = r[1] = r[2] = S[slab_ix(C_SIDES + 0, i)];
-    } else {
-        const Q4<T> q = { S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)],
-                          S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] };
-        const M3<T> R = quat_to_R(q);
-        const T s[3] = { S[slab_ix(C_SIDES + 0, i)], S[slab_ix(C_SIDES + 1, i)], S[slab_ix(C_SIDES + 2, i)] };
-        for (int a = 0; a < 3; a++)
-            r[a] = T(0.5) * (tabs(R.m[a][0] * s[0]) + tabs(R.m[a][1] * s[1]) + tabs(R.m[a][2] * s[2]));
-    }
-    for (int a = 0; a < 3; a++) { lo[a] = p[a] - r[a]; hi[a] = p[a] + r[a]; }
 }
 
 // exact pair search: (i,j), i active, i<j or j a ghost slot, AABBs overlap

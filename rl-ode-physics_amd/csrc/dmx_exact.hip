@@ -56,8 +56,8 @@ template <class T> __device__ __forceinline__ void aabb_of(const T *S, const uin
 template <class T, class F>
 __device__ __forceinline__ void for_each_partner(const T *S, const uint8_t *gtype, int64_t i, const GridParams<T> &G, F f)
 {
-    T lo[3], hi[3];
-    aabb_of<T>(S, gtype, i, lo, hi);
+    const T *bi = G.aabb + 6 * i;            // every body's AABB, left by bp_insert
+    const T lo[3] = { bi[0], bi[1], bi[2] }, hi[3] = { bi[3], bi[4], bi[5] };
     const int ix = (int)floor((double)(S[slab_ix(C_POS + 0, i)] * G.inv_cell));
     const int iz = (int)floor((double)(S[slab_ix(C_POS + 2, i)] * G.inv_cell));
     for (int dz = -1; dz <= 1; dz++)
@@ -72,9 +72,8 @@ __device__ __forceinline__ void for_each_partner(const T *S, const uint8_t *gtyp
                 const int jx = (int)floor((double)(S[slab_ix(C_POS + 0, j)] * G.inv_cell));
                 const int jz = (int)floor((double)(S[slab_ix(C_POS + 2, j)] * G.inv_cell));
                 if (jx != ix + dx || jz != iz + dz) continue;
-                T lo2[3], hi2[3];
-                aabb_of<T>(S, gtype, j, lo2, hi2);
-                if (lo2[0] > hi[0] || lo[0] > hi2[0] || lo2[1] > hi[1] || lo[1] > hi2[1] || lo2[2] > hi[2] || lo[2] > hi2[2])
+                const T *bj = G.aabb + 6 * j;
+                if (bj[0] > hi[0] || lo[0] > bj[3] || bj[1] > hi[1] || lo[1] > bj[4] || bj[2] > hi[2] || lo[2] > bj[5])
                     continue;
                 f(j);
             }
@@ -98,6 +97,13 @@ __global__ __launch_bounds__(256) void ex_pair_count(const T *__restrict__ S, co
             if (j >= n_active) { if (atomicOr(&C->cross, 1u) == 0u) { C->cross_a = (uint32_t)i; C->cross_b = (uint32_t)j; } }
             else if (j > i) owned++;
         });
+        // static box geoms are "big geoms against everyone": a body whose AABB overlaps one goes through the exact path too
+        const T *bi = G.aabb + 6 * i;
+        for (int s = 0; s < G.n_static; s++) {
+            const T *b = G.sbox + s * SBOX_REALS;
+            if (!(bi[0] > b[SBOX_HI + 0] || b[SBOX_LO + 0] > bi[3] || bi[1] > b[SBOX_HI + 1] || b[SBOX_LO + 1] > bi[4] ||
+                  bi[2] > b[SBOX_HI + 2] || b[SBOX_LO + 2] > bi[5])) any = 1;
+        }
     }
     pc[i] = ((uint64_t)owned << 32) | any;
     inpair[i] = (uint8_t)any;
@@ -201,19 +207,46 @@ template <class T> __device__ __forceinline__ void put_c(T *gpos, T *gnormal, T 
     gdepth[slot] = d;
 }
 
-// entries [0, cap.inv): ground-plane contacts of involved body k (4 slots at 4k); [cap.inv, cap.inv + cap.pairs): contacts
-// of pair p (8 slots at 4 cap.inv + 8p).  cc[e] = contacts of entry e, 0 for the padding.
+// Entries as ExactCaps lays them out: ground-plane contacts of involved body k, contacts of body k with static box s,
+// contacts of pair p.  cc[e] = contacts of entry e, 0 for the padding.
 template <class T>
 __global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const uint8_t *__restrict__ gtype, const int32_t *__restrict__ inv,
-                                                const int32_t *__restrict__ pairs, StepParams<T> P, ExactCaps cap,
+                                                const int32_t *__restrict__ pairs, const T *__restrict__ aabb, StepParams<T> P, ExactCaps cap,
                                                 T *__restrict__ gpos, T *__restrict__ gnormal, T *__restrict__ gdepth,
                                                 uint32_t *__restrict__ cc, const ExactCounts *__restrict__ C)
 {
     const uint32_t ninv = C->overflow ? 0u : C->ninv, np = C->overflow ? 0u : C->npairs;
-    const uint32_t ne = cap.inv + cap.pairs;
+    const uint32_t ne = cap.entries(), e_pairs = cap.pair_entry0();
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
         int nc = 0;
-        if (e < cap.inv) {
+        if (e >= cap.inv && e < e_pairs) {
+            // body k against static box s: dCollide(static geom, body geom) -- the static geoms were created first
+            // (main.c:115-121), so they are o1; the contact joint is attached (0, body), i.e. reversed: normal negated
+            const uint32_t s = (e - cap.inv) / cap.inv, k = (e - cap.inv) - s * cap.inv;
+            if (k < ninv) {
+                const int64_t i = inv[k];
+                const T *bi = aabb + 6 * i, *sb = P.sbox + s * SBOX_REALS;
+                if (!(bi[0] > sb[SBOX_HI + 0] || sb[SBOX_LO + 0] > bi[3] || bi[1] > sb[SBOX_HI + 1] || sb[SBOX_LO + 1] > bi[4] ||
+                      bi[2] > sb[SBOX_HI + 2] || sb[SBOX_LO + 2] > bi[5])) {
+                    const BodyGeomX<T> Bd = geom_of<T>(S, gtype, i);
+                    const V3<T> sx = { sb[SBOX_POS], sb[SBOX_POS + 1], sb[SBOX_POS + 2] };
+                    M3<T> sR;
+                    for (int a = 0; a < 3; a++) for (int c2 = 0; c2 < 3; c2++) sR.m[a][c2] = sb[SBOX_R + 3 * a + c2];
+                    const T sside[3] = { sb[SBOX_SIDE], sb[SBOX_SIDE + 1], sb[SBOX_SIDE + 2] };
+                    ContactPoint<T> c[8];
+                    const int mc = P.max_contacts > 8 ? 8 : P.max_contacts;
+                    bool negate = true;          // the joint's reversal
+                    if (Bd.gt == GEOM_BOX) nc = box_box(sx, sR, sside, Bd.x, Bd.R, Bd.side, mc, c);
+                    else if (Bd.gt == GEOM_SPHERE) { nc = sphere_box(Bd.x, Bd.side[0], sx, sR, sside, c); negate = false; }   // swapped collider: flipped twice
+                    if (nc > mc) nc = mc;
+                    const size_t base = cap.static_slot0() + (size_t)8 * ((size_t)s * cap.inv + k);
+                    for (int q = 0; q < nc; q++) {
+                        const V3<T> n = negate ? V3<T>{ -c[q].normal.x, -c[q].normal.y, -c[q].normal.z } : c[q].normal;
+                        put_c(gpos, gnormal, gdepth, base + q, c[q].pos, n, c[q].depth);
+                    }
+                }
+            }
+        } else if (e < cap.inv) {
             if (e < ninv && P.plane_on) {
                 const BodyGeomX<T> g = geom_of<T>(S, gtype, inv[e]);
                 V3<T> cp[4]; T cd[4];
@@ -222,7 +255,7 @@ __global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const u
                 for (int c = 0; c < nc; c++) put_c(gpos, gnormal, gdepth, (size_t)4 * e + c, cp[c], P.pn, cd[c]);
             }
         } else {
-            const uint32_t p = e - cap.inv;
+            const uint32_t p = e - e_pairs;
             if (p < np) {
                 const BodyGeomX<T> A = geom_of<T>(S, gtype, pairs[2 * p]);
                 const BodyGeomX<T> B = geom_of<T>(S, gtype, pairs[2 * p + 1]);
@@ -234,7 +267,7 @@ __global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const u
                 else if (A.gt == GEOM_SPHERE && B.gt == GEOM_BOX) nc = sphere_box(A.x, A.side[0], B.x, B.R, B.side, c);
                 else if (A.gt == GEOM_BOX && B.gt == GEOM_SPHERE) { nc = sphere_box(B.x, B.side[0], A.x, A.R, A.side, c); flip = true; }
                 if (nc > mc) nc = mc;
-                const size_t base = (size_t)4 * cap.inv + (size_t)8 * p;
+                const size_t base = cap.pair_slot0() + (size_t)8 * p;
                 for (int k = 0; k < nc; k++) {
                     const V3<T> n = flip ? V3<T>{ -c[k].normal.x, -c[k].normal.y, -c[k].normal.z } : c[k].normal;
                     put_c(gpos, gnormal, gdepth, base + k, c[k].pos, n, c[k].depth);
@@ -252,11 +285,11 @@ __global__ __launch_bounds__(256) void ex_keys(const int32_t *__restrict__ pairs
                                                uint32_t *__restrict__ vals, ExactCounts *C)
 {
     const uint32_t ninv = C->overflow ? 0u : C->ninv, np = C->overflow ? 0u : C->npairs;
-    const uint32_t ne = cap.inv + cap.pairs;
+    const uint32_t ne = cap.entries(), e_pairs = cap.pair_entry0();
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
         uint32_t key = cap.inv;                         // padding sorts behind every island
-        if (e < cap.inv) { if (e < ninv) key = rinc[root[e]] - 1u; }
-        else if (e - cap.inv < np) key = rinc[root[kidx_of(pc, inc, pairs[2 * (e - cap.inv)])]] - 1u;
+        if (e < e_pairs) { const uint32_t k = e % cap.inv; if (k < ninv) key = rinc[root[k]] - 1u; }
+        else if (e - e_pairs < np) key = rinc[root[kidx_of(pc, inc, pairs[2 * (e - e_pairs)])]] - 1u;
         keys[e] = key; vals[e] = e;
         if (e == 0) C->ni = rinc[cap.inv - 1];
     }
@@ -266,7 +299,7 @@ __global__ __launch_bounds__(256) void ex_keys(const int32_t *__restrict__ pairs
 __global__ __launch_bounds__(256) void ex_gather(const uint32_t *__restrict__ keys_s, const uint32_t *__restrict__ vals_s,
                                                  const uint32_t *__restrict__ cc, ExactCaps cap, uint64_t *__restrict__ sc)
 {
-    const uint32_t ne = cap.inv + cap.pairs;
+    const uint32_t ne = cap.entries();
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ne; t += gridDim.x * blockDim.x) {
         uint64_t v = 0;
         if (keys_s[t] < cap.inv) { const uint32_t e = vals_s[t]; v = ((uint64_t)cc[e] << 32) | (e < cap.inv ? 1u : 0u); }
@@ -279,7 +312,7 @@ __global__ __launch_bounds__(256) void ex_bounds(const uint32_t *__restrict__ ke
                                                  const uint64_t *__restrict__ sinc, ExactCaps cap, int *__restrict__ body_off,
                                                  int *__restrict__ con_off, int *__restrict__ row_off, ExactCounts *C)
 {
-    const uint32_t ne = cap.inv + cap.pairs;
+    const uint32_t ne = cap.entries();
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ne; t += gridDim.x * blockDim.x) {
         const uint32_t key = keys_s[t];
         if (key < cap.inv && (t == 0 || keys_s[t - 1] != key)) {
@@ -303,7 +336,7 @@ __global__ __launch_bounds__(256) void ex_fill(const uint32_t *__restrict__ keys
                                                int *__restrict__ bodies, int *__restrict__ cb1, int *__restrict__ cb2,
                                                int *__restrict__ csrc, int *__restrict__ crow)
 {
-    const uint32_t ne = cap.inv + cap.pairs;
+    const uint32_t ne = cap.entries(), e_pairs = cap.pair_entry0();
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ne; t += gridDim.x * blockDim.x) {
         const uint32_t key = keys_s[t];
         if (key >= cap.inv) continue;
@@ -312,7 +345,8 @@ __global__ __launch_bounds__(256) void ex_fill(const uint32_t *__restrict__ keys
         const int d0 = (int)hi32(exc), c0 = con_off[key];
         int b1, b2, src0;
         if (e < cap.inv) { b1 = inv[e]; b2 = -1; src0 = 4 * (int)e; bodies[lo32(exc)] = b1; }
-        else { const uint32_t p = e - cap.inv; b1 = pairs[2 * p]; b2 = pairs[2 * p + 1]; src0 = 4 * (int)cap.inv + 8 * (int)p; }
+        else if (e < e_pairs) { b1 = inv[e % cap.inv]; b2 = -1; src0 = (int)(cap.static_slot0() + (size_t)8 * (e - cap.inv)); }
+        else { const uint32_t p = e - e_pairs; b1 = pairs[2 * p]; b2 = pairs[2 * p + 1]; src0 = (int)(cap.pair_slot0() + (size_t)8 * p); }
         const int nc = (int)cc[e];
         for (int c = 0; c < nc; c++) {
             const int d = d0 + c;
@@ -404,7 +438,7 @@ inline unsigned grid_for(size_t n) { size_t g = (n + 255) / 256; return (unsigne
 size_t exact_temp_bytes(const ExactCaps &cap, int64_t n_active)
 {
     size_t a = 0, b = 0, c = 0, d = 0;
-    const size_t ne = (size_t)cap.inv + cap.pairs;
+    const size_t ne = (size_t)cap.entries();
     (void)rocprim::inclusive_scan(nullptr, a, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)n_active, rocprim::plus<uint64_t>());
     (void)rocprim::inclusive_scan(nullptr, b, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)cap.inv, rocprim::plus<uint32_t>());
     (void)rocprim::inclusive_scan(nullptr, c, (uint64_t *)nullptr, (uint64_t *)nullptr, ne, rocprim::plus<uint64_t>());
@@ -424,21 +458,29 @@ hipError_t exact_init_last(int32_t *last, int64_t n, hipStream_t st)
 #define EX_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
 template <class T>
-hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G, const StepParams<T> &P,
-                              const ExactBuffers<T> &B, const ExactCaps &cap, int rpc, int big_rows, hipStream_t st)
+hipError_t launch_exact_pairs(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G,
+                              const ExactBuffers<T> &B, const ExactCaps &cap, hipStream_t st)
 {
-    const size_t ne = (size_t)cap.inv + cap.pairs;
     size_t tb = B.temp_bytes;
     EX_TRY(hipMemsetAsync(B.counts, 0, sizeof(ExactCounts), st));
     hipLaunchKernelGGL((ex_pair_count<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inpair, B.counts);
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.pc, B.inc, (size_t)n_active, rocprim::plus<uint64_t>(), st));
     hipLaunchKernelGGL((ex_pair_write<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inc,
                        B.pairs, B.inv, B.parent, cap, B.counts);
+    return hipGetLastError();
+}
+
+template <class T>
+hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G, const StepParams<T> &P,
+                              const ExactBuffers<T> &B, const ExactCaps &cap, int rpc, int big_rows, hipStream_t st)
+{
+    const size_t ne = (size_t)cap.entries();
+    size_t tb = B.temp_bytes;
     hipLaunchKernelGGL(ex_unite, dim3(grid_for(cap.pairs)), dim3(256), 0, st, B.pairs, B.pc, B.inc, B.parent, B.counts);
     hipLaunchKernelGGL(ex_flatten, dim3(grid_for(cap.inv)), dim3(256), 0, st, B.parent, B.root, B.rf, cap, B.counts);
     tb = B.temp_bytes;
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.rf, B.rinc, (size_t)cap.inv, rocprim::plus<uint32_t>(), st));
-    hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, P, cap,
+    hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.aabb, P, cap,
                        B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
     hipLaunchKernelGGL(ex_keys, dim3(grid_for(ne)), dim3(256), 0, st, B.pairs, B.pc, B.inc, B.root, B.rinc, cap, B.keys, B.vals, B.counts);
     int bits = 1;
@@ -459,6 +501,10 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
     return hipGetLastError();
 }
 
+template hipError_t launch_exact_pairs<float>(const float *, const uint8_t *, int64_t, const GridParams<float> &, const ExactBuffers<float> &,
+                                              const ExactCaps &, hipStream_t);
+template hipError_t launch_exact_pairs<double>(const double *, const uint8_t *, int64_t, const GridParams<double> &, const ExactBuffers<double> &,
+                                               const ExactCaps &, hipStream_t);
 template hipError_t launch_exact_group<float>(const float *, const uint8_t *, int64_t, const GridParams<float> &, const StepParams<float> &,
                                               const ExactBuffers<float> &, const ExactCaps &, int, int, hipStream_t);
 template hipError_t launch_exact_group<double>(const double *, const uint8_t *, int64_t, const GridParams<double> &, const StepParams<double> &,

@@ -7,8 +7,19 @@
 namespace dmx {
 
 // capacities the host sized the arrays for (estimates from earlier ticks): body pairs, involved bodies, rows of islands
-// that get a workgroup.  Derived sizes: entries = inv + pairs; contact slots = 4 inv + 8 pairs.
-struct ExactCaps { uint32_t pairs, inv, rows; };
+// that get a workgroup.
+struct ExactCaps {
+    uint32_t pairs, inv, rows;
+    uint32_t nstatic;       // static box geoms of the batch (not an estimate)
+    // entries, in joint creation order: [0, inv) involved body k against the ground plane; then for every static box s the
+    // block [inv (1 + s), inv (2 + s)): body k against static box s; then the body pairs
+    __host__ __device__ uint32_t pair_entry0() const { return inv * (1u + nstatic); }
+    __host__ __device__ uint32_t entries() const { return inv * (1u + nstatic) + pairs; }
+    // contact slots: 4 per plane entry, 8 per static entry, 8 per pair entry
+    __host__ __device__ size_t static_slot0() const { return (size_t)4 * inv; }
+    __host__ __device__ size_t pair_slot0() const { return (size_t)4 * inv + (size_t)8 * nstatic * inv; }
+    __host__ __device__ size_t slots() const { return pair_slot0() + (size_t)8 * pairs; }
+};
 
 // what the pipeline found, read back by the host once per tick (device struct, 64 B)
 struct ExactCounts {
@@ -43,7 +54,11 @@ template <class T> struct ExactBuffers {
 
 size_t exact_temp_bytes(const ExactCaps &cap, int64_t n_active);
 hipError_t exact_init_last(int32_t *last, int64_t n, hipStream_t st);
-// the whole pipeline on `st`; the grid G must have been filled (bp_insert) on the same stream before
+// The pipeline on `st` in two parts; the grid G (with its AABB array) must have been filled (bp_insert) on the same stream
+// before.  pairs: canonical pair list, involved bodies, union-find initialised, counts.npairs / ninv.  group: everything else.
+template <class T>
+hipError_t launch_exact_pairs(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G,
+                              const ExactBuffers<T> &B, const ExactCaps &cap, hipStream_t st);
 template <class T>
 hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G, const StepParams<T> &P,
                               const ExactBuffers<T> &B, const ExactCaps &cap, int rpc, int big_rows, hipStream_t st);

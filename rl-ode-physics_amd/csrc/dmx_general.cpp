@@ -39,6 +39,8 @@ template <class T> GridParams<T> grid_of(dmxBatch *b)
     G.count = (uint32_t *)b->bp_count.p;
     G.items = (int32_t *)b->bp_items.p;
     G.flags = (uint32_t *)b->bp_flags.p;
+    G.aabb = (T *)b->ex_aabb.p;             // null until an exact tick has asked for it
+    G.sbox = (const T *)b->sbox.p; G.n_static = b->n_static;
     return G;
 }
 
@@ -261,9 +263,10 @@ int big_island_rows_general()
 template <class T> int ensure_exact_buffers(dmxBatch *b, const ExactCaps &cap, ExactBuffers<T> &B)
 {
     int rc;
-    const size_t ne = (size_t)cap.inv + cap.pairs, nslots = (size_t)4 * cap.inv + (size_t)8 * cap.pairs;
+    const size_t ne = (size_t)cap.entries(), nslots = cap.slots();
     const size_t n = (size_t)b->stride;
     if ((rc = dmx_ensure_dev(b->ex_body, n * (2 * sizeof(uint64_t)))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->ex_aabb, n * 6 * sizeof(T))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->bp_inpair, n)) != DMX_OK) return rc;
     if (!b->ex_last.p) {
         if ((rc = dmx_ensure_dev(b->ex_last, n * sizeof(int32_t))) != DMX_OK) return rc;
@@ -325,13 +328,28 @@ template <class T> int careful_tick(dmxBatch *b, double h)
         cap.pairs = b->ex_cap_pairs;
         cap.inv = (uint32_t)std::min<int64_t>(2 * (int64_t)cap.pairs, b->n_active);
         cap.rows = b->ex_cap_rows;
+        cap.nstatic = (uint32_t)b->n_static;
         if ((rc = ensure_exact_buffers<T>(b, cap, B)) != DMX_OK) return rc;
         if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
-        HIP_TRY(launch_exact_group<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), P, B, cap, rpc,
-                                      big_island_rows_general(), b->stream));
-        HIP_TRY(hipMemcpyAsync(b->bp_flags_host, b->bp_flags.p, BPF_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipMemcpyAsync(&C, B.counts, sizeof(ExactCounts), hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipStreamSynchronize(b->stream));              // the tick's one wait for the device
+        HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), B, cap, b->stream));
+        auto read_back = [&]() -> int {
+            HIP_TRY(hipMemcpyAsync(b->bp_flags_host, b->bp_flags.p, BPF_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(hipMemcpyAsync(&C, B.counts, sizeof(ExactCounts), hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            return DMX_OK;
+        };
+        // The last exact tick found no pair (crowded bounding spheres, nothing touching): most likely this one will not
+        // either, so look at the pair count before enqueueing the rest.  Otherwise the tick waits for the device once.
+        bool looked = false;
+        if (b->ex_prev_pairs == 0) {
+            if ((rc = read_back()) != DMX_OK) return rc;
+            looked = true;
+        }
+        if (!looked || (!b->bp_flags_host[BPF_OVERFLOW] && !(C.overflow & 1u) && C.npairs > 0 && !C.cross)) {
+            HIP_TRY(launch_exact_group<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), P, B, cap, rpc,
+                                          big_island_rows_general(), b->stream));
+            if ((rc = read_back()) != DMX_OK) return rc;
+        }
         if (b->bp_flags_host[BPF_OVERFLOW]) {                  // a column holds more bodies than a bucket: widen and search again
             if ((rc = grow_buckets(b)) != DMX_OK) return rc;
             continue;
@@ -349,6 +367,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
         break;
     }
     b->last_pairs = C.npairs;
+    b->ex_prev_pairs = C.npairs;
     b->stat_careful_ticks++;
     if (C.cross) {
         fprintf(stderr, "libode_mi355: bodies %u and %u touch across two ranks' slabs; an island spanning ranks has to be "
@@ -422,7 +441,7 @@ template <class T> int step_sync_t(dmxBatch *b, double h, int nsteps)
             // Without a ground plane and with gravity along y nothing acts horizontally: every body's (x,z) moves on a
             // straight line during the chunk, and a disc is convex, so a body inside its zone at the chunk's first and
             // last tick is inside it at every tick between -- two checks per chunk prove all of them.
-            const bool ballistic = !b->plane_on && b->g[0] == 0.0 && b->g[2] == 0.0;
+            const bool ballistic = !b->plane_on && b->n_static == 0 && b->g[0] == 0.0 && b->g[2] == 0.0;
             if ((rc = fused_run<T>(b, h, k, ballistic, true, true)) != DMX_OK) return rc;
             if ((rc = read_flags(b)) != DMX_OK) return rc;
             if (!b->bp_flags_host[BPF_VIOLATION]) {
@@ -509,7 +528,7 @@ template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
             if ((rc = snapshot_begin<T>(b)) != DMX_OK) return rc;
             HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, 2 * sizeof(uint32_t), b->stream));
             oc.open = true; oc.ticks = 0; oc.budget = b->bp_chunk; oc.last_checked = false;
-            oc.ballistic = !b->plane_on && b->g[0] == 0.0 && b->g[2] == 0.0;
+            oc.ballistic = !b->plane_on && b->n_static == 0 && b->g[0] == 0.0 && b->g[2] == 0.0;
             oc.segs.clear();
         }
         const int k = std::min(remaining, oc.budget - oc.ticks);
@@ -536,7 +555,7 @@ template <class T> int chunk_begin_t(dmxBatch *b, int *exact_only, int *ballisti
     if ((rc = ensure_buffers(b)) != DMX_OK) return rc;
     if (!b->bp_valid && (rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
     *exact_only = (b->bp_crowded > 0 || b->ext_pending) ? 1 : 0;
-    *ballistic = (!b->plane_on && b->g[0] == 0.0 && b->g[2] == 0.0) ? 1 : 0;
+    *ballistic = (!b->plane_on && b->n_static == 0 && b->g[0] == 0.0 && b->g[2] == 0.0) ? 1 : 0;
     if ((rc = snapshot_begin<T>(b)) != DMX_OK) return rc;
     HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, 2 * sizeof(uint32_t), b->stream));
     return DMX_OK;

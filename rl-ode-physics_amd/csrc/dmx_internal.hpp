@@ -99,7 +99,13 @@ template <class T> struct StepParams {
     // every convex body, written by np_convex_plane and read by step_plane: cbuf[i][k] = (x, y, z, depth), ccount[i]
     const T *hull; int hull_n;
     T *cbuf; int *ccount;
+    // static (body-less) box geoms, AddBodyMap main.c:735-761: SBOX_REALS reals each (see SBOX_*); the safe-zone test of the
+    // fused kernels also asks that a body's bounding sphere stays clear of every static box's AABB
+    const T *sbox; int n_static;
 };
+// layout of one static box in StepParams::sbox / GridParams::sbox
+enum : int { SBOX_POS = 0, SBOX_R = 3, SBOX_SIDE = 12, SBOX_LO = 15, SBOX_HI = 18, SBOX_REALS = 24 };
+constexpr int MAX_STATIC_BOXES = 64;
 
 // StepParams::bp_check for a launch of `ticks` ticks: test at every tick, or only at the launch's first / last tick
 enum : int { BPC_ALL = 1, BPC_FIRST = 2, BPC_LAST = 4 };
@@ -114,6 +120,8 @@ template <class T> struct GridParams {
     uint32_t *count;       // [mask+1]
     int32_t *items;        // [(mask+1) * cap]
     uint32_t *flags;       // [BPF_COUNT]
+    T *aabb;               // optional [6 per slot]: bp_insert leaves every body's AABB (lo3, hi3) here for the exact pair search
+    const T *sbox; int n_static;   // static boxes (StepParams::sbox)
 };
 
 struct StepDiag {

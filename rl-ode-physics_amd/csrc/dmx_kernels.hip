@@ -60,6 +60,18 @@ template <class T> __device__ __forceinline__ int zone_state(T dx, T dz, T safe)
     if (!(d2 < s2)) return 2;
     return (d2 < s2 * T(0.0625)) ? 0 : 1;
 }
+// ... and the same question for the static boxes: does the body's bounding sphere (centre x, radius r) reach into the
+// AABB of any static box?  2 if so (a contact with static geometry may exist: the exact path decides), else 0.
+template <class T> __device__ __forceinline__ int static_state(const StepParams<T> &P, T x, T y, T z, T r)
+{
+    int st = 0;
+    for (int s = 0; s < P.n_static; s++) {
+        const T *b = P.sbox + s * SBOX_REALS;
+        if (!(x - r > b[SBOX_HI + 0] || x + r < b[SBOX_LO + 0] || y - r > b[SBOX_HI + 1] || y + r < b[SBOX_LO + 1] ||
+              z - r > b[SBOX_HI + 2] || z + r < b[SBOX_LO + 2])) st = 2;
+    }
+    return st;
+}
 // one flag write per wave at most, and none once the flag is already up
 __device__ __forceinline__ void report_zone(int state, uint32_t *flags)
 {
@@ -153,7 +165,11 @@ __global__ __launch_bounds__(256, MINW) void integrate_free(T *S, T *So, int64_t
                 int zs = 0;
 #pragma unroll
                 for (int b = 0; b < V; b++) {
-                    const int z = zone_state(c[C_POS].v[b] - bx.v[b], c[C_POS + 2].v[b] - bz.v[b], bs.v[b]);
+                    int z = zone_state(c[C_POS].v[b] - bx.v[b], c[C_POS + 2].v[b] - bz.v[b], bs.v[b]);
+                    if (P.n_static > 0) {
+                        const int z2 = static_state(P, c[C_POS].v[b], c[C_POS + 1].v[b], c[C_POS + 2].v[b], S[slab_ix(C_BPR, i + b)]);
+                        z = z2 > z ? z2 : z;
+                    }
                     zs = z > zs ? z : zs;
                 }
                 report_zone(zs, P.bp_flags);
@@ -220,9 +236,14 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *S, T *So, const uint8
     double my_resid = 0.0;
     if (i < n && !(P.skip != nullptr && P.skip[i])) {
         V3<T> x = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
-        if (P.bp_check)
-            report_zone(zone_state(x.x - S[slab_ix(C_BPX, i)], x.z - S[slab_ix(C_BPZ, i)], S[slab_ix(C_BPSAFE, i)]),
-                        P.bp_flags);
+        if (P.bp_check) {
+            int zs = zone_state(x.x - S[slab_ix(C_BPX, i)], x.z - S[slab_ix(C_BPZ, i)], S[slab_ix(C_BPSAFE, i)]);
+            if (P.n_static > 0) {
+                const int z2 = static_state(P, x.x, x.y, x.z, S[slab_ix(C_BPR, i)]);
+                zs = z2 > zs ? z2 : zs;
+            }
+            report_zone(zs, P.bp_flags);
+        }
         Q4<T> q = { S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)],
                     S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] };
         V3<T> v = { S[slab_ix(C_LVEL + 0, i)], S[slab_ix(C_LVEL + 1, i)], S[slab_ix(C_LVEL + 2, i)] };

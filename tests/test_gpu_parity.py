@@ -905,3 +905,83 @@ def test_chunk_api_rollback_restores_own_and_ghost_slots():
     w.chunk_commit(6)
     assert np.array_equal(w.download(pkg.batch.STATE), moved)
     w.close()
+
+
+# ----------------------------------------------------------------- static box geoms in the batch path (AddBodyMap, main.c:735-761)
+def _oracle_with_map(orc, scene, boxes, spheres_from=None):
+    """plane (if any), then the static boxes, then the bodies: the reference's creation order (main.c:115-121, then AddBody)"""
+    ow = orc.world()
+    if scene.plane is not None:
+        ow.add_plane(*scene.plane)
+    for sides, pos, R12 in boxes:
+        ow.add_static_box(sides, pos, R12)
+    nb = scene.n if spheres_from is None else spheres_from
+    if nb:
+        ow.add_boxes(scene.pos[:nb], scene.quat[:nb], scene.lvel[:nb], scene.avel[:nb], scene.mass[:nb, 0], scene.inertia[:nb], scene.sides[:nb])
+    if nb < scene.n:
+        ow.add_spheres(scene.pos[nb:], scene.quat[nb:], scene.lvel[nb:], scene.avel[nb:], scene.mass[nb:, 0], scene.inertia[nb:], scene.sides[nb:, 0])
+    return ow
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_reference_pen_in_the_batch_path(dtype):
+    """The reference's own scene -- floor + three walls as static boxes (main.c:115-121), boxes and spheres spawned above
+    them as the key-M spawner draws them (main.c:502-521) -- through the batch path: bit-identical to the oracle while the
+    bodies fall, hit the floor, the walls and one another."""
+    spawn = pkg.scenes.reference_spawn(96, seed=7, y_range=(3.0, 12.0))
+    spawn.sort(key=lambda s: -s[0])                      # boxes (type 2) first, spheres behind them
+    n = len(spawn)
+    nb = sum(1 for s in spawn if s[0] == pkg.scenes.GEOM_BOX)
+    sc = pkg.scenes.Scene(np.array([s[2] for s in spawn], float), np.tile([1.0, 0, 0, 0], (n, 1)), np.zeros((n, 3)), np.zeros((n, 3)),
+                          np.ones((n, 1)), np.ones((n, 3)), np.array([s[1] for s in spawn], float),
+                          np.array([s[0] for s in spawn], np.uint8), None).astype(dtype)
+    boxes = pkg.scenes.reference_map()
+    steps = 240
+    ow = _oracle_with_map(_orc(dtype), sc, boxes, spheres_from=nb)
+    contacts = 0
+    for _ in range(steps):
+        ow.tick(H)
+        contacts = max(contacts, ow.n_contacts())
+    assert contacts > 50
+    w = pkg.BatchWorld(n, dtype=dtype)
+    w.load_scene(sc)
+    w.set_static_boxes(boxes)
+    w.step(H, steps)
+    _compare(w.state(), ow.state())
+    assert w.state()[0][:, 1].min() > 0.4              # nobody fell through the floor (its top is at y = 0.5)
+    st = w.collision_stats()
+    assert st["careful_ticks"] > 0
+    w.close()
+
+
+def test_static_floor_and_ground_plane_together():
+    """a ground plane AND a static box above it: plane contacts come first in creation order, then the static boxes'"""
+    scene = pkg.scenes.box_grid(12, 12, seed=9, y_range=(1.2, 2.5), spin=True, box_mass=True, plane=True).astype("float64")
+    slab = [((20.0, 0.5, 8.0), (0.0, 0.25, 0.0), pkg.scenes._rot_z(0.05))]     # a tilted plank across the middle rows
+    ow = _oracle_with_map(_orc("float64"), scene, slab)
+    ow.run(H, 150)
+    w = pkg.BatchWorld(scene.n, dtype="float64")
+    w.load_scene(scene)
+    w.set_static_boxes(slab)
+    w.step(H, 150)
+    _compare(w.state(), ow.state())
+    w.close()
+
+
+def test_hundred_thousand_boxes_on_a_static_floor():
+    """102 400 boxes dropping onto one static floor box: every body is stepped by the exact path (device pair search,
+    device narrowphase against the floor, one-body islands) -- bit-identical to the oracle."""
+    side = 320
+    scene = pkg.scenes.box_grid(side, side, seed=4, y_range=(1.2, 2.0), spin=False, plane=False).astype("float32")
+    floor = [((1000.0, 1.0, 1000.0), (0.0, 0.0, 0.0), pkg.scenes._rot_z(0.0))]
+    steps = 45
+    ow = _oracle_with_map(_orc("float32"), scene, floor)
+    ow.run(H, steps)
+    assert ow.n_contacts() > scene.n                      # landed
+    w = pkg.BatchWorld(scene.n, dtype="float32")
+    w.load_scene(scene)
+    w.set_static_boxes(floor)
+    w.step(H, steps)
+    _compare(w.state(), ow.state())
+    assert w.last_contact_count() == ow.n_contacts()
+    w.close()
