@@ -115,7 +115,7 @@ struct dmxBatch {
     // device-resident bookkeeping of the exact tick (dmx_exact.hip): capacity estimates carried from tick to tick, one arena
     // for the pipeline's arrays, per-body scan arrays, the per-slot level scratch, the pinned read-back record
     uint32_t ex_cap_pairs = 0, ex_cap_rows = 0;
-    uint32_t ex_prev_pairs = 1;                 // body pairs the last exact tick found
+    uint32_t ex_prev_inv = 1;                   // bodies the last exact tick found involved (in a pair / at a static box)
     DevBuf ex_arena, ex_body, ex_last, ex_aabb;
     void *ex_counts_host = nullptr;
     uint32_t *bp_flags_host = nullptr;         // pinned

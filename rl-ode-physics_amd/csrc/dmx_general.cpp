@@ -338,14 +338,14 @@ template <class T> int careful_tick(dmxBatch *b, double h)
             HIP_TRY(hipStreamSynchronize(b->stream));
             return DMX_OK;
         };
-        // The last exact tick found no pair (crowded bounding spheres, nothing touching): most likely this one will not
-        // either, so look at the pair count before enqueueing the rest.  Otherwise the tick waits for the device once.
+        // The last exact tick found no body involved (crowded bounding spheres, nothing touching): most likely this one
+        // will not either, so look at the counts before enqueueing the rest.  Otherwise the tick waits for the device once.
         bool looked = false;
-        if (b->ex_prev_pairs == 0) {
+        if (b->ex_prev_inv == 0) {
             if ((rc = read_back()) != DMX_OK) return rc;
             looked = true;
         }
-        if (!looked || (!b->bp_flags_host[BPF_OVERFLOW] && !(C.overflow & 1u) && C.npairs > 0 && !C.cross)) {
+        if (!looked || (!b->bp_flags_host[BPF_OVERFLOW] && !(C.overflow & 1u) && C.ninv > 0 && !C.cross)) {
             HIP_TRY(launch_exact_group<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), P, B, cap, rpc,
                                           big_island_rows_general(), b->stream));
             if ((rc = read_back()) != DMX_OK) return rc;
@@ -367,18 +367,18 @@ template <class T> int careful_tick(dmxBatch *b, double h)
         break;
     }
     b->last_pairs = C.npairs;
-    b->ex_prev_pairs = C.npairs;
+    b->ex_prev_inv = C.ninv;
     b->stat_careful_ticks++;
     if (C.cross) {
         fprintf(stderr, "libode_mi355: bodies %u and %u touch across two ranks' slabs; an island spanning ranks has to be "
                         "migrated to one owner first\n", C.cross_a, C.cross_b);
         return DMX_ECROSS;
     }
-    if (C.npairs == 0) {
+    if (C.ninv == 0) {                      // nobody in a body pair, nobody at a static box
         b->last_mixed = false;
         return fused_tick<T>(b, h, false, nullptr);
     }
-    b->stat_pair_ticks++;
+    if (C.npairs > 0) b->stat_pair_ticks++;
     // a quiet scene that has turned busy: leave head room so the next ticks do not run the pipeline twice
     if (2ull * C.npairs > b->ex_cap_pairs) b->ex_cap_pairs = (uint32_t)std::min<uint64_t>(2ull * b->ex_cap_pairs, 1ull << 28);
 
