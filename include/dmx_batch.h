@@ -206,6 +206,15 @@ typedef struct dmxContactJoint {
     double mu, bounce, bounce_vel, soft_erp, soft_cfm;   /* dSurfaceParameters (main.c:684-687) */
 } dmxContactJoint;
 int dmxBatchStepJoints(dmxBatchID b, double h, int64_t n_joints, const dmxContactJoint *joints);
+/* Which of ODE's two steppers dmxBatchStepJoints is.  DMX_STEPPER_QUICK (default): dWorldQuickStep, QuickStep's SOR sweeps.
+ * DMX_STEPPER_EXACT: dWorldStep, the reference's own call (main.c:213): every island's system
+ *   A lambda = b + w,  A = J M^-1 J^T + cfm / h,  lo <= lambda <= hi,  w complementary to lambda
+ * -- the same contact rows -- is solved exactly, one workgroup per island (block principal pivoting over a Cholesky of the
+ * free block; A is positive definite, so the solution is the one ODE's Dantzig solver reaches).  Cost grows with the cube
+ * of an island's rows, as dWorldStep's does; a tick with an island above 4096 rows is stepped with the SOR instead (stderr
+ * says so).  dmxBatchStep (the BASELINE configs, which name dWorldQuickStep) is not affected. */
+enum { DMX_STEPPER_QUICK = 0, DMX_STEPPER_EXACT = 1 };
+int dmxBatchSetStepper(dmxBatchID b, int stepper);
 
 /* per-body flags for the island path: dBodyDestroy'ed slots, dBodySetKinematic (main.c:712), gravity / gyro modes */
 enum { DMX_BODY_ALIVE = 1, DMX_BODY_KINEMATIC = 2, DMX_BODY_NOGRAVITY = 4, DMX_BODY_NOGYRO = 8 };

@@ -54,6 +54,13 @@ enum {
                          /* every 8th iteration (RANDOMLY_REORDER_CONSTRAINTS)   */
 };
 
+/* ---- which stepper orc_world_tick runs: the reference calls dWorldStep (main.c:213); BASELINE names dWorldQuickStep ---- */
+enum {
+    ORC_STEPPER_QUICK = 0, /* dWorldQuickStep: 20 SOR sweeps                                              */
+    ORC_STEPPER_EXACT = 1  /* dWorldStep: the island's boxed LCP  A lambda = b + w,  lo <= lambda <= hi,   */
+                           /* solved to complementarity [ODE-recall step.cpp + lcp.cpp: same rows, same A] */
+};
+
 /* ---- gyroscopic torque form ---- */
 enum {
     ORC_GYRO_OFF      = 0,
@@ -79,6 +86,12 @@ void orc_world_set_cfm(orc_world *w, real cfm);
 void orc_world_set_quickstep(orc_world *w, int iters, real sor_w);
 void orc_world_set_row_order(orc_world *w, int mode);
 void orc_world_set_gyro_mode(orc_world *w, int mode);
+void orc_world_set_stepper(orc_world *w, int mode);
+int  orc_world_last_lcp_rounds(orc_world *w);
+/* diagnostics of the last tick's contact joints, in creation order: count; per joint the bodies (b2 = -1: static geometry),
+ * the contact (position, normal into b1, depth) and the normal force the step found */
+int  orc_world_joint_count(orc_world *w);
+void orc_world_joint_info(orc_world *w, int k, int *b1, int *b2, real pos[3], real normal[3], real *depth, real *lambda_n);
 /* contact surface applied by the built-in near callback (main.c:684-687) */
 void orc_world_set_surface(orc_world *w, int mode, real mu, real bounce, real bounce_vel);
 void orc_world_set_max_contacts(orc_world *w, int n);    /* main.c:675 (8) */

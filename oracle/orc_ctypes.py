@@ -61,6 +61,10 @@ class Oracle:
         sig("orc_world_set_quickstep", None, P, C.c_int, real)
         sig("orc_world_set_row_order", None, P, C.c_int)
         sig("orc_world_set_gyro_mode", None, P, C.c_int)
+        sig("orc_world_set_stepper", None, P, C.c_int)
+        sig("orc_world_last_lcp_rounds", C.c_int, P)
+        sig("orc_world_joint_count", C.c_int, P)
+        sig("orc_world_joint_info", None, P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), RP, RP, RP, RP)
         sig("orc_world_set_surface", None, P, C.c_int, real, real, real)
         sig("orc_world_set_max_contacts", None, P, C.c_int)
         sig("orc_world_set_broadphase", None, P, C.c_int)
@@ -204,3 +208,18 @@ class World:
 
     def sor_residual(self):
         return self.lib.orc_world_last_sor_residual(self.w)
+
+    def set_stepper(self, exact):
+        """False: dWorldQuickStep (SOR); True: dWorldStep (every island's LCP solved exactly)"""
+        self.lib.orc_world_set_stepper(self.w, 1 if exact else 0)
+
+    def joints(self):
+        """the last tick's contact joints: [(b1, b2, pos3, normal3, depth, normal force)]"""
+        out = []
+        real = self.o.real
+        for k in range(self.lib.orc_world_joint_count(self.w)):
+            b1, b2 = C.c_int(), C.c_int()
+            pos, nrm, dep, lam = (real * 3)(), (real * 3)(), real(), real()
+            self.lib.orc_world_joint_info(self.w, k, C.byref(b1), C.byref(b2), pos, nrm, C.byref(dep), C.byref(lam))
+            out.append((b1.value, b2.value, list(pos), list(nrm), dep.value, lam.value))
+        return out

@@ -35,6 +35,7 @@ typedef struct {
     real mu, bounce, bounce_vel;
     int b1, b2;               /* b1 >= 0 always; b2 may be -1 */
     int reverse;              /* dJOINT_REVERSE: bodies were swapped at attach */
+    real lambda_n;            /* diagnostics: the normal row's multiplier after the last step (a force: lambda) */
     int tag;
 } orc_joint;
 
@@ -43,6 +44,8 @@ struct orc_world {
     real erp, cfm, sor_w;
     int iters;
     int row_order, gyro_mode;
+    int stepper;              /* ORC_STEPPER_QUICK (SOR, dWorldQuickStep) or ORC_STEPPER_EXACT (dWorldStep: the LCP solved exactly) */
+    int lcp_rounds;           /* diagnostics: pivoting rounds of the last exact solve (largest island) */
     int surf_mode; real surf_mu, surf_bounce, surf_bounce_vel;
     int max_contacts;
     int bp_mode;              /* broadphase: 0 auto, 1 sweep along x, 2 uniform (x,z) grid */

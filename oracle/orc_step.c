@@ -258,6 +258,171 @@ static double sor_lcp(const orc_world *w, int m, int nb, const int *ibody)
     return resid;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * dWorldStep's solve [ODE-recall step.cpp dxStepIsland + lcp.cpp dSolveLCP]: the same rows as QuickStep, but the
+ * island's system  A lambda = b + w,  A = J M^-1 J^T + diag(cfm / h),  lo <= lambda <= hi,  w_i >= 0 at lo, <= 0 at
+ * hi, = 0 between, is solved to complementarity instead of swept 20 times.  With cfm > 0 A is positive definite, so
+ * the solution is unique: any exact pivoting method reaches the lambda ODE's Dantzig solver reaches.  Here: block
+ * principal pivoting (Judice & Pires) -- rows are free / at lo / at hi; solve the free block by Cholesky, flip every
+ * row that violates its condition, and fall back to flipping only the highest violating row when the count of
+ * violations has failed to shrink three times (Murty's rule, finite for P-matrices).
+ * Every loop below has a fixed operation order; csrc/dmx_islands.hip (lcp_island_wg) follows the same order. */
+static struct { real *A, *M, *r, *lam, *wv; int *state, *idx; size_t cap; } L;
+enum { LCP_FREE = 0, LCP_LO = 1, LCP_HI = 2 };
+
+static void lcp_need(size_t m)
+{
+    if (m <= L.cap) return;
+    L.cap = m * 2;
+    L.A = (real *)realloc(L.A, L.cap * L.cap * sizeof(real));
+    L.M = (real *)realloc(L.M, L.cap * L.cap * sizeof(real));
+    L.r = (real *)realloc(L.r, L.cap * sizeof(real));
+    L.lam = (real *)realloc(L.lam, L.cap * sizeof(real));
+    L.wv = (real *)realloc(L.wv, L.cap * sizeof(real));
+    L.state = (int *)realloc(L.state, L.cap * sizeof(int));
+    L.idx = (int *)realloc(L.idx, L.cap * sizeof(int));
+}
+
+static real dot6(const real *a, const real *b, real acc)
+{
+    for (int k = 0; k < 6; k++) acc = FMA(a[k], b[k], acc);
+    return acc;
+}
+
+static double exact_lcp(orc_world *w, int m, int nb, const int *ibody)
+{
+    real *J = S.J, *iMJ = S.iMJ, *b = S.rhs, *lambda = S.lambda, *fc = S.fc;
+    const int *jb = S.jb;
+    lcp_need((size_t)m);
+    /* iMJ = inv(M) J^T */
+    for (int i = 0; i < m; i++) {
+        real *ip = iMJ + 12 * (size_t)i; const real *jp = J + 12 * (size_t)i;
+        int b1 = jb[2 * i], b2 = jb[2 * i + 1];
+        real k = w->bodies[ibody[b1]].flags & ORC_BODY_KINEMATIC ? 0 : w->bodies[ibody[b1]].invMass;
+        for (int j = 0; j < 3; j++) ip[j] = k * jp[j];
+        orc_mul0_331(ip + 3, S.invI + 12 * (size_t)b1, jp + 3);
+        if (b2 >= 0) {
+            k = w->bodies[ibody[b2]].flags & ORC_BODY_KINEMATIC ? 0 : w->bodies[ibody[b2]].invMass;
+            for (int j = 0; j < 3; j++) ip[6 + j] = k * jp[6 + j];
+            orc_mul0_331(ip + 9, S.invI + 12 * (size_t)b2, jp + 9);
+        } else {
+            for (int j = 6; j < 12; j++) ip[j] = 0;
+        }
+    }
+    /* A = J iMJ^T (only rows sharing a body couple) + diag(cfm) */
+    real *A = L.A;
+    for (int i = 0; i < m; i++) {
+        const real *ji = J + 12 * (size_t)i;
+        const int i1 = jb[2 * i], i2 = jb[2 * i + 1];
+        for (int j = 0; j < m; j++) {
+            const real *pj = iMJ + 12 * (size_t)j;
+            const int j1 = jb[2 * j], j2 = jb[2 * j + 1];
+            real a = 0;
+            if (i1 == j1) a = dot6(ji, pj, a);
+            if (j2 >= 0 && i1 == j2) a = dot6(ji, pj + 6, a);
+            if (i2 >= 0 && i2 == j1) a = dot6(ji + 6, pj, a);
+            if (i2 >= 0 && j2 >= 0 && i2 == j2) a = dot6(ji + 6, pj + 6, a);
+            A[(size_t)i * m + j] = a;
+        }
+        A[(size_t)i * m + i] += S.cfm[i];
+    }
+    real bmax = 0;
+    for (int i = 0; i < m; i++) if (orc_fabs(b[i]) > bmax) bmax = orc_fabs(b[i]);
+#ifdef ORC_SINGLE
+    const real tol = R(1e-5) * (R(1.0) + bmax);
+#else
+    const real tol = R(1e-11) * (R(1.0) + bmax);
+#endif
+    int *state = L.state, *idx = L.idx;
+    real *lam = L.lam, *M = L.M, *r = L.r, *wv = L.wv;
+    for (int i = 0; i < m; i++) { state[i] = LCP_FREE; lam[i] = 0; }
+    int best = m + 1, patience = 3, rounds = 0;
+    const int max_rounds = 20 * m + 100;
+    for (;; rounds++) {
+        int nf = 0;
+        for (int i = 0; i < m; i++) {
+            if (state[i] == LCP_FREE) idx[nf++] = i;
+            else lam[i] = state[i] == LCP_LO ? S.lo[i] : S.hi[i];
+        }
+        /* free block and its right-hand side: r_F = b_F - A_F,clamped lambda_clamped */
+        for (int a = 0; a < nf; a++) {
+            const int i = idx[a];
+            real s = b[i];
+            for (int j = 0; j < m; j++) if (state[j] != LCP_FREE && lam[j] != 0) s -= A[(size_t)i * m + j] * lam[j];
+            r[a] = s;
+            for (int c = 0; c <= a; c++) M[(size_t)a * nf + c] = A[(size_t)i * m + idx[c]];
+        }
+        /* Cholesky, right-looking, lower triangle in place */
+        for (int k = 0; k < nf; k++) {
+            real d = M[(size_t)k * nf + k];
+            d = orc_sqrt(d > 0 ? d : tol);
+            M[(size_t)k * nf + k] = d;
+            for (int i = k + 1; i < nf; i++) M[(size_t)i * nf + k] /= d;
+            for (int i = k + 1; i < nf; i++) {
+                const real lik = M[(size_t)i * nf + k];
+                for (int j = k + 1; j <= i; j++) M[(size_t)i * nf + j] -= lik * M[(size_t)j * nf + k];
+            }
+        }
+        /* L y = r (column oriented), L^T x = y */
+        for (int k = 0; k < nf; k++) {
+            r[k] /= M[(size_t)k * nf + k];
+            for (int i = k + 1; i < nf; i++) r[i] -= M[(size_t)i * nf + k] * r[k];
+        }
+        for (int k = nf - 1; k >= 0; k--) {
+            r[k] /= M[(size_t)k * nf + k];
+            for (int i = 0; i < k; i++) r[i] -= M[(size_t)k * nf + i] * r[k];
+        }
+        for (int a = 0; a < nf; a++) lam[idx[a]] = r[a];
+        /* w = A lambda - b */
+        for (int i = 0; i < m; i++) {
+            real s = -b[i];
+            for (int j = 0; j < m; j++) s += A[(size_t)i * m + j] * lam[j];
+            wv[i] = s;
+        }
+        /* violations */
+        int nv = 0, top = -1;
+        for (int i = 0; i < m; i++) {
+            int v = 0;
+            if (state[i] == LCP_FREE) v = (lam[i] < S.lo[i] - tol) ? 1 : (lam[i] > S.hi[i] + tol) ? 2 : 0;
+            else if (state[i] == LCP_LO) v = wv[i] < -tol ? 3 : 0;
+            else v = wv[i] > tol ? 3 : 0;
+            idx[i] = v;                 /* (idx is rebuilt at the top of the next round) */
+            if (v) { nv++; top = i; }
+        }
+        if (nv == 0 || rounds >= max_rounds) break;
+        int all = 1;
+        if (nv < best) { best = nv; patience = 3; }
+        else if (patience > 0) patience--;
+        else all = 0;
+        for (int i = 0; i < m; i++) {
+            if (!idx[i] || (!all && i != top)) continue;
+            state[i] = idx[i] == 1 ? LCP_LO : idx[i] == 2 ? LCP_HI : LCP_FREE;
+        }
+    }
+    w->lcp_rounds = rounds > w->lcp_rounds ? rounds : w->lcp_rounds;
+    /* clamp what the tolerance let through, then cforce = inv(M) J^T lambda */
+    for (int i = 0; i < m; i++) {
+        if (state[i] == LCP_FREE) { if (lam[i] < S.lo[i]) lam[i] = S.lo[i]; if (lam[i] > S.hi[i]) lam[i] = S.hi[i]; }
+        lambda[i] = lam[i];
+    }
+    memset(fc, 0, (size_t)nb * 6 * sizeof(real));
+    for (int i = 0; i < m; i++) {
+        const real *ip = iMJ + 12 * (size_t)i;
+        real *f1 = fc + 6 * (size_t)jb[2 * i];
+        for (int k = 0; k < 6; k++) f1[k] = FMA(lambda[i], ip[k], f1[k]);
+        if (jb[2 * i + 1] >= 0) {
+            real *f2 = fc + 6 * (size_t)jb[2 * i + 1];
+            for (int k = 0; k < 6; k++) f2[k] = FMA(lambda[i], ip[6 + k], f2[k]);
+        }
+    }
+    double resid = 0;      /* complementarity residual: what is left of the conditions */
+    for (int i = 0; i < m; i++) {
+        real v = state[i] == LCP_FREE ? orc_fabs(wv[i]) : (state[i] == LCP_LO ? (wv[i] < 0 ? -wv[i] : 0) : (wv[i] > 0 ? wv[i] : 0));
+        resid += (double)v;
+    }
+    return resid;
+}
+
 static void step_island(orc_world *w, const int *ibody, int nb, const int *ijoint, int nj, real h)
 {
     real stepsize1 = R(1.0) / h;
@@ -311,7 +476,11 @@ static void step_island(orc_world *w, const int *ibody, int nb, const int *ijoin
             S.rhs[i] = FMA(S.c[i], stepsize1, -sum);
             S.cfm[i] *= stepsize1;
         }
-        w->last_residual += sor_lcp(w, m, nb, ibody);
+        w->last_residual += w->stepper == ORC_STEPPER_EXACT ? exact_lcp(w, m, nb, ibody) : sor_lcp(w, m, nb, ibody);
+        for (int k = 0, rr = 0; k < nj; k++) {          /* diagnostics: the normal force of every contact */
+            w->joints[ijoint[k]].lambda_n = S.lambda[rr];
+            rr += contact_m(&w->joints[ijoint[k]]);
+        }
         /* v += h * cforce */
         for (int i = 0; i < nb; i++) {
             orc_body *b = &w->bodies[ibody[i]];
@@ -349,6 +518,7 @@ void orc_quickstep(orc_world *w, real h)
 {
     int nb = w->nb, nj = w->nj;
     w->last_residual = 0;
+    w->lcp_rounds = 0;
     if (nb == 0) return;
     /* adjacency: joints per body, in creation order */
     if ((size_t)nb + 1 > S.cap_adj_b) {

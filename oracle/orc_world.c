@@ -48,6 +48,16 @@ void orc_world_set_erp(orc_world *w, real erp) { w->erp = erp; }
 void orc_world_set_cfm(orc_world *w, real cfm) { w->cfm = cfm; }
 void orc_world_set_quickstep(orc_world *w, int iters, real sor_w) { w->iters = iters; w->sor_w = sor_w; }
 void orc_world_set_row_order(orc_world *w, int mode) { w->row_order = mode; }
+void orc_world_set_stepper(orc_world *w, int mode) { w->stepper = mode; }
+int orc_world_last_lcp_rounds(orc_world *w) { return w->lcp_rounds; }
+int orc_world_joint_count(orc_world *w) { return w->last_contacts; }   /* (the array outlives dJointGroupEmpty until the next tick) */
+void orc_world_joint_info(orc_world *w, int k, int *b1, int *b2, real pos[3], real normal[3], real *depth, real *lambda_n)
+{
+    const orc_joint *j = &w->joints[k];
+    *b1 = j->b1; *b2 = j->b2;
+    for (int i = 0; i < 3; i++) { pos[i] = j->geom.pos[i]; normal[i] = j->reverse ? -j->geom.normal[i] : j->geom.normal[i]; }
+    *depth = j->geom.depth; *lambda_n = j->lambda_n;
+}
 void orc_world_set_gyro_mode(orc_world *w, int mode) { w->gyro_mode = mode; }
 void orc_world_set_surface(orc_world *w, int mode, real mu, real bounce, real bounce_vel)
 { w->surf_mode = mode; w->surf_mu = mu; w->surf_bounce = bounce; w->surf_bounce_vel = bounce_vel; }
@@ -208,7 +218,7 @@ void orc_world_tick(orc_world *w, real h)
 {
     orc_collide_all(w);        /* dSpaceCollide(space, NULL, NearCallback)  main.c:212 */
     w->last_contacts = w->nj;
-    orc_quickstep(w, h);       /* dWorldStep -> QuickStep semantics (F6)    main.c:213 */
+    orc_quickstep(w, h);       /* dWorldStep / dWorldQuickStep (orc_world_set_stepper)  main.c:213 */
     w->nj = 0;                 /* dJointGroupEmpty(contactGroup)            main.c:214 */
 }
 

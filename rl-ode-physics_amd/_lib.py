@@ -23,7 +23,7 @@ BATCH_SYMBOLS = [
     "dmxBatchScatterBodiesOnStream", "dmxBatchSetBoundaryPack",
     "dmxBatchChunkBegin", "dmxBatchChunkTick", "dmxBatchCheckZonesOnStream", "dmxBatchChunkEnd",
     "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream", "dmxBatchSetConvexHull", "dmxBatchChunkTicks", "dmxBatchSetTicksPerLaunch",
-    "dmxBatchSetSnapshotMode", "dmxBatchSetStaticBoxes",
+    "dmxBatchSetSnapshotMode", "dmxBatchSetStaticBoxes", "dmxBatchSetStepper",
 ]
 
 _lib = None
@@ -103,5 +103,6 @@ def load():
     sig("dmxBatchSetTicksPerLaunch", I, P, I)
     sig("dmxBatchSetSnapshotMode", I, P, I)
     sig("dmxBatchSetStaticBoxes", I, P, C.c_int32, P, P, P)
+    sig("dmxBatchSetStepper", I, P, I)
     _lib = lib
     return lib

@@ -137,7 +137,8 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
     if (b->slab_alt) (void)hipFree(b->slab_alt);
     if (b->gtype) (void)hipFree(b->gtype);
     if (b->bflags) (void)hipFree(b->bflags);
-    for (dmxBatch::DevBuf *d : { &b->jd_int, &b->jd_real, &b->jd_rows, &b->jd_rowjb, &b->jd_bscr, &b->jd_local })
+    for (dmxBatch::DevBuf *d : { &b->jd_int, &b->jd_real, &b->jd_rows, &b->jd_rowjb, &b->jd_bscr, &b->jd_local, &b->jd_lcp, &b->jd_lcp_off,
+                                &b->jd_lcp_int })
         if (d->p) (void)hipFree(d->p);
     for (dmxBatch::DevBuf *d : { &b->bp_count, &b->bp_items, &b->bp_flags, &b->bp_pairs, &b->bp_inpair, &b->bp_snapshot, &b->bp_idx, &b->bp_gather,
                                 &b->np_pos, &b->np_normal, &b->np_depth, &b->np_count, &b->np_pairs, &b->hull, &b->cbuf, &b->ccount,
@@ -347,6 +348,14 @@ extern "C" int dmxBatchStep(dmxBatchID b, double h, int nsteps)
     b->ext_pending = false;   // the step cleared the accumulators
     b->last_mixed = false;
     return rc;
+}
+
+extern "C" int dmxBatchSetStepper(dmxBatchID b, int stepper)
+{
+    if (!b || (stepper != DMX_STEPPER_QUICK && stepper != DMX_STEPPER_EXACT)) return DMX_EINVAL;
+    SETTLE(b);
+    b->stepper_exact = stepper == DMX_STEPPER_EXACT;
+    return DMX_OK;
 }
 
 extern "C" int dmxBatchSetSnapshotMode(dmxBatchID b, int mode)

@@ -102,6 +102,9 @@ struct dmxBatch {
     std::vector<uint8_t> h_bflags;             // host mirror
     struct DevBuf { void *p = nullptr; size_t bytes = 0; };
     DevBuf jd_int, jd_real, jd_rows, jd_rowjb, jd_bscr, jd_local;   // device staging / scratch
+    DevBuf jd_lcp, jd_lcp_off, jd_lcp_int;     // dWorldStep's exact island solve: A, factor, vectors per island; offsets; pivoting state
+    std::vector<long long> sc_lcp_off;
+    bool stepper_exact = false;                // dmxBatchSetStepper: dmxBatchStepJoints solves every island's LCP exactly
     void *jh_int = nullptr, *jh_real = nullptr;                      // pinned host staging
     // body-body broadphase (dmx_broadphase.hip / dmx_general.cpp)
     int bp_enabled = 1;                        // dmxBatchSetBodyCollisions

@@ -138,6 +138,11 @@ hipError_t launch_step(T *S, T *So, const uint8_t *gtype, int64_t stride, int64_
 template <class T>
 hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
                           StepDiag *diag, hipStream_t st);
+// dWorldStep: every island with rows is solved exactly (boxed LCP, block principal pivoting) by one workgroup;
+// scratch = per island 2 m^2 + 3 m reals at scratch_off[k] (k = index in I.big_list), iscratch = 9 ints per reserved row
+template <class T>
+hipError_t launch_islands_exact(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
+                                StepDiag *diag, T *scratch, const long long *scratch_off, int *iscratch, int max_rows, hipStream_t st);
 template <class T>
 hipError_t launch_bp_insert(T *S, const uint8_t *gtype, int64_t stride, int64_t n, const GridParams<T> &G, hipStream_t st);
 template <class T>

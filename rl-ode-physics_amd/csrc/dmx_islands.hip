@@ -156,7 +156,8 @@ __device__ __forceinline__ void body_tmp(const T *S, int64_t stride, T *b, int s
 }
 
 // ---- row i: rhs = c/h - J (v/h + M^-1 f); cfm /= h; iMJ = M^-1 J^T; Ad = w/(J iMJ + cfm); J *= Ad; rhs *= Ad; Ad *= cfm
-template <class T>
+// SOR = false (the exact solve of dWorldStep): stop after iMJ -- J and rhs stay unscaled, row[RW_AD] = cfm / h
+template <class T, bool SOR = true>
 __device__ __forceinline__ void row_setup(T *rows, const int *jb, const T *bs, int i, T hinv, T sor_w)
 {
     T *row = rows + (size_t)i * RW_COUNT;
@@ -184,6 +185,7 @@ __device__ __forceinline__ void row_setup(T *rows, const int *jb, const T *bs, i
     } else {
         for (int j = 6; j < 12; j++) iMJ[j] = T(0);
     }
+    if (!SOR) return;
     T s2 = T(0);
     for (int j = 0; j < 6; j++) s2 = fma_(iMJ[j], J[j], s2);
     if (l2 >= 0) for (int j = 6; j < 12; j++) s2 = fma_(iMJ[j], J[j], s2);
@@ -456,6 +458,224 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
     if (tid == 0) atomicAdd(&diag->contacts, (unsigned long long)nc);
 }
 
+// ================================================================================ dWorldStep: the island's LCP solved exactly
+// One workgroup per island with rows.  Same rows as the SOR kernels (stage_body / contact_rows / body_tmp / row_setup),
+// then  A = J M^-1 J^T + diag(cfm / h)  and block principal pivoting on  A lambda = b + w, lo <= lambda <= hi  (free /
+// at-lo / at-hi sets, Cholesky of the free block, flip the violators; Murty's single flip once the violation count has
+// stalled three times) -- the algorithm and operation order of oracle/orc_step.c exact_lcp.  A lives in HBM/L2 (m^2 reals
+// per island, scratch sized by the host); the free block's factor is staged in LDS when it fits.
+enum : int { LCP_FREE = 0, LCP_LO = 1, LCP_HI = 2 };
+
+template <class T> __device__ __forceinline__ T dot6acc(const T *a, const T *b, T acc)
+{
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc = fma_(a[k], b[k], acc);
+    return acc;
+}
+
+template <class T, int WG>
+__global__ __launch_bounds__(WG) void lcp_island_wg(T *__restrict__ S, const uint8_t *__restrict__ bflags, int64_t stride,
+                                                    IslandSet<T> I, StepParams<T> P, StepDiag *__restrict__ diag,
+                                                    T *__restrict__ scratch, const long long *__restrict__ scratch_off,
+                                                    int *__restrict__ iscratch, int lds_rows)
+{
+    const int isl = I.big_list[blockIdx.x];
+    const int tid = threadIdx.x;
+    const T h = P.h, hinv = T(1) / h;
+    const int b0 = I.body_off[isl], nb = I.body_off[isl + 1] - b0;
+    const int c0 = I.con_off[isl], nc = I.con_off[isl + 1] - c0;
+    const int r0 = I.row_off[isl];
+    T *bs = I.bscr + (size_t)b0 * BW_COUNT;
+    T *rows = I.rows + (size_t)r0 * RW_COUNT;
+    int *jb = I.rowjb + 2 * (size_t)r0;
+    // rows of this island: contacts are laid out by crow (first row of each contact), rpc rows each
+    const int m = nc > 0 ? I.crow[c0 + nc - 1] + contact_rpc(I, P, c0 + nc - 1) : 0;
+
+    for (int k = tid; k < nb; k += WG) stage_body(S, bflags, stride, I, P, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], k);
+    __syncthreads();
+    for (int c = tid; c < nc; c += WG) contact_rows(S, stride, I, P, rows, jb, c0 + c, I.crow[c0 + c], hinv);
+    for (int k = tid; k < nb; k += WG) body_tmp(S, stride, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], hinv);
+    __syncthreads();
+    for (int i = tid; i < m; i += WG) row_setup<T, false>(rows, jb, bs, i, hinv, P.sor_w);
+    __syncthreads();
+
+    T *A = scratch + scratch_off[blockIdx.x];
+    T *Mg = A + (size_t)m * m, *rg = Mg + (size_t)m * m, *lam = rg + m, *wv = lam + m;
+    int *state = iscratch + 3 * (size_t)r0, *idx = state + m, *viol = idx + m;
+    extern __shared__ __align__(16) unsigned char lcp_raw[];
+    __shared__ int s_nf, s_done;
+    __shared__ T s_tol;
+
+    // A = J iMJ^T over shared bodies + diag(cfm / h)
+    for (long long e = tid; e < (long long)m * m; e += WG) {
+        const int i = (int)(e / m), j = (int)(e - (long long)i * m);
+        const T *ji = rows + (size_t)i * RW_COUNT + RW_J, *pj = rows + (size_t)j * RW_COUNT + RW_IMJ;
+        const int i1 = jb[2 * i], i2 = jb[2 * i + 1], j1 = jb[2 * j], j2 = jb[2 * j + 1];
+        T a = T(0);
+        if (i1 == j1) a = dot6acc(ji, pj, a);
+        if (j2 >= 0 && i1 == j2) a = dot6acc(ji, pj + 6, a);
+        if (i2 >= 0 && i2 == j1) a = dot6acc(ji + 6, pj, a);
+        if (i2 >= 0 && j2 >= 0 && i2 == j2) a = dot6acc(ji + 6, pj + 6, a);
+        if (i == j) a += rows[(size_t)i * RW_COUNT + RW_AD];
+        A[e] = a;
+    }
+    if (tid == 0) {
+        T bmax = T(0);
+        for (int i = 0; i < m; i++) { const T v = tabs(rows[(size_t)i * RW_COUNT + RW_RHS]); if (v > bmax) bmax = v; }
+        s_tol = (sizeof(T) == 4 ? T(1e-5) : T(1e-11)) * (T(1) + bmax);
+    }
+    for (int i = tid; i < m; i += WG) { state[i] = LCP_FREE; lam[i] = T(0); }
+    __syncthreads();
+    const T tol = s_tol;
+    int best = m + 1, patience = 3;                     // (only thread 0's copies matter)
+    const int max_rounds = 20 * m + 100;
+    for (int round = 0;; round++) {
+        if (tid == 0) {
+            int nf = 0;
+            for (int i = 0; i < m; i++) {
+                if (state[i] == LCP_FREE) idx[nf++] = i;
+                else lam[i] = state[i] == LCP_LO ? rows[(size_t)i * RW_COUNT + RW_LO] : rows[(size_t)i * RW_COUNT + RW_HI];
+            }
+            s_nf = nf;
+        }
+        __syncthreads();
+        const int nf = s_nf;
+        const bool in_lds = nf <= lds_rows;             // the free block's factor and right-hand side fit in LDS
+        T *M = in_lds ? reinterpret_cast<T *>(lcp_raw) : Mg;
+        T *r = in_lds ? M + (size_t)nf * nf : rg;
+        for (int a = tid; a < nf; a += WG) {
+            const int i = idx[a];
+            T s = rows[(size_t)i * RW_COUNT + RW_RHS];
+            for (int j = 0; j < m; j++) if (state[j] != LCP_FREE && lam[j] != T(0)) s -= A[(size_t)i * m + j] * lam[j];
+            r[a] = s;
+        }
+        for (long long e = tid; e < (long long)nf * nf; e += WG) {
+            const int a = (int)(e / nf), c = (int)(e - (long long)a * nf);
+            if (c <= a) M[e] = A[(size_t)idx[a] * m + idx[c]];
+        }
+        __syncthreads();
+        // Cholesky, right-looking, lower triangle in place
+        for (int k = 0; k < nf; k++) {
+            if (tid == 0) { T d = M[(size_t)k * nf + k]; d = tsqrt<T>(d > T(0) ? d : tol); M[(size_t)k * nf + k] = d; }
+            __syncthreads();
+            const T d = M[(size_t)k * nf + k];
+            for (int i = k + 1 + tid; i < nf; i += WG) M[(size_t)i * nf + k] /= d;
+            __syncthreads();
+            const int cnt = nf - k - 1;
+            const long long total = (long long)cnt * (cnt + 1) / 2;
+            for (long long e = tid; e < total; e += WG) {
+                int ii = (int)((tsqrt<double>(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+                while ((long long)ii * (ii + 1) / 2 > e) ii--;
+                while ((long long)(ii + 1) * (ii + 2) / 2 <= e) ii++;
+                const int jj = (int)(e - (long long)ii * (ii + 1) / 2);
+                const int i = k + 1 + ii, j = k + 1 + jj;
+                M[(size_t)i * nf + j] -= M[(size_t)i * nf + k] * M[(size_t)j * nf + k];
+            }
+            __syncthreads();
+        }
+        // L y = r (column oriented), L^T x = y
+        for (int k = 0; k < nf; k++) {
+            if (tid == 0) r[k] /= M[(size_t)k * nf + k];
+            __syncthreads();
+            const T rk = r[k];
+            for (int i = k + 1 + tid; i < nf; i += WG) r[i] -= M[(size_t)i * nf + k] * rk;
+            __syncthreads();
+        }
+        for (int k = nf - 1; k >= 0; k--) {
+            if (tid == 0) r[k] /= M[(size_t)k * nf + k];
+            __syncthreads();
+            const T rk = r[k];
+            for (int i = tid; i < k; i += WG) r[i] -= M[(size_t)k * nf + i] * rk;
+            __syncthreads();
+        }
+        for (int a = tid; a < nf; a += WG) lam[idx[a]] = r[a];
+        __syncthreads();
+        for (int i = tid; i < m; i += WG) {
+            T s = -rows[(size_t)i * RW_COUNT + RW_RHS];
+            for (int j = 0; j < m; j++) s += A[(size_t)i * m + j] * lam[j];
+            wv[i] = s;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int nv = 0, top = -1;
+            for (int i = 0; i < m; i++) {
+                const T lo = rows[(size_t)i * RW_COUNT + RW_LO], hi = rows[(size_t)i * RW_COUNT + RW_HI];
+                int v = 0;
+                if (state[i] == LCP_FREE) v = (lam[i] < lo - tol) ? 1 : (lam[i] > hi + tol) ? 2 : 0;
+                else if (state[i] == LCP_LO) v = wv[i] < -tol ? 3 : 0;
+                else v = wv[i] > tol ? 3 : 0;
+                viol[i] = v;
+                if (v) { nv++; top = i; }
+            }
+            int done = (nv == 0 || round >= max_rounds) ? 1 : 0;
+            if (!done) {
+                bool all = true;
+                if (nv < best) { best = nv; patience = 3; }
+                else if (patience > 0) patience--;
+                else all = false;
+                for (int i = 0; i < m; i++) {
+                    if (!viol[i] || (!all && i != top)) continue;
+                    state[i] = viol[i] == 1 ? LCP_LO : viol[i] == 2 ? LCP_HI : LCP_FREE;
+                }
+            }
+            s_done = done;
+        }
+        __syncthreads();
+        if (s_done) break;
+    }
+    // clamp what the tolerance let through; cforce = M^-1 J^T lambda, rows in order per body
+    for (int i = tid; i < m; i += WG) {
+        T l = lam[i];
+        if (state[i] == LCP_FREE) {
+            const T lo = rows[(size_t)i * RW_COUNT + RW_LO], hi = rows[(size_t)i * RW_COUNT + RW_HI];
+            if (l < lo) l = lo;
+            if (l > hi) l = hi;
+        }
+        lam[i] = l;
+        rows[(size_t)i * RW_COUNT + RW_LAM] = l;
+    }
+    __syncthreads();
+    double resid = 0.0;
+    for (int k = tid; k < nb; k += WG) {
+        T f[6] = { T(0), T(0), T(0), T(0), T(0), T(0) };
+        for (int i = 0; i < m; i++) {
+            const T *ip = rows + (size_t)i * RW_COUNT + RW_IMJ;
+            if (jb[2 * i] == k) { for (int q = 0; q < 6; q++) f[q] = fma_(lam[i], ip[q], f[q]); }
+            if (jb[2 * i + 1] == k) { for (int q = 0; q < 6; q++) f[q] = fma_(lam[i], ip[6 + q], f[q]); }
+        }
+        for (int q = 0; q < 6; q++) bs[(size_t)k * BW_COUNT + BW_FC + q] = f[q];
+    }
+    for (int i = tid; i < m; i += WG) {
+        const T w_i = wv[i];
+        resid += (double)(state[i] == LCP_FREE ? tabs(w_i) : (state[i] == LCP_LO ? (w_i < T(0) ? -w_i : T(0)) : (w_i > T(0) ? w_i : T(0))));
+    }
+    for (int k = tid; k < nb; k += WG) finish_body(S, bflags, stride, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], m > 0, h);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) resid += __shfl_xor(resid, o, 64);
+    if ((tid & 63) == 0) atomicAdd(&diag->residual, resid);
+    if (tid == 0) atomicAdd(&diag->contacts, (unsigned long long)nc);
+}
+
+template <class T>
+hipError_t launch_islands_exact(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
+                                StepDiag *diag, T *scratch, const long long *scratch_off, int *iscratch, int max_rows, hipStream_t st)
+{
+    if (I.n_islands <= 0) return hipSuccess;
+    if (I.n_big < I.n_islands) {       // islands without rows: free bodies
+        const unsigned grid = (unsigned)((I.n_islands + 63) / 64);
+        hipLaunchKernelGGL((solve_islands<T>), dim3(grid), dim3(64), 0, st, S, bflags, stride, I, P, diag);
+    }
+    if (I.n_big > 0) {
+        // LDS for the free block's factor + right-hand side, up to 60 KB
+        int lds_rows = 0;
+        while ((size_t)(lds_rows + 1) * (lds_rows + 2) * sizeof(T) <= (size_t)60 * 1024 && lds_rows < max_rows) lds_rows++;
+        const size_t lds = (size_t)lds_rows * (lds_rows + 1) * sizeof(T);
+        hipLaunchKernelGGL((lcp_island_wg<T, 256>), dim3((unsigned)I.n_big), dim3(256), lds, st, S, bflags, stride, I, P, diag,
+                           scratch, scratch_off, iscratch, lds_rows);
+    }
+    return hipGetLastError();
+}
+
 template <class T>
 hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
                           StepDiag *diag, hipStream_t st)
@@ -477,6 +697,10 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
     return hipGetLastError();
 }
 
+template hipError_t launch_islands_exact<float>(float *, const uint8_t *, int64_t, const IslandSet<float> &, const StepParams<float> &,
+                                                StepDiag *, float *, const long long *, int *, int, hipStream_t);
+template hipError_t launch_islands_exact<double>(double *, const uint8_t *, int64_t, const IslandSet<double> &, const StepParams<double> &,
+                                                 StepDiag *, double *, const long long *, int *, int, hipStream_t);
 template hipError_t launch_islands<float>(float *, const uint8_t *, int64_t, const IslandSet<float> &,
                                           const StepParams<float> &, StepDiag *, hipStream_t);
 template hipError_t launch_islands<double>(double *, const uint8_t *, int64_t, const IslandSet<double> &,

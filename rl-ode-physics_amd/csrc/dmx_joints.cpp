@@ -17,6 +17,8 @@ namespace {
 // One lane walking an island pays a dependent L2 round trip per row and sweep, so anything beyond a body or two is
 // better off with a workgroup: 500-body reference scene 5.2 / 3.3 / 2.4 / 1.7 / 1.3 / 1.1 / 0.8 ms per tick at 384 / 128 /
 // 64 / 32 / 16 / 8 / 4 rows (profiles/r01_big_island_threshold.txt).
+constexpr int kMaxExactRows = 4096;      // dWorldStep's exact solve keeps A (m x m) and its factor per island: 2 x 128 MB in f64 at this size
+
 int big_island_rows()
 {
     static const int v = [] { const char *e = getenv("DMX_BIG_ISLAND_ROWS"); return e ? atoi(e) : 4; }();
@@ -47,6 +49,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
                                      const uint8_t *include, const DevGeometry *geo)
 {
     const int n = (int)b->n;
+    bool exact = b->stepper_exact;          // dWorldStep: islands solved exactly (decided per tick: see the row limit below)
     // per-slot scratch that persists between ticks: parent = identity, island = -1, last = -1 outside a tick
     if ((int)b->sc_parent.size() != n) {
         b->sc_parent.resize((size_t)n); std::iota(b->sc_parent.begin(), b->sc_parent.end(), 0);
@@ -138,20 +141,45 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
         std::vector<int> &row_base = b->sc_iv[11];
         row_base.clear();
         int rows_total = 0;
+        if (exact)
+            for (int i = 0; i < ni; i++)
+                if (m_of[(size_t)i] > kMaxExactRows) {
+                    static bool warned = false;
+                    if (!warned) fprintf(stderr, "libode_mi355: dWorldStep: an island of %d constraint rows exceeds the exact solver's limit (%d); "
+                                                 "such ticks are stepped with QuickStep's SOR instead\n", m_of[(size_t)i], kMaxExactRows);
+                    warned = true;
+                    exact = false;
+                    break;
+                }
         for (int i = 0; i < ni; i++) {
-            if (m_of[(size_t)i] < big_island_rows()) continue;
+            if (m_of[(size_t)i] < (exact ? 1 : big_island_rows())) continue;
             big_list_h.push_back(i);
             row_base.push_back(rows_total);
             rows_total += m_of[(size_t)i];
             big_max_bodies = std::max(big_max_bodies, island_bodies[(size_t)i]);
         }
         const int nbig = (int)big_list_h.size();
+        if (exact) {
+            // no level schedules: the exact solve is not a sweep.  Per-island scratch offsets instead (2 m^2 + 3 m reals).
+            b->sc_lcp_off.resize((size_t)nbig + 1);
+            long long at = 0;
+            for (int k = 0; k < nbig; k++) {
+                b->sc_lcp_off[(size_t)k] = at;
+                const long long m = m_of[(size_t)big_list_h[(size_t)k]];
+                at += 2 * m * m + 3 * m;
+            }
+            b->sc_lcp_off[(size_t)nbig] = at;
+            lev_count_h.assign((size_t)nbig, 0);
+            for (int k = 0; k < nbig; k++) big_h[(size_t)big_list_h[(size_t)k]] = 0;
+            rows_total = 0;
+        }
+        const int nbig_sched = exact ? 0 : nbig;
         // (3) row r's level = 1 + the latest level of an earlier row sharing a body with it (creation order)
         std::vector<int> &lvl = lvl_all;                // row -> level, laid out like lev_rows (island k's rows from row_base[k])
         lvl.assign((size_t)rows_total, 0);
         lev_count_h.assign((size_t)nbig, 0);
         std::vector<int> &last = b->sc_last;          // per slot: level of the latest row touching the body; islands own disjoint slots
-        dmx_parallel_for(nbig, 64, [&](int64_t lo, int64_t hi, int) {
+        dmx_parallel_for(nbig_sched, 64, [&](int64_t lo, int64_t hi, int) {
             for (int64_t k = lo; k < hi; k++) {
                 const int i = big_list_h[(size_t)k];
                 int *lv_out = lvl.data() + row_base[(size_t)k];
@@ -180,12 +208,12 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
         // (4) offsets of every island's level table, then (5) its rows grouped by level (counting sort)
         std::vector<int> &off_base = b->sc_iv[12];
         off_base.assign((size_t)nbig + 1, 0);
-        for (int k = 0; k < nbig; k++) off_base[(size_t)k + 1] = off_base[(size_t)k] + lev_count_h[(size_t)k] + 1;
-        lev_off_h.assign((size_t)off_base[(size_t)nbig], 0);
+        for (int k = 0; k < nbig_sched; k++) off_base[(size_t)k + 1] = off_base[(size_t)k] + lev_count_h[(size_t)k] + 1;
+        lev_off_h.assign((size_t)off_base[(size_t)nbig_sched], 0);
         lev_rows_h.assign((size_t)rows_total, 0);
         std::vector<int> &width_of = b->sc_iv[13];
         width_of.assign((size_t)nbig, 0);
-        dmx_parallel_for(nbig, 64, [&](int64_t lo, int64_t hi, int) {
+        dmx_parallel_for(nbig_sched, 64, [&](int64_t lo, int64_t hi, int) {
             std::vector<int> fill;
             for (int64_t k = lo; k < hi; k++) {
                 const int i = big_list_h[(size_t)k], m = m_of[(size_t)i], nlev = lev_count_h[(size_t)k], base = row_base[(size_t)k];
@@ -201,7 +229,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
                 for (int q = 0; q < m; q++) lev_rows_h[(size_t)fill[(size_t)lv[q]]++] = q;
             }
         });
-        for (int k = 0; k < nbig; k++) {
+        for (int k = 0; k < nbig_sched; k++) {
             big_h[(size_t)big_list_h[(size_t)k]] = off_base[(size_t)k];
             big_max_width = std::max(big_max_width, width_of[(size_t)k]);
         }
@@ -298,7 +326,20 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
 
     StepParams<T> P = dmx_make_params<T>(b, h);
     HIP_TRY(hipMemsetAsync(b->diag_isl, 0, sizeof(StepDiag), b->stream));
-    HIP_TRY(launch_islands<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, b->stream));
+    if (exact) {
+        const size_t nbig = (size_t)n_big;
+        if ((rc = dmx_ensure_dev(b->jd_lcp, (size_t)(b->sc_lcp_off[nbig] + 1) * sizeof(T))) != DMX_OK) return rc;
+        if ((rc = dmx_ensure_dev(b->jd_lcp_off, (nbig + 1) * sizeof(long long))) != DMX_OK) return rc;
+        if ((rc = dmx_ensure_dev(b->jd_lcp_int, (nrows + 1) * 3 * sizeof(int))) != DMX_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(b->jd_lcp_off.p, b->sc_lcp_off.data(), (nbig + 1) * sizeof(long long), hipMemcpyHostToDevice, b->stream));
+        int max_rows = 0;
+        for (int k = 0; k < n_big; k++) max_rows = std::max(max_rows, b->sc_iv[10][(size_t)big_list_h[(size_t)k]]);
+        HIP_TRY(launch_islands_exact<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, (T *)b->jd_lcp.p,
+                                        (const long long *)b->jd_lcp_off.p, (int *)b->jd_lcp_int.p, max_rows, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));      // sc_lcp_off is pageable host memory: the copy must have read it before the next tick rewrites it
+    } else {
+        HIP_TRY(launch_islands<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, b->stream));
+    }
     b->last_islands = true;
     b->ext_pending = false;
     b->stepped_with_plane = true;     // diagnostics are valid

@@ -230,11 +230,12 @@ extern "C" int dWorldGetQuickStepNumIterations(dWorldID w) { return w->iters; }
 extern "C" void dWorldSetQuickStepW(dWorldID w, dReal v) { w->sor_w = v; }
 extern "C" dReal dWorldGetQuickStepW(dWorldID w) { return w->sor_w; }
 
-extern "C" int dWorldQuickStep(dWorldID w, dReal h)
+static int world_step(dWorldID w, dReal h, int stepper)
 {
     if (!w || !(h > 0)) return 0;
     w->to_device();
     w->push_params();
+    DMX_MUST(dmxBatchSetStepper(w->batch, stepper));
     w->cj.clear();
     for (const dxJoint *j : w->joints) {
         dmxContactJoint c;
@@ -252,8 +253,10 @@ extern "C" int dWorldQuickStep(dWorldID w, dReal h)
     w->dev_newer = true;
     return 1;
 }
-// the reference calls dWorldStep (main.c:213); it is served with QuickStep semantics
-extern "C" int dWorldStep(dWorldID w, dReal h) { return dWorldQuickStep(w, h); }
+// dWorldQuickStep: QuickStep's SOR sweeps.  dWorldStep -- what the reference calls, main.c:213 -- the same rows with
+// every island's LCP solved exactly (include/dmx_batch.h, dmxBatchSetStepper).
+extern "C" int dWorldQuickStep(dWorldID w, dReal h) { return world_step(w, h, DMX_STEPPER_QUICK); }
+extern "C" int dWorldStep(dWorldID w, dReal h) { return world_step(w, h, DMX_STEPPER_EXACT); }
 
 // ================================================================================ mass
 extern "C" void dMassSetZero(dMass *m) { memset(m, 0, sizeof(*m)); }

@@ -59,7 +59,7 @@ static double rd(void)
 
 int main(void)
 {
-    int steps, use_plane, n_static, n_body, i, k, s, up_front, every, readback, created;
+    int steps, use_plane, n_static, n_body, i, k, s, up_front, every, readback, created, quick;
     double dt, sink = 0;
     struct spawn { int type; dReal size[3], pos[3]; dMatrix3 rm; } *spawn;
     dBodyID *bodies;
@@ -104,6 +104,7 @@ int main(void)
     up_front = n_body; every = 0; readback = 0;
     if (getenv("HARNESS_SPAWN") && sscanf(getenv("HARNESS_SPAWN"), "%d %d", &up_front, &every) != 2) { up_front = n_body; every = 0; }
     if (getenv("HARNESS_READBACK")) readback = atoi(getenv("HARNESS_READBACK"));
+    quick = getenv("HARNESS_STEPPER") && getenv("HARNESS_STEPPER")[0] == 'q';
     created = 0;
     for (s = 0; s <= steps; s++) {
         while (created < n_body && (created < up_front || s == steps || (every > 0 && s >= (created - up_front + 1) * every))) {
@@ -119,7 +120,8 @@ int main(void)
         }
         if (s == steps) break;
         dSpaceCollide(space, NULL, near_callback);
-        dWorldStep(world, (dReal)dt);
+        if (quick) dWorldQuickStep(world, (dReal)dt);          /* HARNESS_STEPPER=quick: BASELINE's configs name dWorldQuickStep */
+        else dWorldStep(world, (dReal)dt);                     /* the reference's call, main.c:213 */
         dJointGroupEmpty(contactGroup);
         if (readback > 0 && (s + 1) % readback == 0)
             for (i = 0; i < created; i++) {

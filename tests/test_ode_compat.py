@@ -36,12 +36,13 @@ def _scene_text(dt, steps, use_plane, statics, bodies):
     return "\n".join(lines) + "\n"
 
 
-def _oracle_poses(dtype, dt, steps, use_plane, statics, bodies, up_front=None, every=0):
+def _oracle_poses(dtype, dt, steps, use_plane, statics, bodies, up_front=None, every=0, exact=False):
     from oracle.orc_ctypes import Oracle
     import ctypes as C
     orc = Oracle(dtype)
     lib = orc.lib
     ow = orc.world()
+    ow.set_stepper(exact)
     if use_plane:
         ow.add_plane(0, 1, 0, 0)
     for size, pos, R in statics:
@@ -144,9 +145,11 @@ def test_reference_spawner_draws():
 
 
 # ------------------------------------------------------------------------------------------------ GPU
-def _run_harness(exe, text, env=None):
+def _run_harness(exe, text, env=None, stepper="quick"):
+    """stepper: "quick" -> the harness calls dWorldQuickStep (bit-identical to the oracle's SOR); "exact" -> dWorldStep, the
+    reference's own call (main.c:213), every island's LCP solved exactly"""
     p = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=600,
-                       env=None if env is None else {**os.environ, **env})
+                       env={**os.environ, "HARNESS_STEPPER": stepper, **(env or {})})
     assert p.returncode == 0, p.stderr[-2000:]
     return np.array([[float(v) for v in line.split()] for line in p.stdout.strip().splitlines()])
 
@@ -155,8 +158,8 @@ def _run_harness(exe, text, env=None):
 @pytest.mark.parametrize("single", [False, True])
 def test_reference_scene_through_ode_api_matches_oracle(tmp_path, single):
     """The reference's map (floor + 3 walls, static boxes) and 48 spawned boxes/spheres dropped from
-    y in [1.5, 9]: box-box, sphere-box, sphere-sphere contacts and multi-body islands, dWorldStep at
-    1/120 s (main.c:208, 213), 360 ticks."""
+    y in [1.5, 9]: box-box, sphere-box, sphere-sphere contacts and multi-body islands, QuickStep at
+    1/120 s (main.c:208), 360 ticks."""
     dtype = "float32" if single else "float64"
     statics = pkg.scenes.reference_map()
     bodies = pkg.scenes.reference_spawn(48, seed=7, y_range=(1.5, 9.0))
@@ -318,3 +321,42 @@ def test_ode_api_forces_kinematic_slot_reuse_and_snapshot():
     pn = lib.dBodyGetPosition(n)
     assert abs(pn[1] + 9.8 * h * h) < 1e-15 and pn[0] == 0.0
     lib.dWorldDestroy(w)
+
+
+# ------------------------------------------------------------------------------------------------ dWorldStep: the exact solve
+def _rel(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("single", [False, True])
+def test_dworldstep_stack_of_three_matches_the_oracles_exact_solve(tmp_path, single):
+    """dWorldStep (main.c:213) on a stack of three boxes on the reference's floor: the island's LCP is solved exactly on
+    the device (lcp_island_wg); poses agree with the oracle's exact stepper within north_star's 1e-5."""
+    dtype = "float32" if single else "float64"
+    statics = pkg.scenes.reference_map()[:1]
+    bodies = [(2, (1.0, 1.0, 1.0), (0.0, 1.0 + 1.0 * k, 0.0)) for k in range(3)]      # floor top at y = 0.5: resting, depth 0
+    dt, steps = 1.0 / 120.0, 120
+    exe = _build_harness(str(tmp_path), single)
+    got = _run_harness(exe, _scene_text(dt, steps, False, statics, bodies), stepper="exact")
+    ref, ow = _oracle_poses(dtype, dt, steps, False, statics, bodies, exact=True)
+    assert ow.n_contacts() == 12
+    assert _rel(got.astype(ref.dtype), ref) <= 1e-5
+    # and the stack stands: the exact solve carries the weight without the drift 20 SOR sweeps leave behind
+    assert np.max(np.abs(got[:, 13] - np.array([1.0, 2.0, 3.0]))) < 2e-3
+
+
+@pytest.mark.gpu
+def test_dworldstep_in_the_reference_pen_matches_the_oracles_exact_solve(tmp_path):
+    """the reference's scene stepped with the reference's call: 24 boxes and spheres dropping into the pen, 200 ticks of
+    dWorldStep at 1/120 s -- multi-body islands, box-box / sphere-box contacts against floor, walls and one another"""
+    statics = pkg.scenes.reference_map()
+    bodies = pkg.scenes.reference_spawn(24, seed=21, y_range=(1.2, 5.0))
+    dt, steps = 1.0 / 120.0, 200
+    exe = _build_harness(str(tmp_path), False)
+    got = _run_harness(exe, _scene_text(dt, steps, False, statics, bodies), stepper="exact")
+    ref, ow = _oracle_poses("float64", dt, steps, False, statics, bodies, exact=True)
+    assert ow.n_contacts() > 24
+    assert _rel(got, ref) <= 1e-5
+    quick, _ = _oracle_poses("float64", dt, steps, False, statics, bodies, exact=False)
+    assert _rel(quick, ref) > 1e-5                       # the two steppers are not the same computation

@@ -460,3 +460,103 @@ def test_kat8_head_on_spheres_conserve_momentum_and_separate_at_the_row_velocity
     assert w.n_contacts() == 1
     _, _, lvel, _ = w.state()
     assert np.allclose((m[:, None] * lvel).sum(axis=0), (m[:, None] * v).sum(axis=0), rtol=0, atol=1e-13)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# dWorldStep's exact solve (ORC_STEPPER_EXACT): known answers that 20 SOR sweeps do not reach
+def _stack(orc, n, exact, erp=0.0, iters=None):
+    ow = orc.world()
+    ow.add_plane(0, 1, 0, 0)
+    pos = np.array([[0.0, 0.5 + k, 0.0] for k in range(n)])
+    quat = np.tile([1.0, 0, 0, 0], (n, 1))
+    z = np.zeros((n, 3))
+    ow.add_boxes(pos, quat, z, z, np.ones(n), np.ones((n, 3)), np.ones((n, 3)))
+    orc.lib.orc_world_set_erp(ow.w, erp)
+    if iters is not None:
+        orc.lib.orc_world_set_quickstep(ow.w, iters, 1.3)
+    ow.set_stepper(exact)
+    return ow
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-6), ("float32", 0.05)])
+def test_exact_step_carries_a_stack_with_the_analytic_normal_forces(dtype, tol):
+    """three unit boxes (m = 1) stacked on the plane at rest, ERP 0: the interfaces carry 3 m g, 2 m g and m g (summed over
+    each interface's contacts) and the stack does not move -- the LCP's solution, not an iteration's approximation"""
+    from oracle.orc_ctypes import Oracle
+    orc = Oracle(dtype)
+    ow = _stack(orc, 3, exact=True)
+    ow.tick(1.0 / 60.0)
+    force = {}
+    for b1, b2, _p, _n, _d, lam in ow.joints():
+        force[(b1, b2)] = force.get((b1, b2), 0.0) + lam
+    assert abs(force[(0, -1)] - 3 * 9.8) < tol and abs(force[(0, 1)] - 2 * 9.8) < tol and abs(force[(1, 2)] - 9.8) < tol
+    assert np.max(np.abs(ow.state()[2])) < (1e-8 if dtype == "float64" else 1e-3)     # v stays 0 (cfm lets ~1e-9 through)
+    # twenty SOR sweeps leave the stack moving by millimetres per second
+    sor = _stack(orc, 3, exact=False)
+    sor.tick(1.0 / 60.0)
+    assert np.max(np.abs(sor.state()[2])) > 1e-3
+
+
+def test_sor_converges_to_the_exact_solution():
+    """the SOR's fixed point is the LCP's solution: with thousands of sweeps QuickStep's velocities approach the exact ones"""
+    from oracle.orc_ctypes import Oracle
+    orc = Oracle("float64")
+    ex = _stack(orc, 3, exact=True, erp=0.2)
+    sor = _stack(orc, 3, exact=False, erp=0.2, iters=20000)
+    # start from a slightly interpenetrating, moving state so the right-hand side is not trivial
+    for w in (ex, sor):
+        for k in range(3):
+            orc.lib.orc_body_set_position(w.w, k, 0.0, 0.5 + k * 0.999, 0.0)
+            orc.lib.orc_body_set_linear_vel(w.w, k, 0.01 * k, -0.2, 0.0)
+        w.tick(1.0 / 60.0)
+    for a, b in zip(ex.state(), sor.state()):
+        assert np.max(np.abs(a - b)) < 1e-6
+
+
+def test_exact_step_on_a_frictionless_slope():
+    """mu = 0, plane tilted by theta: the box accelerates along the slope with g sin(theta), nothing moves along the normal,
+    and the contacts carry m g cos(theta) between them"""
+    import math
+    from oracle.orc_ctypes import Oracle
+    orc = Oracle("float64")
+    th, h = 0.3, 1.0 / 60.0
+    n = np.array([math.sin(th), math.cos(th), 0.0])
+    t = np.array([math.cos(th), -math.sin(th), 0.0])
+    ow = orc.world()
+    ow.add_plane(n[0], n[1], 0.0, 0.0)
+    orc.lib.orc_world_set_surface(ow.w, 0, 0.0, 0.0, 0.0)
+    orc.lib.orc_world_set_erp(ow.w, 0.0)
+    q = np.array([[math.cos(th / 2), 0.0, 0.0, -math.sin(th / 2)]])           # the box's y axis along the plane's normal
+    ow.add_boxes((0.499 * n)[None, :], q, np.zeros((1, 3)), np.zeros((1, 3)), np.ones(1), np.ones((1, 3)), np.ones((1, 3)))
+    ow.set_stepper(True)
+    ow.tick(h)
+    v = ow.state()[2][0]
+    joints = ow.joints()
+    assert len(joints) == 4
+    assert abs(v @ n) < 1e-8
+    assert abs(v @ t - h * 9.8 * math.sin(th)) < 1e-12
+    assert abs(sum(j[5] for j in joints) - 9.8 * math.cos(th)) < 1e-6
+    assert ow.sor_residual() < 1e-9                                             # complementarity holds
+
+
+def test_exact_step_reaches_complementarity_on_a_pile():
+    from oracle.orc_ctypes import Oracle
+    orc = Oracle("float64")
+    ow = orc.world()
+    ow.add_plane(0, 1, 0, 0)
+    rng = np.random.default_rng(3)
+    nb = 12
+    pos = np.stack([rng.uniform(-0.15, 0.15, nb), 0.45 + 0.85 * np.arange(nb), rng.uniform(-0.15, 0.15, nb)], axis=1)   # a column, no overlap
+    quat = np.tile([1.0, 0, 0, 0], (nb, 1))
+    z = np.zeros((nb, 3))
+    ow.add_boxes(pos, quat, z, z, np.ones(nb), np.ones((nb, 3)), np.full((nb, 3), 0.8))
+    ow.set_stepper(True)
+    worst = 0.0
+    most = 0
+    for _ in range(150):
+        ow.tick(1.0 / 120.0)
+        worst = max(worst, ow.sor_residual())
+        most = max(most, ow.n_contacts())
+    assert most > 2 * nb and np.all(np.isfinite(ow.state()[0]))
+    assert worst < 1e-5                                   # summed over the rows, against right-hand sides of order 1e2-1e3
+    assert orc.lib.orc_world_last_lcp_rounds(ow.w) < 200
