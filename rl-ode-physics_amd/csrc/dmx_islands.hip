@@ -462,7 +462,7 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
 // One workgroup per island with rows.  Same rows as the SOR kernels (stage_body / contact_rows / body_tmp / row_setup),
 // then  A = J M^-1 J^T + diag(cfm / h)  and block principal pivoting on  A lambda = b + w, lo <= lambda <= hi  (free /
 // at-lo / at-hi sets, Cholesky of the free block, flip the violators; Murty's single flip once the violation count has
-// stalled three times) -- the algorithm and operation order of oracle/orc_step.c exact_lcp.  A lives in HBM/L2 (m^2 reals
+// stalled three times); every loop has a fixed operation order, whatever the thread mapping.  A lives in HBM/L2 (m^2 reals
 // per island, scratch sized by the host); the free block's factor is staged in LDS when it fits.
 enum : int { LCP_FREE = 0, LCP_LO = 1, LCP_HI = 2 };
 
