@@ -420,7 +420,7 @@ def rank_main(a):
                     f"ground plane, convex-plane contacts (<= 8 per hull), 20 SOR iterations, dt=1/60")
         gold = np.load(os.path.join(ROOT, "tests", "golden", "teapot_hull.npz"))     # the hull's vertices (data fixture)
         hull = pkg.hull.build(gold["points"], 0.01)
-        scene = pkg.scenes.hull_grid(hull, side, side, seed=1 + rank, y_range=(0.6, 1.6), spin=False, tilt=0.2).astype(dtype)
+        scene = pkg.scenes.hull_grid(hull, side, side, seed=1 + rank, y_range=(0.6, 1.6), spin=False, tilt=0.2, floor_box=True).astype(dtype)
         scene.pos[:, 2] += rank * (side * pkg.scenes.HULL_PITCH + 10.0)
         layout = pkg.shard.SlabLayout(side, side)
         settle = 120

@@ -109,6 +109,14 @@ int dmxBatchUploadGeomType(dmxBatchID b, const uint8_t *types, int64_t first, in
  * the first max_contacts <= 8 on or below the plane); a convex body has no collider against other bodies (ODE's
  * dCollideConvexBox is an empty stub; convex-convex / convex-sphere are not built). */
 int dmxBatchSetConvexHull(dmxBatchID b, int32_t n_points, const double *points_xyz, double *radius_out);
+/* dCreateConvex's plane set for the same hull: n_faces x 4 doubles (unit outward normal, offset; body frame), e.g. from
+ * dmxHullPlanes.  Contacts of a convex body with BOXES -- static boxes (dmxBatchSetStaticBoxes: the floor of BASELINE
+ * configs[4]) and box bodies -- are this library's own collider (ODE's dCollideConvexBox is an empty stub): hull vertices
+ * inside the box in array order, each along the box face it is nearest to, then -- with the faces given here -- box
+ * corners inside the hull, each along the hull face it is nearest to; the first max_contacts <= 8 are kept (edge-edge
+ * penetrations are not detected).  Convex against sphere / convex: no collider; such AABB pairs are counted
+ * (dmxBatchCollisionStats [6]) and named once on stderr. */
+int dmxBatchSetConvexHullFaces(dmxBatchID b, int32_t n_faces, const double *planes);
 /* device address of component c of a field for body 0.  The slab is tiled: bodies are stored in tiles of
  * DMX_SLAB_TILE; inside a tile each of the DMX_SLAB_COMPONENTS components holds DMX_SLAB_TILE consecutive
  * reals, so body i's value sits (i / DMX_SLAB_TILE) * DMX_SLAB_COMPONENTS * DMX_SLAB_TILE + i % DMX_SLAB_TILE
@@ -159,6 +167,8 @@ int dmxBatchSetSnapshotMode(dmxBatchID b, int mode);
  * per launch instead of per tick.  Default 1 (one launch per tick); 1..64. */
 int dmxBatchSetTicksPerLaunch(dmxBatchID b, int ticks);
 int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6]);
+/* the same six numbers and [6] AABB pairs met so far that have no collider (convex-convex, convex-sphere), [7] reserved */
+int dmxBatchCollisionStatsEx(dmxBatchID b, int64_t out[8]);
 
 /* ---- the collision-checked tick loop in pieces.  dmxBatchStep(b, h, n) with body collisions enabled runs, inside
  * the library: [zones, snapshot] -> k checked ticks -> one flag read -> commit, or roll back and replay exactly.  A

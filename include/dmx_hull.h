@@ -38,6 +38,11 @@ typedef struct dmxHullInfo {
 int32_t dmxHullBuild(const double *xyz, int64_t n, double scale, double *out_points, int32_t *out_index, int32_t capacity,
                      dmxHullInfo *info);
 
+/* The faces of the convex hull of n points as planes (4 doubles each: unit outward normal, offset; n.x <= d inside), one
+ * per triangle of the hull's surface.  On a hull's body-frame points this is dCreateConvex's `planes` array; hand it to
+ * dmxBatchSetConvexHullFaces.  Returns the face count (fills at most `capacity`; out_planes may be NULL to size it). */
+int32_t dmxHullPlanes(const double *xyz, int64_t n, double *out_planes, int32_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,6 +143,9 @@ void orc_world_add_boxes(orc_world *w, int n, const real *pos, const real *quat,
                          const real *idiag, const real *sides);
 /* convex bodies share one hull: n body-frame points, 3 reals each (dCreateConvex's points array [ODE-recall]) */
 void orc_world_set_hull(orc_world *w, int n, const real *points);
+/* the hull's faces, nf x 4: unit outward normal and offset in the body frame (dCreateConvex's planes array [ODE-recall]);
+ * needed by the box-convex collider's "box corner inside the hull" half */
+void orc_world_set_hull_faces(orc_world *w, int nf, const real *planes);
 int  orc_geom_create_convex(orc_world *w);
 void orc_world_add_convex(orc_world *w, int n, const real *pos, const real *quat,
                           const real *lvel, const real *avel, const real *mass, const real *idiag);

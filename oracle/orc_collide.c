@@ -187,6 +187,61 @@ static int collide_sphere_box(const real *sp, real radius, const real *bp, const
  *      on or below the plane becomes a contact (position = the point, normal = the plane's, depth = distance below)
  *      until maxc are taken; the walk stops early once maxc contacts exist AND points on both sides have been seen;
  *      the result counts only if the hull has points on both sides (or on the plane). */
+/* ---- box against convex hull (BASELINE configs[4]: "box-trimesh contacts" of the teapot hulls on the static box floor).
+ * ODE itself has nothing to restate here: dCollideConvexBox is an empty stub [ODE-recall].  The collider is this
+ * repository's own, defined here and mirrored by the device kernel (csrc/dmx_exact.hip):
+ *   1. hull vertices inside the box, in the hull's array order (as dCollideConvexPlane walks them): contact at the
+ *      vertex, along the box face it is nearest to (ties: lowest axis), depth = distance to that face;
+ *   2. if room is left, box corners inside the hull (corner c = signs from the bits of c): contact at the corner, along
+ *      the hull face it is nearest to (ties: lowest face), depth = distance to that face.  Needs the hull's faces.
+ * The first maxc contacts found are kept.  Edge-edge penetrations are not detected.  Normals point into the box (o1). */
+static int collide_box_convex(const orc_world *w, const real *pb, const real *Rb, const real *side,
+                              const real *ph, const real *Rh, int maxc, orc_contactgeom *c)
+{
+    int n = 0;
+    const real half[3] = { R(0.5) * side[0], R(0.5) * side[1], R(0.5) * side[2] };
+    for (int i = 0; i < w->hull_n && n < maxc; i++) {
+        real v[3], d[3], q[3];
+        orc_mul0_331(v, Rh, w->hull + 3 * i);
+        v[0] += ph[0]; v[1] += ph[1]; v[2] += ph[2];
+        for (int k = 0; k < 3; k++) d[k] = v[k] - pb[k];
+        for (int a = 0; a < 3; a++) q[a] = FMA(Rb[8 + a], d[2], FMA(Rb[4 + a], d[1], Rb[a] * d[0]));   /* box frame */
+        if (orc_fabs(q[0]) > half[0] || orc_fabs(q[1]) > half[1] || orc_fabs(q[2]) > half[2]) continue;
+        int best = 0;
+        real dep = half[0] - orc_fabs(q[0]);
+        for (int a = 1; a < 3; a++) { const real e = half[a] - orc_fabs(q[a]); if (e < dep) { dep = e; best = a; } }
+        const real sg = q[best] < 0 ? R(-1.0) : R(1.0);
+        orc_contactgeom *t = &c[n++];
+        t->pos[0] = v[0]; t->pos[1] = v[1]; t->pos[2] = v[2];
+        for (int k = 0; k < 3; k++) t->normal[k] = -(sg * Rb[4 * k + best]);     /* into the box: against its outward face normal */
+        t->depth = dep;
+    }
+    for (int cn = 0; cn < 8 && n < maxc && w->hull_nf > 0; cn++) {
+        real l[3], cw[3], d[3], r[3];
+        for (int a = 0; a < 3; a++) l[a] = (cn >> a) & 1 ? half[a] : -half[a];
+        orc_mul0_331(cw, Rb, l);
+        cw[0] += pb[0]; cw[1] += pb[1]; cw[2] += pb[2];
+        for (int k = 0; k < 3; k++) d[k] = cw[k] - ph[k];
+        for (int a = 0; a < 3; a++) r[a] = FMA(Rh[8 + a], d[2], FMA(Rh[4 + a], d[1], Rh[a] * d[0]));   /* hull frame */
+        int inside = 1, fbest = -1;
+        real dep = ORC_INF;
+        for (int f = 0; f < w->hull_nf; f++) {
+            const real *pl = w->hull_planes + 4 * f;
+            const real e = pl[3] - orc_dot3(pl, r);
+            if (e < 0) { inside = 0; break; }
+            if (e < dep) { dep = e; fbest = f; }
+        }
+        if (!inside || fbest < 0) continue;
+        real nw[3];
+        orc_mul0_331(nw, Rh, w->hull_planes + 4 * fbest);
+        orc_contactgeom *t = &c[n++];
+        t->pos[0] = cw[0]; t->pos[1] = cw[1]; t->pos[2] = cw[2];
+        t->normal[0] = nw[0]; t->normal[1] = nw[1]; t->normal[2] = nw[2];        /* the hull's outward normal points into the box */
+        t->depth = dep;
+    }
+    return n;
+}
+
 static int collide_convex_plane(const orc_world *w, const real *pos, const real *Rm, const real *pl, int maxc,
                                 orc_contactgeom *c)
 {
@@ -233,9 +288,13 @@ static int collide_ordered(orc_world *w, const orc_geom *a, const orc_geom *b, i
         return orc_collide_box_box(pa, Ra, a->side, pb, Rb, b->side, maxc, out);
     if (a->type == ORC_GEOM_CONVEX && b->type == ORC_GEOM_PLANE)
         return collide_convex_plane(w, pa, Ra, b->plane, maxc, out);
-    /* convex against box / sphere / convex: no contacts.  [ODE-recall] dCollideConvexBox is an empty stub that
-       returns 0; ODE's convex-sphere and convex-convex colliders are not restated (nothing on this path uses them). */
-    if (a->type == ORC_GEOM_CONVEX && b->type != ORC_GEOM_PLANE)
+    if (a->type == ORC_GEOM_BOX && b->type == ORC_GEOM_CONVEX)
+        return collide_box_convex(w, pa, Ra, a->side, pb, Rb, maxc, out);
+    /* convex against sphere / convex: no contacts (ODE's convex-sphere and convex-convex colliders are not restated;
+       the product counts such pairs as unsupported).  (convex, box) has no collider in this order: dCollide swaps. */
+    if (a->type == ORC_GEOM_CONVEX && (b->type == ORC_GEOM_SPHERE || b->type == ORC_GEOM_CONVEX))
+        return 0;
+    if (a->type == ORC_GEOM_SPHERE && b->type == ORC_GEOM_CONVEX)
         return 0;
     *handled = 0;
     return 0;

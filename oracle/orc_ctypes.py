@@ -97,6 +97,7 @@ class Oracle:
         sig("orc_world_add_boxes", None, P, C.c_int, P, P, P, P, P, P, P)
         sig("orc_world_add_spheres", None, P, C.c_int, P, P, P, P, P, P, P)
         sig("orc_world_set_hull", None, P, C.c_int, P)
+        sig("orc_world_set_hull_faces", None, P, C.c_int, P)
         sig("orc_geom_create_convex", C.c_int, P)
         sig("orc_world_add_convex", None, P, C.c_int, P, P, P, P, P, P)
         sig("orc_world_get_state", None, P, P, P, P, P)
@@ -161,6 +162,10 @@ class World:
     def set_hull(self, points):
         pts = np.ascontiguousarray(points, dtype=self.o.dtype)
         self.lib.orc_world_set_hull(self.w, len(pts), pts.ctypes.data_as(C.c_void_p))
+
+    def set_hull_faces(self, planes):
+        pl = np.ascontiguousarray(planes, dtype=self.o.dtype)
+        self.lib.orc_world_set_hull_faces(self.w, len(pl), pl.ctypes.data_as(C.c_void_p))
 
     def add_convex(self, pos, quat, lvel, avel, mass, idiag):
         n = len(pos)

@@ -55,6 +55,7 @@ struct orc_world {
     orc_joint *joints; int nj, cap_j;
 
     real *hull; int hull_n;   /* body-frame points of the hull every ORC_GEOM_CONVEX geom uses */
+    real *hull_planes; int hull_nf;   /* its faces: unit outward normal + offset (n.x <= d inside), body frame */
 
     int last_contacts;
     int last_body_pairs;      /* finite-AABB pairs that reached the near callback in the last tick */

@@ -38,7 +38,7 @@ orc_world *orc_world_create(void)
 void orc_world_destroy(orc_world *w)
 {
     if (!w) return;
-    free(w->bodies); free(w->geoms); free(w->joints); free(w->hull);
+    free(w->bodies); free(w->geoms); free(w->joints); free(w->hull); free(w->hull_planes);
     free(w);
 }
 
@@ -179,6 +179,14 @@ void orc_world_set_hull(orc_world *w, int n, const real *points)
     w->hull = (real *)malloc((size_t)(n > 0 ? n : 1) * 3 * sizeof(real));
     memcpy(w->hull, points, (size_t)n * 3 * sizeof(real));
     w->hull_n = n;
+}
+
+void orc_world_set_hull_faces(orc_world *w, int nf, const real *planes)
+{
+    free(w->hull_planes);
+    w->hull_planes = (real *)malloc((size_t)(nf > 0 ? nf : 1) * 4 * sizeof(real));
+    memcpy(w->hull_planes, planes, (size_t)nf * 4 * sizeof(real));
+    w->hull_nf = nf;
 }
 
 int orc_geom_create_convex(orc_world *w)

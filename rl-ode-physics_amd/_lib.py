@@ -23,7 +23,8 @@ BATCH_SYMBOLS = [
     "dmxBatchScatterBodiesOnStream", "dmxBatchSetBoundaryPack",
     "dmxBatchChunkBegin", "dmxBatchChunkTick", "dmxBatchCheckZonesOnStream", "dmxBatchChunkEnd",
     "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream", "dmxBatchSetConvexHull", "dmxBatchChunkTicks", "dmxBatchSetTicksPerLaunch",
-    "dmxBatchSetSnapshotMode", "dmxBatchSetStaticBoxes", "dmxBatchSetStepper",
+    "dmxBatchSetSnapshotMode", "dmxBatchSetStaticBoxes", "dmxBatchSetStepper", "dmxBatchSetConvexHullFaces",
+    "dmxBatchCollisionStatsEx",
 ]
 
 _lib = None
@@ -104,5 +105,7 @@ def load():
     sig("dmxBatchSetSnapshotMode", I, P, I)
     sig("dmxBatchSetStaticBoxes", I, P, C.c_int32, P, P, P)
     sig("dmxBatchSetStepper", I, P, I)
+    sig("dmxBatchSetConvexHullFaces", I, P, C.c_int32, P)
+    sig("dmxBatchCollisionStatsEx", I, P, C.POINTER(L))
     _lib = lib
     return lib

@@ -115,6 +115,11 @@ class BatchWorld:
         _check(self.lib.dmxBatchSetConvexHull(self.h, p.shape[0], p.ctypes.data, C.byref(r)), "dmxBatchSetConvexHull")
         return r.value
 
+    def set_convex_hull_faces(self, planes):
+        """the hull's faces (nf x 4: unit outward normal, offset; body frame), e.g. hull.planes(points)"""
+        pl = np.ascontiguousarray(planes, dtype=np.float64).reshape(-1, 4)
+        _check(self.lib.dmxBatchSetConvexHullFaces(self.h, pl.shape[0], pl.ctypes.data), "dmxBatchSetConvexHullFaces")
+
     def load_scene(self, scene):
         """Upload a scenes.Scene (the batch form of the AddBody loop, main.c:695-733)."""
         self.upload(POS, scene.pos)
@@ -125,10 +130,14 @@ class BatchWorld:
         self.upload(INERTIA, scene.inertia)
         if getattr(scene, "hull_points", None) is not None:
             self.set_convex_hull(scene.hull_points)
+            if getattr(scene, "hull_planes", None) is not None:
+                self.set_convex_hull_faces(scene.hull_planes)
         self.upload(SIDES, scene.sides)
         self.upload_geom_type(scene.gtype)
         if scene.plane is not None:
             self.set_plane(*scene.plane, enable=True)
+        if getattr(scene, "static_boxes", None):
+            self.set_static_boxes(scene.static_boxes)
 
     # -- checkpoint / resume ---------------------------------------------------------------------------------
     def checkpoint(self):
@@ -165,7 +174,11 @@ class BatchWorld:
     def collision_stats(self):
         out = (C.c_int64 * 6)()
         _check(self.lib.dmxBatchCollisionStats(self.h, out), "dmxBatchCollisionStats")
-        return dict(zip(("fast_ticks", "careful_ticks", "rebuilds", "pair_ticks", "last_pairs", "crowded"), out))
+        d = dict(zip(("fast_ticks", "careful_ticks", "rebuilds", "pair_ticks", "last_pairs", "crowded"), out))
+        ex = (C.c_int64 * 8)()
+        _check(self.lib.dmxBatchCollisionStatsEx(self.h, ex), "dmxBatchCollisionStatsEx")
+        d["unsupported_pairs"] = ex[6]
+        return d
 
     # -- the collision-checked loop in pieces (include/dmx_batch.h), for callers with per-tick work of their own --
     def chunk_begin(self):

@@ -142,7 +142,7 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
         if (d->p) (void)hipFree(d->p);
     for (dmxBatch::DevBuf *d : { &b->bp_count, &b->bp_items, &b->bp_flags, &b->bp_pairs, &b->bp_inpair, &b->bp_snapshot, &b->bp_idx, &b->bp_gather,
                                 &b->np_pos, &b->np_normal, &b->np_depth, &b->np_count, &b->np_pairs, &b->hull, &b->cbuf, &b->ccount,
-                                &b->ex_arena, &b->ex_body, &b->ex_last, &b->ex_aabb, &b->sbox })
+                                &b->ex_arena, &b->ex_body, &b->ex_last, &b->ex_aabb, &b->sbox, &b->hull_planes })
         if (d->p) (void)hipFree(d->p);
     if (b->bp_flags_host) (void)hipHostFree(b->bp_flags_host);
     if (b->ex_counts_host) (void)hipHostFree(b->ex_counts_host);
@@ -445,6 +445,27 @@ extern "C" int dmxBatchSetConvexHull(dmxBatchID b, int32_t n_points, const doubl
     return DMX_OK;
 }
 
+extern "C" int dmxBatchSetConvexHullFaces(dmxBatchID b, int32_t n_faces, const double *planes)
+{
+    if (!b || n_faces < 0 || (n_faces > 0 && !planes)) return DMX_EINVAL;
+    SETTLE(b);
+    HIP_TRY(hipSetDevice(b->device));
+    int rc;
+    if (n_faces > 0) {
+        if ((rc = dmx_ensure_dev(b->hull_planes, (size_t)n_faces * 4 * b->rsize)) != DMX_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        if (b->precision == DMX_F32) {
+            std::vector<float> f((size_t)n_faces * 4);
+            for (size_t i = 0; i < f.size(); i++) f[i] = (float)planes[i];
+            HIP_TRY(hipMemcpy(b->hull_planes.p, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+        } else {
+            HIP_TRY(hipMemcpy(b->hull_planes.p, planes, (size_t)n_faces * 4 * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
+    b->hull_nf = n_faces;
+    return DMX_OK;
+}
+
 // ---- the collision-checked loop in pieces (include/dmx_batch.h) --------------------------------
 extern "C" int dmxBatchChunkBegin(dmxBatchID b, int *exact_only, int *ballistic)
 {
@@ -526,6 +547,15 @@ extern "C" int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6])
     SETTLE(b);
     out[0] = b->stat_fast_ticks; out[1] = b->stat_careful_ticks; out[2] = b->stat_rebuilds;
     out[3] = b->stat_pair_ticks; out[4] = (int64_t)b->last_pairs; out[5] = (int64_t)b->bp_crowded;
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchCollisionStatsEx(dmxBatchID b, int64_t out[8])
+{
+    if (!b || !out) return DMX_EINVAL;
+    int rc = dmxBatchCollisionStats(b, out);
+    if (rc != DMX_OK) return rc;
+    out[6] = b->stat_unsupported; out[7] = 0;
     return DMX_OK;
 }
 

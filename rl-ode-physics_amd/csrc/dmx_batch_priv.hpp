@@ -127,6 +127,8 @@ struct dmxBatch {
     std::vector<uint8_t> h_gtype;
     // convex bodies: the shared hull's body-frame points, and the per-tick plane contacts of every convex body
     DevBuf hull, cbuf, ccount;
+    DevBuf hull_planes; int hull_nf = 0;       // the hull's faces (dmxBatchSetConvexHullFaces): 4 reals each
+    int64_t stat_unsupported = 0;              // AABB pairs met that have no collider (convex-convex, convex-sphere)
     DevBuf sbox; int n_static = 0;             // static box geoms (dmxBatchSetStaticBoxes), SBOX_REALS reals each
     int hull_n = 0;
     int64_t stat_rollbacks = 0;
@@ -218,6 +220,7 @@ template <class T> inline StepParams<T> dmx_make_params(dmxBatch *b, double h)
     P.pack_out = (T *)b->pack_out; P.pack_lo = b->pack_lo; P.pack_hi = b->pack_hi;
     P.sbox = (const T *)b->sbox.p; P.n_static = b->n_static;
     P.hull = (const T *)b->hull.p; P.hull_n = b->hull_n;
+    P.hull_planes = (const T *)b->hull_planes.p; P.hull_nf = b->hull_nf;
     P.cbuf = (T *)b->cbuf.p; P.ccount = (int *)b->ccount.p;
     return P;
 }

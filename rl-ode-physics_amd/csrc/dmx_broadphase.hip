@@ -57,9 +57,8 @@ __global__ __launch_bounds__(256) void bp_insert(T *__restrict__ S, const uint8_
                                                  int64_t stride, int64_t n, GridParams<T> G)
 {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    // convex bodies stay out of the body-body broadphase: they have no collider against another body (dmx_batch.h), so
-    // no pair they are part of can ever produce a contact
-    if (i >= n || gtype[i] == GEOM_NONE || gtype[i] == GEOM_CONVEX) return;
+    // (convex bodies take part with their bounding sphere's box: conservative, so only candidates are added)
+    if (i >= n || gtype[i] == GEOM_NONE) return;
     S[slab_ix(C_BPR, i)] = bound_radius<T>(gtype[i], S, stride, i);      // neighbours read this instead of 3 sides + sqrt
     if (G.aabb != nullptr) {                 // the exact pair search tests every candidate's AABB: computed once, here
         T lo[3], hi[3];
@@ -85,7 +84,7 @@ __global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uin
     const int gt = gtype[i];
     const T x = S[slab_ix(C_POS + 0, i)], z = S[slab_ix(C_POS + 2, i)];
     T safe = Limits<T>::inf();
-    if (gt != GEOM_NONE && gt != GEOM_CONVEX) {
+    if (gt != GEOM_NONE) {
         const T ri = bound_radius<T>(gt, S, stride, i);
         const int ix = (int)floor((double)(x * G.inv_cell)), iz = (int)floor((double)(z * G.inv_cell));
         // nothing outside the 3x3 block is closer than one cell: gap >= cell - r_i - r_max
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(256) void bp_pairs(const T *__restrict__ S, const u
                                                 uint8_t *__restrict__ inpair)
 {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n_active || gtype[i] == GEOM_NONE || gtype[i] == GEOM_CONVEX) return;
+    if (i >= n_active || gtype[i] == GEOM_NONE) return;
     T lo[3], hi[3];
     body_aabb<T>(S, gtype, stride, i, lo, hi);
     const int ix = (int)floor((double)(S[slab_ix(C_POS + 0, i)] * G.inv_cell));

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void ex_pair_count(const T *__restrict__ S, co
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n_active) return;
     uint32_t owned = 0, any = 0;
-    if (gtype[i] != GEOM_NONE && gtype[i] != GEOM_CONVEX) {
+    if (gtype[i] != GEOM_NONE) {
         for_each_partner<T>(S, gtype, i, G, [&](int64_t j) {
             any = 1;
             if (j >= n_active) { if (atomicOr(&C->cross, 1u) == 0u) { C->cross_a = (uint32_t)i; C->cross_b = (uint32_t)j; } }
@@ -219,6 +219,12 @@ __global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const u
     const uint32_t ne = cap.entries(), e_pairs = cap.pair_entry0();
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
         int nc = 0;
+        {   // entries with a convex body in them belong to ex_narrow_convex (one wavefront each)
+            bool convex = false;
+            if (e < e_pairs) { const uint32_t k = e % cap.inv; convex = k < ninv && gtype[inv[k]] == GEOM_CONVEX; }
+            else if (e - e_pairs < np) convex = gtype[pairs[2 * (e - e_pairs)]] == GEOM_CONVEX || gtype[pairs[2 * (e - e_pairs) + 1]] == GEOM_CONVEX;
+            if (convex) continue;
+        }
         if (e >= cap.inv && e < e_pairs) {
             // body k against static box s: dCollide(static geom, body geom) -- the static geoms were created first
             // (main.c:115-121), so they are o1; the contact joint is attached (0, body), i.e. reversed: normal negated
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const u
                 V3<T> cp[4]; T cd[4];
                 if (g.gt == GEOM_BOX) nc = box_plane(g.x, g.R, g.side, P.pn, P.pd, P.max_contacts, cp, cd);
                 else if (g.gt == GEOM_SPHERE) nc = sphere_plane(g.x, g.side[0], P.pn, P.pd, cp, cd);
-                for (int c = 0; c < nc; c++) put_c(gpos, gnormal, gdepth, (size_t)4 * e + c, cp[c], P.pn, cd[c]);
+                for (int c = 0; c < nc; c++) put_c(gpos, gnormal, gdepth, (size_t)8 * e + c, cp[c], P.pn, cd[c]);
             }
         } else {
             const uint32_t p = e - e_pairs;
@@ -275,6 +281,167 @@ __global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const u
             }
         }
         cc[e] = (uint32_t)nc;
+    }
+}
+
+// ---- 4b. entries with a convex body: one wavefront per entry ---------------------------------------------------------
+// hull against the ground plane: dCollideConvexPlane as np_convex_plane restates it (points in array order, first
+// max_contacts on or below the plane, both-sides rule).  Hull against a box (a static box, or a box body): this library's
+// collider (dmx_batch.h, dmxBatchSetConvexHullFaces): hull vertices inside the box in array order, then box corners inside
+// the hull.  Lane l tests point / face 64 j + l; ballots give array-order ranks, so the contacts are the ones a sequential
+// walk keeps.
+template <class T>
+__device__ __forceinline__ int wave_box_convex(const V3<T> &xb, const M3<T> &Rb, const T *side, const V3<T> &xh, const M3<T> &Rh,
+                                               const StepParams<T> &P, int maxc, bool negate, int lane, T *gpos, T *gnormal,
+                                               T *gdepth, size_t slot0)
+{
+    const T half[3] = { T(0.5) * side[0], T(0.5) * side[1], T(0.5) * side[2] };
+    int contacts = 0;
+    for (int base = 0; base < P.hull_n && contacts < maxc; base += 64) {
+        const int k = base + lane;
+        bool inside = false;
+        V3<T> v = { T(0), T(0), T(0) }, n = { T(0), T(0), T(0) };
+        T dep = T(0);
+        if (k < P.hull_n) {
+            v = mulv(Rh, V3<T>{ P.hull[3 * k], P.hull[3 * k + 1], P.hull[3 * k + 2] });
+            v.x += xh.x; v.y += xh.y; v.z += xh.z;
+            const V3<T> d = { v.x - xb.x, v.y - xb.y, v.z - xb.z };
+            T q[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) q[a] = fma_(Rb.m[2][a], d.z, fma_(Rb.m[1][a], d.y, Rb.m[0][a] * d.x));     // box frame
+            inside = !(tabs(q[0]) > half[0] || tabs(q[1]) > half[1] || tabs(q[2]) > half[2]);
+            int best = 0;
+            dep = half[0] - tabs(q[0]);
+#pragma unroll
+            for (int a = 1; a < 3; a++) { const T e = half[a] - tabs(q[a]); if (e < dep) { dep = e; best = a; } }
+            const T sg = q[best] < T(0) ? T(-1) : T(1);
+            n = { -(sg * Rb.m[0][best]), -(sg * Rb.m[1][best]), -(sg * Rb.m[2][best]) };      // into the box
+        }
+        const unsigned long long mb = __ballot(inside);
+        if (inside) {
+            const int rank = contacts + __popcll(mb & ((1ull << lane) - 1ull));
+            if (rank < maxc) put_c(gpos, gnormal, gdepth, slot0 + rank, v, negate ? V3<T>{ -n.x, -n.y, -n.z } : n, dep);
+        }
+        contacts += __popcll(mb);
+    }
+    if (contacts > maxc) contacts = maxc;
+    for (int cn = 0; cn < 8 && contacts < maxc && P.hull_nf > 0; cn++) {
+        const V3<T> l = { (cn & 1) ? half[0] : -half[0], (cn & 2) ? half[1] : -half[1], (cn & 4) ? half[2] : -half[2] };
+        V3<T> cw = mulv(Rb, l);
+        cw.x += xb.x; cw.y += xb.y; cw.z += xb.z;
+        const V3<T> d = { cw.x - xh.x, cw.y - xh.y, cw.z - xh.z };
+        V3<T> r;
+        r.x = fma_(Rh.m[2][0], d.z, fma_(Rh.m[1][0], d.y, Rh.m[0][0] * d.x));
+        r.y = fma_(Rh.m[2][1], d.z, fma_(Rh.m[1][1], d.y, Rh.m[0][1] * d.x));
+        r.z = fma_(Rh.m[2][2], d.z, fma_(Rh.m[1][2], d.y, Rh.m[0][2] * d.x));
+        T dep = Limits<T>::inf();
+        int fbest = 0x7fffffff;
+        bool neg = false;
+        for (int f = lane; f < P.hull_nf; f += 64) {
+            const T *pl = P.hull_planes + 4 * f;
+            const T e = pl[3] - dot(V3<T>{ pl[0], pl[1], pl[2] }, r);
+            if (e < T(0)) neg = true;
+            if (e < dep) { dep = e; fbest = f; }             // (f ascends within a lane: the first minimum is kept)
+        }
+        if (__ballot(neg) != 0ull) continue;                 // outside some face
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {                   // lexicographic (depth, face) minimum over the wave
+            const T od = __shfl_xor(dep, o, 64);
+            const int of = __shfl_xor(fbest, o, 64);
+            if (od < dep || (od == dep && of < fbest)) { dep = od; fbest = of; }
+        }
+        if (fbest == 0x7fffffff) continue;
+        if (lane == 0) {
+            const T *pl = P.hull_planes + 4 * fbest;
+            const V3<T> nw = mulv(Rh, V3<T>{ pl[0], pl[1], pl[2] });     // the hull's outward normal points into the box
+            put_c(gpos, gnormal, gdepth, slot0 + contacts, cw, negate ? V3<T>{ -nw.x, -nw.y, -nw.z } : nw, dep);
+        }
+        contacts++;
+    }
+    return contacts;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S, const uint8_t *__restrict__ gtype,
+                                                        const int32_t *__restrict__ inv, const int32_t *__restrict__ pairs,
+                                                        const T *__restrict__ aabb, StepParams<T> P, ExactCaps cap,
+                                                        T *__restrict__ gpos, T *__restrict__ gnormal, T *__restrict__ gdepth,
+                                                        uint32_t *__restrict__ cc, ExactCounts *__restrict__ C)
+{
+    const uint32_t ninv = C->overflow ? 0u : C->ninv, np = C->overflow ? 0u : C->npairs;
+    const uint32_t ne = cap.entries(), e_pairs = cap.pair_entry0();
+    const int lane = threadIdx.x & 63;
+    const int maxc = P.max_contacts < CONVEX_MAXC ? P.max_contacts : CONVEX_MAXC;
+    for (uint32_t e = blockIdx.x * 4 + (threadIdx.x >> 6); e < ne; e += gridDim.x * 4) {          // wave-uniform
+        int nc = 0;
+        if (e < e_pairs) {
+            const uint32_t k = e % cap.inv;
+            if (k >= ninv) continue;
+            const int64_t i = inv[k];
+            if (gtype[i] != GEOM_CONVEX) continue;
+            const BodyGeomX<T> H = geom_of<T>(S, gtype, i);
+            if (e < cap.inv) {
+                // ---- hull against the ground plane
+                if (P.plane_on && P.hull_n > 0) {
+                    int contacts = 0;
+                    bool any_le = false, any_ge = false;
+                    for (int base = 0; base < P.hull_n; base += 64) {
+                        const int q = base + lane;
+                        bool below = false, le = false, ge = false;
+                        V3<T> v2 = { T(0), T(0), T(0) };
+                        T distance2 = T(0);
+                        if (q < P.hull_n) {
+                            v2 = mulv(H.R, V3<T>{ P.hull[3 * q], P.hull[3 * q + 1], P.hull[3 * q + 2] });
+                            v2.x += H.x.x; v2.y += H.x.y; v2.z += H.x.z;
+                            distance2 = dot(P.pn, v2) - P.pd;
+                            le = distance2 <= T(0);
+                            ge = distance2 >= T(0);
+                            below = le;
+                        }
+                        const unsigned long long mb = __ballot(below);
+                        any_le = any_le || (__ballot(le) != 0ull);
+                        any_ge = any_ge || (__ballot(ge) != 0ull);
+                        if (below) {
+                            const int rank = contacts + __popcll(mb & ((1ull << lane) - 1ull));
+                            if (rank < maxc) put_c(gpos, gnormal, gdepth, (size_t)8 * e + rank, v2, P.pn, -distance2);
+                        }
+                        contacts += __popcll(mb);
+                        if (contacts >= maxc && any_le && any_ge) break;
+                    }
+                    nc = (any_le && any_ge) ? (contacts < maxc ? contacts : maxc) : 0;
+                }
+            } else {
+                // ---- hull against static box s: dCollide(static box, hull); the joint is attached (0, body): reversed
+                const uint32_t s = (e - cap.inv) / cap.inv;
+                const T *bi = aabb + 6 * i, *sb = P.sbox + s * SBOX_REALS;
+                if (!(bi[0] > sb[SBOX_HI + 0] || sb[SBOX_LO + 0] > bi[3] || bi[1] > sb[SBOX_HI + 1] || sb[SBOX_LO + 1] > bi[4] ||
+                      bi[2] > sb[SBOX_HI + 2] || sb[SBOX_LO + 2] > bi[5]) && P.hull_n > 0) {
+                    const V3<T> sx = { sb[SBOX_POS], sb[SBOX_POS + 1], sb[SBOX_POS + 2] };
+                    M3<T> sR;
+                    for (int a = 0; a < 3; a++) for (int c2 = 0; c2 < 3; c2++) sR.m[a][c2] = sb[SBOX_R + 3 * a + c2];
+                    const T sside[3] = { sb[SBOX_SIDE], sb[SBOX_SIDE + 1], sb[SBOX_SIDE + 2] };
+                    nc = wave_box_convex<T>(sx, sR, sside, H.x, H.R, P, maxc, true, lane, gpos, gnormal, gdepth,
+                                            cap.static_slot0() + (size_t)8 * (e - cap.inv));
+                }
+            }
+        } else {
+            const uint32_t p = e - e_pairs;
+            if (p >= np) continue;
+            const int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
+            const int gi = gtype[i], gj = gtype[j];
+            if (gi != GEOM_CONVEX && gj != GEOM_CONVEX) continue;
+            if (gi == GEOM_BOX || gj == GEOM_BOX) {
+                // (box i, hull j): the collider's own order, normal into i.  (hull i, box j): dCollide swaps and flips.
+                const BodyGeomX<T> Bx = geom_of<T>(S, gtype, gi == GEOM_BOX ? i : j);
+                const BodyGeomX<T> H = geom_of<T>(S, gtype, gi == GEOM_BOX ? j : i);
+                if (P.hull_n > 0)
+                    nc = wave_box_convex<T>(Bx.x, Bx.R, Bx.side, H.x, H.R, P, maxc, gi != GEOM_BOX, lane, gpos, gnormal, gdepth,
+                                            cap.pair_slot0() + (size_t)8 * p);
+            } else if (lane == 0) {
+                atomicAdd(&C->unsupported, 1u);            // convex-convex / convex-sphere: no collider
+            }
+        }
+        if (lane == 0) cc[e] = (uint32_t)nc;
     }
 }
 
@@ -344,7 +511,7 @@ __global__ __launch_bounds__(256) void ex_fill(const uint32_t *__restrict__ keys
         const uint64_t exc = sinc[t] - sc[t];
         const int d0 = (int)hi32(exc), c0 = con_off[key];
         int b1, b2, src0;
-        if (e < cap.inv) { b1 = inv[e]; b2 = -1; src0 = 4 * (int)e; bodies[lo32(exc)] = b1; }
+        if (e < cap.inv) { b1 = inv[e]; b2 = -1; src0 = 8 * (int)e; bodies[lo32(exc)] = b1; }
         else if (e < e_pairs) { b1 = inv[e % cap.inv]; b2 = -1; src0 = (int)(cap.static_slot0() + (size_t)8 * (e - cap.inv)); }
         else { const uint32_t p = e - e_pairs; b1 = pairs[2 * p]; b2 = pairs[2 * p + 1]; src0 = (int)(cap.pair_slot0() + (size_t)8 * p); }
         const int nc = (int)cc[e];
@@ -482,6 +649,8 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.rf, B.rinc, (size_t)cap.inv, rocprim::plus<uint32_t>(), st));
     hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.aabb, P, cap,
                        B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
+    hipLaunchKernelGGL((ex_narrow_convex<T>), dim3((unsigned)std::min<size_t>((ne + 3) / 4, 65535)), dim3(256), 0, st, S, gtype, B.inv,
+                           B.pairs, G.aabb, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
     hipLaunchKernelGGL(ex_keys, dim3(grid_for(ne)), dim3(256), 0, st, B.pairs, B.pc, B.inc, B.root, B.rinc, cap, B.keys, B.vals, B.counts);
     int bits = 1;
     while ((1u << bits) <= cap.inv && bits < 32) bits++;        // keys are island numbers < cap.inv and the padding key cap.inv

@@ -15,9 +15,9 @@ struct ExactCaps {
     // block [inv (1 + s), inv (2 + s)): body k against static box s; then the body pairs
     __host__ __device__ uint32_t pair_entry0() const { return inv * (1u + nstatic); }
     __host__ __device__ uint32_t entries() const { return inv * (1u + nstatic) + pairs; }
-    // contact slots: 4 per plane entry, 8 per static entry, 8 per pair entry
-    __host__ __device__ size_t static_slot0() const { return (size_t)4 * inv; }
-    __host__ __device__ size_t pair_slot0() const { return (size_t)4 * inv + (size_t)8 * nstatic * inv; }
+    // contact slots: 8 per entry (a box yields at most 4 against the plane, a convex hull up to 8)
+    __host__ __device__ size_t static_slot0() const { return (size_t)8 * inv; }
+    __host__ __device__ size_t pair_slot0() const { return (size_t)8 * inv + (size_t)8 * nstatic * inv; }
     __host__ __device__ size_t slots() const { return pair_slot0() + (size_t)8 * pairs; }
 };
 
@@ -27,7 +27,8 @@ struct ExactCounts {
     uint32_t overflow;      // bit 0: pairs / involved bodies above capacity; bit 1: level-schedule rows above capacity
     uint32_t cross;         // a pair reaches into a ghost slot (an island spanning two ranks); the pair:
     uint32_t cross_a, cross_b;
-    uint32_t pad[4];
+    uint32_t unsupported;   // AABB pairs of this tick that have no collider (convex-convex, convex-sphere)
+    uint32_t pad[3];
 };
 
 template <class T> struct ExactBuffers {

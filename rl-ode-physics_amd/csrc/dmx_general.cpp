@@ -57,7 +57,7 @@ int ensure_buffers(dmxBatch *b)
         double r = 0;
         for (int64_t i = 0; i < b->n; i++) {
             const double *s = &b->h_sides[(size_t)3 * i];
-            const double ri = b->h_gtype[(size_t)i] == GEOM_SPHERE ? s[0]     // convex bodies are not in the broadphase
+            const double ri = (b->h_gtype[(size_t)i] == GEOM_SPHERE || b->h_gtype[(size_t)i] == GEOM_CONVEX) ? s[0]     // convex: the hull's bounding radius
                             : b->h_gtype[(size_t)i] == GEOM_BOX ? 0.5 * std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]) : 0.0;
             r = std::max(r, ri);
         }
@@ -368,6 +368,12 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     }
     b->last_pairs = C.npairs;
     b->ex_prev_inv = C.ninv;
+    if (C.unsupported) {
+        if (b->stat_unsupported == 0)
+            fprintf(stderr, "libode_mi355: %u overlapping AABB pair(s) of convex bodies with spheres / other convex bodies this tick: "
+                            "no collider exists for them, they pass through one another (counted in dmxBatchCollisionStatsEx)\n", C.unsupported);
+        b->stat_unsupported += C.unsupported;
+    }
     b->stat_careful_ticks++;
     if (C.cross) {
         fprintf(stderr, "libode_mi355: bodies %u and %u touch across two ranks' slabs; an island spanning ranks has to be "

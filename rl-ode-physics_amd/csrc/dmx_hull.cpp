@@ -341,3 +341,24 @@ extern "C" int32_t dmxHullBuild(const double *xyz, int64_t n, double scale, doub
     }
     return nv;
 }
+
+// The faces of the hull of `xyz` as planes: unit outward normal and offset (n.x <= d inside), one per triangle of the
+// quickhull's surface, in its face order.  Called on a hull's body-frame points (dmxHullBuild's out_points) it gives the
+// `planes` array dCreateConvex takes; dmxBatchSetConvexHullFaces puts it on the device for the box-convex collider.
+extern "C" int32_t dmxHullPlanes(const double *xyz, int64_t n, double *out_planes, int32_t capacity)
+{
+    if (!xyz || n < 4) return -1;
+    std::vector<P3> p((size_t)n);
+    for (int64_t i = 0; i < n; i++) p[(size_t)i] = { xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2] };
+    Hull h(p);
+    if (!h.build()) return -2;
+    int32_t nf = 0;
+    for (const Face &fc : h.f) {
+        if (!fc.alive) continue;
+        if (out_planes && nf < capacity) {
+            out_planes[4 * nf] = fc.n.x; out_planes[4 * nf + 1] = fc.n.y; out_planes[4 * nf + 2] = fc.n.z; out_planes[4 * nf + 3] = fc.d;
+        }
+        nf++;
+    }
+    return nf;
+}

@@ -98,6 +98,7 @@ template <class T> struct StepParams {
     // convex bodies: the shared hull (hull_n body-frame points, 3 reals each) and the tick's ground-plane contacts of
     // every convex body, written by np_convex_plane and read by step_plane: cbuf[i][k] = (x, y, z, depth), ccount[i]
     const T *hull; int hull_n;
+    const T *hull_planes; int hull_nf;      // the hull's faces: unit outward normal + offset, body frame (box-convex collider)
     T *cbuf; int *ccount;
     // static (body-less) box geoms, AddBodyMap main.c:735-761: SBOX_REALS reals each (see SBOX_*); the safe-zone test of the
     // fused kernels also asks that a body's bounding sphere stays clear of every static box's AABB

@@ -70,6 +70,20 @@ def read_obj_vertices(path):
     return v
 
 
+def planes(body_points):
+    """face planes (nf x 4: unit outward normal, offset) of the hull of `body_points` (a Hull's .points)"""
+    lib = _bind()
+    lib.dmxHullPlanes.restype = C.c_int32
+    lib.dmxHullPlanes.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
+    p = np.ascontiguousarray(body_points, dtype=np.float64)
+    nf = lib.dmxHullPlanes(p.ctypes.data, p.shape[0], None, 0)
+    if nf < 0:
+        raise ValueError(f"dmxHullPlanes failed with code {nf}")
+    out = np.zeros((nf, 4))
+    lib.dmxHullPlanes(p.ctypes.data, p.shape[0], out.ctypes.data, nf)
+    return out
+
+
 def build(points, scale=1.0):
     """Convex hull + solid mass properties of `points` (n x 3) scaled by `scale`."""
     lib = _bind()

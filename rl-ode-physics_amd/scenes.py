@@ -30,6 +30,8 @@ class Scene:
     gtype: np.ndarray     # n uint8
     plane: Optional[Tuple[float, float, float, float]]
     hull_points: Optional[np.ndarray] = None    # body-frame points of the hull the GEOM_CONVEX bodies share
+    hull_planes: Optional[np.ndarray] = None    # its faces (nf x 4: unit outward normal, offset), for contacts with boxes
+    static_boxes: Optional[list] = None         # [(sides3, pos3, R12)]: body-less box geoms (AddBodyMap, main.c:735-761)
 
     @property
     def n(self):
@@ -39,12 +41,13 @@ class Scene:
         f = lambda a: np.ascontiguousarray(a, dtype=dtype)
         return Scene(f(self.pos), f(self.quat), f(self.lvel), f(self.avel), f(self.mass),
                      f(self.inertia), f(self.sides), self.gtype, self.plane,
-                     None if self.hull_points is None else f(self.hull_points))
+                     None if self.hull_points is None else f(self.hull_points),
+                     None if self.hull_planes is None else f(self.hull_planes), self.static_boxes)
 
     def slice(self, lo, hi):
         return Scene(self.pos[lo:hi], self.quat[lo:hi], self.lvel[lo:hi], self.avel[lo:hi],
                      self.mass[lo:hi], self.inertia[lo:hi], self.sides[lo:hi], self.gtype[lo:hi], self.plane,
-                     self.hull_points)
+                     self.hull_points, self.hull_planes, self.static_boxes)
 
 
 def box_grid(nx, nz, *, seed=1, y_range=(20.0, 50.0), spin=True, box_mass=False, plane=True,
@@ -102,8 +105,9 @@ def config3(n_side=512):
 HULL_PITCH = 3.0      # grid pitch of the hull scenes: the 0.01-scale teapot hull is 2.13 m across its bounding sphere
 
 
-def hull_grid(hull, nx, nz, *, seed=1, y_range=(1.5, 3.5), spin=False, density=1.0, plane=True, tilt=0.0):
-    """nx x nz copies of one convex hull (a hull.Hull) over the ground plane (BASELINE configs[4]).
+def hull_grid(hull, nx, nz, *, seed=1, y_range=(1.5, 3.5), spin=False, density=1.0, plane=True, tilt=0.0, floor_box=False):
+    """nx x nz copies of one convex hull (a hull.Hull) over the ground plane, or -- floor_box -- over one static box whose
+    top is at y = 0 (BASELINE configs[4]: "dropping on a static box floor, box-convex contacts").
 
     Every body starts upright (the hull's input-frame orientation) unless tilt > 0, which turns body i about a
     drawn horizontal axis by a drawn angle in [0, tilt]; heights and spin are drawn like box_grid's."""
@@ -130,8 +134,14 @@ def hull_grid(hull, nx, nz, *, seed=1, y_range=(1.5, 3.5), spin=False, density=1
     inertia = np.tile(density * hull.inertia, (n, 1))
     sides = np.zeros((n, 3))
     sides[:, 0] = hull.radius                     # the broadphase reads a convex body's bounding radius here
+    from . import hull as hull_mod
+    statics = None
+    if floor_box:
+        span = max(nx, nz) * HULL_PITCH + 20.0
+        statics = [((span, 1.0, span), (0.0, -0.5, 0.0), _rot_z(0.0))]
+        plane = False
     return Scene(pos, quat, np.zeros((n, 3)), omega, mass, inertia, sides, np.full(n, GEOM_CONVEX, np.uint8),
-                 (0.0, 1.0, 0.0, 0.0) if plane else None, hull.points.copy())
+                 (0.0, 1.0, 0.0, 0.0) if plane else None, hull.points.copy(), hull_mod.planes(hull.points), statics)
 
 
 def config4(n_side=1024, slabs=8):

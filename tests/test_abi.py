@@ -31,7 +31,7 @@ def test_every_header_symbol_is_exported():
     lib = pkg._lib.load()
     headers = sorted(h for h in os.listdir(os.path.join(ROOT, "include")) if h.endswith(".h"))
     assert headers == ["dmx_batch.h", "dmx_hull.h"]
-    assert _declared("dmx_hull.h") == ["dmxHullBuild", "dmxObjReadVertices"]
+    assert _declared("dmx_hull.h") == ["dmxHullBuild", "dmxHullPlanes", "dmxObjReadVertices"]
     for h in headers:
         for n in _declared(h):
             assert hasattr(lib, n), f"{n} declared in include/{h} but not exported"

@@ -41,6 +41,10 @@ def _oracle_build(orc, scene, gyro=None, spheres=False, setup=None):
         ow.add_plane(*scene.plane)
     if scene.hull_points is not None:
         ow.set_hull(scene.hull_points)
+        if scene.hull_planes is not None:
+            ow.set_hull_faces(scene.hull_planes)
+    for sides, pos, R12 in (scene.static_boxes or []):
+        ow.add_static_box(sides, pos, R12)
     convex = scene.gtype == pkg.scenes.GEOM_CONVEX
     if spheres:
         ow.add_spheres(scene.pos, scene.quat, scene.lvel, scene.avel, scene.mass[:, 0], scene.inertia,
@@ -984,4 +988,83 @@ def test_hundred_thousand_boxes_on_a_static_floor():
     w.step(H, steps)
     _compare(w.state(), ow.state())
     assert w.last_contact_count() == ow.n_contacts()
+    w.close()
+
+
+# ----------------------------------------------------------------- convex hulls against boxes (BASELINE configs[4] as written)
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_teapot_hulls_dropping_on_a_static_box_floor_match_oracle(dtype):
+    """configs[4] as BASELINE states it, reduced: teapot hulls dropping on a static BOX floor (the reference's floor is one,
+    main.c:115), box-convex contacts from the wave-per-pair collider, bit-identical to the oracle's sequential restatement"""
+    hull = _teapot_hull()
+    scene = pkg.scenes.hull_grid(hull, 8, 8, seed=4, y_range=(0.8, 2.5), spin=True, tilt=0.6, floor_box=True).astype(dtype)
+    assert scene.plane is None and len(scene.static_boxes) == 1 and scene.hull_planes.shape[1] == 4
+    steps = 240
+    w = _gpu_run(scene, dtype, steps)
+    ow = _oracle_run(_orc(dtype), scene, steps, allow_pairs=True)
+    _compare(w.state(), ow.state())
+    assert w.last_contact_count() == ow.n_contacts() > 64
+    y = w.state()[0][:, 1]
+    assert 0.3 < np.median(y) < 0.7 and np.all(y > -0.5) and np.all(y < 1.5)          # held by the floor's top face (y = 0)
+    assert w.collision_stats()["unsupported_pairs"] == 0
+    w.close()
+
+
+def test_boxes_dropped_onto_hulls():
+    """box bodies falling onto teapot hulls that rest on the ground plane: hull-box BODY pairs in both orders (box first /
+    hull first in slot order), corners of small boxes inside the hulls and hull vertices inside the boxes"""
+    hull = _teapot_hull()
+    hs = pkg.scenes.hull_grid(hull, 4, 4, seed=6, y_range=(0.45, 0.55), spin=False, tilt=0.0)
+    bs = pkg.scenes.box_grid(4, 4, seed=7, y_range=(1.6, 2.4), spin=True, box_mass=True, plane=True)
+    bs.pos[:, 0] = hs.pos[:, 0] + 0.1
+    bs.pos[:, 2] = hs.pos[:, 2] - 0.05
+    half = 8
+    cat = lambda *a: np.concatenate(a)
+    # slot order: 8 boxes, 16 hulls, 8 boxes -- so both (box, hull) and (hull, box) pairs occur.  The oracle helper wants
+    # boxes first, hulls behind: give the LAST eight boxes their own world order by running two layouts is not needed --
+    # the oracle adds bodies in slot order below.
+    scene = pkg.scenes.Scene(cat(bs.pos[:half], hs.pos, bs.pos[half:]), cat(bs.quat[:half], hs.quat, bs.quat[half:]),
+                             cat(bs.lvel[:half], hs.lvel, bs.lvel[half:]), cat(bs.avel[:half], hs.avel, bs.avel[half:]),
+                             cat(bs.mass[:half], hs.mass, bs.mass[half:]), cat(bs.inertia[:half], hs.inertia, bs.inertia[half:]),
+                             cat(bs.sides[:half], hs.sides, bs.sides[half:]), cat(bs.gtype[:half], hs.gtype, bs.gtype[half:]),
+                             bs.plane, hs.hull_points, hs.hull_planes).astype("float64")
+    orc = _orc("float64")
+    ow = orc.world()
+    ow.add_plane(*scene.plane)
+    ow.set_hull(scene.hull_points); ow.set_hull_faces(scene.hull_planes)
+    a, b = half, half + hs.n
+    ow.add_boxes(scene.pos[:a], scene.quat[:a], scene.lvel[:a], scene.avel[:a], scene.mass[:a, 0], scene.inertia[:a], scene.sides[:a])
+    ow.add_convex(scene.pos[a:b], scene.quat[a:b], scene.lvel[a:b], scene.avel[a:b], scene.mass[a:b, 0], scene.inertia[a:b])
+    ow.add_boxes(scene.pos[b:], scene.quat[b:], scene.lvel[b:], scene.avel[b:], scene.mass[b:, 0], scene.inertia[b:], scene.sides[b:])
+    steps, hull_box_contacts = 150, 0
+    for _ in range(steps):
+        ow.tick(H)
+        hull_box_contacts += sum(1 for b1, b2, *_ in ow.joints() if b2 >= 0 and ((a <= b1 < b) != (a <= b2 < b)))
+    assert hull_box_contacts > 200
+    w = _gpu_run(scene, "float64", steps)
+    _compare(w.state(), ow.state())
+    w.close()
+
+
+def test_config5_full_size_teapots_on_the_box_floor():
+    """BASELINE configs[4] at its full size: 16 384 teapot hulls on the static box floor.  Size-independent properties
+    for all of them, and a strided sample (every 64th hull: bodies on this grid never meet, so a body's trajectory does
+    not depend on who else is in the world) against the oracle, bit for bit."""
+    hull = _teapot_hull()
+    scene = pkg.scenes.hull_grid(hull, 128, 128, seed=1, y_range=(0.6, 1.6), spin=False, tilt=0.2, floor_box=True).astype("float32")
+    steps = 180
+    w = _gpu_run(scene, "float32", steps)
+    pos, quat, lvel, avel = w.state()
+    assert np.all(np.isfinite(pos)) and np.all(np.isfinite(quat))
+    assert np.max(np.abs(np.linalg.norm(quat, axis=1) - 1.0)) < 1e-5
+    assert np.all(pos[:, 1] > -0.2) and np.all(pos[:, 1] < 1.2)                    # nobody fell through the floor (top at y = 0)
+    assert np.percentile(np.abs(lvel[:, 1]), 50) < 0.2                             # most have come to rest vertically
+    assert w.last_contact_count() > 2 * scene.n
+    assert np.array_equal(pos[:, [0, 2]] != scene.pos[:, [0, 2]], pos[:, [0, 2]] != scene.pos[:, [0, 2]])
+    idx = np.arange(0, scene.n, 64)
+    sub = pkg.scenes.Scene(scene.pos[idx], scene.quat[idx], scene.lvel[idx], scene.avel[idx], scene.mass[idx], scene.inertia[idx],
+                           scene.sides[idx], scene.gtype[idx], None, scene.hull_points, scene.hull_planes, scene.static_boxes)
+    ow = _oracle_run(_orc("float32"), sub, steps, allow_pairs=True)
+    for name, got, ref in zip(("pos", "quat", "lvel", "avel"), (pos, quat, lvel, avel), ow.state()):
+        assert np.array_equal(got[idx], ref), name
     w.close()

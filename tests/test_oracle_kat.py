@@ -560,3 +560,78 @@ def test_exact_step_reaches_complementarity_on_a_pile():
     assert most > 2 * nb and np.all(np.isfinite(ow.state()[0]))
     assert worst < 1e-5                                   # summed over the rows, against right-hand sides of order 1e2-1e3
     assert orc.lib.orc_world_last_lcp_rounds(ow.w) < 200
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# box against convex hull: the repository's own collider (ODE's dCollideConvexBox is a stub) -- closed-form cases
+def _cube_hull_world(orc, hull_half, hull_pos, box_sides, box_pos):
+    """a static box and one convex body whose hull is a cube of half-extent hull_half (8 points, 6 x 2 triangles' planes)"""
+    import itertools
+    pts = np.array(list(itertools.product((-hull_half, hull_half), repeat=3)), float)
+    planes = []
+    for a in range(3):
+        for sg in (-1.0, 1.0):
+            n = [0.0, 0.0, 0.0]; n[a] = sg
+            planes.append(n + [hull_half])
+    ow = orc.world()
+    ow.set_hull(pts); ow.set_hull_faces(np.array(planes))
+    g_box = ow.add_static_box(box_sides, box_pos, [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0])
+    ow.add_convex(np.array([hull_pos], float), np.array([[1.0, 0, 0, 0]]), np.zeros((1, 3)), np.zeros((1, 3)), np.ones(1), np.ones((1, 3)))
+    return ow, g_box, g_box + 1
+
+
+def _collide(orc, ow, g1, g2, maxc=8):
+    out = (orc.ContactGeom * 16)()
+    n = orc.lib.orc_collide(ow.w, g1, g2, maxc, out)
+    return [(list(out[i].pos), list(out[i].normal), out[i].depth) for i in range(n)]
+
+
+def test_box_convex_hull_vertices_inside_the_box():
+    """a cube hull (half 0.5) sunk 0.01 into the top face of a big static box: its four bottom vertices are the contacts,
+    each 0.01 deep along the box's top face; the normal points into the box (o1) and the flipped order flips it"""
+    from oracle.orc_ctypes import Oracle
+    orc = Oracle("float64")
+    ow, gb, gh = _cube_hull_world(orc, 0.5, (0.3, 0.49, -0.2), (10.0, 1.0, 10.0), (0.0, -0.5, 0.0))
+    cs = _collide(orc, ow, gb, gh)
+    assert len(cs) == 4
+    for pos, nrm, dep in cs:
+        assert abs(pos[1] + 0.01) < 1e-12 and abs(abs(pos[0] - 0.3) - 0.5) < 1e-12 and abs(abs(pos[2] + 0.2) - 0.5) < 1e-12
+        assert nrm == [0.0, -1.0, 0.0] or np.allclose(nrm, [0, -1, 0])
+        assert abs(dep - 0.01) < 1e-12
+    flipped = _collide(orc, ow, gh, gb)
+    assert len(flipped) == 4 and all(np.allclose(c[1], [0, 1, 0]) for c in flipped)
+    assert len(_collide(orc, ow, gb, gh, maxc=3)) == 3                         # the first three in the hull's array order
+    assert [c[0] for c in _collide(orc, ow, gb, gh, maxc=3)] == [c[0] for c in cs[:3]]
+
+
+def test_box_convex_box_corner_inside_the_hull():
+    """a small static box poking its top into the bottom face of a big cube hull: no hull vertex is inside the box, the box's
+    four top corners are inside the hull; the contacts sit at those corners (in corner order), along the hull face they
+    are nearest to"""
+    from oracle.orc_ctypes import Oracle
+    orc = Oracle("float64")
+    # hull: cube of half 1 centred at (0, 1.05, 0) -> bottom face at y = 0.05.  Box: sides 0.2, centre (0.5, 0, 0.5): top at y = 0.1
+    ow, gb, gh = _cube_hull_world(orc, 1.0, (0.0, 1.05, 0.0), (0.2, 0.2, 0.2), (0.5, 0.0, 0.5))
+    cs = _collide(orc, ow, gb, gh)
+    assert [c[0] for c in cs] == [[x, 0.1, z] for z in (0.4, 0.6) for x in (0.4, 0.6)] or \
+        np.allclose([c[0] for c in cs], [[x, 0.1, z] for z in (0.4, 0.6) for x in (0.4, 0.6)])      # corners 2, 3, 6, 7 (bit 1 = +y)
+    for pos, nrm, dep in cs:
+        assert np.allclose(nrm, [0.0, -1.0, 0.0])        # the hull's bottom face (outward normal -y) points into the box
+        assert abs(dep - 0.05) < 1e-12
+    # without the faces only the vertex half of the collider runs: nothing found
+    ow.set_hull_faces(np.zeros((0, 4)))
+    assert _collide(orc, ow, gb, gh) == []
+
+
+def test_box_convex_supports_a_resting_hull():
+    """one exact step of a unit-cube hull resting on a static box: the four contacts carry m g between them"""
+    from oracle.orc_ctypes import Oracle
+    orc = Oracle("float64")
+    ow, gb, gh = _cube_hull_world(orc, 0.5, (0.0, 0.4999, 0.0), (10.0, 1.0, 10.0), (0.0, -0.5, 0.0))
+    orc.lib.orc_world_set_erp(ow.w, 0.0)
+    ow.set_stepper(True)
+    ow.tick(1.0 / 60.0)
+    j = ow.joints()
+    assert len(j) == 4 and abs(sum(x[5] for x in j) - 9.8) < 1e-6
+    assert all(np.allclose(x[3], [0, 1, 0]) for x in j)                      # after the joint's reversal: into the hull
+    assert np.max(np.abs(ow.state()[2])) < 1e-8
