@@ -438,7 +438,12 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
                     nc = wave_box_convex<T>(Bx.x, Bx.R, Bx.side, H.x, H.R, P, maxc, gi != GEOM_BOX, lane, gpos, gnormal, gdepth,
                                             cap.pair_slot0() + (size_t)8 * p);
             } else if (lane == 0) {
-                atomicAdd(&C->unsupported, 1u);            // convex-convex / convex-sphere: no collider
+                // convex-convex / convex-sphere: no collider.  Counted when the bounding spheres reach one another (the
+                // AABBs of convex bodies are their spheres' boxes: an AABB pair alone says little)
+                const T dx = S[slab_ix(C_POS + 0, i)] - S[slab_ix(C_POS + 0, j)], dy = S[slab_ix(C_POS + 1, i)] - S[slab_ix(C_POS + 1, j)],
+                        dz = S[slab_ix(C_POS + 2, i)] - S[slab_ix(C_POS + 2, j)];
+                const T rr = S[slab_ix(C_SIDES, i)] + S[slab_ix(C_SIDES, j)];
+                if (dx * dx + dy * dy + dz * dz < rr * rr) atomicAdd(&C->unsupported, 1u);
             }
         }
         if (lane == 0) cc[e] = (uint32_t)nc;

@@ -370,8 +370,8 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     b->ex_prev_inv = C.ninv;
     if (C.unsupported) {
         if (b->stat_unsupported == 0)
-            fprintf(stderr, "libode_mi355: %u overlapping AABB pair(s) of convex bodies with spheres / other convex bodies this tick: "
-                            "no collider exists for them, they pass through one another (counted in dmxBatchCollisionStatsEx)\n", C.unsupported);
+            fprintf(stderr, "libode_mi355: %u pair(s) of convex bodies with spheres / other convex bodies whose bounding spheres overlap this "
+                            "tick: no collider exists for them, they pass through one another (counted in dmxBatchCollisionStatsEx)\n", C.unsupported);
         b->stat_unsupported += C.unsupported;
     }
     b->stat_careful_ticks++;
