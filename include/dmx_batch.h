@@ -204,6 +204,13 @@ int dmxBatchChunkCommit(dmxBatchID b, int ticks, int refresh_zones);
 int dmxBatchChunkRollback(dmxBatchID b);
 int dmxBatchExactTick(dmxBatchID b, double h);
 
+/* ---- dSpaceCollide's pair search alone (main.c:212), for the callback form of the tick: the device finds every pair of
+ * bodies (i < j, ascending i then j) whose geoms' AABBs overlap, and the bodies "involved" -- in such a pair, or with
+ * their AABB overlapping a static box's (dmxBatchSetStaticBoxes) -- ascending.  The arrays are host memory owned by the
+ * batch, valid until its next call.  The ODE API face (dSpaceCollide in libode_mi355) feeds the user's near callback from
+ * this list when the world is large enough for the device search to pay. */
+int dmxBatchFindPairs(dmxBatchID b, const int32_t **pairs, int64_t *n_pairs, const int32_t **involved, int64_t *n_involved);
+
 /* ---- explicit contact joints: the callback form of the tick.  The reference's near callback makes one
  * dJointCreateContact + dJointAttach per contact (main.c:683-692) and then calls dWorldStep (main.c:213);
  * this entry takes the whole tick's contact joints at once, groups them into dynamics islands, and steps

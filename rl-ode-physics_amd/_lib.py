@@ -24,7 +24,7 @@ BATCH_SYMBOLS = [
     "dmxBatchChunkBegin", "dmxBatchChunkTick", "dmxBatchCheckZonesOnStream", "dmxBatchChunkEnd",
     "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream", "dmxBatchSetConvexHull", "dmxBatchChunkTicks", "dmxBatchSetTicksPerLaunch",
     "dmxBatchSetSnapshotMode", "dmxBatchSetStaticBoxes", "dmxBatchSetStepper", "dmxBatchSetConvexHullFaces",
-    "dmxBatchCollisionStatsEx",
+    "dmxBatchCollisionStatsEx", "dmxBatchFindPairs",
 ]
 
 _lib = None
@@ -107,5 +107,6 @@ def load():
     sig("dmxBatchSetStepper", I, P, I)
     sig("dmxBatchSetConvexHullFaces", I, P, C.c_int32, P)
     sig("dmxBatchCollisionStatsEx", I, P, C.POINTER(L))
+    sig("dmxBatchFindPairs", I, P, C.POINTER(P), C.POINTER(L), C.POINTER(P), C.POINTER(L))
     _lib = lib
     return lib

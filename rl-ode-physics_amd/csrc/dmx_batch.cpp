@@ -541,6 +541,18 @@ extern "C" int dmxBatchExactTick(dmxBatchID b, double h)
     return dmx_exact_tick(b, h);
 }
 
+extern "C" int dmxBatchFindPairs(dmxBatchID b, const int32_t **pairs, int64_t *n_pairs, const int32_t **involved, int64_t *n_involved)
+{
+    if (!b || !pairs || !n_pairs || !involved || !n_involved) return DMX_EINVAL;
+    SETTLE(b);
+    HIP_TRY(hipSetDevice(b->device));
+    const int rc = dmx_find_pairs(b);
+    if (rc != DMX_OK) return rc;
+    *pairs = b->fp_pairs.data(); *n_pairs = (int64_t)(b->fp_pairs.size() / 2);
+    *involved = b->fp_inv.data(); *n_involved = (int64_t)b->fp_inv.size();
+    return DMX_OK;
+}
+
 extern "C" int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6])
 {
     if (!b || !out) return DMX_EINVAL;

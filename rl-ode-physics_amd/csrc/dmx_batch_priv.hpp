@@ -121,6 +121,7 @@ struct dmxBatch {
     uint32_t ex_prev_inv = 1;                   // bodies the last exact tick found involved (in a pair / at a static box)
     DevBuf ex_arena, ex_body, ex_last, ex_aabb;
     void *ex_counts_host = nullptr;
+    std::vector<int32_t> fp_pairs, fp_inv;      // dmxBatchFindPairs' results
     uint32_t *bp_flags_host = nullptr;         // pinned
     int bp_max_pairs = 0;
     std::vector<double> h_sides;               // host mirror of DMX_SIDES (exact values of the batch precision)
@@ -182,6 +183,7 @@ int dmx_chunk_end(dmxBatch *b, int *violated, int *warn);
 int dmx_chunk_commit(dmxBatch *b, int ticks, int refresh_zones);
 int dmx_chunk_rollback(dmxBatch *b);
 int dmx_exact_tick(dmxBatch *b, double h);
+int dmx_find_pairs(dmxBatch *b);           // -> b->fp_pairs / b->fp_inv
 
 
 template <class T> inline void dmx_normalize_plane(const double in[4], T out[4])

@@ -584,6 +584,50 @@ template <class T> int check_zones_t(dmxBatch *b, hipStream_t st, int64_t first,
 
 }  // namespace
 
+namespace {
+template <class T> int find_pairs_t(dmxBatch *b)
+{
+    int rc;
+    if ((rc = ensure_buffers(b)) != DMX_OK) return rc;
+    if (!b->ex_counts_host) HIP_TRY(hipHostMalloc((void **)&b->ex_counts_host, sizeof(ExactCounts)));
+    ExactBuffers<T> B;
+    ExactCounts &C = *(ExactCounts *)b->ex_counts_host;
+    if (b->ex_cap_pairs == 0) { b->ex_cap_pairs = 1024; b->ex_cap_rows = 16384; }
+    for (int attempt = 0;; attempt++) {
+        if (attempt > 40) return DMX_ECAPACITY;
+        ExactCaps cap;
+        cap.pairs = b->ex_cap_pairs;
+        cap.inv = (uint32_t)std::min<int64_t>(2 * (int64_t)cap.pairs, b->n_active);
+        cap.rows = b->ex_cap_rows;
+        cap.nstatic = (uint32_t)b->n_static;
+        if ((rc = ensure_exact_buffers<T>(b, cap, B)) != DMX_OK) return rc;
+        if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
+        HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), B, cap, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->bp_flags_host, b->bp_flags.p, BPF_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(&C, B.counts, sizeof(ExactCounts), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        if (b->bp_flags_host[BPF_OVERFLOW]) { if ((rc = grow_buckets(b)) != DMX_OK) return rc; continue; }
+        if (C.overflow & 1u) {
+            const uint64_t need = std::max<uint64_t>(C.npairs, (uint64_t)(C.ninv + 1) / 2);
+            b->ex_cap_pairs = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * cap.pairs, need + need / 4 + 64), 1ull << 28);
+            continue;
+        }
+        break;
+    }
+    b->fp_pairs.resize((size_t)2 * C.npairs);
+    b->fp_inv.resize((size_t)C.ninv);
+    if (C.npairs) HIP_TRY(hipMemcpyAsync(b->fp_pairs.data(), B.pairs, b->fp_pairs.size() * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+    if (C.ninv) HIP_TRY(hipMemcpyAsync(b->fp_inv.data(), B.inv, b->fp_inv.size() * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return DMX_OK;
+}
+}  // namespace
+
+int dmx_find_pairs(dmxBatch *b)
+{
+    return b->precision == DMX_F32 ? find_pairs_t<float>(b) : find_pairs_t<double>(b);
+}
+
 int dmx_settle(dmxBatch *b)
 {
     if (!b->oc.open) return DMX_OK;

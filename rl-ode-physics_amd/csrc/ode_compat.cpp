@@ -102,6 +102,8 @@ struct dxWorld {
     int iters = 20;
     bool dev_newer = false;            // device holds newer body state than the host mirrors
     bool host_dirty = true;            // host mirrors hold changes the device has not seen
+    bool geom_dirty = true;            // the bodies' geoms (class, extents) changed since the device last saw them
+    std::vector<double> dev_statics;   // the static boxes the device holds (18 doubles each), for the device pair search
     std::vector<dReal> buf;
     std::vector<dmxContactJoint> cj;
 
@@ -166,6 +168,9 @@ struct dxWorld {
         DMX_MUST(dmxBatchUploadBodyFlags(batch, fl.data(), 0, cap));
         host_dirty = false;
     }
+    // extents and classes of the bodies' geoms, for the device pair search (dSpaceCollide); false when some body's
+    // geometry is not one box / sphere geom (the host search handles those worlds)
+    bool geometry_to_device();
     void grow()
     {
         to_host();
@@ -174,6 +179,8 @@ struct dxWorld {
         batch = nullptr;
         create_batch(cap * 2);
         std::copy(keep.begin(), keep.end(), slots.begin());
+        geom_dirty = true;
+        dev_statics.clear();
     }
 };
 
@@ -187,6 +194,26 @@ void touch(dxBody *b) { b->world->to_host(); b->world->host_dirty = true; }
 void sync_geom(const dxGeom *g) { if (g->body) g->body->world->to_host(); }
 
 }  // namespace
+
+bool dxWorld::geometry_to_device()
+{
+    if (!geom_dirty) return true;
+    std::vector<dReal> sides((size_t)cap * 3, 0);
+    std::vector<uint8_t> gt((size_t)cap, DMX_GEOM_NONE);
+    for (int s = 0; s < cap; s++) {
+        const dxBody *b = slots[(size_t)s];
+        if (!b || b->geoms.empty()) continue;                  // a body without geoms collides with nothing
+        if (b->geoms.size() != 1) return false;
+        const dxGeom *g = b->geoms[0];
+        if (g->cls == dBoxClass) { gt[(size_t)s] = DMX_GEOM_BOX; for (int k = 0; k < 3; k++) sides[(size_t)s * 3 + k] = g->side[k]; }
+        else if (g->cls == dSphereClass) { gt[(size_t)s] = DMX_GEOM_SPHERE; sides[(size_t)s * 3] = g->side[0]; }
+        else return false;
+    }
+    DMX_MUST(dmxBatchUpload(batch, DMX_SIDES, sides.data(), 0, cap));
+    DMX_MUST(dmxBatchUploadGeomType(batch, gt.data(), 0, cap));
+    geom_dirty = false;
+    return true;
+}
 
 // ================================================================================ lifecycle
 extern "C" void dInitODE(void) { (void)dInitODE2(0); }
@@ -409,16 +436,16 @@ extern "C" dGeomID dCreatePlane(dSpaceID space, dReal a, dReal b, dReal c, dReal
 extern "C" void dGeomDestroy(dGeomID g)
 {
     if (!g) return;
-    if (g->body) { auto &v = g->body->geoms; v.erase(std::remove(v.begin(), v.end(), g), v.end()); }
+    if (g->body) { auto &v = g->body->geoms; v.erase(std::remove(v.begin(), v.end(), g), v.end()); g->body->world->geom_dirty = true; }
     if (g->space) { auto &v = g->space->geoms; v.erase(std::remove(v.begin(), v.end(), g), v.end()); }
     delete g;
 }
 extern "C" void dGeomSetBody(dGeomID g, dBodyID b)
 {
     if (g->body == b) return;
-    if (g->body) { auto &v = g->body->geoms; v.erase(std::remove(v.begin(), v.end(), g), v.end()); }
+    if (g->body) { auto &v = g->body->geoms; v.erase(std::remove(v.begin(), v.end(), g), v.end()); g->body->world->geom_dirty = true; }
     g->body = b;
-    if (b) b->geoms.push_back(g);
+    if (b) { b->geoms.push_back(g); b->world->geom_dirty = true; }
 }
 extern "C" dBodyID dGeomGetBody(dGeomID g) { return g->body; }
 extern "C" void dGeomSetPosition(dGeomID g, dReal x, dReal y, dReal z)
@@ -522,9 +549,122 @@ extern "C" int dCollide(dGeomID o1, dGeomID o2, int flags, dContactGeom *contact
 }
 
 // ---- dSpaceCollide -----------------------------------------------------------------------------------
+namespace {
+
+struct GeomBox { dReal lo[3], hi[3]; };
+GeomBox aabb_of(const dxGeom *g)
+{
+    const dReal *p = geom_pos(g), *R = geom_R(g);
+    GeomBox b;
+    for (int i = 0; i < 3; i++) {
+        const dReal r = g->cls == dSphereClass
+                            ? g->side[0]
+                            : (dReal)0.5 * (dmx::tabs(R[4 * i] * g->side[0]) + dmx::tabs(R[4 * i + 1] * g->side[1]) +
+                                            dmx::tabs(R[4 * i + 2] * g->side[2]));
+        b.lo[i] = p[i] - r; b.hi[i] = p[i] + r;
+    }
+    return b;
+}
+bool boxes_overlap(const GeomBox &a, const GeomBox &b)
+{
+    return !(b.lo[0] > a.hi[0] || a.lo[0] > b.hi[0] || b.lo[1] > a.hi[1] || a.lo[1] > b.hi[1] || b.lo[2] > a.hi[2] || a.lo[2] > b.hi[2]);
+}
+bool pair_passes(const dxGeom *a, const dxGeom *b)
+{
+    if (a->body && a->body == b->body) return false;
+    return ((a->cat & b->col) || (b->cat & a->col)) != 0;
+}
+
+// worlds of at least this many bodies take their body pairs from the device (DMX_COMPAT_DEVICE_PAIRS: 1 = always, 0 = never;
+// a number >= 2 = that many bodies).  Below it the host sweep is quicker than a device round trip.
+int device_pairs_threshold()
+{
+    static const int v = [] {
+        const char *e = getenv("DMX_COMPAT_DEVICE_PAIRS");
+        if (!e) return 2048;
+        const int x = atoi(e);
+        return x == 0 ? 0x7fffffff : x;
+    }();
+    return v;
+}
+
+// The pair search of dSpaceCollide on the device: body-body AABB pairs and the bodies near static boxes come from
+// dmxBatchFindPairs (hashed-grid search, dmx_exact.hip); planes, the static boxes' own pairs and the category / collide
+// filter are a few host loops over that short list.  false = this space is not of the shape the device search covers
+// (bodies of several worlds, bodies with several geoms, static geoms other than boxes and planes): the host search runs.
+bool device_pairs(dxSpace *space, std::vector<std::pair<dxGeom *, dxGeom *>> &pairs)
+{
+    dxWorld *w = nullptr;
+    std::vector<dxGeom *> planes, statics;
+    int nbodies = 0;
+    for (dxGeom *g : space->geoms) {
+        if (g->cls == dPlaneClass) { planes.push_back(g); continue; }
+        if (!g->body) { if (g->cls != dBoxClass) return false; statics.push_back(g); continue; }
+        if (w && g->body->world != w) return false;
+        w = g->body->world;
+        nbodies++;
+    }
+    if (!w || nbodies < device_pairs_threshold() || (int)statics.size() > DMX_MAX_STATIC_BOXES) return false;
+    for (const dxBody *b : w->slots) if (b) for (const dxGeom *g : b->geoms) if (g->space != space) return false;
+    w->to_device();
+    if (!w->geometry_to_device()) return false;
+    std::vector<double> st;
+    for (const dxGeom *g : statics) {
+        for (int k = 0; k < 3; k++) st.push_back(g->side[k]);
+        for (int k = 0; k < 3; k++) st.push_back(g->pos[k]);
+        for (int k = 0; k < 12; k++) st.push_back(g->R[k]);
+    }
+    if (st != w->dev_statics) {
+        std::vector<double> sides, pos, rot;
+        for (size_t s = 0; s < statics.size(); s++) {
+            sides.insert(sides.end(), st.begin() + 18 * s, st.begin() + 18 * s + 3);
+            pos.insert(pos.end(), st.begin() + 18 * s + 3, st.begin() + 18 * s + 6);
+            rot.insert(rot.end(), st.begin() + 18 * s + 6, st.begin() + 18 * s + 18);
+        }
+        DMX_MUST(dmxBatchSetStaticBoxes(w->batch, (int32_t)statics.size(), sides.data(), pos.data(), rot.data()));
+        w->dev_statics = st;
+    }
+    const int32_t *bp = nullptr, *inv = nullptr;
+    int64_t nbp = 0, ninv = 0;
+    DMX_MUST(dmxBatchFindPairs(w->batch, &bp, &nbp, &inv, &ninv));
+    w->to_host();                                 // dCollide reads poses from the host mirrors: one bulk copy per tick
+    auto push = [&](dxGeom *a, dxGeom *b) { if (a->id < b->id) pairs.emplace_back(a, b); else pairs.emplace_back(b, a); };
+    for (int64_t k = 0; k < nbp; k++) {
+        dxGeom *a = w->slots[(size_t)bp[2 * k]]->geoms[0], *b = w->slots[(size_t)bp[2 * k + 1]]->geoms[0];
+        if (pair_passes(a, b)) push(a, b);
+    }
+    std::vector<GeomBox> sbox;
+    for (const dxGeom *g : statics) sbox.push_back(aabb_of(g));
+    for (int64_t k = 0; k < ninv; k++) {
+        dxGeom *g = w->slots[(size_t)inv[k]]->geoms[0];
+        const GeomBox gb = aabb_of(g);
+        for (size_t s = 0; s < statics.size(); s++)
+            if (boxes_overlap(gb, sbox[s]) && pair_passes(g, statics[s])) push(g, statics[s]);
+    }
+    for (size_t s = 0; s < statics.size(); s++)               // static-static pairs reach the callback too (SURVEY a-5)
+        for (size_t t = s + 1; t < statics.size(); t++)
+            if (boxes_overlap(sbox[s], sbox[t]) && pair_passes(statics[s], statics[t])) push(statics[s], statics[t]);
+    for (dxGeom *pl : planes)
+        for (dxGeom *g : space->geoms)
+            if (g->cls != dPlaneClass && pair_passes(pl, g)) push(pl, g);
+    return true;
+}
+
+}  // namespace
+
 extern "C" void dSpaceCollide(dSpaceID space, void *data, dNearCallback *callback)
 {
     if (!space || !callback) return;
+    {
+        std::vector<std::pair<dxGeom *, dxGeom *>> dpairs;
+        if (device_pairs(space, dpairs)) {
+            std::sort(dpairs.begin(), dpairs.end(), [](const auto &a, const auto &b) {
+                return a.first->id < b.first->id || (a.first->id == b.first->id && a.second->id < b.second->id);
+            });
+            for (auto &pr : dpairs) callback(data, pr.first, pr.second);          // NearCallback, main.c:674
+            return;
+        }
+    }
     struct Box { dReal lo[3], hi[3]; dxGeom *g; };
     std::vector<Box> bb;
     std::vector<dxGeom *> planes;

@@ -199,10 +199,13 @@ def test_plane_scene_through_ode_api_matches_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("device_pairs", ["0", "1"])
 @pytest.mark.parametrize("seed", range(10))
-def test_random_spawns_through_ode_api_match_oracle(tmp_path, seed):
+def test_random_spawns_through_ode_api_match_oracle(tmp_path, seed, device_pairs):
     """The reference's spawner (main.c:502-521) with other seeds, counts, drop heights and step sizes, in the reference's
-    pen or on a plane, both precisions: poses after the run are the oracle's, bit for bit."""
+    pen or on a plane, both precisions: poses after the run are the oracle's, bit for bit -- with dSpaceCollide's pairs
+    found by the host sweep (small worlds' default) and by the device search (DMX_COMPAT_DEVICE_PAIRS=1: what worlds of
+    thousands of bodies use), the user's callback seeing the same pairs in the same order either way."""
     rng = np.random.default_rng(500 + seed)
     single = bool(seed % 2)
     n = int(rng.integers(8, 160))
@@ -212,7 +215,7 @@ def test_random_spawns_through_ode_api_match_oracle(tmp_path, seed):
     dt = 1.0 / float(rng.choice([60.0, 120.0]))
     steps = int(rng.integers(120, 320))
     exe = _build_harness(str(tmp_path), single)
-    got = _run_harness(exe, _scene_text(dt, steps, use_plane, statics, bodies))
+    got = _run_harness(exe, _scene_text(dt, steps, use_plane, statics, bodies), env={"DMX_COMPAT_DEVICE_PAIRS": device_pairs})
     ref, ow = _oracle_poses("float32" if single else "float64", dt, steps, use_plane, statics, bodies)
     assert np.all(np.isfinite(ref))
     assert np.array_equal(got.astype(ref.dtype), ref), (seed, n, use_plane, dt, steps, np.abs(got - ref).max())
@@ -234,7 +237,8 @@ def test_bodies_spawned_between_ticks_and_poses_read_every_frame(tmp_path, seed)
     dt = 1.0 / 120.0
     exe = _build_harness(str(tmp_path), single)
     got = _run_harness(exe, _scene_text(dt, steps, use_plane, statics, bodies),
-                       env={"HARNESS_SPAWN": f"{up_front} {every}", "HARNESS_READBACK": str(int(rng.integers(1, 4)))})
+                       env={"HARNESS_SPAWN": f"{up_front} {every}", "HARNESS_READBACK": str(int(rng.integers(1, 4))),
+                            "DMX_COMPAT_DEVICE_PAIRS": str(seed % 2)})
     ref, ow = _oracle_poses("float32" if single else "float64", dt, steps, use_plane, statics, bodies, up_front, every)
     assert np.array_equal(got.astype(ref.dtype), ref), (seed, n, up_front, every, steps, np.abs(got - ref).max())
 
@@ -360,3 +364,24 @@ def test_dworldstep_in_the_reference_pen_matches_the_oracles_exact_solve(tmp_pat
     assert _rel(got, ref) <= 1e-5
     quick, _ = _oracle_poses("float64", dt, steps, False, statics, bodies, exact=False)
     assert _rel(quick, ref) > 1e-5                       # the two steppers are not the same computation
+
+
+@pytest.mark.gpu
+def test_large_world_through_ode_api_takes_its_pairs_from_the_device(tmp_path):
+    """3 000 bodies through the ODE API (well past MAX_BODIES, inc/body.h:6): above 2 048 bodies dSpaceCollide's pair search
+    runs on the device by default; poses equal the oracle's, which equal the host search's"""
+    rng = np.random.default_rng(77)
+    n = 3000
+    bodies = []
+    for k in range(n):                        # a 60 x 50 grid of the spawner's boxes / spheres, close enough to collide as they tumble
+        kind, size, _ = pkg.scenes.reference_spawn(1, seed=1000 + k)[0]
+        bodies.append((kind, size, (1.1 * (k % 60) - 33.0, 1.0 + 2.0 * rng.random(), 1.1 * (k // 60) - 27.0)))
+    statics = [((100.0, 1.0, 100.0), (0.0, 0.0, 0.0), pkg.scenes._rot_z(0.0))]
+    dt, steps = 1.0 / 60.0, 40
+    exe = _build_harness(str(tmp_path), False)
+    text = _scene_text(dt, steps, False, statics, bodies)
+    got = _run_harness(exe, text)
+    ref, ow = _oracle_poses("float64", dt, steps, False, statics, bodies)
+    assert ow.n_body_pairs() > 100
+    assert np.array_equal(got, ref), np.abs(got - ref).max()
+    assert np.array_equal(_run_harness(exe, text, env={"DMX_COMPAT_DEVICE_PAIRS": "0"}), ref)
