@@ -141,9 +141,11 @@ class BatchWorld:
 
     # -- checkpoint / resume ---------------------------------------------------------------------------------
     def checkpoint(self):
-        """Everything a later `restore` needs to continue bit for bit: the 13-real state, the accumulators and the
-        per-body constants (the reference keeps no resumable state -- its 60 Hz snapshot holds poses only, SURVEY
-        section 5 -- so this is new surface, built on Download)."""
+        """The per-body data a later `restore` needs to continue bit for bit: the 13-real state, the force / torque
+        accumulators and the per-body constants (mass, inertia, extents).  NOT in it: geometry classes, the hull, static
+        boxes, plane, gravity, solver and surface parameters, active count -- a fresh batch is set up from the scene first,
+        then restored.  (The reference keeps no resumable state -- its 60 Hz snapshot holds poses only, SURVEY section 5 --
+        so this is new surface, built on Download.)"""
         self.synchronize()
         return {"state": self.download(STATE), "force": self.download(FORCE), "torque": self.download(TORQUE),
                 "mass": self.download(MASS), "inertia": self.download(INERTIA), "sides": self.download(SIDES)}
@@ -151,8 +153,8 @@ class BatchWorld:
     def restore(self, ckpt):
         self.upload(MASS, ckpt["mass"]); self.upload(INERTIA, ckpt["inertia"]); self.upload(SIDES, ckpt["sides"])
         self.upload(STATE, ckpt["state"])                    # stored as given: no renormalisation of the quaternions
-        if np.any(ckpt["force"]) or np.any(ckpt["torque"]):
-            self.upload(FORCE, ckpt["force"]); self.upload(TORQUE, ckpt["torque"])
+        # always, zeros included: accumulators added to the live batch since the checkpoint must not act after the restore
+        self.upload(FORCE, ckpt["force"]); self.upload(TORQUE, ckpt["torque"])
 
     def state(self):
         return (self.download(POS), self.download(QUAT), self.download(LVEL), self.download(AVEL))

@@ -784,6 +784,7 @@ def test_checkpoint_and_resume_continue_bit_for_bit():
         w.step(H, 90); w.synchronize()
         ref = w.state()
         w.step(H, 13)                                       # wander off, then come back
+        w.upload(pkg.batch.FORCE, np.full((scene.n, 3), 5.0, np.float32))     # dBodyAddForce since the checkpoint: must not survive the restore
         w.restore(ck)
         w.step(H, 90); w.synchronize()
         _compare(w.state(), ref)
