@@ -528,13 +528,17 @@ __global__ __launch_bounds__(256) void ex_fill(const uint32_t *__restrict__ keys
 }
 
 // ---- 9. which islands get a workgroup: bg[isl] = (rows << 32 | 1) for those, 0 otherwise and for the padding -------
-__global__ __launch_bounds__(256) void ex_bigflags(const int *__restrict__ con_off, ExactCaps cap, int rpc, int big_rows,
-                                                   uint64_t *__restrict__ bg, const ExactCounts *__restrict__ C)
+__global__ __launch_bounds__(256) void ex_bigflags(const int *__restrict__ con_off, const int *__restrict__ body_off, ExactCaps cap,
+                                                   int rpc, int big_rows, uint64_t *__restrict__ bg, const ExactCounts *__restrict__ C)
 {
     const uint32_t ni = C->overflow ? 0u : C->ni;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap.inv; i += gridDim.x * blockDim.x) {
         uint64_t v = 0;
-        if (i < ni) { const int m = rpc * (con_off[i + 1] - con_off[i]); if (m >= big_rows) v = ((uint64_t)(uint32_t)m << 32) | 1u; }
+        if (i < ni) {
+            const int nc = con_off[i + 1] - con_off[i], m = rpc * nc;
+            const bool single = (body_off[i + 1] - body_off[i]) == 1 && nc >= 1 && nc <= 4;      // solve_singles' islands
+            if (m >= big_rows && !single) v = ((uint64_t)(uint32_t)m << 32) | 1u;
+        }
         bg[i] = v;
     }
 }
@@ -667,7 +671,7 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
     hipLaunchKernelGGL(ex_bounds, dim3(grid_for(ne)), dim3(256), 0, st, B.keys_s, B.sc, B.sinc, cap, B.body_off, B.con_off, B.row_off, B.counts);
     hipLaunchKernelGGL(ex_fill, dim3(grid_for(ne)), dim3(256), 0, st, B.keys_s, B.vals_s, B.sc, B.sinc, B.cc, B.inv, B.pairs, B.con_off, cap, rpc,
                        B.bodies, B.cb1, B.cb2, B.csrc, B.crow);
-    hipLaunchKernelGGL(ex_bigflags, dim3(grid_for(cap.inv)), dim3(256), 0, st, B.con_off, cap, rpc, big_rows, B.bg, B.counts);
+    hipLaunchKernelGGL(ex_bigflags, dim3(grid_for(cap.inv)), dim3(256), 0, st, B.con_off, B.body_off, cap, rpc, big_rows, B.bg, B.counts);
     tb = B.temp_bytes;
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.bg, B.binc, (size_t)cap.inv, rocprim::plus<uint64_t>(), st));
     hipLaunchKernelGGL(ex_levels, dim3((unsigned)(((size_t)cap.inv + 63) / 64)), dim3(64), 0, st, B.con_off, B.body_off, B.cb1, B.cb2, B.bg, B.binc,

@@ -405,6 +405,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     I.lev_off = B.lev_off; I.lev_rows = B.lev_rows; I.row_level = B.row_level;
     I.big_max_bodies = (int)C.big_max_bodies; I.big_max_width = (int)C.big_max_width;
     I.rows = (T *)b->jd_rows.p; I.rowjb = (int *)b->jd_rowjb.p; I.bscr = (T *)b->jd_bscr.p; I.local = (int *)b->jd_local.p;
+    I.singles = 1;
     // (cmode / cmu / cbounce ... stay null: every contact carries the batch's surface, NearCallback's policy, main.c:684-687)
     HIP_TRY(hipMemsetAsync(b->diag_isl, 0, sizeof(StepDiag), b->stream));
     HIP_TRY(launch_islands<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, b->stream));

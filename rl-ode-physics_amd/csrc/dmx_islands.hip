@@ -289,6 +289,144 @@ __device__ __forceinline__ void finish_body(T *S, const uint8_t *bflags, int64_t
     for (int j = 0; j < 6; j++) S[slab_ix(C_FORCE + j, s)] = T(0);
 }
 
+// ================================================================================ one lane per single-body island, rows in registers
+// A body touching static geometry only (the ground plane, static boxes) is an island of its own: all its rows share the one
+// body, so the sweep is a pure chain -- a wavefront per island (solve_island_wg) would run one lane at a time.  Here a LANE
+// owns the island: up to SINGLE_MAXC contacts x 3 rows live in its registers (no row traffic at all), 64 islands per wave.
+// Same phase arithmetic as stage_body / contact_rows / body_tmp / row_setup / row_sor / finish_body with the second body
+// absent, operation for operation: same bits.  (What a box resting on the reference's floor, main.c:115, costs per tick.)
+constexpr int SINGLE_MAXC = 4;
+
+template <class T> __device__ __forceinline__ bool island_is_single(const IslandSet<T> &I, int isl)
+{
+    const int nb = I.body_off[isl + 1] - I.body_off[isl], nc = I.con_off[isl + 1] - I.con_off[isl];
+    return nb == 1 && nc >= 1 && nc <= SINGLE_MAXC;
+}
+
+template <class T> struct RowS { T J[6], iMJ[6], rhs, ad, lam; };
+
+template <class T>
+__global__ __launch_bounds__(64) void solve_singles(T *__restrict__ S, const uint8_t *__restrict__ bflags, int64_t stride,
+                                                    IslandSet<T> I, StepParams<T> P, StepDiag *__restrict__ diag)
+{
+    const int isl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (isl >= I.n_islands || !island_is_single(I, isl)) return;
+    const T h = P.h, hinv = T(1) / h;
+    const int s = I.bodies[I.body_off[isl]];
+    const int c0 = I.con_off[isl], nc = I.con_off[isl + 1] - c0;
+    T b[BW_COUNT];
+    stage_body(S, bflags, stride, I, P, b, s, 0);
+    const bool own_surface = I.cmu != nullptr, ind = I.csrc != nullptr;
+    const V3<T> x1 = ldS(S, stride, C_POS, s), v1 = ldS(S, stride, C_LVEL, s), w1 = ldS(S, stride, C_AVEL, s);
+    constexpr int MAXR = 3 * SINGLE_MAXC;
+    RowS<T> row[MAXR];
+    bool valid[MAXR];
+    T lo_f[SINGLE_MAXC], hi_f[SINGLE_MAXC];           // friction bounds of contact c (normal rows: [0, inf))
+    // ---- contact_rows, second body absent
+#pragma unroll
+    for (int c = 0; c < SINGLE_MAXC; c++) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) valid[3 * c + d] = false;
+        lo_f[c] = hi_f[c] = T(0);
+        if (c < nc) {
+            const int ci = c0 + c;
+            const size_t gi = ind ? (size_t)I.csrc[ci] : (size_t)ci;
+            const V3<T> normal = ld3((ind ? I.gnormal : I.cnormal) + 3 * gi);
+            const V3<T> cpos = ld3((ind ? I.gpos : I.cpos) + 3 * gi);
+            const V3<T> c1 = { cpos.x - x1.x, cpos.y - x1.y, cpos.z - x1.z };
+            const int mode = own_surface ? I.cmode[ci] : P.surf_mode;
+            T mu = own_surface ? I.cmu[ci] : P.mu;
+            if (mu < 0) mu = 0;
+            const int rpc = mu > 0 ? 3 : 1;
+            V3<T> dir[3];
+            dir[0] = normal;
+            dir[1] = dir[2] = { T(0), T(0), T(0) };
+            if (rpc == 3) plane_space(normal, dir[1], dir[2]);
+            lo_f[c] = -mu; hi_f[c] = mu;
+#pragma unroll
+            for (int dnum = 0; dnum < 3; dnum++) {
+                if (dnum < rpc) {
+                    RowS<T> &r = row[3 * c + dnum];
+                    valid[3 * c + dnum] = true;
+                    r.J[0] = dir[dnum].x; r.J[1] = dir[dnum].y; r.J[2] = dir[dnum].z;
+                    const V3<T> a = cross(c1, dir[dnum]);
+                    r.J[3] = a.x; r.J[4] = a.y; r.J[5] = a.z;
+                    T cval = T(0), cfm = P.cfm;
+                    if (dnum == 0) {
+                        T erp = P.erp;
+                        if (mode & SURF_SOFT_ERP) erp = own_surface ? I.csoft_erp[ci] : T(0);
+                        if (mode & SURF_SOFT_CFM) cfm = own_surface ? I.csoft_cfm[ci] : T(0);
+                        T depth = ind ? I.gdepth[gi] : I.cdepth[ci];
+                        if (depth < 0) depth = 0;
+                        cval = (hinv * erp) * depth;
+                        if (mode & SURF_BOUNCE) {
+                            const T outgoing = dot3p(r.J, v1) + dot3p(r.J + 3, w1);
+                            const T bv = own_surface ? I.cbounce_vel[ci] : P.bounce_vel;
+                            if (bv >= 0 && (-outgoing) > bv) {
+                                const T newc = -(own_surface ? I.cbounce[ci] : P.bounce) * outgoing;
+                                if (newc > cval) cval = newc;
+                            }
+                        }
+                    }
+                    r.rhs = cval; r.ad = cfm; r.lam = T(0);
+                }
+            }
+        }
+    }
+    body_tmp(S, stride, b, s, hinv);
+    // ---- row_setup
+#pragma unroll
+    for (int i = 0; i < MAXR; i++) {
+        if (valid[i]) {
+            RowS<T> &r = row[i];
+            T sum = T(0);
+#pragma unroll
+            for (int j = 0; j < 6; j++) sum = fma_(r.J[j], b[BW_TMP + j], sum);
+            r.rhs = fma_(r.rhs, hinv, -sum);
+            r.ad *= hinv;
+#pragma unroll
+            for (int j = 0; j < 3; j++) r.iMJ[j] = b[BW_INVM] * r.J[j];
+            const V3<T> ja1 = { r.J[3], r.J[4], r.J[5] };
+            r.iMJ[3] = dot3p(b + BW_INVI + 0, ja1); r.iMJ[4] = dot3p(b + BW_INVI + 3, ja1); r.iMJ[5] = dot3p(b + BW_INVI + 6, ja1);
+            T s2 = T(0);
+#pragma unroll
+            for (int j = 0; j < 6; j++) s2 = fma_(r.iMJ[j], r.J[j], s2);
+            const T cfm = r.ad;
+            const T ad = P.sor_w / (s2 + cfm);
+#pragma unroll
+            for (int j = 0; j < 6; j++) r.J[j] *= ad;
+            r.rhs *= ad;
+            r.ad = ad * cfm;
+        }
+    }
+    // ---- the sweeps (row_sor), rows in creation order
+    double resid = 0.0;
+    T *fc = b + BW_FC;
+    for (int it = 0; it < P.iters; it++) {
+        const bool last = (it == P.iters - 1);
+#pragma unroll
+        for (int i = 0; i < MAXR; i++) {
+            if (valid[i]) {
+                RowS<T> &r = row[i];
+                const T old = r.lam;
+                T delta = fma_(-old, r.ad, r.rhs);
+                delta -= fma_(fc[5], r.J[5], fma_(fc[4], r.J[4], fma_(fc[3], r.J[3], fma_(fc[2], r.J[2], fma_(fc[1], r.J[1], fc[0] * r.J[0])))));
+                const T lo = (i % 3 == 0) ? T(0) : lo_f[i / 3], hi = (i % 3 == 0) ? Limits<T>::inf() : hi_f[i / 3];
+                const T nl = old + delta;
+                if (nl < lo) { delta = lo - old; r.lam = lo; }
+                else if (nl > hi) { delta = hi - old; r.lam = hi; }
+                else r.lam = nl;
+#pragma unroll
+                for (int j = 0; j < 6; j++) fc[j] = fma_(delta, r.iMJ[j], fc[j]);
+                if (last) resid += (double)tabs(delta);
+            }
+        }
+    }
+    finish_body(S, bflags, stride, b, s, true, h);
+    atomicAdd(&diag->contacts, (unsigned long long)nc);
+    atomicAdd(&diag->residual, resid);
+}
+
 // ================================================================================ one lane per island
 template <class T>
 __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uint8_t *__restrict__ bflags,
@@ -298,6 +436,7 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
     const int isl = blockIdx.x * blockDim.x + threadIdx.x;
     if (isl >= I.n_islands) return;
     if (I.big != nullptr && I.big[isl] >= 0) return;          // a workgroup owns this one (solve_island_wg)
+    if (I.singles && island_is_single(I, isl)) return;        // one body, a few static contacts: solve_singles
     const T h = P.h, hinv = T(1) / h;
     const int b0 = I.body_off[isl], nb = I.body_off[isl + 1] - b0;
     const int c0 = I.con_off[isl], nc = I.con_off[isl + 1] - c0;
@@ -684,6 +823,7 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
     if (I.n_big < I.n_islands) {
         const unsigned grid = (unsigned)((I.n_islands + 63) / 64);
         hipLaunchKernelGGL((solve_islands<T>), dim3(grid), dim3(64), 0, st, S, bflags, stride, I, P, diag);
+        if (I.singles) hipLaunchKernelGGL((solve_singles<T>), dim3(grid), dim3(64), 0, st, S, bflags, stride, I, P, diag);
     }
     if (I.n_big > 0) {
         const size_t want = (size_t)I.big_max_bodies * 6 * sizeof(T);

@@ -153,6 +153,8 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
                 }
         for (int i = 0; i < ni; i++) {
             if (m_of[(size_t)i] < (exact ? 1 : big_island_rows())) continue;
+            // one body with 1..4 contacts: solve_singles' island (one lane, rows in registers), never a workgroup's
+            if (!exact && island_bodies[(size_t)i] == 1 && con_start[(size_t)i + 1] - con_start[(size_t)i] <= 4) continue;
             big_list_h.push_back(i);
             row_base.push_back(rows_total);
             rows_total += m_of[(size_t)i];
@@ -323,6 +325,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     I.cpos = dr; I.cnormal = dr + 3 * (size_t)nc; I.cdepth = I.cnormal + 3 * (size_t)nc; I.cmu = I.cdepth + nc;
     I.cbounce = I.cmu + nc; I.cbounce_vel = I.cbounce + nc; I.csoft_erp = I.cbounce_vel + nc; I.csoft_cfm = I.csoft_erp + nc;
     I.rows = (T *)b->jd_rows.p; I.rowjb = (int *)b->jd_rowjb.p; I.bscr = (T *)b->jd_bscr.p; I.local = (int *)b->jd_local.p;
+    I.singles = exact ? 0 : 1;
 
     StepParams<T> P = dmx_make_params<T>(b, h);
     HIP_TRY(hipMemsetAsync(b->diag_isl, 0, sizeof(StepDiag), b->stream));
