@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uin
                 if (cnt > (uint32_t)G.cap) cnt = (uint32_t)G.cap;
                 for (uint32_t s = 0; s < cnt; s++) {
                     const int64_t j = G.items[(size_t)h * G.cap + s];
-                    if (j == i) continue;
+                    if (j == i || !classes_collide(gt, gtype[j])) continue;
                     const T ddx = S[slab_ix(C_POS + 0, j)] - x, ddz = S[slab_ix(C_POS + 2, j)] - z;
                     const T g = tsqrt<T>(ddx * ddx + ddz * ddz) - ri - S[slab_ix(C_BPR, j)];
                     if (g < gap) gap = g;

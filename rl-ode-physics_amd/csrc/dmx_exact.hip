@@ -54,7 +54,8 @@ template <class T> __device__ __forceinline__ void aabb_of(const T *S, const uin
 
 // Walk the 3x3 columns around body i and call f(j) for every other body whose AABB overlaps i's (each once).
 template <class T, class F>
-__device__ __forceinline__ void for_each_partner(const T *S, const uint8_t *gtype, int64_t i, const GridParams<T> &G, F f)
+__device__ __forceinline__ void for_each_partner(const T *S, const uint8_t *gtype, int64_t i, const GridParams<T> &G, F f,
+                                                 uint32_t *unsupported = nullptr)
 {
     const T *bi = G.aabb + 6 * i;            // every body's AABB, left by bp_insert
     const T lo[3] = { bi[0], bi[1], bi[2] }, hi[3] = { bi[3], bi[4], bi[5] };
@@ -68,6 +69,17 @@ __device__ __forceinline__ void for_each_partner(const T *S, const uint8_t *gtyp
             for (uint32_t s = 0; s < cnt; s++) {
                 const int64_t j = G.items[(size_t)h * G.cap + s];
                 if (j == i) continue;
+                if (!classes_collide(gtype[i], gtype[j])) {
+                    // no collider for this pair of classes (convex-convex, convex-sphere): not a pair; said once per pair when
+                    // the bounding spheres reach one another
+                    if (j > i && unsupported != nullptr) {
+                        const T dx = S[slab_ix(C_POS + 0, i)] - S[slab_ix(C_POS + 0, j)], dy = S[slab_ix(C_POS + 1, i)] - S[slab_ix(C_POS + 1, j)],
+                                dz = S[slab_ix(C_POS + 2, i)] - S[slab_ix(C_POS + 2, j)];
+                        const T rr = S[slab_ix(C_BPR, i)] + S[slab_ix(C_BPR, j)];
+                        if (dx * dx + dy * dy + dz * dz < rr * rr) atomicAdd(unsupported, 1u);
+                    }
+                    continue;
+                }
                 // hashed buckets can mix columns: keep only true 3x3 neighbours so (i,j) is met in one cell only
                 const int jx = (int)floor((double)(S[slab_ix(C_POS + 0, j)] * G.inv_cell));
                 const int jz = (int)floor((double)(S[slab_ix(C_POS + 2, j)] * G.inv_cell));
@@ -96,7 +108,7 @@ __global__ __launch_bounds__(256) void ex_pair_count(const T *__restrict__ S, co
             any = 1;
             if (j >= n_active) { if (atomicOr(&C->cross, 1u) == 0u) { C->cross_a = (uint32_t)i; C->cross_b = (uint32_t)j; } }
             else if (j > i) owned++;
-        });
+        }, &C->unsupported);
         // static box geoms are "big geoms against everyone": a body whose AABB overlaps one goes through the exact path too
         const T *bi = G.aabb + 6 * i;
         for (int s = 0; s < G.n_static; s++) {
@@ -292,8 +304,8 @@ __global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const u
 // walk keeps.
 template <class T>
 __device__ __forceinline__ int wave_box_convex(const V3<T> &xb, const M3<T> &Rb, const T *side, const V3<T> &xh, const M3<T> &Rh,
-                                               const StepParams<T> &P, int maxc, bool negate, int lane, T *gpos, T *gnormal,
-                                               T *gdepth, size_t slot0)
+                                               T hull_radius, const StepParams<T> &P, int maxc, bool negate, int lane, T *gpos,
+                                               T *gnormal, T *gdepth, size_t slot0)
 {
     const T half[3] = { T(0.5) * side[0], T(0.5) * side[1], T(0.5) * side[2] };
     int contacts = 0;
@@ -330,6 +342,9 @@ __device__ __forceinline__ int wave_box_convex(const V3<T> &xb, const M3<T> &Rb,
         V3<T> cw = mulv(Rb, l);
         cw.x += xb.x; cw.y += xb.y; cw.z += xb.z;
         const V3<T> d = { cw.x - xh.x, cw.y - xh.y, cw.z - xh.z };
+        // a corner inside the hull is inside the hull's bounding sphere (slack for rounding): most corners of a floor-sized
+        // box are nowhere near it and skip the walk over the faces
+        if (d.x * d.x + d.y * d.y + d.z * d.z > hull_radius * hull_radius * T(1.0001)) continue;
         V3<T> r;
         r.x = fma_(Rh.m[2][0], d.z, fma_(Rh.m[1][0], d.y, Rh.m[0][0] * d.x));
         r.y = fma_(Rh.m[2][1], d.z, fma_(Rh.m[1][1], d.y, Rh.m[0][1] * d.x));
@@ -420,7 +435,7 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
                     M3<T> sR;
                     for (int a = 0; a < 3; a++) for (int c2 = 0; c2 < 3; c2++) sR.m[a][c2] = sb[SBOX_R + 3 * a + c2];
                     const T sside[3] = { sb[SBOX_SIDE], sb[SBOX_SIDE + 1], sb[SBOX_SIDE + 2] };
-                    nc = wave_box_convex<T>(sx, sR, sside, H.x, H.R, P, maxc, true, lane, gpos, gnormal, gdepth,
+                    nc = wave_box_convex<T>(sx, sR, sside, H.x, H.R, H.side[0], P, maxc, true, lane, gpos, gnormal, gdepth,
                                             cap.static_slot0() + (size_t)8 * (e - cap.inv));
                 }
             }
@@ -435,16 +450,9 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
                 const BodyGeomX<T> Bx = geom_of<T>(S, gtype, gi == GEOM_BOX ? i : j);
                 const BodyGeomX<T> H = geom_of<T>(S, gtype, gi == GEOM_BOX ? j : i);
                 if (P.hull_n > 0)
-                    nc = wave_box_convex<T>(Bx.x, Bx.R, Bx.side, H.x, H.R, P, maxc, gi != GEOM_BOX, lane, gpos, gnormal, gdepth,
+                    nc = wave_box_convex<T>(Bx.x, Bx.R, Bx.side, H.x, H.R, H.side[0], P, maxc, gi != GEOM_BOX, lane, gpos, gnormal, gdepth,
                                             cap.pair_slot0() + (size_t)8 * p);
-            } else if (lane == 0) {
-                // convex-convex / convex-sphere: no collider.  Counted when the bounding spheres reach one another (the
-                // AABBs of convex bodies are their spheres' boxes: an AABB pair alone says little)
-                const T dx = S[slab_ix(C_POS + 0, i)] - S[slab_ix(C_POS + 0, j)], dy = S[slab_ix(C_POS + 1, i)] - S[slab_ix(C_POS + 1, j)],
-                        dz = S[slab_ix(C_POS + 2, i)] - S[slab_ix(C_POS + 2, j)];
-                const T rr = S[slab_ix(C_SIDES, i)] + S[slab_ix(C_SIDES, j)];
-                if (dx * dx + dy * dy + dz * dz < rr * rr) atomicAdd(&C->unsupported, 1u);
-            }
+            }       // (pairs of classes without a collider never reach the pair list: for_each_partner)
         }
         if (lane == 0) cc[e] = (uint32_t)nc;
     }

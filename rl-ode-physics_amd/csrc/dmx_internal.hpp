@@ -42,6 +42,16 @@ __host__ __device__ __forceinline__ int64_t slab_ix(int c, int64_t i)
 
 // GEOM_CONVEX: the batch's one convex hull (StepParams::hull); its bounding radius sits in sides[0] like a sphere's
 enum : int { GEOM_NONE = 0, GEOM_SPHERE = 1, GEOM_BOX = 2, GEOM_CONVEX = 3 };
+// can a geom of class a ever produce a contact with one of class b?  A convex hull has colliders against boxes (and the
+// ground plane / static boxes) only; convex-convex and convex-sphere pairs pass through one another, so the broadphase
+// need not keep them apart nor hand them to the narrowphase
+__host__ __device__ __forceinline__ bool classes_collide(int a, int b)
+{
+    if (a == GEOM_NONE || b == GEOM_NONE) return false;
+    if (a == GEOM_CONVEX) return b == GEOM_BOX;
+    if (b == GEOM_CONVEX) return a == GEOM_BOX;
+    return true;
+}
 constexpr int CONVEX_MAXC = 8;      // contact slots per convex body per tick (the reference's MAX_CONTACTS, main.c:675)
 enum : int { SURF_BOUNCE = 0x004, SURF_SOFT_ERP = 0x008, SURF_SOFT_CFM = 0x010 };
 // per-slot body flags (uint8 array)
