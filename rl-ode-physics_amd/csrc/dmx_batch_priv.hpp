@@ -111,7 +111,7 @@ struct dmxBatch {
     bool bp_valid = false;                     // safe zones match the current constant data
     int bp_chunk = 0;                          // current fast-chunk length in ticks (adaptive, dmx_general.cpp)
     uint32_t bp_crowded = 0;                   // bodies whose safe radius is <= 0 at the last build
-    double bp_rmax = 0;
+    double bp_rmax = 0, bp_rmax_box = 0, bp_rmax_solid = 0;
     uint32_t bp_mask = 0; int bp_cap = 8; int bp_xbits = -1;      // -1: not chosen yet
     DevBuf bp_count, bp_items, bp_flags, bp_pairs, bp_inpair, bp_snapshot, bp_idx, bp_gather;
     DevBuf np_pos, np_normal, np_depth, np_count, np_pairs;   // device narrowphase output of the exact tick

@@ -87,8 +87,9 @@ __global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uin
     if (gt != GEOM_NONE) {
         const T ri = bound_radius<T>(gt, S, stride, i);
         const int ix = (int)floor((double)(x * G.inv_cell)), iz = (int)floor((double)(z * G.inv_cell));
-        // nothing outside the 3x3 block is closer than one cell: gap >= cell - r_i - r_max
-        T gap = G.cell - ri - G.r_max;
+        // nothing outside the 3x3 block is closer than one cell: gap >= cell - r_i - (largest radius of a class i collides with)
+        const T rm = gt == GEOM_CONVEX ? G.r_max_box : gt == GEOM_SPHERE ? G.r_max_solid : G.r_max;
+        T gap = rm > T(0) ? G.cell - ri - rm : Limits<T>::inf();
         for (int dz = -1; dz <= 1; dz++)
             for (int dx = -1; dx <= 1; dx++) {
                 const uint32_t h = cell_hash(ix + dx, iz + dz, G.mask, G.xbits);

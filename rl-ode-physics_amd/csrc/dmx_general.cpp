@@ -31,6 +31,7 @@ template <class T> GridParams<T> grid_of(dmxBatch *b)
 {
     GridParams<T> G;
     G.r_max = (T)b->bp_rmax;
+    G.r_max_box = (T)b->bp_rmax_box; G.r_max_solid = (T)b->bp_rmax_solid;
     G.cell = (T)(2.0 * kSkin * b->bp_rmax);
     G.inv_cell = T(1) / G.cell;
     G.mask = b->bp_mask;
@@ -54,14 +55,17 @@ int read_flags(dmxBatch *b)
 int ensure_buffers(dmxBatch *b)
 {
     if (b->bp_rmax <= 0) {
-        double r = 0;
+        double r = 0, rbox = 0, rsolid = 0;
         for (int64_t i = 0; i < b->n; i++) {
             const double *s = &b->h_sides[(size_t)3 * i];
             const double ri = (b->h_gtype[(size_t)i] == GEOM_SPHERE || b->h_gtype[(size_t)i] == GEOM_CONVEX) ? s[0]     // convex: the hull's bounding radius
                             : b->h_gtype[(size_t)i] == GEOM_BOX ? 0.5 * std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]) : 0.0;
             r = std::max(r, ri);
+            if (b->h_gtype[(size_t)i] == GEOM_BOX) rbox = std::max(rbox, ri);
+            if (b->h_gtype[(size_t)i] == GEOM_BOX || b->h_gtype[(size_t)i] == GEOM_SPHERE) rsolid = std::max(rsolid, ri);
         }
         b->bp_rmax = r > 0 ? r : 1.0;
+        b->bp_rmax_box = rbox; b->bp_rmax_solid = rsolid;
     }
     if (!b->bp_mask) {
         uint32_t h = 1024;

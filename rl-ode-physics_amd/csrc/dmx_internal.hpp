@@ -126,6 +126,8 @@ enum : int { BPC_ALL = 1, BPC_FIRST = 2, BPC_LAST = 4 };
 enum : int { BPF_OVERFLOW = 0, BPF_CROWDED = 1, BPF_NPAIRS = 2, BPF_VIOLATION = 3, BPF_WARN = 4, BPF_COUNT = 5 };
 template <class T> struct GridParams {
     T cell, inv_cell, r_max;
+    T r_max_box, r_max_solid;   // largest bounding radius among the boxes / among boxes and spheres (0: none): what a convex hull /
+                                // a sphere can collide with at all (classes_collide)
     uint32_t mask;         // table size - 1 (power of two)
     int xbits;             // > 0: the table is a 2-D torus of 2^xbits columns per row (neighbouring cells are neighbouring
                            // entries: coalesced lookups); 0: scrambled hash (scenes too elongated for the torus)
