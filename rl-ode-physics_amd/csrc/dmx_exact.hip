@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void ex_bigflags(const int *__restrict__ con_o
         uint64_t v = 0;
         if (i < ni) {
             const int nc = con_off[i + 1] - con_off[i], m = rpc * nc;
-            const bool single = (body_off[i + 1] - body_off[i]) == 1 && nc >= 1 && nc <= 4;      // solve_singles' islands
+            const bool single = (body_off[i + 1] - body_off[i]) == 1 && nc >= 1 && nc <= 8;      // solve_singles' / solve_singles_lds' islands
             if (m >= big_rows && !single) v = ((uint64_t)(uint32_t)m << 32) | 1u;
         }
         bg[i] = v;

@@ -83,7 +83,7 @@ template <class T> struct IslandSet {
     // the widest level of any schedule (64 lanes per island are enough when no level is wider)
     int big_max_bodies, big_max_width;
     const int *row_level;  // level of every scheduled row, laid out like lev_rows (an island's rows start at its lev_off[0])
-    int singles;           // 1: islands of one body with 1..4 contacts are left to solve_singles (one lane each, rows in registers);
+    int singles;           // 1: islands of one body with 1..8 contacts are left to solve_singles / solve_singles_lds (one lane each);
                            // whoever builds `big` must then keep such islands out of it
 };
 

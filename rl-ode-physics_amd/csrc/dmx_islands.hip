@@ -295,12 +295,13 @@ __device__ __forceinline__ void finish_body(T *S, const uint8_t *bflags, int64_t
 // owns the island: up to SINGLE_MAXC contacts x 3 rows live in its registers (no row traffic at all), 64 islands per wave.
 // Same phase arithmetic as stage_body / contact_rows / body_tmp / row_setup / row_sor / finish_body with the second body
 // absent, operation for operation: same bits.  (What a box resting on the reference's floor, main.c:115, costs per tick.)
-constexpr int SINGLE_MAXC = 4;
+constexpr int SINGLE_MAXC = 4;          // rows in registers (solve_singles)
+constexpr int SINGLE_MAXC_LDS = 8;      // rows in LDS (solve_singles_lds): a convex hull's eight contacts with the floor
 
 template <class T> __device__ __forceinline__ bool island_is_single(const IslandSet<T> &I, int isl)
 {
     const int nb = I.body_off[isl + 1] - I.body_off[isl], nc = I.con_off[isl + 1] - I.con_off[isl];
-    return nb == 1 && nc >= 1 && nc <= SINGLE_MAXC;
+    return nb == 1 && nc >= 1 && nc <= SINGLE_MAXC_LDS;
 }
 
 template <class T> struct RowS { T J[6], iMJ[6], rhs, ad, lam; };
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(64) void solve_singles(T *__restrict__ S, const uin
     const T h = P.h, hinv = T(1) / h;
     const int s = I.bodies[I.body_off[isl]];
     const int c0 = I.con_off[isl], nc = I.con_off[isl + 1] - c0;
+    if (nc > SINGLE_MAXC) return;                             // five to eight contacts: solve_singles_lds
     T b[BW_COUNT];
     stage_body(S, bflags, stride, I, P, b, s, 0);
     const bool own_surface = I.cmu != nullptr, ind = I.csrc != nullptr;
@@ -420,6 +422,123 @@ __global__ __launch_bounds__(64) void solve_singles(T *__restrict__ S, const uin
                 for (int j = 0; j < 6; j++) fc[j] = fma_(delta, r.iMJ[j], fc[j]);
                 if (last) resid += (double)tabs(delta);
             }
+        }
+    }
+    finish_body(S, bflags, stride, b, s, true, h);
+    atomicAdd(&diag->contacts, (unsigned long long)nc);
+    atomicAdd(&diag->residual, resid);
+}
+
+// The same island shape with five to eight contacts (a convex hull on the floor: up to 24 rows): too many rows for a lane's
+// registers, so they live in LDS, one column per lane (field f of row r of lane l at [(r * RS_FIELDS + f) * lanes + l]: a
+// wavefront's access to one field is one conflict-free LDS row).  64 islands per wave in f32 (90 KB of the CU's 160 KB), 32 in
+// f64.  Plain loops instead of unrolled register code; the arithmetic per row is the same sequence once more.
+enum : int { RS_J = 0, RS_IMJ = 6, RS_RHS = 12, RS_AD = 13, RS_LAM = 14, RS_FIELDS = 15 };
+
+template <class T>
+__global__ __launch_bounds__(64) void solve_singles_lds(T *__restrict__ S, const uint8_t *__restrict__ bflags, int64_t stride,
+                                                        IslandSet<T> I, StepParams<T> P, StepDiag *__restrict__ diag)
+{
+    extern __shared__ __align__(16) unsigned char rs_raw[];
+    T *rs = reinterpret_cast<T *>(rs_raw);
+    const int lanes = blockDim.x, lane = threadIdx.x;
+    const int isl = blockIdx.x * lanes + lane;
+    if (isl >= I.n_islands || !island_is_single(I, isl)) return;
+    const int c0 = I.con_off[isl], nc = I.con_off[isl + 1] - c0;
+    if (nc <= SINGLE_MAXC) return;                            // solve_singles has it
+    const T h = P.h, hinv = T(1) / h;
+    const int s = I.bodies[I.body_off[isl]];
+    T b[BW_COUNT];
+    stage_body(S, bflags, stride, I, P, b, s, 0);
+    const bool own_surface = I.cmu != nullptr, ind = I.csrc != nullptr;
+    const V3<T> x1 = ldS(S, stride, C_POS, s), v1 = ldS(S, stride, C_LVEL, s), w1 = ldS(S, stride, C_AVEL, s);
+    auto at = [&](int r, int f) -> T & { return rs[(size_t)(r * RS_FIELDS + f) * lanes + lane]; };
+    constexpr int MAXR = 3 * SINGLE_MAXC_LDS;
+    unsigned valid = 0;                                       // bit r: slot r (= 3 * contact + direction) holds a row
+    T lo_f[SINGLE_MAXC_LDS], hi_f[SINGLE_MAXC_LDS];
+    for (int c = 0; c < SINGLE_MAXC_LDS; c++) {
+        lo_f[c] = hi_f[c] = T(0);
+        if (c >= nc) continue;
+        const int ci = c0 + c;
+        const size_t gi = ind ? (size_t)I.csrc[ci] : (size_t)ci;
+        const V3<T> normal = ld3((ind ? I.gnormal : I.cnormal) + 3 * gi);
+        const V3<T> cpos = ld3((ind ? I.gpos : I.cpos) + 3 * gi);
+        const V3<T> c1 = { cpos.x - x1.x, cpos.y - x1.y, cpos.z - x1.z };
+        const int mode = own_surface ? I.cmode[ci] : P.surf_mode;
+        T mu = own_surface ? I.cmu[ci] : P.mu;
+        if (mu < 0) mu = 0;
+        const int rpc = mu > 0 ? 3 : 1;
+        V3<T> dir[3];
+        dir[0] = normal;
+        dir[1] = dir[2] = { T(0), T(0), T(0) };
+        if (rpc == 3) plane_space(normal, dir[1], dir[2]);
+        lo_f[c] = -mu; hi_f[c] = mu;
+        for (int dnum = 0; dnum < rpc; dnum++) {
+            const int r = 3 * c + dnum;
+            valid |= 1u << r;
+            T J[6] = { dir[dnum].x, dir[dnum].y, dir[dnum].z, T(0), T(0), T(0) };
+            const V3<T> a = cross(c1, dir[dnum]);
+            J[3] = a.x; J[4] = a.y; J[5] = a.z;
+            T cval = T(0), cfm = P.cfm;
+            if (dnum == 0) {
+                T erp = P.erp;
+                if (mode & SURF_SOFT_ERP) erp = own_surface ? I.csoft_erp[ci] : T(0);
+                if (mode & SURF_SOFT_CFM) cfm = own_surface ? I.csoft_cfm[ci] : T(0);
+                T depth = ind ? I.gdepth[gi] : I.cdepth[ci];
+                if (depth < 0) depth = 0;
+                cval = (hinv * erp) * depth;
+                if (mode & SURF_BOUNCE) {
+                    const T outgoing = dot3p(J, v1) + dot3p(J + 3, w1);
+                    const T bv = own_surface ? I.cbounce_vel[ci] : P.bounce_vel;
+                    if (bv >= 0 && (-outgoing) > bv) {
+                        const T newc = -(own_surface ? I.cbounce[ci] : P.bounce) * outgoing;
+                        if (newc > cval) cval = newc;
+                    }
+                }
+            }
+            for (int j = 0; j < 6; j++) at(r, RS_J + j) = J[j];
+            at(r, RS_RHS) = cval; at(r, RS_AD) = cfm; at(r, RS_LAM) = T(0);
+        }
+    }
+    body_tmp(S, stride, b, s, hinv);
+    for (int i = 0; i < MAXR; i++) {                          // row_setup
+        if (!(valid >> i & 1u)) continue;
+        T J[6], iMJ[6];
+        for (int j = 0; j < 6; j++) J[j] = at(i, RS_J + j);
+        T sum = T(0);
+        for (int j = 0; j < 6; j++) sum = fma_(J[j], b[BW_TMP + j], sum);
+        T rhs = fma_(at(i, RS_RHS), hinv, -sum);
+        const T cfm = at(i, RS_AD) * hinv;
+        for (int j = 0; j < 3; j++) iMJ[j] = b[BW_INVM] * J[j];
+        const V3<T> ja1 = { J[3], J[4], J[5] };
+        iMJ[3] = dot3p(b + BW_INVI + 0, ja1); iMJ[4] = dot3p(b + BW_INVI + 3, ja1); iMJ[5] = dot3p(b + BW_INVI + 6, ja1);
+        T s2 = T(0);
+        for (int j = 0; j < 6; j++) s2 = fma_(iMJ[j], J[j], s2);
+        const T ad = P.sor_w / (s2 + cfm);
+        for (int j = 0; j < 6; j++) { at(i, RS_J + j) = J[j] * ad; at(i, RS_IMJ + j) = iMJ[j]; }
+        rhs *= ad;
+        at(i, RS_RHS) = rhs;
+        at(i, RS_AD) = ad * cfm;
+    }
+    double resid = 0.0;
+    T *fc = b + BW_FC;
+    for (int it = 0; it < P.iters; it++) {                    // the sweeps (row_sor), rows in creation order
+        const bool last = (it == P.iters - 1);
+        for (int i = 0; i < MAXR; i++) {
+            if (!(valid >> i & 1u)) continue;
+            const T old = at(i, RS_LAM);
+            T delta = fma_(-old, at(i, RS_AD), at(i, RS_RHS));
+            delta -= fma_(fc[5], at(i, RS_J + 5), fma_(fc[4], at(i, RS_J + 4), fma_(fc[3], at(i, RS_J + 3),
+                     fma_(fc[2], at(i, RS_J + 2), fma_(fc[1], at(i, RS_J + 1), fc[0] * at(i, RS_J + 0))))));
+            const T lo = (i % 3 == 0) ? T(0) : lo_f[i / 3], hi = (i % 3 == 0) ? Limits<T>::inf() : hi_f[i / 3];
+            const T nl = old + delta;
+            T lam = nl;
+            if (nl < lo) { delta = lo - old; lam = lo; }
+            else if (nl > hi) { delta = hi - old; lam = hi; }
+            at(i, RS_LAM) = lam;
+#pragma unroll
+            for (int j = 0; j < 6; j++) fc[j] = fma_(delta, at(i, RS_IMJ + j), fc[j]);
+            if (last) resid += (double)tabs(delta);
         }
     }
     finish_body(S, bflags, stride, b, s, true, h);
@@ -823,7 +942,19 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
     if (I.n_big < I.n_islands) {
         const unsigned grid = (unsigned)((I.n_islands + 63) / 64);
         hipLaunchKernelGGL((solve_islands<T>), dim3(grid), dim3(64), 0, st, S, bflags, stride, I, P, diag);
-        if (I.singles) hipLaunchKernelGGL((solve_singles<T>), dim3(grid), dim3(64), 0, st, S, bflags, stride, I, P, diag);
+        if (I.singles) {
+            hipLaunchKernelGGL((solve_singles<T>), dim3(grid), dim3(64), 0, st, S, bflags, stride, I, P, diag);
+            // islands of 5..8 contacts keep their rows in LDS: 64 lanes x 24 rows x 15 fields (f32: 90 KB), 32 lanes in f64
+            const int lanes = sizeof(T) == 4 ? 64 : 32;
+            const size_t lds = (size_t)lanes * 3 * SINGLE_MAXC_LDS * RS_FIELDS * sizeof(T);
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_singles_lds<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((solve_singles_lds<T>), dim3((unsigned)((I.n_islands + lanes - 1) / lanes)), dim3(lanes), lds, st, S, bflags,
+                               stride, I, P, diag);
+        }
     }
     if (I.n_big > 0) {
         const size_t want = (size_t)I.big_max_bodies * 6 * sizeof(T);

@@ -153,8 +153,8 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
                 }
         for (int i = 0; i < ni; i++) {
             if (m_of[(size_t)i] < (exact ? 1 : big_island_rows())) continue;
-            // one body with 1..4 contacts: solve_singles' island (one lane, rows in registers), never a workgroup's
-            if (!exact && island_bodies[(size_t)i] == 1 && con_start[(size_t)i + 1] - con_start[(size_t)i] <= 4) continue;
+            // one body with 1..8 contacts: solve_singles' / solve_singles_lds' island (one lane), never a workgroup's
+            if (!exact && island_bodies[(size_t)i] == 1 && con_start[(size_t)i + 1] - con_start[(size_t)i] <= 8) continue;
             big_list_h.push_back(i);
             row_base.push_back(rows_total);
             rows_total += m_of[(size_t)i];
