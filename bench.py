@@ -231,7 +231,7 @@ def measure(cx, a, scene, layout, kind, dtype, *, exchanging, every_tick=False, 
     try:
         w.load_scene(scene)
         if exchanging:
-            w.set_active_count(scene.n)         # the slots behind are ghosts of the neighbours' boundary rows
+            w.set_active_count(layout.n_active)     # the slots behind are ghosts of the neighbours' boundary rows
         w.set_gyro_mode(a.gyro)
         if ticks_per_launch > 1:
             w.set_ticks_per_launch(ticks_per_launch)
@@ -246,7 +246,8 @@ def measure(cx, a, scene, layout, kind, dtype, *, exchanging, every_tick=False, 
             ops = pkg.shard.DeviceOps(w, cx.device, cx.stream)      # --force-exchange: the collective degenerates to a copy
         st = pkg.shard.ShardedStepper(w, layout, cx.rank, cx.world, exchange="boundary" if exchanging else "none",
                                       device=cx.device, stream=cx.stream, collide=collide and exchanging,
-                                      geometry=(scene.sides, scene.gtype), ops=ops, exchange_every_tick=every_tick,
+                                      geometry=(scene.sides, scene.gtype, scene.mass[:, 0], scene.inertia), ops=ops,
+                                      exchange_every_tick=every_tick,
                                       lazy=True)
         if settle_steps:
             st.run(H, settle_steps)             # let the bodies land: timed steps are all in contact

@@ -24,7 +24,7 @@ BATCH_SYMBOLS = [
     "dmxBatchChunkBegin", "dmxBatchChunkTick", "dmxBatchCheckZonesOnStream", "dmxBatchChunkEnd",
     "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream", "dmxBatchSetConvexHull", "dmxBatchChunkTicks", "dmxBatchSetTicksPerLaunch",
     "dmxBatchSetSnapshotMode", "dmxBatchSetStaticBoxes", "dmxBatchSetStepper", "dmxBatchSetConvexHullFaces",
-    "dmxBatchCollisionStatsEx", "dmxBatchFindPairs",
+    "dmxBatchCollisionStatsEx", "dmxBatchFindPairs", "dmxBatchCrossPairs",
 ]
 
 _lib = None
@@ -108,5 +108,6 @@ def load():
     sig("dmxBatchSetConvexHullFaces", I, P, C.c_int32, P)
     sig("dmxBatchCollisionStatsEx", I, P, C.POINTER(L))
     sig("dmxBatchFindPairs", I, P, C.POINTER(P), C.POINTER(L), C.POINTER(P), C.POINTER(L))
+    sig("dmxBatchCrossPairs", I, P, C.POINTER(P), C.POINTER(L))
     _lib = lib
     return lib

@@ -21,12 +21,14 @@ SNAPSHOT_PINGPONG, SNAPSHOT_COPY = 0, 1
 
 
 class DmxError(RuntimeError):
-    pass
+    def __init__(self, msg, code=0):
+        super().__init__(msg)
+        self.code = code
 
 
 def _check(rc, what):
     if rc != 0:
-        raise DmxError(f"{what} failed with code {rc}")
+        raise DmxError(f"{what} failed with code {rc}", rc)
 
 
 class BatchWorld:
@@ -223,6 +225,15 @@ class BatchWorld:
 
     def exact_tick(self, h):
         _check(self.lib.dmxBatchExactTick(self.h, h), "dmxBatchExactTick")
+
+    def find_pairs(self):
+        """dSpaceCollide's pair search alone: -> (pairs [np, 2], involved [ni], cross [nc, 2] = (own body, ghost slot))"""
+        pp, ip, cp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        npairs, ninv, nc = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(self.lib.dmxBatchFindPairs(self.h, C.byref(pp), C.byref(npairs), C.byref(ip), C.byref(ninv)), "dmxBatchFindPairs")
+        _check(self.lib.dmxBatchCrossPairs(self.h, C.byref(cp), C.byref(nc)), "dmxBatchCrossPairs")
+        grab = lambda p, n: np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), shape=(n,)).copy() if n else np.zeros(0, np.int32)
+        return (grab(pp, 2 * npairs.value).reshape(-1, 2), grab(ip, ninv.value), grab(cp, 2 * nc.value).reshape(-1, 2))
 
     def set_active_count(self, n_active):
         _check(self.lib.dmxBatchSetActiveCount(self.h, n_active), "dmxBatchSetActiveCount")

@@ -553,6 +553,13 @@ extern "C" int dmxBatchFindPairs(dmxBatchID b, const int32_t **pairs, int64_t *n
     return DMX_OK;
 }
 
+extern "C" int dmxBatchCrossPairs(dmxBatchID b, const int32_t **pairs, int64_t *n_pairs)
+{
+    if (!b || !pairs || !n_pairs) return DMX_EINVAL;
+    *pairs = b->fp_cross.data(); *n_pairs = (int64_t)(b->fp_cross.size() / 2);
+    return DMX_OK;
+}
+
 extern "C" int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6])
 {
     if (!b || !out) return DMX_EINVAL;

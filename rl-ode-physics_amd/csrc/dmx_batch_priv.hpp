@@ -121,7 +121,7 @@ struct dmxBatch {
     uint32_t ex_prev_inv = 1;                   // bodies the last exact tick found involved (in a pair / at a static box)
     DevBuf ex_arena, ex_body, ex_last, ex_aabb;
     void *ex_counts_host = nullptr;
-    std::vector<int32_t> fp_pairs, fp_inv;      // dmxBatchFindPairs' results
+    std::vector<int32_t> fp_pairs, fp_inv, fp_cross;      // dmxBatchFindPairs' results; (own body, ghost slot) pairs it met
     uint32_t *bp_flags_host = nullptr;         // pinned
     int bp_max_pairs = 0;
     std::vector<double> h_sides;               // host mirror of DMX_SIDES (exact values of the batch precision)

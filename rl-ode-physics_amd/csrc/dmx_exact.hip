@@ -98,7 +98,7 @@ __device__ __forceinline__ void for_each_partner(const T *S, const uint8_t *gtyp
 template <class T>
 __global__ __launch_bounds__(256) void ex_pair_count(const T *__restrict__ S, const uint8_t *__restrict__ gtype, int64_t n_active,
                                                      GridParams<T> G, uint64_t *__restrict__ pc, uint8_t *__restrict__ inpair,
-                                                     ExactCounts *__restrict__ C)
+                                                     ExactCounts *__restrict__ C, int32_t *__restrict__ cross_list)
 {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n_active) return;
@@ -106,7 +106,11 @@ __global__ __launch_bounds__(256) void ex_pair_count(const T *__restrict__ S, co
     if (gtype[i] != GEOM_NONE) {
         for_each_partner<T>(S, gtype, i, G, [&](int64_t j) {
             any = 1;
-            if (j >= n_active) { if (atomicOr(&C->cross, 1u) == 0u) { C->cross_a = (uint32_t)i; C->cross_b = (uint32_t)j; } }
+            if (j >= n_active) {
+                if (atomicOr(&C->cross, 1u) == 0u) { C->cross_a = (uint32_t)i; C->cross_b = (uint32_t)j; }
+                const uint32_t at = atomicAdd(&C->ncross, 1u);
+                if (at < EX_CROSS_CAP) { cross_list[2 * at] = (int32_t)i; cross_list[2 * at + 1] = (int32_t)j; }
+            }
             else if (j > i) owned++;
         }, &C->unsupported);
         // static box geoms are "big geoms against everyone": a body whose AABB overlaps one goes through the exact path too
@@ -647,7 +651,7 @@ hipError_t launch_exact_pairs(const T *S, const uint8_t *gtype, int64_t n_active
 {
     size_t tb = B.temp_bytes;
     EX_TRY(hipMemsetAsync(B.counts, 0, sizeof(ExactCounts), st));
-    hipLaunchKernelGGL((ex_pair_count<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inpair, B.counts);
+    hipLaunchKernelGGL((ex_pair_count<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inpair, B.counts, B.cross_list);
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.pc, B.inc, (size_t)n_active, rocprim::plus<uint64_t>(), st));
     hipLaunchKernelGGL((ex_pair_write<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inc,
                        B.pairs, B.inv, B.parent, cap, B.counts);

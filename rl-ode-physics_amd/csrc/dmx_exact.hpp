@@ -28,11 +28,15 @@ struct ExactCounts {
     uint32_t cross;         // a pair reaches into a ghost slot (an island spanning two ranks); the pair:
     uint32_t cross_a, cross_b;
     uint32_t unsupported;   // AABB pairs of this tick that have no collider (convex-convex, convex-sphere)
-    uint32_t pad[3];
+    uint32_t ncross;        // pairs (own body, ghost slot) met; the first EX_CROSS_CAP of them are in ExactBuffers::cross_list
+    uint32_t pad[2];
 };
+
+constexpr uint32_t EX_CROSS_CAP = 256;
 
 template <class T> struct ExactBuffers {
     ExactCounts *counts;
+    int32_t *cross_list;                        // [2 EX_CROSS_CAP] (own body, ghost slot): islands spanning two ranks
     void *temp; size_t temp_bytes;              // rocPRIM scratch
     uint64_t *pc, *inc;                         // [n_active] per body: (owned pairs << 32 | involved), and its inclusive scan
     uint8_t *inpair;                            // [stride] the fused kernel's skip mask

@@ -280,7 +280,7 @@ template <class T> int ensure_exact_buffers(dmxBatch *b, const ExactCaps &cap, E
     // one arena, carved up in 256-byte steps
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) / 256 * 256; return at; };
-    const size_t o_counts = take(sizeof(ExactCounts)), o_temp = take(temp), o_pairs = take(2 * (size_t)cap.pairs * 4),
+    const size_t o_counts = take(sizeof(ExactCounts)), o_cross = take(2 * EX_CROSS_CAP * sizeof(int32_t)), o_temp = take(temp), o_pairs = take(2 * (size_t)cap.pairs * 4),
                  o_inv = take((size_t)cap.inv * 4), o_parent = take((size_t)cap.inv * 4), o_root = take((size_t)cap.inv * 4),
                  o_rf = take((size_t)cap.inv * 4), o_rinc = take((size_t)cap.inv * 4),
                  o_gpos = take(nslots * 3 * sizeof(T)), o_gnormal = take(nslots * 3 * sizeof(T)), o_gdepth = take(nslots * sizeof(T)),
@@ -295,6 +295,7 @@ template <class T> int ensure_exact_buffers(dmxBatch *b, const ExactCaps &cap, E
     if ((rc = dmx_ensure_dev(b->ex_arena, off)) != DMX_OK) return rc;
     char *A = (char *)b->ex_arena.p;
     B.counts = (ExactCounts *)(A + o_counts);
+    B.cross_list = (int32_t *)(A + o_cross);
     B.temp = A + o_temp; B.temp_bytes = temp;
     B.pc = (uint64_t *)b->ex_body.p; B.inc = B.pc + n;
     B.inpair = (uint8_t *)b->bp_inpair.p;
@@ -621,6 +622,9 @@ template <class T> int find_pairs_t(dmxBatch *b)
     }
     b->fp_pairs.resize((size_t)2 * C.npairs);
     b->fp_inv.resize((size_t)C.ninv);
+    b->fp_cross.resize((size_t)2 * std::min<uint32_t>(C.ncross, EX_CROSS_CAP));
+    if (!b->fp_cross.empty())
+        HIP_TRY(hipMemcpyAsync(b->fp_cross.data(), B.cross_list, b->fp_cross.size() * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
     if (C.npairs) HIP_TRY(hipMemcpyAsync(b->fp_pairs.data(), B.pairs, b->fp_pairs.size() * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
     if (C.ninv) HIP_TRY(hipMemcpyAsync(b->fp_inv.data(), B.inv, b->fp_inv.size() * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));

@@ -91,7 +91,7 @@ __device__ __forceinline__ void pack_boundary(const StepParams<T> &P, int64_t i,
     if (P.pack_out == nullptr) return;
     int64_t slot;
     if (i < P.pack_lo) slot = i;
-    else if (i >= P.pack_hi) slot = P.pack_lo + (i - P.pack_hi);
+    else if (i >= P.pack_hi && i < P.pack_hi + P.pack_lo) slot = P.pack_lo + (i - P.pack_hi);     // (slots behind the upper row: spare slots of the rank, not boundary bodies)
     else return;
     T *o = P.pack_out + slot * C_MASS;
     o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = q.w; o[4] = q.x; o[5] = q.y; o[6] = q.z;

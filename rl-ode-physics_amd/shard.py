@@ -41,20 +41,25 @@ STATE_REALS = 13      # pos3 quat4 lvel3 avel3
 
 
 class SlabLayout:
-    """Row-major slab: body i sits in grid row i // side (z) and column i % side (x)."""
+    """Row-major slab: body i sits in grid row i // side (z) and column i % side (x).
 
-    def __init__(self, side, rows):
-        self.side, self.rows = int(side), int(rows)
+    Slots: [0, n) the rank's own bodies; [n, n_active) `spare` empty slots (stepped, geometry class NONE) that take bodies
+    adopted from the upper neighbour when an island spans the shared face; [n_active, n_total) ghost copies of the
+    neighbours' boundary rows."""
+
+    def __init__(self, side, rows, spare=0):
+        self.side, self.rows, self.spare = int(side), int(rows), int(spare)
         self.n = self.side * self.rows
-        assert self.rows >= 2 and self.side % 4 == 0
+        assert self.rows >= 2 and self.side % 4 == 0 and self.spare % 4 == 0
+        self.n_active = self.n + self.spare
         self.lower = np.arange(0, self.side, dtype=np.int32)                 # first row: faces rank-1
         self.upper = np.arange(self.n - self.side, self.n, dtype=np.int32)   # last row:  faces rank+1
         self.send_idx = np.concatenate([self.lower, self.upper])
         self.n_send = 2 * self.side
         # ghost slots behind the active bodies: rank-1's upper row, then rank+1's lower row
-        self.ghost_lo = np.arange(self.n, self.n + self.side, dtype=np.int32)
-        self.ghost_hi = np.arange(self.n + self.side, self.n + 2 * self.side, dtype=np.int32)
-        self.n_total = self.n + 2 * self.side
+        self.ghost_lo = np.arange(self.n_active, self.n_active + self.side, dtype=np.int32)
+        self.ghost_hi = np.arange(self.n_active + self.side, self.n_active + 2 * self.side, dtype=np.int32)
+        self.n_total = self.n_active + 2 * self.side
 
     @property
     def interior(self):
@@ -227,35 +232,44 @@ class BoundaryExchange:
             hi = self.recv[self.rank + 1, 0:side] if self.rank < self.world - 1 else None     # upper neighbour's lower row
             if hasattr(self.ops, "refresh_ghosts"):
                 if lo is not None or hi is not None:
-                    self.ops.refresh_ghosts(self.L.n, side, lo, side, hi, check_ghosts)
+                    self.ops.refresh_ghosts(self.L.n_active, side, lo, side, hi, check_ghosts)
             else:
                 if lo is not None:
                     self.ops.scatter(self.ghost_lo, lo)
                 if hi is not None:
                     self.ops.scatter(self.ghost_hi, hi)
                 if check_ghosts:
-                    self.ops.check_ghosts(self.L.n, 2 * side)
+                    self.ops.check_ghosts(self.L.n_active, 2 * side)
         self.ops.after_exchange(self.k)
         self.k += 1
         self.count += 1
 
-    def share_geometry(self, upload_ghost, sides, gtype):
-        """Once, at set-up: the neighbours' boundary bodies' extents and geometry types into the ghost slots, so the
-        broadphase sees the ghosts at their true size.  sides [n,3] / gtype [n] describe this rank's own bodies;
-        upload_ghost(first_slot, sides_rows, gtype_rows) writes ghost slots."""
+    def share_geometry(self, upload_ghost, sides, gtype, mass=None, inertia=None):
+        """Once, at set-up: the neighbours' boundary bodies' extents, geometry types and mass properties into the ghost
+        slots, so the broadphase sees the ghosts at their true size and a ghost can be adopted as it stands when an island
+        spans the face.  sides [n,3] / gtype [n] / mass [n] / inertia [n,3] describe this rank's own bodies;
+        upload_ghost(first_slot, sides_rows, gtype_rows, mass_rows, inertia_rows) writes ghost slots.  The geometry types of
+        the ghost rows are kept (`ghost_gtype`): an adopted body takes its class from there."""
         L, side = self.L, self.L.side
-        mine = self.ops.empty(L.n_send, 4)
-        rows = np.concatenate([np.asarray(sides)[L.send_idx], np.asarray(gtype, dtype=np.float64)[L.send_idx, None]], axis=1)
+        n = len(np.asarray(gtype))
+        mass = np.ones(n) if mass is None else np.asarray(mass, dtype=np.float64).reshape(n)
+        inertia = np.ones((n, 3)) if inertia is None else np.asarray(inertia, dtype=np.float64).reshape(n, 3)
+        mine = self.ops.empty(L.n_send, 8)
+        rows = np.concatenate([np.asarray(sides)[L.send_idx], np.asarray(gtype, dtype=np.float64)[L.send_idx, None],
+                               mass[L.send_idx, None], inertia[L.send_idx]], axis=1)
         mine.copy_(torch.from_numpy(np.ascontiguousarray(rows)).to(mine.dtype))
-        flat = self.ops.empty(self.world * L.n_send, 4)
+        flat = self.ops.empty(self.world * L.n_send, 8)
         self._all_gather(flat, mine)
-        got = flat.view(self.world, L.n_send, 4).cpu().numpy()
+        got = flat.view(self.world, L.n_send, 8).cpu().numpy()
+        self.ghost_gtype = np.zeros(2 * side, np.uint8)          # by ghost slot - n_active
         if self.rank > 0:
             r = got[self.rank - 1, side:2 * side]
-            upload_ghost(int(L.ghost_lo[0]), r[:, :3], r[:, 3].astype(np.uint8))
+            upload_ghost(int(L.ghost_lo[0]), r[:, :3], r[:, 3].astype(np.uint8), r[:, 4], r[:, 5:8])
+            self.ghost_gtype[:side] = r[:, 3].astype(np.uint8)
         if self.rank < self.world - 1:
             r = got[self.rank + 1, 0:side]
-            upload_ghost(int(L.ghost_hi[0]), r[:, :3], r[:, 3].astype(np.uint8))
+            upload_ghost(int(L.ghost_hi[0]), r[:, :3], r[:, 3].astype(np.uint8), r[:, 4], r[:, 5:8])
+            self.ghost_gtype[side:] = r[:, 3].astype(np.uint8)
 
     def prime(self):
         """Set-up: one exchange of the current boundary rows, so the ghost slots hold the neighbours' bodies where they
@@ -283,9 +297,14 @@ class ShardedStepper:
 
     CHUNK_MIN, CHUNK_MAX = 32, 256
 
+    NOTICE_CAP = 64        # bodies one rank can adopt in one migration round
+
     def __init__(self, world_batch, layout, rank, world_size, exchange="boundary", device=None, stream=None,
                  collide=False, geometry=None, ops=None, group=None, exchange_every_tick=False, lazy=False):
         self.w, self.L = world_batch, layout
+        self.rank, self.world = rank, world_size
+        self.spare_used = 0
+        self.adopted, self.retired = [], []      # (spare slot, index in the upper neighbour's lower row); own slots given away
         # lazy: ballistic chunks stay open across run() calls (a caller that issues a few ticks per call does not pay a
         # chunk's exchange, flag read and flag all-reduce per call); settle() closes the open chunk
         self.lazy = bool(lazy)
@@ -301,13 +320,17 @@ class ShardedStepper:
         self.chunk = self.CHUNK_MIN
         self.ballistic_graph = None
         if self.collide and geometry is not None:
-            sides, gtype = geometry
+            sides, gtype = geometry[0], geometry[1]
+            mass = geometry[2] if len(geometry) > 2 else None
+            inertia = geometry[3] if len(geometry) > 3 else None
 
-            def upload_ghost(first, s_rows, g_rows):
-                from .batch import SIDES
+            def upload_ghost(first, s_rows, g_rows, m_rows, i_rows):
+                from .batch import SIDES, MASS, INERTIA
                 world_batch.upload(SIDES, s_rows, first=first)
                 world_batch.upload_geom_type(g_rows, first=first)
-            self.exchange.share_geometry(upload_ghost, sides, gtype)
+                world_batch.upload(MASS, m_rows, first=first)
+                world_batch.upload(INERTIA, i_rows, first=first)
+            self.exchange.share_geometry(upload_ghost, sides, gtype, mass, inertia)
         if self.collide:
             self.exchange.prime()
 
@@ -331,10 +354,69 @@ class ShardedStepper:
         kernels, so the boundary rows are gathered after the tick instead of packed inside the step kernel"""
         ex = self.exchange
         ex.drain()
+        self._migrate()
         ex.before_step(fused=False)
         self.w.exact_tick(h)
         ex.pack(fused=False)
         ex.exchange()
+
+    # -- islands that span two ranks -------------------------------------------------------------------------
+    def _migrate(self):
+        """Before an exact tick: if a body of some rank touches a neighbour's boundary body (an (own, ghost) AABB pair),
+        their island spans two ranks and has to be stepped by one.  The LOWER rank adopts: it copies the upper
+        neighbour's boundary body out of its ghost slot (state as of the last exchange, extents and mass properties shared
+        at set-up) into a spare slot, switches the ghost off, and tells the upper rank, which retires its copy (geometry
+        class NONE, parked far below).  One small all-gather of notices per round; rounds repeat until no rank sees a
+        crossing pair (an adopted body may reach further boundary bodies).  A rank's body touching the LOWER neighbour's
+        ghost is adopted by that neighbour when it is in this rank's boundary row -- the neighbour sees the same pair --
+        and is reported (DMX_ECROSS) otherwise: bodies that reach across the face from behind the boundary row are not
+        handled."""
+        from .batch import STATE, MASS, INERTIA, SIDES, POS, LVEL, AVEL, DmxError
+        ex, w, L, ops = self.exchange, self.w, self.L, self.exchange.ops
+        if not hasattr(w, "find_pairs") or not hasattr(ex, "ghost_gtype"):
+            return                                         # (host doubles of the batch in the CPU tests: nothing to probe)
+        side = L.side
+        for _round in range(8):
+            cross = w.find_pairs()[2]
+            (any_cross,) = ops.any_rank([len(cross) > 0], ex.group)
+            if not any_cross:
+                return
+            hi0, lo0 = int(L.ghost_hi[0]), int(L.ghost_lo[0])
+            adopt = sorted({int(g) for _i, g in cross if g >= hi0})
+            stuck = [(int(i), int(g)) for i, g in cross if lo0 <= g < hi0 and int(i) >= side]
+            notice = np.zeros(self.NOTICE_CAP + 2)
+            notice[0] = len(adopt); notice[1] = len(stuck)
+            if len(adopt) > self.NOTICE_CAP or self.spare_used + len(adopt) > L.spare:
+                notice[1] += 1                             # out of spare slots: reported like a stuck pair, on every rank
+                adopt = []
+                notice[0] = 0
+            notice[2:2 + len(adopt)] = [g - hi0 for g in adopt]
+            mine = ops.empty(self.NOTICE_CAP + 2)
+            mine.copy_(torch.from_numpy(notice).to(mine.dtype))
+            flat = ops.empty(self.world * (self.NOTICE_CAP + 2))
+            ex._all_gather(flat, mine)
+            got = flat.view(self.world, self.NOTICE_CAP + 2).cpu().numpy()
+            if got[:, 1].sum() > 0:
+                raise DmxError(f"rank {self.rank}: an island spans two ranks and cannot be migrated (a body beyond the boundary "
+                               f"row reaches across the face, or the spare slots are used up): {stuck}", -6)
+            for g in adopt:                                # this rank is the lower one: the ghost becomes a body of its own
+                slot = L.n + self.spare_used
+                self.spare_used += 1
+                for field in (STATE, MASS, INERTIA, SIDES):
+                    w.upload(field, w.download(field, g, 1), first=slot)
+                w.upload_geom_type(ex.ghost_gtype[g - L.n_active:g - L.n_active + 1], first=slot)
+                w.upload_geom_type(np.zeros(1, np.uint8), first=g)          # the ghost is switched off for good
+                self.adopted.append((slot, g - hi0))
+            if self.rank > 0:                              # notices of the lower neighbour: it adopted these bodies of my first row
+                cnt = int(got[self.rank - 1, 0])
+                for idx in got[self.rank - 1, 2:2 + cnt].astype(int):
+                    j = int(idx)                           # my lower row is slots [0, side)
+                    w.upload_geom_type(np.zeros(1, np.uint8), first=j)
+                    w.upload(POS, np.array([[0.0, -1.0e6 - j, 0.0]]), first=j)
+                    w.upload(LVEL, np.zeros((1, 3)), first=j)
+                    w.upload(AVEL, np.zeros((1, 3)), first=j)
+                    self.retired.append(j)
+        raise DmxError(f"rank {self.rank}: islands spanning two ranks keep growing after 8 migration rounds", -6)
 
     # -- the loop ------------------------------------------------------------------------------------------
     def run(self, h, nsteps):
@@ -422,7 +504,7 @@ class ShardedStepper:
         if not oc["checked"]:
             # closed before its length: the poses after its last tick inside their zones prove the ticks before
             # (straight horizontal lines, convex zones); the boundary rows go out by an explicit gather
-            ex.ops.check_active(0, self.L.n)
+            ex.ops.check_active(0, self.L.n_active)
             ex.before_step(fused=False)
             ex.pack(fused=False)
             ex.exchange(check_ghosts=True)
