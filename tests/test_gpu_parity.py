@@ -473,8 +473,9 @@ def _one_rank_group():
     return dist
 
 
-@pytest.mark.parametrize("graph_steps,speed", [(0, 3.0), (8, 3.0), (8, 0.1), (0, 0.1)])
-def test_sharded_loop_carries_the_collision_proof(graph_steps, speed):
+@pytest.mark.parametrize("graph_steps,speed,lazy", [(0, 3.0, False), (8, 3.0, False), (8, 0.1, False), (0, 0.1, False),
+                                                    (0, 3.0, True), (0, 0.1, True)])
+def test_sharded_loop_carries_the_collision_proof(graph_steps, speed, lazy):
     """shard.ShardedStepper(collide=True) on a one-rank group (the collective degenerates to a copy): chunks, ghost
     checks, collective rollback and exact replay give the oracle's bits, mid-air box-box contacts included."""
     import torch
@@ -495,10 +496,15 @@ def test_sharded_loop_carries_the_collision_proof(graph_steps, speed):
         with torch.cuda.stream(stream):
             w.set_stream(stream.cuda_stream)
             ops = pkg.shard.DeviceOps(w, torch.device("cuda", 0), stream)
-            st = pkg.shard.ShardedStepper(w, L, 0, 1, collide=True, geometry=(scene.sides, scene.gtype), ops=ops)
+            st = pkg.shard.ShardedStepper(w, L, 0, 1, collide=True, geometry=(scene.sides, scene.gtype), ops=ops, lazy=lazy)
             if graph_steps:
                 st.capture(H, graph_steps, stream)
-            st.run(H, steps)
+            if lazy:                              # what bench.py does: a few ticks per call, chunks closed lazily, close() at the end
+                for k in range(0, steps, 7):
+                    st.run(H, min(7, steps - k))
+                st.close()
+            else:
+                st.run(H, steps)
             st.drain()
             w.synchronize()
             got = [a[:scene.n] for a in w.state()]
