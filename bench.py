@@ -481,6 +481,16 @@ def rank_main(a):
                        "ms_per_step": m["dt"] * 1e3 / m["steps"], "bodies_per_gpu": wscene.n, "bodies_total": wscene.n * world,
                        "blocks": m["blocks"], "parallelism": parallelism_text(m, wscene.n),
                        "roofline_frac_per_gpu": roofline_of(m, "free", rsize)["frac"]}
+        if a.fused_ticks > 1 and not a.exchange_every_tick:
+            # the strong-scaled slabs with 2 and with --fused-ticks ticks per launch (bit-identical results; the reference reads
+            # poses every other physics tick, main.c:208, 218): what the launch-bound 131 072-body slab does when a launch carries
+            # more than one tick.  Companions; the headline above stays one launch per tick.
+            out["fused"] = {}
+            for k in sorted({2, a.fused_ticks}):
+                m = measure(cx, a, scene, layout, kind, dtype, exchanging=use_exchange, ticks_per_launch=k)
+                out["fused"][f"ticks_per_launch_{k}"] = {"scaling": "strong", "value": total_bodies * m["steps"] / m["dt"],
+                                                         "unit": "body-steps/s", "ms_per_step": m["dt"] * 1e3 / m["steps"],
+                                                         "blocks": m["blocks"]}
         if use_exchange and not a.exchange_every_tick:
             # north_star's wording taken literally: the boundary rows all-gathered at EVERY tick, issued eagerly from the host
             # (a companion number, measured last: should it fail, the headline above stands and the failure is reported here)

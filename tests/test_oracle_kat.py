@@ -635,3 +635,85 @@ def test_box_convex_supports_a_resting_hull():
     assert len(j) == 4 and abs(sum(x[5] for x in j) - 9.8) < 1e-6
     assert all(np.allclose(x[3], [0, 1, 0]) for x in j)                      # after the joint's reversal: into the hull
     assert np.max(np.abs(ow.state()[2])) < 1e-8
+
+
+# ---------------------------------------------------------------- more closed forms for the colliders (round 2)
+def test_kat6_box_box_fewer_contacts_than_found_keeps_the_deepest(orc64):
+    """a cube tipped slightly onto another's top face: the clipped face region has four points of DIFFERENT depths; asking for
+    1, 2 or 3 contacts keeps the deepest one first and only points of the full set (ODE's cullPoints picks around the
+    centroid starting from the deepest)"""
+    tilt = 0.05
+    q = np.array([math.cos(tilt / 2), 0, 0, math.sin(tilt / 2)])              # a small turn about z: one bottom edge dips
+    w = orc64.world()
+    w.add_boxes([(0.0, 0.0, 0.0), (0.0, 0.95, 0.0)], [(1, 0, 0, 0), tuple(q)], None, None, None, None,
+                [(2.0, 1.0, 2.0), (1.0, 1.0, 1.0)])
+    full = _pair_contacts(orc64, w, 0, 1)
+    assert len(full) == 4
+    depths = sorted(d for _, _, d in full)
+    assert depths[-1] - depths[0] > 0.02                                      # the tilt makes them differ: 2 deep, 2 shallow
+    for _, n, _ in full:
+        assert np.allclose(np.abs(n), [0, 1, 0], atol=1e-12)                   # the reference face is box 1's top
+    pts = [tuple(np.round(p, 9)) for p, _, _ in full]
+    for maxc in (1, 2, 3):
+        c = _pair_contacts(orc64, w, 0, 1, maxc=maxc)
+        assert len(c) == maxc
+        assert abs(c[0][2] - depths[-1]) < 1e-12                               # deepest first
+        assert all(tuple(np.round(p, 9)) in pts for p, _, _ in c)
+    # closed form of the deepest point's depth: the dipping bottom corner sits at y = 0.95 - (0.5 cos t + 0.5 sin t)
+    expect = 0.5 - (0.95 - 0.5 * (math.cos(tilt) + math.sin(tilt)))
+    assert abs(depths[-1] - expect) < 1e-12
+
+
+def test_kat6_box_box_parallel_edges_take_the_degenerate_branch(orc64):
+    """edge-edge with (nearly) parallel edges: dLineClosestApproach's determinant d = 1 - (ua.ub)^2 is <= 1e-4 and ODE sets
+    alpha = beta = 0, i.e. the contact is the midpoint of the two edges' reference points, unshifted [ODE-recall].  Two
+    cubes turned 45 degrees about the SAME axis, ridge over ridge: the separating axis is an edge cross product only when the
+    edges are not parallel, so with parallel ridges the face axes win and the result is a face contact -- what is pinned here
+    is that nothing blows up and the contact is where the ridges meet."""
+    a = math.pi / 4
+    qz = np.array([math.cos(a / 2), 0, 0, math.sin(a / 2)])
+    gap = 2 * math.sqrt(0.5) - 0.02
+    w = orc64.world()
+    w.add_boxes([(0.0, 0.0, 0.0), (0.0, gap, 0.0)], [tuple(qz), tuple(qz)], None, None, None, None,
+                [(1.0, 1.0, 1.0), (1.0, 1.0, 1.0)])
+    c = _pair_contacts(orc64, w, 0, 1)
+    assert 1 <= len(c) <= 8
+    for p, n, d in c:
+        assert np.all(np.isfinite(p)) and np.all(np.isfinite(n)) and abs(np.linalg.norm(n) - 1) < 1e-12
+        assert -1e-12 <= d <= 0.02 + 1e-12
+        assert abs(p[0]) < 0.02 and abs(p[1] - gap / 2) < 0.02                 # on the line where the two ridges overlap
+    assert max(d for _, _, d in c) > 0.0
+
+
+def test_kat6_sphere_centre_inside_a_box(orc64):
+    """dCollideSphereBox with the sphere's centre INSIDE the box: the contact sits at the centre, the normal is the box face
+    nearest to it, the depth is the distance to that face plus the radius [ODE-recall]"""
+    w = orc64.world()
+    w.add_spheres([(0.3, 0.1, -0.05)], None, None, None, None, None, [0.1])
+    w.add_boxes([(0.0, 0.0, 0.0)], None, None, None, None, None, [(1.0, 1.0, 1.0)])
+    c = _pair_contacts(orc64, w, 0, 1)
+    assert len(c) == 1
+    p, n, d = c[0]
+    assert np.allclose(p, [0.3, 0.1, -0.05], atol=1e-15)
+    assert np.allclose(n, [1, 0, 0], atol=1e-15)                                # out through the +x face, 0.2 away
+    assert abs(d - (0.2 + 0.1)) < 1e-15
+
+
+def test_kat5_convex_plane_needs_points_on_both_sides():
+    """dCollideConvexPlane returns contacts only if the hull has points on both sides of the plane (or on it): a hull wholly
+    below the plane yields NONE [ODE-recall]; one that straddles it yields its penetrating points in array order"""
+    from oracle.orc_ctypes import Oracle
+    import itertools
+    orc = Oracle("float64")
+    pts = np.array(list(itertools.product((-0.5, 0.5), repeat=3)), float)
+    for y, expect in ((-2.0, 0), (0.4, 4), (0.0, 4), (0.5, 4), (0.6, 0)):
+        ow = orc.world()
+        ow.set_hull(pts)
+        g_plane = ow.add_plane(0, 1, 0, 0)
+        ow.add_convex(np.array([[0.0, y, 0.0]]), np.array([[1.0, 0, 0, 0]]), np.zeros((1, 3)), np.zeros((1, 3)), np.ones(1), np.ones((1, 3)))
+        out = (orc.ContactGeom * 16)()
+        n = orc.lib.orc_collide(ow.w, g_plane + 1, g_plane, 8, out)
+        assert n == expect, (y, n)
+        for i in range(n):
+            assert abs(out[i].depth - (0.5 - y)) < 1e-15 and list(out[i].normal) == [0.0, 1.0, 0.0]
+            assert out[i].pos[1] == y - 0.5
