@@ -53,7 +53,17 @@ def _scene(seed):
                   mu=float("inf") if rng.random() < 0.5 else float(rng.uniform(0.0, 2.0)),
                   bounce_on=bool(rng.random() < 0.7), bounce=float(rng.uniform(0.0, 0.8)),
                   bounce_vel=float(rng.uniform(0.0, 0.5)), max_contacts=int(rng.integers(1, 9)))
-    sc = pkg.scenes.Scene(pos, quat, lvel, avel, mass, inertia, sides, gtype, plane, hull_points).astype(dtype)
+    # round 2: static box geoms (AddBodyMap, main.c:735-761) in two scenes out of three -- slabs and posts in and around the
+    # cluster, turned about z -- and the hull's faces whenever there are hulls (contacts of hulls with boxes, both kinds)
+    statics = None
+    if seed % 3 != 1:
+        statics = []
+        for _ in range(int(rng.integers(1, 4))):
+            sz = (float(rng.uniform(0.5, 6.0)), float(rng.uniform(0.3, 2.0)), float(rng.uniform(0.5, 6.0)))
+            at = (float(rng.uniform(-spread, spread)), float(rng.uniform(-0.2, 1.5)), float(rng.uniform(-spread, spread)))
+            statics.append((sz, at, pkg.scenes._rot_z(float(rng.uniform(-0.4, 0.4)))))
+    hull_planes = pkg.hull.planes(hull_points) if hull_points is not None else None
+    sc = pkg.scenes.Scene(pos, quat, lvel, avel, mass, inertia, sides, gtype, plane, hull_points, hull_planes, statics).astype(dtype)
     return sc, dtype, params, nb
 
 
@@ -81,6 +91,9 @@ def test_random_scene_matches_oracle(seed):
     ow.add_plane(*scene.plane)
     if scene.hull_points is not None:
         ow.set_hull(scene.hull_points)
+        ow.set_hull_faces(scene.hull_planes)
+    for sz, at, R12 in (scene.static_boxes or []):
+        ow.add_static_box(sz, at, R12)
     for i in range(scene.n):                         # body by body: geometry classes are interleaved
         b = lib.orc_body_create(ow.w)
         lib.orc_body_set_position(ow.w, b, *scene.pos[i])
@@ -149,11 +162,19 @@ def test_random_call_sequences_match_oracle(seed, one_rank_group):
     else:
         w = pkg.BatchWorld(n, dtype=dtype)
         w.load_scene(scene)
+    # every fifth seed drops the grid onto a static plank as well (AddBodyMap): static contacts, bodies involved every tick
+    statics = []
+    if not sharded and seed % 5 == 2:
+        statics = [((float(rng.uniform(6, 20)), 0.6, float(rng.uniform(6, 20))), (float(rng.uniform(-3, 3)), 0.3, float(rng.uniform(-3, 3))),
+                    pkg.scenes._rot_z(float(rng.uniform(-0.1, 0.1))))]
+        w.set_static_boxes(statics)
     orc = Oracle(dtype)
     lib = orc.lib
     ow = orc.world()
     if plane:
         ow.add_plane(*scene.plane)
+    for sz, at, R12 in statics:
+        ow.add_static_box(sz, at, R12)
     ow.add_boxes(scene.pos, scene.quat, scene.lvel, scene.avel, scene.mass[:, 0], scene.inertia, scene.sides)
     rt = orc.dtype.type
 
