@@ -4,10 +4,14 @@
 // binned by the (x,z) column of their centre into a hashed table of fixed-capacity buckets; the cell size is
 // at least the largest bounding-sphere diameter, so two bodies whose AABBs overlap always sit in adjacent
 // columns (3x3 neighbourhood).  Two consumers:
-//   * bp_pairs     -- the exact pair search: every (i<j) whose AABBs overlap (what reaches NearCallback);
+//   * the exact pair search (dmx_exact.hip; bp_pairs here is its one-pass predecessor): every (i<j) whose AABBs overlap
+//     (what reaches NearCallback);
 //   * bp_safe_zone -- per body, half the horizontal gap to its nearest neighbour's bounding sphere.  While every
 //                     body stays inside its safe zone (a 3-real check fused into the step kernels) no two
-//                     bounding spheres can touch, so the pair set is provably empty without a search.
+//                     bounding spheres can touch, so no collider can return a CONTACT (each body lies inside its
+//                     sphere) and the fused single-body kernels are exact.  AABB pairs may still exist -- the AABBs of
+//                     two tilted boxes placed diagonally overlap while their spheres are apart -- they would all come
+//                     back from dCollide empty, and are not enumerated on this path.
 // Integer / index work: coalesced loads of positions, hashed bucket atomics in L2, no MFMA, no LDS reuse to stage.
 #include <hip/hip_runtime.h>
 #include "dmx_internal.hpp"

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const u
     const uint32_t ne = cap.entries(), e_pairs = cap.pair_entry0();
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
         int nc = 0;
-        {   // entries with a convex body in them belong to ex_narrow_convex (one wavefront each)
+        if (P.hull_n > 0) {   // entries with a convex body in them belong to ex_narrow_convex (one wavefront each; not launched without a hull)
             bool convex = false;
             if (e < e_pairs) { const uint32_t k = e % cap.inv; convex = k < ninv && gtype[inv[k]] == GEOM_CONVEX; }
             else if (e - e_pairs < np) convex = gtype[pairs[2 * (e - e_pairs)]] == GEOM_CONVEX || gtype[pairs[2 * (e - e_pairs) + 1]] == GEOM_CONVEX;
@@ -670,7 +670,8 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.rf, B.rinc, (size_t)cap.inv, rocprim::plus<uint32_t>(), st));
     hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.aabb, P, cap,
                        B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
-    hipLaunchKernelGGL((ex_narrow_convex<T>), dim3((unsigned)std::min<size_t>((ne + 3) / 4, 65535)), dim3(256), 0, st, S, gtype, B.inv,
+    if (P.hull_n > 0)
+        hipLaunchKernelGGL((ex_narrow_convex<T>), dim3((unsigned)std::min<size_t>((ne + 3) / 4, 65535)), dim3(256), 0, st, S, gtype, B.inv,
                            B.pairs, G.aabb, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
     hipLaunchKernelGGL(ex_keys, dim3(grid_for(ne)), dim3(256), 0, st, B.pairs, B.pc, B.inc, B.root, B.rinc, cap, B.keys, B.vals, B.counts);
     int bits = 1;

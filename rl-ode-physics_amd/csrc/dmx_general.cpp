@@ -3,15 +3,16 @@
 //
 // Fast mode (the normal case for the BASELINE scenes): every body carries a broadphase safe zone -- half
 // the horizontal gap to its nearest neighbour's bounding sphere at build time.  While every body is inside
-// its zone no two bounding spheres can touch, so the tick's body-pair set is provably empty and the fused
-// single-body-island kernels are exact; the 3-real check rides inside those kernels.  Ticks are enqueued in
-// chunks with no host round trip; the violation flag is read once per chunk.
+// its zone no two bounding spheres can touch, so no collider could return a contact (AABB pairs may exist; they
+// would all be empty) and the fused single-body-island kernels are exact; the 3-real check rides inside those
+// kernels.  Ticks are enqueued in chunks with no host round trip; the violation flag is read once per chunk, and not
+// before the chunk has reached its length or somebody looks (lazy chunks, below).
 //
-// Careful mode (a body left its zone, or bodies are crowded): the chunk is rolled back to its snapshot and
-// replayed tick by tick: exact device pair search (bp_insert + bp_pairs) -> pair count to the host -> for
-// bodies in pairs, device narrowphase (np_plane, np_pairs) -> contact counts to the host -> island grouping
-// (integer bookkeeping) -> solve_islands on the device; every other body takes the fused kernel with those bodies masked out.
-// Both modes give the same bits as the sequential CPU oracle.
+// Careful mode (a body left its zone, bodies are crowded or at a static box): the chunk is rolled back to its snapshot
+// (a pointer swap between the batch's two slabs) and replayed tick by tick: the whole bookkeeping of an exact tick --
+// pair search, islands, narrowphase, joints by island, level schedules -- runs on the device (dmx_exact.hip), the host
+// reads one 64-byte record per tick, then the island kernels; every other body takes the fused kernel with those bodies
+// masked out.  Both modes give the same bits as the sequential CPU restatement the tests compare with.
 #include <string.h>
 #include <algorithm>
 #include <memory>
