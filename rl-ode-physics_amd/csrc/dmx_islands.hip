@@ -430,10 +430,10 @@ __global__ __launch_bounds__(64) void solve_singles(T *__restrict__ S, const uin
 }
 
 // The same island shape with five to eight contacts (a convex hull on the floor: up to 24 rows): too many rows for a lane's
-// registers, so they live in LDS, one column per lane (field f of row r of lane l at [(r * RS_FIELDS + f) * lanes + l]: a
-// wavefront's access to one field is one conflict-free LDS row).  64 islands per wave in f32 (90 KB of the CU's 160 KB), 32 in
-// f64.  Plain loops instead of unrolled register code; the arithmetic per row is the same sequence once more.
-enum : int { RS_J = 0, RS_IMJ = 6, RS_RHS = 12, RS_AD = 13, RS_LAM = 14, RS_FIELDS = 15 };
+// registers, so their J and M^-1 J^T live in LDS, one column per lane (field f of row r of lane l at
+// [(r * RS_FIELDS + f) * lanes + l]: a wavefront's access to one field is one conflict-free LDS row); rhs, Ad cfm and lambda
+// stay in registers.  A row update is one batch of twelve independent LDS reads, then arithmetic: the same sequence once more.
+enum : int { RS_J = 0, RS_IMJ = 6, RS_FIELDS = 12 };      // per row in LDS: J (scaled by Ad) and M^-1 J^T; rhs, Ad cfm, lambda stay in registers
 
 template <class T>
 __global__ __launch_bounds__(64) void solve_singles_lds(T *__restrict__ S, const uint8_t *__restrict__ bflags, int64_t stride,
@@ -441,6 +441,7 @@ __global__ __launch_bounds__(64) void solve_singles_lds(T *__restrict__ S, const
 {
     extern __shared__ __align__(16) unsigned char rs_raw[];
     T *rs = reinterpret_cast<T *>(rs_raw);
+    constexpr int MAXR = 3 * SINGLE_MAXC_LDS;
     const int lanes = blockDim.x, lane = threadIdx.x;
     const int isl = blockIdx.x * lanes + lane;
     if (isl >= I.n_islands || !island_is_single(I, isl)) return;
@@ -453,9 +454,12 @@ __global__ __launch_bounds__(64) void solve_singles_lds(T *__restrict__ S, const
     const bool own_surface = I.cmu != nullptr, ind = I.csrc != nullptr;
     const V3<T> x1 = ldS(S, stride, C_POS, s), v1 = ldS(S, stride, C_LVEL, s), w1 = ldS(S, stride, C_AVEL, s);
     auto at = [&](int r, int f) -> T & { return rs[(size_t)(r * RS_FIELDS + f) * lanes + lane]; };
-    constexpr int MAXR = 3 * SINGLE_MAXC_LDS;
     unsigned valid = 0;                                       // bit r: slot r (= 3 * contact + direction) holds a row
     T lo_f[SINGLE_MAXC_LDS], hi_f[SINGLE_MAXC_LDS];
+    T rhsr[MAXR], adr[MAXR], lamr[MAXR];
+#pragma unroll
+    for (int q = 0; q < MAXR; q++) rhsr[q] = adr[q] = lamr[q] = T(0);
+#pragma unroll
     for (int c = 0; c < SINGLE_MAXC_LDS; c++) {
         lo_f[c] = hi_f[c] = T(0);
         if (c >= nc) continue;
@@ -473,7 +477,9 @@ __global__ __launch_bounds__(64) void solve_singles_lds(T *__restrict__ S, const
         dir[1] = dir[2] = { T(0), T(0), T(0) };
         if (rpc == 3) plane_space(normal, dir[1], dir[2]);
         lo_f[c] = -mu; hi_f[c] = mu;
-        for (int dnum = 0; dnum < rpc; dnum++) {
+#pragma unroll
+        for (int dnum = 0; dnum < 3; dnum++) {
+            if (dnum >= rpc) continue;
             const int r = 3 * c + dnum;
             valid |= 1u << r;
             T J[6] = { dir[dnum].x, dir[dnum].y, dir[dnum].z, T(0), T(0), T(0) };
@@ -497,47 +503,58 @@ __global__ __launch_bounds__(64) void solve_singles_lds(T *__restrict__ S, const
                 }
             }
             for (int j = 0; j < 6; j++) at(r, RS_J + j) = J[j];
-            at(r, RS_RHS) = cval; at(r, RS_AD) = cfm; at(r, RS_LAM) = T(0);
+#pragma unroll
+            for (int q = 0; q < MAXR; q++) if (q == r) { rhsr[q] = cval; adr[q] = cfm; }      // (static indices keep the arrays in registers)
         }
     }
     body_tmp(S, stride, b, s, hinv);
+#pragma unroll
     for (int i = 0; i < MAXR; i++) {                          // row_setup
         if (!(valid >> i & 1u)) continue;
         T J[6], iMJ[6];
+#pragma unroll
         for (int j = 0; j < 6; j++) J[j] = at(i, RS_J + j);
         T sum = T(0);
+#pragma unroll
         for (int j = 0; j < 6; j++) sum = fma_(J[j], b[BW_TMP + j], sum);
-        T rhs = fma_(at(i, RS_RHS), hinv, -sum);
-        const T cfm = at(i, RS_AD) * hinv;
+        T rhs = fma_(rhsr[i], hinv, -sum);
+        const T cfm = adr[i] * hinv;
         for (int j = 0; j < 3; j++) iMJ[j] = b[BW_INVM] * J[j];
         const V3<T> ja1 = { J[3], J[4], J[5] };
         iMJ[3] = dot3p(b + BW_INVI + 0, ja1); iMJ[4] = dot3p(b + BW_INVI + 3, ja1); iMJ[5] = dot3p(b + BW_INVI + 6, ja1);
         T s2 = T(0);
         for (int j = 0; j < 6; j++) s2 = fma_(iMJ[j], J[j], s2);
         const T ad = P.sor_w / (s2 + cfm);
+#pragma unroll
         for (int j = 0; j < 6; j++) { at(i, RS_J + j) = J[j] * ad; at(i, RS_IMJ + j) = iMJ[j]; }
         rhs *= ad;
-        at(i, RS_RHS) = rhs;
-        at(i, RS_AD) = ad * cfm;
+        rhsr[i] = rhs;
+        adr[i] = ad * cfm;
+        lamr[i] = T(0);
     }
     double resid = 0.0;
     T *fc = b + BW_FC;
     for (int it = 0; it < P.iters; it++) {                    // the sweeps (row_sor), rows in creation order
         const bool last = (it == P.iters - 1);
+#pragma unroll
         for (int i = 0; i < MAXR; i++) {
             if (!(valid >> i & 1u)) continue;
-            const T old = at(i, RS_LAM);
-            T delta = fma_(-old, at(i, RS_AD), at(i, RS_RHS));
-            delta -= fma_(fc[5], at(i, RS_J + 5), fma_(fc[4], at(i, RS_J + 4), fma_(fc[3], at(i, RS_J + 3),
-                     fma_(fc[2], at(i, RS_J + 2), fma_(fc[1], at(i, RS_J + 1), fc[0] * at(i, RS_J + 0))))));
+            // the row's twelve LDS words in one batch of independent reads (one wait), then arithmetic only
+            T rw[RS_FIELDS];
+#pragma unroll
+            for (int f = 0; f < RS_FIELDS; f++) rw[f] = at(i, f);
+            const T old = lamr[i];
+            T delta = fma_(-old, adr[i], rhsr[i]);
+            delta -= fma_(fc[5], rw[RS_J + 5], fma_(fc[4], rw[RS_J + 4], fma_(fc[3], rw[RS_J + 3],
+                     fma_(fc[2], rw[RS_J + 2], fma_(fc[1], rw[RS_J + 1], fc[0] * rw[RS_J + 0])))));
             const T lo = (i % 3 == 0) ? T(0) : lo_f[i / 3], hi = (i % 3 == 0) ? Limits<T>::inf() : hi_f[i / 3];
             const T nl = old + delta;
             T lam = nl;
             if (nl < lo) { delta = lo - old; lam = lo; }
             else if (nl > hi) { delta = hi - old; lam = hi; }
-            at(i, RS_LAM) = lam;
+            lamr[i] = lam;
 #pragma unroll
-            for (int j = 0; j < 6; j++) fc[j] = fma_(delta, at(i, RS_IMJ + j), fc[j]);
+            for (int j = 0; j < 6; j++) fc[j] = fma_(delta, rw[RS_IMJ + j], fc[j]);
             if (last) resid += (double)tabs(delta);
         }
     }
@@ -944,8 +961,9 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
         hipLaunchKernelGGL((solve_islands<T>), dim3(grid), dim3(64), 0, st, S, bflags, stride, I, P, diag);
         if (I.singles) {
             hipLaunchKernelGGL((solve_singles<T>), dim3(grid), dim3(64), 0, st, S, bflags, stride, I, P, diag);
-            // islands of 5..8 contacts keep their rows in LDS: 64 lanes x 24 rows x 15 fields (f32: 90 KB), 32 lanes in f64
-            const int lanes = sizeof(T) == 4 ? 64 : 32;
+            // islands of 5..8 contacts keep their rows' J and M^-1 J^T in LDS: 64 lanes x 24 rows x 12 fields (f32: 72 KB, two waves
+            // per CU; f64: 144 KB of the CU's 160 KB)
+            const int lanes = 64;
             const size_t lds = (size_t)lanes * 3 * SINGLE_MAXC_LDS * RS_FIELDS * sizeof(T);
             static bool attr_set = false;
             if (!attr_set) {
