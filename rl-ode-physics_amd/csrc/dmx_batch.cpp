@@ -140,8 +140,7 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
     for (dmxBatch::DevBuf *d : { &b->jd_int, &b->jd_real, &b->jd_rows, &b->jd_rowjb, &b->jd_bscr, &b->jd_local, &b->jd_lcp, &b->jd_lcp_off,
                                 &b->jd_lcp_int })
         if (d->p) (void)hipFree(d->p);
-    for (dmxBatch::DevBuf *d : { &b->bp_count, &b->bp_items, &b->bp_flags, &b->bp_pairs, &b->bp_inpair, &b->bp_snapshot, &b->bp_idx, &b->bp_gather,
-                                &b->np_pos, &b->np_normal, &b->np_depth, &b->np_count, &b->np_pairs, &b->hull, &b->cbuf, &b->ccount,
+    for (dmxBatch::DevBuf *d : { &b->bp_count, &b->bp_items, &b->bp_flags, &b->bp_inpair, &b->bp_snapshot, &b->hull, &b->cbuf, &b->ccount,
                                 &b->ex_arena, &b->ex_body, &b->ex_last, &b->ex_aabb, &b->sbox, &b->hull_planes })
         if (d->p) (void)hipFree(d->p);
     if (b->bp_flags_host) (void)hipHostFree(b->bp_flags_host);

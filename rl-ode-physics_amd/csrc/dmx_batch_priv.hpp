@@ -78,14 +78,8 @@ struct dmxBatch {
     bool ext_pending = false;
     // host scratch of the island grouping, persistent between ticks (dmx_joints.cpp) and of the exact tick (dmx_general.cpp)
     std::vector<int> sc_parent, sc_island, sc_last, sc_slots;
-    std::vector<int32_t> sc_last_count;         // counting-sort scratch of the pair ordering
     std::vector<int> sc_iv[16];                 // work arrays of the island grouping (dmx_joints.cpp)
-    std::vector<int32_t> sc_i32[4];             // ... and of the exact tick (dmx_general.cpp)
-    std::vector<std::pair<int32_t, int32_t>> sc_pairs, sc_pairs2;
-    std::vector<int64_t> sc_joff;
     std::vector<DmxCanonicalJoint> sc_cj;
-    std::vector<dmxContactJoint> sc_joints;     // the exact tick's joint list and, per joint, its narrowphase slot
-    std::vector<int32_t> sc_src;
     std::vector<uint8_t> sc_include;            // per slot: 1 while the body is in this tick's island subset
     const int32_t *sc_include_list = nullptr;   // that subset as an ascending list (set around dmx_step_joints by the exact tick)
     int64_t sc_include_count = 0;
@@ -113,8 +107,7 @@ struct dmxBatch {
     uint32_t bp_crowded = 0;                   // bodies whose safe radius is <= 0 at the last build
     double bp_rmax = 0, bp_rmax_box = 0, bp_rmax_solid = 0;
     uint32_t bp_mask = 0; int bp_cap = 8; int bp_xbits = -1;      // -1: not chosen yet
-    DevBuf bp_count, bp_items, bp_flags, bp_pairs, bp_inpair, bp_snapshot, bp_idx, bp_gather;
-    DevBuf np_pos, np_normal, np_depth, np_count, np_pairs;   // device narrowphase output of the exact tick
+    DevBuf bp_count, bp_items, bp_flags, bp_inpair, bp_snapshot;
     // device-resident bookkeeping of the exact tick (dmx_exact.hip): capacity estimates carried from tick to tick, one arena
     // for the pipeline's arrays, per-body scan arrays, the per-slot level scratch, the pinned read-back record
     uint32_t ex_cap_pairs = 0, ex_cap_rows = 0;
@@ -123,7 +116,6 @@ struct dmxBatch {
     void *ex_counts_host = nullptr;
     std::vector<int32_t> fp_pairs, fp_inv, fp_cross;      // dmxBatchFindPairs' results; (own body, ghost slot) pairs it met
     uint32_t *bp_flags_host = nullptr;         // pinned
-    int bp_max_pairs = 0;
     std::vector<double> h_sides;               // host mirror of DMX_SIDES (exact values of the batch precision)
     std::vector<uint8_t> h_gtype;
     // convex bodies: the shared hull's body-frame points, and the per-tick plane contacts of every convex body

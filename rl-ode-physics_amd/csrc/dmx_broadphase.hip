@@ -4,8 +4,7 @@
 // binned by the (x,z) column of their centre into a hashed table of fixed-capacity buckets; the cell size is
 // at least the largest bounding-sphere diameter, so two bodies whose AABBs overlap always sit in adjacent
 // columns (3x3 neighbourhood).  Two consumers:
-//   * the exact pair search (dmx_exact.hip; bp_pairs here is its one-pass predecessor): every (i<j) whose AABBs overlap
-//     (what reaches NearCallback);
+//   * the exact pair search (dmx_exact.hip): every (i<j) whose AABBs overlap (what reaches NearCallback);
 //   * bp_safe_zone -- per body, half the horizontal gap to its nearest neighbour's bounding sphere.  While every
 //                     body stays inside its safe zone (a 3-real check fused into the step kernels) no two
 //                     bounding spheres can touch, so no collider can return a CONTACT (each body lies inside its
@@ -122,42 +121,6 @@ __global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uin
     S[slab_ix(C_BPSAFE, i)] = safe;
 }
 
-// exact pair search: (i,j), i active, i<j or j a ghost slot, AABBs overlap
-template <class T>
-__global__ __launch_bounds__(256) void bp_pairs(const T *__restrict__ S, const uint8_t *__restrict__ gtype,
-                                                int64_t stride, int64_t n_active, GridParams<T> G,
-                                                int32_t *__restrict__ pairs, int max_pairs,
-                                                uint8_t *__restrict__ inpair)
-{
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n_active || gtype[i] == GEOM_NONE) return;
-    T lo[3], hi[3];
-    body_aabb<T>(S, gtype, stride, i, lo, hi);
-    const int ix = (int)floor((double)(S[slab_ix(C_POS + 0, i)] * G.inv_cell));
-    const int iz = (int)floor((double)(S[slab_ix(C_POS + 2, i)] * G.inv_cell));
-    for (int dz = -1; dz <= 1; dz++)
-        for (int dx = -1; dx <= 1; dx++) {
-            const uint32_t h = cell_hash(ix + dx, iz + dz, G.mask, G.xbits);
-            uint32_t cnt = G.count[h];
-            if (cnt > (uint32_t)G.cap) cnt = (uint32_t)G.cap;
-            for (uint32_t s = 0; s < cnt; s++) {
-                const int64_t j = G.items[(size_t)h * G.cap + s];
-                if (j <= i) continue;                       // each unordered pair once
-                // hashed buckets can mix columns: keep only true 3x3 neighbours so (i,j) is met in one cell only
-                const int jx = (int)floor((double)(S[slab_ix(C_POS + 0, j)] * G.inv_cell));
-                const int jz = (int)floor((double)(S[slab_ix(C_POS + 2, j)] * G.inv_cell));
-                if (jx != ix + dx || jz != iz + dz) continue;
-                T lo2[3], hi2[3];
-                body_aabb<T>(S, gtype, stride, j, lo2, hi2);
-                if (lo2[0] > hi[0] || lo[0] > hi2[0] || lo2[1] > hi[1] || lo[1] > hi2[1] || lo2[2] > hi[2] || lo[2] > hi2[2])
-                    continue;
-                const uint32_t k = atomicAdd(&G.flags[BPF_NPAIRS], 1u);
-                if (k < (uint32_t)max_pairs) { pairs[2 * k] = (int32_t)i; pairs[2 * k + 1] = (int32_t)j; }
-                inpair[i] = 1; inpair[j] = 1;
-            }
-        }
-}
-
 static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 template <class T>
@@ -174,20 +137,9 @@ hipError_t launch_bp_safe_zone(T *S, const uint8_t *gtype, int64_t stride, int64
     hipLaunchKernelGGL((bp_safe_zone<T>), dim3(nblk(n_active)), dim3(256), 0, st, S, gtype, stride, n_active, G);
     return hipGetLastError();
 }
-template <class T>
-hipError_t launch_bp_pairs(const T *S, const uint8_t *gtype, int64_t stride, int64_t n_active, const GridParams<T> &G,
-                           int32_t *pairs, int max_pairs, uint8_t *inpair, hipStream_t st)
-{
-    if (n_active <= 0) return hipSuccess;
-    hipLaunchKernelGGL((bp_pairs<T>), dim3(nblk(n_active)), dim3(256), 0, st, S, gtype, stride, n_active, G, pairs, max_pairs, inpair);
-    return hipGetLastError();
-}
-
 #define DMX_BP_INST(T)                                                                                              \
     template hipError_t launch_bp_insert<T>(T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, hipStream_t); \
-    template hipError_t launch_bp_safe_zone<T>(T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, hipStream_t);    \
-    template hipError_t launch_bp_pairs<T>(const T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, int32_t *,     \
-                                           int, uint8_t *, hipStream_t);
+    template hipError_t launch_bp_safe_zone<T>(T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, hipStream_t);
 DMX_BP_INST(float)
 DMX_BP_INST(double)
 

@@ -76,7 +76,6 @@ int ensure_buffers(dmxBatch *b)
         int bits = 0;
         while ((1u << bits) < h) bits++;
         b->bp_xbits = (bits + 1) / 2;          // a square torus to start with; see grow_buckets
-        b->bp_max_pairs = (int)std::min<int64_t>(4 * b->n + 1024, 1 << 24);
     }
     int rc;
     const size_t tbl = (size_t)b->bp_mask + 1;
@@ -131,27 +130,6 @@ template <class T> int build_safe_zones(dmxBatch *b)
     b->bp_valid = true;
     b->stat_rebuilds++;
     return DMX_OK;
-}
-
-// canonical pair order (ascending first body, then second).  Many pairs: counting sort on the first body over the
-// batch's slots, then each body's short run of partners; few: a comparison sort.
-void sort_pairs(std::vector<std::pair<int32_t, int32_t>> &pairs, int64_t n, std::vector<int32_t> &count,
-                std::vector<std::pair<int32_t, int32_t>> &out, std::vector<int32_t> &fill)
-{
-    const size_t np = pairs.size();
-    if ((int64_t)np * 16 < n) { std::sort(pairs.begin(), pairs.end()); return; }
-    count.assign((size_t)n + 1, 0);
-    for (auto &p : pairs) count[(size_t)p.first + 1]++;
-    for (int64_t i = 0; i < n; i++) count[(size_t)i + 1] += count[(size_t)i];
-    out.resize(np);
-    {
-        fill.assign(count.begin(), count.end() - 1);
-        for (auto &p : pairs) out[(size_t)fill[(size_t)p.first]++] = p;
-    }
-    for (int64_t i = 0; i < n; i++)
-        if (count[(size_t)i + 1] - count[(size_t)i] > 1)
-            std::sort(out.begin() + count[(size_t)i], out.begin() + count[(size_t)i + 1]);
-    pairs.swap(out);
 }
 
 // ---- the chunk's rollback snapshot ------------------------------------------------------------------------

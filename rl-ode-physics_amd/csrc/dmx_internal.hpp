@@ -162,20 +162,9 @@ template <class T>
 hipError_t launch_bp_insert(T *S, const uint8_t *gtype, int64_t stride, int64_t n, const GridParams<T> &G, hipStream_t st);
 template <class T>
 hipError_t launch_bp_safe_zone(T *S, const uint8_t *gtype, int64_t stride, int64_t n_active, const GridParams<T> &G, hipStream_t st);
-template <class T>
-hipError_t launch_bp_pairs(const T *S, const uint8_t *gtype, int64_t stride, int64_t n_active, const GridParams<T> &G,
-                           int32_t *pairs, int max_pairs, uint8_t *inpair, hipStream_t st);
-// device narrowphase of the exact tick: ground-plane contacts of the listed bodies (4 slots each) and contacts of the
-// listed body pairs (8 slots each) into one geometry array; counts per body / per pair
-template <class T>
-hipError_t launch_np_plane(const T *S, const uint8_t *gtype, int64_t stride, const int32_t *bodies, int nb,
-                           const StepParams<T> &P, T *gpos, T *gnormal, T *gdepth, int32_t *count, hipStream_t st);
 // ground-plane contacts of the convex bodies among [0, n): one wavefront per body walks the hull (dCollideConvexPlane)
 template <class T>
 hipError_t launch_np_convex_plane(const T *S, const uint8_t *gtype, int64_t n, const StepParams<T> &P, hipStream_t st);
-template <class T>
-hipError_t launch_np_pairs(const T *S, const uint8_t *gtype, int64_t stride, const int32_t *pairs, int np, int maxc,
-                           int base_slot, T *gpos, T *gnormal, T *gdepth, int32_t *count, hipStream_t st);
 template <class T>
 hipError_t launch_pack_transforms(const T *S, int64_t stride, int64_t first, int64_t count, T *out, hipStream_t st);
 template <class T>
