@@ -236,6 +236,15 @@ int dmxBatchStepJoints(dmxBatchID b, double h, int64_t n_joints, const dmxContac
  * says so).  dmxBatchStep (the BASELINE configs, which name dWorldQuickStep) is not affected. */
 enum { DMX_STEPPER_QUICK = 0, DMX_STEPPER_EXACT = 1 };
 int dmxBatchSetStepper(dmxBatchID b, int stepper);
+/* The order QuickStep's SOR sweeps an island's rows in (dmxBatchStepJoints, DMX_STEPPER_QUICK).  DMX_ORDER_CREATION (default):
+ * the order the contact joints were created in, every sweep -- deterministic, and what lets islands be solved by workgroups
+ * under a level schedule.  DMX_ORDER_ODE: what stock ODE does [ODE-recall]: rows numbered in the order its island builder
+ * discovers the joints (depth-first from the newest body, each body's joints newest first) and re-shuffled before sweeps
+ * 0, 8, 16, ... with ODE's linear congruential generator (RANDOMLY_REORDER_CONSTRAINTS), seeded here per batch (`seed` =
+ * dRandSetSeed; ODE's generator is process-global).  Islands are then swept sequentially, one lane each: an option for
+ * comparing with ODE's own sequence, not a fast path.  "Newest body" is the highest slot. */
+enum { DMX_ORDER_CREATION = 0, DMX_ORDER_ODE = 1 };
+int dmxBatchSetRowOrder(dmxBatchID b, int order, uint32_t seed);
 
 /* per-body flags for the island path: dBodyDestroy'ed slots, dBodySetKinematic (main.c:712), gravity / gyro modes */
 enum { DMX_BODY_ALIVE = 1, DMX_BODY_KINEMATIC = 2, DMX_BODY_NOGRAVITY = 4, DMX_BODY_NOGYRO = 8 };

@@ -24,7 +24,7 @@ BATCH_SYMBOLS = [
     "dmxBatchChunkBegin", "dmxBatchChunkTick", "dmxBatchCheckZonesOnStream", "dmxBatchChunkEnd",
     "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream", "dmxBatchSetConvexHull", "dmxBatchChunkTicks", "dmxBatchSetTicksPerLaunch",
     "dmxBatchSetSnapshotMode", "dmxBatchSetStaticBoxes", "dmxBatchSetStepper", "dmxBatchSetConvexHullFaces",
-    "dmxBatchCollisionStatsEx", "dmxBatchFindPairs", "dmxBatchCrossPairs",
+    "dmxBatchCollisionStatsEx", "dmxBatchFindPairs", "dmxBatchCrossPairs", "dmxBatchSetRowOrder",
 ]
 
 _lib = None
@@ -109,5 +109,6 @@ def load():
     sig("dmxBatchCollisionStatsEx", I, P, C.POINTER(L))
     sig("dmxBatchFindPairs", I, P, C.POINTER(P), C.POINTER(L), C.POINTER(P), C.POINTER(L))
     sig("dmxBatchCrossPairs", I, P, C.POINTER(P), C.POINTER(L))
+    sig("dmxBatchSetRowOrder", I, P, I, C.c_uint32)
     _lib = lib
     return lib

@@ -138,7 +138,7 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
     if (b->gtype) (void)hipFree(b->gtype);
     if (b->bflags) (void)hipFree(b->bflags);
     for (dmxBatch::DevBuf *d : { &b->jd_int, &b->jd_real, &b->jd_rows, &b->jd_rowjb, &b->jd_bscr, &b->jd_local, &b->jd_lcp, &b->jd_lcp_off,
-                                &b->jd_lcp_int })
+                                &b->jd_lcp_int, &b->jd_order })
         if (d->p) (void)hipFree(d->p);
     for (dmxBatch::DevBuf *d : { &b->bp_count, &b->bp_items, &b->bp_flags, &b->bp_inpair, &b->bp_snapshot, &b->hull, &b->cbuf, &b->ccount,
                                 &b->ex_arena, &b->ex_body, &b->ex_last, &b->ex_aabb, &b->sbox, &b->hull_planes })
@@ -354,6 +354,15 @@ extern "C" int dmxBatchSetStepper(dmxBatchID b, int stepper)
     if (!b || (stepper != DMX_STEPPER_QUICK && stepper != DMX_STEPPER_EXACT)) return DMX_EINVAL;
     SETTLE(b);
     b->stepper_exact = stepper == DMX_STEPPER_EXACT;
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchSetRowOrder(dmxBatchID b, int order, uint32_t seed)
+{
+    if (!b || (order != DMX_ORDER_CREATION && order != DMX_ORDER_ODE)) return DMX_EINVAL;
+    SETTLE(b);
+    b->row_order_ode = order == DMX_ORDER_ODE;
+    b->ode_rand = seed;
     return DMX_OK;
 }
 

@@ -99,6 +99,11 @@ struct dmxBatch {
     DevBuf jd_lcp, jd_lcp_off, jd_lcp_int;     // dWorldStep's exact island solve: A, factor, vectors per island; offsets; pivoting state
     std::vector<long long> sc_lcp_off;
     bool stepper_exact = false;                // dmxBatchSetStepper: dmxBatchStepJoints solves every island's LCP exactly
+    bool row_order_ode = false;                // dmxBatchSetRowOrder: ODE's joint-discovery row order + periodic LCG shuffle (QuickStep)
+    uint32_t ode_rand = 0;                     // that LCG's state (ODE's is process-global; here it belongs to the batch)
+    std::vector<int> sc_ode_proc, sc_ode_iv[4], sc_ode_order;
+    std::vector<uint8_t> sc_ode_tag_b, sc_ode_tag_j;
+    DevBuf jd_order;
     void *jh_int = nullptr, *jh_real = nullptr;                      // pinned host staging
     // body-body broadphase (dmx_broadphase.hip / dmx_general.cpp)
     int bp_enabled = 1;                        // dmxBatchSetBodyCollisions

@@ -83,6 +83,8 @@ template <class T> struct IslandSet {
     // the widest level of any schedule (64 lanes per island are enough when no level is wider)
     int big_max_bodies, big_max_width;
     const int *row_level;  // level of every scheduled row, laid out like lev_rows (an island's rows start at its lev_off[0])
+    const int *order;      // optional (dmxBatchSetRowOrder, DMX_ORDER_ODE): sweep `it` visits row order[(it / 8) * order_stride +
+    int order_stride;      //   row_off[island] + i] at its i-th step; null: rows in creation order (solve_islands only)
     int singles;           // 1: islands of one body with 1..8 contacts are left to solve_singles / solve_singles_lds (one lane each);
                            // whoever builds `big` must then keep such islands out of it
 };

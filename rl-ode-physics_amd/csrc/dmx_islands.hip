@@ -593,8 +593,9 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
         for (int i = 0; i < m; i++) row_setup(rows, jb, bs, i, hinv, P.sor_w);
         for (int it = 0; it < P.iters; it++) {
             const bool last = (it == P.iters - 1);
+            const int *ord = I.order != nullptr ? I.order + (size_t)(it >> 3) * I.order_stride + r0 : nullptr;
             for (int i = 0; i < m; i++) {
-                const T d = row_sor(rows, jb, bs, i);
+                const T d = row_sor(rows, jb, bs, ord != nullptr ? ord[i] : i);
                 if (last) resid += (double)d;
             }
         }

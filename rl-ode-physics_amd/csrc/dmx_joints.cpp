@@ -113,6 +113,51 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
         f.assign(con_start.begin(), con_start.end() - 1);
         for (int k = 0; k < nc; k++) con_sorted[(size_t)f[(size_t)island_of[(size_t)cj[(size_t)k].b1]]++] = k;
     }
+    // ---- ODE's own row order (dmxBatchSetRowOrder): within an island ODE numbers the rows in the order its island builder
+    // discovers the joints -- a depth-first walk from the newest body, each body's joint list newest first [ODE-recall
+    // dxProcessIslands, head-inserted lists] -- and QuickStep re-shuffles that order with the global LCG at every 8th
+    // sweep (RANDOMLY_REORDER_CONSTRAINTS).  The LCG is consumed island by island in the walk's order, so the walk is
+    // replayed here; the shuffled orders are made below, once the islands' row counts are known.
+    const bool ode_order = b->row_order_ode && !exact;
+    std::vector<int> &proc = b->sc_ode_proc;          // islands in the order ODE steps them
+    proc.clear();
+    if (ode_order) {
+        std::vector<int> &adj_off = b->sc_ode_iv[0], &adj = b->sc_ode_iv[1], &fill = b->sc_ode_iv[2], &stack = b->sc_ode_iv[3];
+        std::vector<uint8_t> &tag_b = b->sc_ode_tag_b, &tag_j = b->sc_ode_tag_j;
+        adj_off.assign((size_t)n + 1, 0);
+        for (const CJ &c : cj) { adj_off[(size_t)c.b1 + 1]++; if (c.b2 >= 0) adj_off[(size_t)c.b2 + 1]++; }
+        for (int s = 0; s < n; s++) adj_off[(size_t)s + 1] += adj_off[(size_t)s];
+        adj.resize((size_t)adj_off[(size_t)n] + 1);
+        fill.assign(adj_off.begin(), adj_off.end() - 1);
+        for (int k = 0; k < nc; k++) {
+            adj[(size_t)fill[(size_t)cj[(size_t)k].b1]++] = k;
+            if (cj[(size_t)k].b2 >= 0) adj[(size_t)fill[(size_t)cj[(size_t)k].b2]++] = k;
+        }
+        tag_b.assign((size_t)n, 0); tag_j.assign((size_t)nc + 1, 0);
+        stack.clear();
+        for (int q = nlive - 1; q >= 0; q--) {
+            const int bb = slots[(size_t)q];
+            if (tag_b[(size_t)bb]) continue;
+            tag_b[(size_t)bb] = 1;
+            const int isl = island_of[(size_t)bb];
+            int at = con_start[(size_t)isl];
+            int body = bb;
+            for (;;) {
+                const int lo = adj_off[(size_t)body], hi = adj_off[(size_t)body + 1];
+                for (int t = 0; t < hi - lo; t++) {
+                    const int j = adj[(size_t)(hi - 1 - t)];
+                    if (tag_j[(size_t)j]) continue;
+                    tag_j[(size_t)j] = 1;
+                    con_sorted[(size_t)at++] = j;
+                    const int other = cj[(size_t)j].b1 == body ? cj[(size_t)j].b2 : cj[(size_t)j].b1;
+                    if (other >= 0 && !tag_b[(size_t)other]) { tag_b[(size_t)other] = 1; stack.push_back(other); }
+                }
+                if (stack.empty()) break;
+                body = stack.back(); stack.pop_back();
+            }
+            proc.push_back(isl);
+        }
+    }
     std::vector<int> &crow_h = b->sc_iv[2];           // island-relative first row of each (sorted) contact
     crow_h.assign((size_t)nc, 0);
     std::vector<int> &big_h = b->sc_iv[3], &big_list_h = b->sc_iv[4], &lev_count_h = b->sc_iv[5], &lev_off_h = b->sc_iv[6],
@@ -152,6 +197,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
                     break;
                 }
         for (int i = 0; i < ni; i++) {
+            if (ode_order) break;                     // shuffled sweeps are sequential: every island takes solve_islands
             if (m_of[(size_t)i] < (exact ? 1 : big_island_rows())) continue;
             // one body with 1..8 contacts: solve_singles' / solve_singles_lds' island (one lane), never a workgroup's
             if (!exact && island_bodies[(size_t)i] == 1 && con_start[(size_t)i + 1] - con_start[(size_t)i] <= 8) continue;
@@ -325,7 +371,34 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     I.cpos = dr; I.cnormal = dr + 3 * (size_t)nc; I.cdepth = I.cnormal + 3 * (size_t)nc; I.cmu = I.cdepth + nc;
     I.cbounce = I.cmu + nc; I.cbounce_vel = I.cbounce + nc; I.csoft_erp = I.cbounce_vel + nc; I.csoft_cfm = I.csoft_erp + nc;
     I.rows = (T *)b->jd_rows.p; I.rowjb = (int *)b->jd_rowjb.p; I.bscr = (T *)b->jd_bscr.p; I.local = (int *)b->jd_local.p;
-    I.singles = exact ? 0 : 1;
+    I.singles = (exact || ode_order) ? 0 : 1;
+    I.order = nullptr; I.order_stride = 0;
+    if (ode_order) {
+        // the shuffled row orders, one per 8 sweeps, islands in ODE's processing order (the LCG is global and sequential)
+        const int epochs = (b->iters + 7) / 8;
+        const size_t R = nrows + 1;
+        std::vector<int> &ord_h = b->sc_ode_order, &cur = b->sc_ode_iv[0];
+        ord_h.assign((size_t)std::max(epochs, 1) * R, 0);
+        const std::vector<int> &m_of = b->sc_iv[10];
+        for (int isl : proc) {
+            const int m = m_of[(size_t)isl];
+            if (m <= 0) continue;
+            const size_t base = (size_t)3 * con_start[(size_t)isl];
+            cur.resize((size_t)m);
+            for (int q = 0; q < m; q++) cur[(size_t)q] = q;
+            for (int e = 0; e < epochs; e++) {
+                for (int q = 1; q < m; q++) {
+                    b->ode_rand = 1664525u * b->ode_rand + 1013904223u;                 // dRand [ODE-recall misc.cpp]
+                    const int sw = (int)(((uint64_t)b->ode_rand * (uint32_t)(q + 1)) >> 32);   // dRandInt(q + 1)
+                    std::swap(cur[(size_t)q], cur[(size_t)sw]);
+                }
+                memcpy(ord_h.data() + (size_t)e * R + base, cur.data(), (size_t)m * sizeof(int));
+            }
+        }
+        if ((rc = dmx_ensure_dev(b->jd_order, ord_h.size() * sizeof(int))) != DMX_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(b->jd_order.p, ord_h.data(), ord_h.size() * sizeof(int), hipMemcpyHostToDevice, b->stream));
+        I.order = (const int *)b->jd_order.p; I.order_stride = (int)R;
+    }
 
     StepParams<T> P = dmx_make_params<T>(b, h);
     HIP_TRY(hipMemsetAsync(b->diag_isl, 0, sizeof(StepDiag), b->stream));
@@ -342,6 +415,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
         HIP_TRY(hipStreamSynchronize(b->stream));      // sc_lcp_off is pageable host memory: the copy must have read it before the next tick rewrites it
     } else {
         HIP_TRY(launch_islands<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, b->stream));
+        if (ode_order) HIP_TRY(hipStreamSynchronize(b->stream));      // the order table came from pageable host memory
     }
     b->last_islands = true;
     b->ext_pending = false;

@@ -102,6 +102,7 @@ struct dxWorld {
     int iters = 20;
     bool dev_newer = false;            // device holds newer body state than the host mirrors
     bool host_dirty = true;            // host mirrors hold changes the device has not seen
+    uint32_t order_seed = 0; bool order_seeded = false;     // DMX_ROW_ORDER=ode:<seed>
     bool geom_dirty = true;            // the bodies' geoms (class, extents) changed since the device last saw them
     std::vector<double> dev_statics;   // the static boxes the device holds (18 doubles each), for the device pair search
     std::vector<dReal> buf;
@@ -110,6 +111,12 @@ struct dxWorld {
     void create_batch(int capacity)
     {
         DMX_MUST(dmxBatchCreate(&batch, capacity, kPrecision, 0));
+        if (const char *e = getenv("DMX_ROW_ORDER")) {          // "ode" or "ode:<seed>": stock ODE's row order and shuffle for dWorldQuickStep
+            if (strncmp(e, "ode", 3) == 0) {
+                if (!order_seeded) { order_seed = e[3] == ':' ? (uint32_t)strtoul(e + 4, nullptr, 10) : 0u; order_seeded = true; }
+                DMX_MUST(dmxBatchSetRowOrder(batch, DMX_ORDER_ODE, order_seed));
+            }
+        }
         cap = capacity;
         slots.resize((size_t)cap, nullptr);
         host_dirty = true;

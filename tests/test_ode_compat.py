@@ -36,13 +36,16 @@ def _scene_text(dt, steps, use_plane, statics, bodies):
     return "\n".join(lines) + "\n"
 
 
-def _oracle_poses(dtype, dt, steps, use_plane, statics, bodies, up_front=None, every=0, exact=False):
+def _oracle_poses(dtype, dt, steps, use_plane, statics, bodies, up_front=None, every=0, exact=False, ode_order_seed=None):
     from oracle.orc_ctypes import Oracle
     import ctypes as C
     orc = Oracle(dtype)
     lib = orc.lib
     ow = orc.world()
     ow.set_stepper(exact)
+    if ode_order_seed is not None:          # stock ODE's row order: joint-discovery numbering + the LCG shuffle every 8th sweep
+        lib.orc_world_set_row_order(ow.w, 1)
+        lib.orc_rand_seed(ode_order_seed)
     if use_plane:
         ow.add_plane(0, 1, 0, 0)
     for size, pos, R in statics:
@@ -385,3 +388,23 @@ def test_large_world_through_ode_api_takes_its_pairs_from_the_device(tmp_path):
     assert ow.n_body_pairs() > 100
     assert np.array_equal(got, ref), np.abs(got - ref).max()
     assert np.array_equal(_run_harness(exe, text, env={"DMX_COMPAT_DEVICE_PAIRS": "0"}), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("single,seed", [(False, 12345), (True, 7), (False, 0)])
+def test_quickstep_with_odes_own_row_order_and_shuffle_matches_the_oracle(tmp_path, single, seed):
+    """DMX_ROW_ORDER=ode:<seed>: dWorldQuickStep numbers an island's rows as ODE's island builder discovers the joints and
+    re-shuffles them with ODE's LCG before sweeps 0, 8 and 16 (RANDOMLY_REORDER_CONSTRAINTS) -- the oracle's ORC_ORDER_ODE
+    mode, bit for bit, in the reference's pen with piles (multi-body islands, so the order matters)."""
+    dtype = "float32" if single else "float64"
+    statics = pkg.scenes.reference_map()
+    bodies = pkg.scenes.reference_spawn(60, seed=41, y_range=(1.2, 7.0))
+    dt, steps = 1.0 / 120.0, 240
+    exe = _build_harness(str(tmp_path), single)
+    text = _scene_text(dt, steps, False, statics, bodies)
+    got = _run_harness(exe, text, env={"DMX_ROW_ORDER": f"ode:{seed}"})
+    ref, ow = _oracle_poses(dtype, dt, steps, False, statics, bodies, ode_order_seed=seed)
+    assert ow.n_contacts() > 60 and ow.n_body_pairs() > 5
+    assert np.array_equal(got.astype(ref.dtype), ref), np.abs(got - ref).max()
+    fixed, _ = _oracle_poses(dtype, dt, steps, False, statics, bodies)
+    assert not np.array_equal(fixed, ref)                  # and it is not the creation-order sweep
