@@ -235,7 +235,7 @@ template <class T> int fused_run(dmxBatch *b, double h, int n, bool ends_only, b
 // joints grouped by island in creation order, level schedules.  The host enqueues the pipeline with capacities
 // estimated from earlier ticks, reads ONE 64-byte record back (counts + overflow flags; the stream synchronisation of
 // the tick), then launches the island solve with the exact shape and the fused kernel for everyone else.
-constexpr int kBigIslandRows = 4;        // islands with at least this many rows get a workgroup (see dmx_joints.cpp)
+constexpr int kBigIslandRows = 1;        // multi-body islands with at least this many rows get a workgroup (see dmx_joints.cpp)
 
 int big_island_rows_general()
 {
