@@ -13,15 +13,16 @@
 
 namespace {
 
-// islands with at least this many rows get a workgroup and a level schedule (DMX_BIG_ISLAND_ROWS overrides, for tests).
-// One lane walking an island pays a dependent L2 round trip per row and sweep, so anything beyond a body or two is
-// better off with a workgroup: 500-body reference scene 5.2 / 3.3 / 2.4 / 1.7 / 1.3 / 1.1 / 0.8 ms per tick at 384 / 128 /
-// 64 / 32 / 16 / 8 / 4 rows (profiles/r01_big_island_threshold.txt).
 constexpr int kMaxExactRows = 4096;      // dWorldStep's exact solve keeps A (m x m) and its factor per island: 2 x 128 MB in f64 at this size
 
+// multi-body islands with at least this many rows get a workgroup and a level schedule (DMX_BIG_ISLAND_ROWS overrides, for
+// tests).  One lane walking an island pays a dependent L2 round trip per row and sweep, so every island with rows is better
+// off with a wavefront: 500-body reference scene 5.2 / 3.3 / 2.4 / 1.7 / 1.3 / 1.1 / 0.8 ms per tick at 384 / 128 / 64 / 32 / 16 /
+// 8 / 4 rows (profiles/r01_big_island_threshold.txt), 0.90 -> 0.67 from 4 to 1 with the one-body islands on solve_singles
+// (profiles/r02_island_threshold.txt).
 int big_island_rows()
 {
-    static const int v = [] { const char *e = getenv("DMX_BIG_ISLAND_ROWS"); return e ? atoi(e) : 4; }();
+    static const int v = [] { const char *e = getenv("DMX_BIG_ISLAND_ROWS"); return e ? atoi(e) : 1; }();
     return v;
 }
 
