@@ -95,6 +95,7 @@ class DeviceOps:
     def arm_pack(self, out, layout):
         """Point the next whole-slab tick's boundary pack at `out`."""
         self.w.set_boundary_pack(out.data_ptr(), layout.side, layout.n - layout.side)
+        self._armed = True
 
     def gather(self, idx, out):
         self.w.gather_bodies(idx.data_ptr(), idx.numel(), out.data_ptr())
@@ -128,7 +129,9 @@ class DeviceOps:
         self.have_done = [False] * self.ring
 
     def disarm_pack(self):
-        self.w.set_boundary_pack(0, 0, 0)
+        if getattr(self, "_armed", True):            # (a call through the C ABI each time would be the only host work of a short run() call)
+            self.w.set_boundary_pack(0, 0, 0)
+            self._armed = False
 
     def refresh_ghosts(self, first, count_lo, src_lo, count_hi, src_hi, check):
         """both neighbours' rows into the ghost slots (and their zone test) in one launch on the side stream"""
