@@ -271,6 +271,11 @@ template <class T> int ensure_exact_buffers(dmxBatch *b, const ExactCaps &cap, E
                  o_bg = take((size_t)cap.inv * 8), o_binc = take((size_t)cap.inv * 8),
                  o_big = take((size_t)cap.inv * 4), o_big_list = take((size_t)cap.inv * 4), o_lev_count = take((size_t)cap.inv * 4),
                  o_lev_off = take(((size_t)cap.rows + cap.inv + 1) * 4), o_lev_rows = take((size_t)cap.rows * 4), o_row_level = take((size_t)cap.rows * 4);
+    if (off > ((size_t)128 << 30)) {         // (involved bodies x (1 + static boxes) entries, 8 contact slots each: say so rather than fail in hipMalloc)
+        fprintf(stderr, "libode_mi355: the exact tick would need %.1f GB of work arrays (%u involved bodies x %u static boxes)\n",
+                (double)off / 1e9, cap.inv, cap.nstatic);
+        return DMX_ECAPACITY;
+    }
     if ((rc = dmx_ensure_dev(b->ex_arena, off)) != DMX_OK) return rc;
     char *A = (char *)b->ex_arena.p;
     B.counts = (ExactCounts *)(A + o_counts);
