@@ -15,44 +15,9 @@
 #include <hip/hip_runtime.h>
 #include "dmx_internal.hpp"
 #include "dmx_math.hpp"
+#include "dmx_grid.hpp"
 
 namespace dmx {
-
-// Cell (ix, iz) -> bucket.  Torus form: entry (iz mod rows) * 2^xbits + (ix mod 2^xbits), so a wavefront of bodies
-// adjacent in space looks up adjacent entries (a handful of cache lines instead of one per lookup); cells a whole
-// torus period apart share a bucket, which callers tell apart by the bodies' true cells.  Scenes far longer than
-// wide wrap too often for that; they use the scrambled form (xbits = 0).
-__device__ __forceinline__ uint32_t cell_hash(int ix, int iz, uint32_t mask, int xbits)
-{
-    if (xbits > 0) return ((((uint32_t)iz) << xbits) | ((uint32_t)ix & ((1u << xbits) - 1u))) & mask;
-    return ((uint32_t)ix * 73856093u ^ (uint32_t)iz * 19349663u) & mask;
-}
-
-template <class T> __device__ __forceinline__ T bound_radius(int gt, const T *S, int64_t stride, int64_t i)
-{
-    const T sx = S[slab_ix(C_SIDES + 0, i)];
-    if (gt == GEOM_SPHERE || gt == GEOM_CONVEX) return sx;       // convex: hull bounding radius
-    const T sy = S[slab_ix(C_SIDES + 1, i)], sz = S[slab_ix(C_SIDES + 2, i)];
-    return T(0.5) * tsqrt<T>(sx * sx + sy * sy + sz * sz);
-}
-
-template <class T> __device__ __forceinline__ void body_aabb(const T *S, const uint8_t *gtype, int64_t stride,
-                                                             int64_t i, T lo[3], T hi[3])
-{
-    const T p[3] = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
-    T r[3];
-    if (gtype[i] == GEOM_SPHERE || gtype[i] == GEOM_CONVEX) {      // convex: the bounding sphere's box (conservative)
-        r[0] = r[1] = r[2] = S[slab_ix(C_SIDES + 0, i)];
-    } else {
-        const Q4<T> q = { S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)],
-                          S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] };
-        const M3<T> R = quat_to_R(q);
-        const T s[3] = { S[slab_ix(C_SIDES + 0, i)], S[slab_ix(C_SIDES + 1, i)], S[slab_ix(C_SIDES + 2, i)] };
-        for (int a = 0; a < 3; a++)
-            r[a] = T(0.5) * (tabs(R.m[a][0] * s[0]) + tabs(R.m[a][1] * s[1]) + tabs(R.m[a][2] * s[2]));
-    }
-    for (int a = 0; a < 3; a++) { lo[a] = p[a] - r[a]; hi[a] = p[a] + r[a]; }
-}
 
 // bodies [0,n) -> buckets of their (x,z) column
 template <class T>
@@ -60,21 +25,7 @@ __global__ __launch_bounds__(256) void bp_insert(T *__restrict__ S, const uint8_
                                                  int64_t stride, int64_t n, GridParams<T> G)
 {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    // (convex bodies take part with their bounding sphere's box: conservative, so only candidates are added)
-    if (i >= n || gtype[i] == GEOM_NONE) return;
-    S[slab_ix(C_BPR, i)] = bound_radius<T>(gtype[i], S, stride, i);      // neighbours read this instead of 3 sides + sqrt
-    if (G.aabb != nullptr) {                 // the exact pair search tests every candidate's AABB: computed once, here
-        T lo[3], hi[3];
-        body_aabb<T>(S, gtype, stride, i, lo, hi);
-        T *o = G.aabb + 6 * i;
-        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
-    }
-    const int ix = (int)floor((double)(S[slab_ix(C_POS + 0, i)] * G.inv_cell));
-    const int iz = (int)floor((double)(S[slab_ix(C_POS + 2, i)] * G.inv_cell));
-    const uint32_t h = cell_hash(ix, iz, G.mask, G.xbits);
-    const uint32_t slot = atomicAdd(&G.count[h], 1u);
-    if (slot < (uint32_t)G.cap) G.items[(size_t)h * G.cap + slot] = (int32_t)i;
-    else atomicOr(&G.flags[BPF_OVERFLOW], 1u);
+    if (i < n) grid_insert<T>(S, gtype, i, G);
 }
 
 // per active body: build position (x,z) and safe radius = half the horizontal gap to the nearest bounding sphere
@@ -88,7 +39,7 @@ __global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uin
     const T x = S[slab_ix(C_POS + 0, i)], z = S[slab_ix(C_POS + 2, i)];
     T safe = Limits<T>::inf();
     if (gt != GEOM_NONE) {
-        const T ri = bound_radius<T>(gt, S, stride, i);
+        const T ri = bound_radius<T>(gt, S, i);
         const int ix = (int)floor((double)(x * G.inv_cell)), iz = (int)floor((double)(z * G.inv_cell));
         // nothing outside the 3x3 block is closer than one cell: gap >= cell - r_i - (largest radius of a class i collides with)
         const T rm = gt == GEOM_CONVEX ? G.r_max_box : gt == GEOM_SPHERE ? G.r_max_solid : G.r_max;

@@ -18,9 +18,11 @@
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/block/block_radix_sort.hpp>
 #include "dmx_internal.hpp"
 #include "dmx_math.hpp"
 #include "dmx_collide.hpp"
+#include "dmx_grid.hpp"
 #include "dmx_exact.hpp"
 
 namespace dmx {
@@ -29,28 +31,6 @@ namespace {
 
 __device__ __forceinline__ uint32_t lo32(uint64_t v) { return (uint32_t)v; }
 __device__ __forceinline__ uint32_t hi32(uint64_t v) { return (uint32_t)(v >> 32); }
-
-__device__ __forceinline__ uint32_t cell_hash_x(int ix, int iz, uint32_t mask, int xbits)
-{
-    if (xbits > 0) return ((((uint32_t)iz) << xbits) | ((uint32_t)ix & ((1u << xbits) - 1u))) & mask;
-    return ((uint32_t)ix * 73856093u ^ (uint32_t)iz * 19349663u) & mask;
-}
-
-template <class T> __device__ __forceinline__ void aabb_of(const T *S, const uint8_t *gtype, int64_t i, T lo[3], T hi[3])
-{
-    const T p[3] = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
-    T r[3];
-    if (gtype[i] == GEOM_SPHERE || gtype[i] == GEOM_CONVEX) {
-        r[0] = r[1] = r[2] = S[slab_ix(C_SIDES + 0, i)];
-    } else {
-        const Q4<T> q = { S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)], S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] };
-        const M3<T> R = quat_to_R(q);
-        const T s[3] = { S[slab_ix(C_SIDES + 0, i)], S[slab_ix(C_SIDES + 1, i)], S[slab_ix(C_SIDES + 2, i)] };
-        for (int a = 0; a < 3; a++)
-            r[a] = T(0.5) * (tabs(R.m[a][0] * s[0]) + tabs(R.m[a][1] * s[1]) + tabs(R.m[a][2] * s[2]));
-    }
-    for (int a = 0; a < 3; a++) { lo[a] = p[a] - r[a]; hi[a] = p[a] + r[a]; }
-}
 
 // Walk the 3x3 columns around body i and call f(j) for every other body whose AABB overlaps i's (each once).
 template <class T, class F>
@@ -63,7 +43,7 @@ __device__ __forceinline__ void for_each_partner(const T *S, const uint8_t *gtyp
     const int iz = (int)floor((double)(S[slab_ix(C_POS + 2, i)] * G.inv_cell));
     for (int dz = -1; dz <= 1; dz++)
         for (int dx = -1; dx <= 1; dx++) {
-            const uint32_t h = cell_hash_x(ix + dx, iz + dz, G.mask, G.xbits);
+            const uint32_t h = cell_hash(ix + dx, iz + dz, G.mask, G.xbits);
             uint32_t cnt = G.count[h];
             if (cnt > (uint32_t)G.cap) cnt = (uint32_t)G.cap;
             for (uint32_t s = 0; s < cnt; s++) {
@@ -96,71 +76,86 @@ __device__ __forceinline__ void for_each_partner(const T *S, const uint8_t *gtyp
 // pc[i] = (owned pairs << 32) | in-any-pair; inpair[i] = in-any-pair (the fused kernel's skip mask).  A partner in a ghost
 // slot means an island spanning two ranks.
 template <class T>
+__device__ __forceinline__ void st_pair_count(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G, uint64_t *pc,
+                                              uint8_t *inpair, ExactCounts *C, int32_t *cross_list, int64_t first, int64_t step)
+{
+    for (int64_t i = first; i < n_active; i += step) {
+        uint32_t owned = 0, any = 0;
+        if (gtype[i] != GEOM_NONE) {
+            for_each_partner<T>(S, gtype, i, G, [&](int64_t j) {
+                any = 1;
+                if (j >= n_active) {
+                    if (atomicOr(&C->cross, 1u) == 0u) { C->cross_a = (uint32_t)i; C->cross_b = (uint32_t)j; }
+                    const uint32_t at = atomicAdd(&C->ncross, 1u);
+                    if (at < EX_CROSS_CAP) { cross_list[2 * at] = (int32_t)i; cross_list[2 * at + 1] = (int32_t)j; }
+                }
+                else if (j > i) owned++;
+            }, &C->unsupported);
+            // static box geoms are "big geoms against everyone": a body whose AABB overlaps one goes through the exact path too
+            const T *bi = G.aabb + 6 * i;
+            for (int s = 0; s < G.n_static; s++) {
+                const T *b = G.sbox + s * SBOX_REALS;
+                if (!(bi[0] > b[SBOX_HI + 0] || b[SBOX_LO + 0] > bi[3] || bi[1] > b[SBOX_HI + 1] || b[SBOX_LO + 1] > bi[4] ||
+                      bi[2] > b[SBOX_HI + 2] || b[SBOX_LO + 2] > bi[5])) any = 1;
+            }
+        }
+        pc[i] = ((uint64_t)owned << 32) | any;
+        inpair[i] = (uint8_t)any;
+    }
+}
+template <class T>
 __global__ __launch_bounds__(256) void ex_pair_count(const T *__restrict__ S, const uint8_t *__restrict__ gtype, int64_t n_active,
                                                      GridParams<T> G, uint64_t *__restrict__ pc, uint8_t *__restrict__ inpair,
                                                      ExactCounts *__restrict__ C, int32_t *__restrict__ cross_list)
 {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n_active) return;
-    uint32_t owned = 0, any = 0;
-    if (gtype[i] != GEOM_NONE) {
-        for_each_partner<T>(S, gtype, i, G, [&](int64_t j) {
-            any = 1;
-            if (j >= n_active) {
-                if (atomicOr(&C->cross, 1u) == 0u) { C->cross_a = (uint32_t)i; C->cross_b = (uint32_t)j; }
-                const uint32_t at = atomicAdd(&C->ncross, 1u);
-                if (at < EX_CROSS_CAP) { cross_list[2 * at] = (int32_t)i; cross_list[2 * at + 1] = (int32_t)j; }
-            }
-            else if (j > i) owned++;
-        }, &C->unsupported);
-        // static box geoms are "big geoms against everyone": a body whose AABB overlaps one goes through the exact path too
-        const T *bi = G.aabb + 6 * i;
-        for (int s = 0; s < G.n_static; s++) {
-            const T *b = G.sbox + s * SBOX_REALS;
-            if (!(bi[0] > b[SBOX_HI + 0] || b[SBOX_LO + 0] > bi[3] || bi[1] > b[SBOX_HI + 1] || b[SBOX_LO + 1] > bi[4] ||
-                  bi[2] > b[SBOX_HI + 2] || b[SBOX_LO + 2] > bi[5])) any = 1;
-        }
-    }
-    pc[i] = ((uint64_t)owned << 32) | any;
-    inpair[i] = (uint8_t)any;
+    st_pair_count<T>(S, gtype, n_active, G, pc, inpair, C, cross_list, blockIdx.x * (int64_t)blockDim.x + threadIdx.x,
+                     (int64_t)gridDim.x * blockDim.x);
 }
 
 // ---- 2. pairs in canonical order, the involved bodies ascending, union-find initialised ----------------------------
 // inc = inclusive scan of pc.  Body i owns pairs [hi(exc), hi(exc) + owned) and, if involved, is entry lo(exc) of `inv`.
+template <class T>
+__device__ __forceinline__ void st_pair_write(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G, const uint64_t *pc,
+                                              const uint64_t *inc, int32_t *pairs, int32_t *inv, int32_t *parent, const ExactCaps &cap,
+                                              ExactCounts *C, int64_t first, int64_t step)
+{
+    const uint64_t tot = inc[n_active - 1];
+    if (first == 0) {
+        C->npairs = hi32(tot); C->ninv = lo32(tot);
+        if (hi32(tot) > cap.pairs || lo32(tot) > cap.inv) atomicOr(&C->overflow, 1u);
+    }
+    if (hi32(tot) > cap.pairs || lo32(tot) > cap.inv) return;            // the host grows the capacity and runs again
+    for (int64_t i = first; i < n_active; i += step) {
+        const uint64_t mine = pc[i], exc = inc[i] - mine;
+        if (lo32(mine)) {
+            const uint32_t k = lo32(exc);
+            inv[k] = (int32_t)i;
+            parent[k] = (int32_t)k;
+        }
+        const uint32_t owned = hi32(mine);
+        if (owned == 0) continue;
+        int32_t *out = pairs + 2 * (size_t)hi32(exc);
+        uint32_t w = 0;
+        for_each_partner<T>(S, gtype, i, G, [&](int64_t j) {
+            if (j > i && j < n_active && w < owned) { out[2 * w] = (int32_t)i; out[2 * w + 1] = (int32_t)j; w++; }
+        });
+        // this thread's own run of partners, ascending (runs are short: insertion sort in place)
+        for (uint32_t a = 1; a < w; a++) {
+            const int32_t v = out[2 * a + 1];
+            uint32_t q = a;
+            while (q > 0 && out[2 * (q - 1) + 1] > v) { out[2 * q + 1] = out[2 * (q - 1) + 1]; q--; }
+            out[2 * q + 1] = v;
+        }
+    }
+}
 template <class T>
 __global__ __launch_bounds__(256) void ex_pair_write(const T *__restrict__ S, const uint8_t *__restrict__ gtype, int64_t n_active,
                                                      GridParams<T> G, const uint64_t *__restrict__ pc, const uint64_t *__restrict__ inc,
                                                      int32_t *__restrict__ pairs, int32_t *__restrict__ inv, int32_t *__restrict__ parent,
                                                      ExactCaps cap, ExactCounts *__restrict__ C)
 {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n_active) return;
-    const uint64_t tot = inc[n_active - 1];
-    if (i == 0) {
-        C->npairs = hi32(tot); C->ninv = lo32(tot);
-        if (hi32(tot) > cap.pairs || lo32(tot) > cap.inv) atomicOr(&C->overflow, 1u);
-    }
-    if (hi32(tot) > cap.pairs || lo32(tot) > cap.inv) return;            // the host grows the capacity and runs again
-    const uint64_t mine = pc[i], exc = inc[i] - mine;
-    if (lo32(mine)) {
-        const uint32_t k = lo32(exc);
-        inv[k] = (int32_t)i;
-        parent[k] = (int32_t)k;
-    }
-    const uint32_t owned = hi32(mine);
-    if (owned == 0) return;
-    int32_t *out = pairs + 2 * (size_t)hi32(exc);
-    uint32_t w = 0;
-    for_each_partner<T>(S, gtype, i, G, [&](int64_t j) {
-        if (j > i && j < n_active && w < owned) { out[2 * w] = (int32_t)i; out[2 * w + 1] = (int32_t)j; w++; }
-    });
-    // this thread's own run of partners, ascending (runs are short: insertion sort in place)
-    for (uint32_t a = 1; a < w; a++) {
-        const int32_t v = out[2 * a + 1];
-        uint32_t q = a;
-        while (q > 0 && out[2 * (q - 1) + 1] > v) { out[2 * q + 1] = out[2 * (q - 1) + 1]; q--; }
-        out[2 * q + 1] = v;
-    }
+    st_pair_write<T>(S, gtype, n_active, G, pc, inc, pairs, inv, parent, cap, C, blockIdx.x * (int64_t)blockDim.x + threadIdx.x,
+                     (int64_t)gridDim.x * blockDim.x);
 }
 
 // ---- 3. connected components: lock-free union-find over the involved bodies' indices k (ascending slot order) -------
@@ -185,24 +180,34 @@ __device__ __forceinline__ void uf_unite(int32_t *p, int a, int b)
 }
 __device__ __forceinline__ uint32_t kidx_of(const uint64_t *pc, const uint64_t *inc, int32_t s) { return lo32(inc[s] - pc[s]); }
 
+__device__ __forceinline__ void st_unite(const int32_t *pairs, const uint64_t *pc, const uint64_t *inc, int32_t *parent,
+                                         const ExactCounts *C, uint32_t first, uint32_t step)
+{
+    const uint32_t np = C->overflow ? 0u : C->npairs;
+    for (uint32_t p = first; p < np; p += step)
+        uf_unite(parent, (int)kidx_of(pc, inc, pairs[2 * p]), (int)kidx_of(pc, inc, pairs[2 * p + 1]));
+}
 __global__ __launch_bounds__(256) void ex_unite(const int32_t *__restrict__ pairs, const uint64_t *__restrict__ pc,
                                                 const uint64_t *__restrict__ inc, int32_t *parent, const ExactCounts *__restrict__ C)
 {
-    const uint32_t np = C->overflow ? 0u : C->npairs;
-    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < np; p += gridDim.x * blockDim.x)
-        uf_unite(parent, (int)kidx_of(pc, inc, pairs[2 * p]), (int)kidx_of(pc, inc, pairs[2 * p + 1]));
+    st_unite(pairs, pc, inc, parent, C, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // root[k]; rf[k] = 1 for roots, 0 elsewhere and for the padding up to the capacity (scanned next: island numbers)
-__global__ __launch_bounds__(256) void ex_flatten(int32_t *parent, int32_t *__restrict__ root, uint32_t *__restrict__ rf,
-                                                  ExactCaps cap, const ExactCounts *__restrict__ C)
+__device__ __forceinline__ void st_flatten(int32_t *parent, int32_t *root, uint32_t *rf, const ExactCaps &cap, const ExactCounts *C,
+                                           uint32_t first, uint32_t step)
 {
     const uint32_t ninv = C->overflow ? 0u : C->ninv;
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < cap.inv; k += gridDim.x * blockDim.x) {
+    for (uint32_t k = first; k < cap.inv; k += step) {
         uint32_t f = 0;
         if (k < ninv) { const int r = uf_find(parent, (int)k); root[k] = r; f = (r == (int)k) ? 1u : 0u; }
         rf[k] = f;
     }
+}
+__global__ __launch_bounds__(256) void ex_flatten(int32_t *parent, int32_t *__restrict__ root, uint32_t *__restrict__ rf,
+                                                  ExactCaps cap, const ExactCounts *__restrict__ C)
+{
+    st_flatten(parent, root, rf, cap, C, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // ---- 4. narrowphase with device-side counts (same colliders as np_plane / np_pairs) --------------------------------
@@ -463,41 +468,46 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
 }
 
 // ---- 5. sort keys: entry e -> its island (rinc = inclusive scan of the root flags: island of root r = rinc[r] - 1) ---
+__device__ __forceinline__ uint32_t entry_key(uint32_t e, const int32_t *pairs, const uint64_t *pc, const uint64_t *inc, const int32_t *root,
+                                              const uint32_t *rinc, const ExactCaps &cap, uint32_t ninv, uint32_t np)
+{
+    const uint32_t e_pairs = cap.pair_entry0();
+    if (e < e_pairs) { const uint32_t k = e % cap.inv; if (k < ninv) return rinc[root[k]] - 1u; }
+    else if (e - e_pairs < np) return rinc[root[kidx_of(pc, inc, pairs[2 * (e - e_pairs)])]] - 1u;
+    return cap.inv;                                     // padding sorts behind every island
+}
 __global__ __launch_bounds__(256) void ex_keys(const int32_t *__restrict__ pairs, const uint64_t *__restrict__ pc,
                                                const uint64_t *__restrict__ inc, const int32_t *__restrict__ root,
                                                const uint32_t *__restrict__ rinc, ExactCaps cap, uint32_t *__restrict__ keys,
                                                uint32_t *__restrict__ vals, ExactCounts *C)
 {
     const uint32_t ninv = C->overflow ? 0u : C->ninv, np = C->overflow ? 0u : C->npairs;
-    const uint32_t ne = cap.entries(), e_pairs = cap.pair_entry0();
+    const uint32_t ne = cap.entries();
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
-        uint32_t key = cap.inv;                         // padding sorts behind every island
-        if (e < e_pairs) { const uint32_t k = e % cap.inv; if (k < ninv) key = rinc[root[k]] - 1u; }
-        else if (e - e_pairs < np) key = rinc[root[kidx_of(pc, inc, pairs[2 * (e - e_pairs)])]] - 1u;
-        keys[e] = key; vals[e] = e;
+        keys[e] = entry_key(e, pairs, pc, inc, root, rinc, cap, ninv, np); vals[e] = e;
         if (e == 0) C->ni = rinc[cap.inv - 1];
     }
 }
 
 // ---- 6. sorted entries -> (contacts << 32 | is-body-entry), scanned next ------------------------------------------
+__device__ __forceinline__ uint64_t gathered(uint32_t key, uint32_t e, const uint32_t *cc, const ExactCaps &cap)
+{
+    return key < cap.inv ? (((uint64_t)cc[e] << 32) | (e < cap.inv ? 1u : 0u)) : 0ull;
+}
 __global__ __launch_bounds__(256) void ex_gather(const uint32_t *__restrict__ keys_s, const uint32_t *__restrict__ vals_s,
                                                  const uint32_t *__restrict__ cc, ExactCaps cap, uint64_t *__restrict__ sc)
 {
     const uint32_t ne = cap.entries();
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ne; t += gridDim.x * blockDim.x) {
-        uint64_t v = 0;
-        if (keys_s[t] < cap.inv) { const uint32_t e = vals_s[t]; v = ((uint64_t)cc[e] << 32) | (e < cap.inv ? 1u : 0u); }
-        sc[t] = v;
-    }
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ne; t += gridDim.x * blockDim.x)
+        sc[t] = gathered(keys_s[t], vals_s[t], cc, cap);
 }
 
 // ---- 7. island boundaries: first sorted entry of each island gives its offsets ------------------------------------
-__global__ __launch_bounds__(256) void ex_bounds(const uint32_t *__restrict__ keys_s, const uint64_t *__restrict__ sc,
-                                                 const uint64_t *__restrict__ sinc, ExactCaps cap, int *__restrict__ body_off,
-                                                 int *__restrict__ con_off, int *__restrict__ row_off, ExactCounts *C)
+__device__ __forceinline__ void st_bounds(const uint32_t *keys_s, const uint64_t *sc, const uint64_t *sinc, const ExactCaps &cap,
+                                          int *body_off, int *con_off, int *row_off, ExactCounts *C, uint32_t first, uint32_t step)
 {
     const uint32_t ne = cap.entries();
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ne; t += gridDim.x * blockDim.x) {
+    for (uint32_t t = first; t < ne; t += step) {
         const uint32_t key = keys_s[t];
         if (key < cap.inv && (t == 0 || keys_s[t - 1] != key)) {
             const uint64_t exc = sinc[t] - sc[t];
@@ -511,17 +521,21 @@ __global__ __launch_bounds__(256) void ex_bounds(const uint32_t *__restrict__ ke
         }
     }
 }
+__global__ __launch_bounds__(256) void ex_bounds(const uint32_t *__restrict__ keys_s, const uint64_t *__restrict__ sc,
+                                                 const uint64_t *__restrict__ sinc, ExactCaps cap, int *__restrict__ body_off,
+                                                 int *__restrict__ con_off, int *__restrict__ row_off, ExactCounts *C)
+{
+    st_bounds(keys_s, sc, sinc, cap, body_off, con_off, row_off, C, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
 
 // ---- 8. the island-grouped body list and contact arrays -------------------------------------------------------------
-__global__ __launch_bounds__(256) void ex_fill(const uint32_t *__restrict__ keys_s, const uint32_t *__restrict__ vals_s,
-                                               const uint64_t *__restrict__ sc, const uint64_t *__restrict__ sinc,
-                                               const uint32_t *__restrict__ cc, const int32_t *__restrict__ inv,
-                                               const int32_t *__restrict__ pairs, const int *__restrict__ con_off, ExactCaps cap, int rpc,
-                                               int *__restrict__ bodies, int *__restrict__ cb1, int *__restrict__ cb2,
-                                               int *__restrict__ csrc, int *__restrict__ crow)
+__device__ __forceinline__ void st_fill(const uint32_t *keys_s, const uint32_t *vals_s, const uint64_t *sc, const uint64_t *sinc,
+                                        const uint32_t *cc, const int32_t *inv, const int32_t *pairs, const int *con_off,
+                                        const ExactCaps &cap, int rpc, int *bodies, int *cb1, int *cb2, int *csrc, int *crow,
+                                        uint32_t first, uint32_t step)
 {
     const uint32_t ne = cap.entries(), e_pairs = cap.pair_entry0();
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ne; t += gridDim.x * blockDim.x) {
+    for (uint32_t t = first; t < ne; t += step) {
         const uint32_t key = keys_s[t];
         if (key >= cap.inv) continue;
         const uint32_t e = vals_s[t];
@@ -538,13 +552,23 @@ __global__ __launch_bounds__(256) void ex_fill(const uint32_t *__restrict__ keys
         }
     }
 }
+__global__ __launch_bounds__(256) void ex_fill(const uint32_t *__restrict__ keys_s, const uint32_t *__restrict__ vals_s,
+                                               const uint64_t *__restrict__ sc, const uint64_t *__restrict__ sinc,
+                                               const uint32_t *__restrict__ cc, const int32_t *__restrict__ inv,
+                                               const int32_t *__restrict__ pairs, const int *__restrict__ con_off, ExactCaps cap, int rpc,
+                                               int *__restrict__ bodies, int *__restrict__ cb1, int *__restrict__ cb2,
+                                               int *__restrict__ csrc, int *__restrict__ crow)
+{
+    st_fill(keys_s, vals_s, sc, sinc, cc, inv, pairs, con_off, cap, rpc, bodies, cb1, cb2, csrc, crow,
+            blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
 
 // ---- 9. which islands get a workgroup: bg[isl] = (rows << 32 | 1) for those, 0 otherwise and for the padding -------
-__global__ __launch_bounds__(256) void ex_bigflags(const int *__restrict__ con_off, const int *__restrict__ body_off, ExactCaps cap,
-                                                   int rpc, int big_rows, uint64_t *__restrict__ bg, const ExactCounts *__restrict__ C)
+__device__ __forceinline__ void st_bigflags(const int *con_off, const int *body_off, const ExactCaps &cap, int rpc, int big_rows,
+                                            uint64_t *bg, const ExactCounts *C, uint32_t first, uint32_t step)
 {
     const uint32_t ni = C->overflow ? 0u : C->ni;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cap.inv; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = first; i < cap.inv; i += step) {
         uint64_t v = 0;
         if (i < ni) {
             const int nc = con_off[i + 1] - con_off[i], m = rpc * nc;
@@ -554,19 +578,22 @@ __global__ __launch_bounds__(256) void ex_bigflags(const int *__restrict__ con_o
         bg[i] = v;
     }
 }
+__global__ __launch_bounds__(256) void ex_bigflags(const int *__restrict__ con_off, const int *__restrict__ body_off, ExactCaps cap,
+                                                   int rpc, int big_rows, uint64_t *__restrict__ bg, const ExactCounts *__restrict__ C)
+{
+    st_bigflags(con_off, body_off, cap, rpc, big_rows, bg, C, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
 
 // ---- 10. level schedules.  One lane per island; islands own disjoint bodies, so `last` (per slot, -1 when idle) is
 //          private to the lane while it works.  lev_off of island k (big index) lives at row_base + k, nlev + 1 <= rows + 1
 //          entries; lev_rows / row_level at row_base. -----------------------------------------------------------------------
-__global__ __launch_bounds__(64) void ex_levels(const int *__restrict__ con_off, const int *__restrict__ body_off,
-                                                const int *__restrict__ cb1, const int *__restrict__ cb2,
-                                                const uint64_t *__restrict__ bg, const uint64_t *__restrict__ binc, ExactCaps cap, int rpc,
-                                                int *__restrict__ big, int *__restrict__ big_list, int *__restrict__ lev_count,
-                                                int *__restrict__ lev_off, int *__restrict__ lev_rows, int *__restrict__ row_level,
-                                                int *__restrict__ last, ExactCounts *C)
+__device__ __forceinline__ void st_levels(const int *con_off, const int *body_off, const int *cb1, const int *cb2, const uint64_t *bg,
+                                          const uint64_t *binc, const ExactCaps &cap, int rpc, int *big, int *big_list, int *lev_count,
+                                          int *lev_off, int *lev_rows, int *row_level, int *last, ExactCounts *C, uint32_t first,
+                                          uint32_t step)
 {
     const uint32_t ni = C->overflow ? 0u : C->ni;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ni; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = first; i < ni; i += step) {
         if (i == 0) {
             const uint64_t tot = binc[cap.inv - 1];
             C->nbig = lo32(tot); C->big_rows = hi32(tot);
@@ -610,6 +637,136 @@ __global__ __launch_bounds__(64) void ex_levels(const int *__restrict__ con_off,
         for (int q = 0; q < m; q++) rows_out[off[lv_out[q]]++ - base] = q;
         for (int q = nlev; q > 0; q--) off[q] = off[q - 1];
         off[0] = base;
+    }
+}
+__global__ __launch_bounds__(64) void ex_levels(const int *__restrict__ con_off, const int *__restrict__ body_off,
+                                                const int *__restrict__ cb1, const int *__restrict__ cb2,
+                                                const uint64_t *__restrict__ bg, const uint64_t *__restrict__ binc, ExactCaps cap, int rpc,
+                                                int *__restrict__ big, int *__restrict__ big_list, int *__restrict__ lev_count,
+                                                int *__restrict__ lev_off, int *__restrict__ lev_rows, int *__restrict__ row_level,
+                                                int *__restrict__ last, ExactCounts *C)
+{
+    st_levels(con_off, body_off, cb1, cb2, bg, binc, cap, rpc, big, big_list, lev_count, lev_off, lev_rows, row_level, last, C,
+              blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// ================================================================================================ small scenes
+// A scene of a few thousand bodies gives every stage above a few microseconds of work for one workgroup; launched one by
+// one, the ~25 stages (rocPRIM's scans and sort are two or three launches each, plus the memsets) cost a launch apiece and
+// the tick is all launch latency (configs[0]: ~120 us of it per exact tick).  The same stage functions, in the same order,
+// as two one-workgroup kernels around the narrowphase: barriers instead of launches, workgroup scans, one block radix sort
+// of (island << entry bits | entry) keys -- stable by construction.  The back kernel leaves the counts and the broadphase
+// flags in pinned host memory itself, so the tick's one wait on the device is all the host does.
+constexpr int EXS_WG = 1024, EXS_ITEMS = 8;
+
+template <class V> __device__ __forceinline__ V wave_scan_inclusive(V x, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const V y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    return x;
+}
+// out[i] = in[0] + ... + in[i], i < n; thread t owns the run [t per, (t + 1) per).  wt: EXS_WG / 64 values of LDS.
+template <class V> __device__ __forceinline__ void block_scan_inclusive(const V *in, V *out, uint32_t n, V *wt)
+{
+    const uint32_t tid = threadIdx.x, per = (n + EXS_WG - 1) / EXS_WG;
+    const uint32_t a = tid * per < n ? tid * per : n, e = a + per < n ? a + per : n;
+    V sum = 0;
+    for (uint32_t i = a; i < e; i++) sum += in[i];
+    const int lane = (int)(tid & 63u);
+    const V x = wave_scan_inclusive<V>(sum, lane);
+    if (lane == 63) wt[tid >> 6] = x;
+    __syncthreads();
+    if (tid < 64) {
+        const V t = wave_scan_inclusive<V>(tid < EXS_WG / 64 ? wt[tid] : V(0), lane);
+        if (tid < EXS_WG / 64) wt[tid] = t;
+    }
+    __syncthreads();
+    V run = ((tid >> 6) > 0 ? wt[(tid >> 6) - 1] : V(0)) + x - sum;
+    for (uint32_t i = a; i < e; i++) { run += in[i]; out[i] = run; }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void publish_counts(const ExactCounts *C, const uint32_t *flags, ExactCounts *host_counts, uint32_t *host_flags)
+{
+    if (host_counts == nullptr) return;
+    for (int k = 0; k < (int)(sizeof(ExactCounts) / 4); k++) ((volatile uint32_t *)host_counts)[k] = ((const volatile uint32_t *)C)[k];
+    for (int k = 0; k < BPF_COUNT; k++) ((volatile uint32_t *)host_flags)[k] = ((const volatile uint32_t *)flags)[k];
+    __threadfence_system();
+}
+
+// grid fill (fill_grid's memsets + bp_insert) and stages 1-3: pairs, involved bodies, islands' roots
+template <class T>
+__global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gtype, int64_t n, int64_t n_active, GridParams<T> G,
+                                                         ExactBuffers<T> B, ExactCaps cap, ExactCounts *host_counts, uint32_t *host_flags)
+{
+    __shared__ uint64_t wt[EXS_WG / 64];
+    const uint32_t tid = threadIdx.x;
+    ExactCounts *C = B.counts;
+    for (uint32_t k = tid; k <= G.mask; k += EXS_WG) G.count[k] = 0u;
+    if (tid < (uint32_t)BPF_COUNT) G.flags[tid] = 0u;
+    if (tid < sizeof(ExactCounts) / 4) ((uint32_t *)C)[tid] = 0u;
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += EXS_WG) grid_insert<T>(S, gtype, i, G);      // ghosts included
+    __syncthreads();
+    st_pair_count<T>(S, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG);
+    __syncthreads();
+    block_scan_inclusive<uint64_t>(B.pc, B.inc, (uint32_t)n_active, wt);
+    st_pair_write<T>(S, gtype, n_active, G, B.pc, B.inc, B.pairs, B.inv, B.parent, cap, C, tid, EXS_WG);
+    __syncthreads();
+    st_unite(B.pairs, B.pc, B.inc, B.parent, C, tid, EXS_WG);
+    __syncthreads();
+    st_flatten(B.parent, B.root, B.rf, cap, C, tid, EXS_WG);
+    __syncthreads();
+    block_scan_inclusive<uint32_t>(B.rf, B.rinc, cap.inv, reinterpret_cast<uint32_t *>(wt));
+    if (tid == 0) publish_counts(C, G.flags, host_counts, host_flags);
+}
+
+// stages 5-10 (the narrowphase ran in between): entries sorted by island, joints in creation order, level schedules
+template <class T>
+__global__ __launch_bounds__(EXS_WG) void ex_small_back(ExactBuffers<T> B, ExactCaps cap, int rpc, int big_rows, const uint32_t *flags,
+                                                        StepDiag *diag, ExactCounts *host_counts, uint32_t *host_flags)
+{
+    using sort_t = rocprim::block_radix_sort<uint32_t, EXS_WG, EXS_ITEMS>;
+    __shared__ typename sort_t::storage_type sort_storage;
+    __shared__ uint64_t wt[EXS_WG / 64];
+    const uint32_t tid = threadIdx.x;
+    ExactCounts *C = B.counts;
+    const uint32_t ninv = C->overflow ? 0u : C->ninv, np = C->overflow ? 0u : C->npairs;
+    const uint32_t ne = cap.entries();
+    unsigned ebits = 1, kbits = 1;
+    while ((1u << ebits) < ne) ebits++;                 // an entry's index
+    while ((1u << kbits) <= cap.inv) kbits++;           // island numbers < cap.inv and the padding key cap.inv
+    uint32_t keys[EXS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < EXS_ITEMS; j++) {
+        const uint32_t e = tid * EXS_ITEMS + j;
+        keys[j] = e < ne ? ((entry_key(e, B.pairs, B.pc, B.inc, B.root, B.rinc, cap, ninv, np) << ebits) | e) : 0xffffffffu;
+    }
+    if (tid == 0) C->ni = B.rinc[cap.inv - 1];
+    sort_t().sort(keys, sort_storage, 0, ebits + kbits);
+#pragma unroll
+    for (int j = 0; j < EXS_ITEMS; j++) {
+        const uint32_t t = tid * EXS_ITEMS + j;
+        if (t < ne) {
+            const uint32_t key = keys[j] >> ebits, e = keys[j] & ((1u << ebits) - 1u);
+            B.keys_s[t] = key; B.vals_s[t] = e;
+            B.sc[t] = gathered(key, e, B.cc, cap);
+        }
+    }
+    __syncthreads();
+    block_scan_inclusive<uint64_t>(B.sc, B.sinc, ne, wt);
+    st_bounds(B.keys_s, B.sc, B.sinc, cap, B.body_off, B.con_off, B.row_off, C, tid, EXS_WG);
+    __syncthreads();
+    st_fill(B.keys_s, B.vals_s, B.sc, B.sinc, B.cc, B.inv, B.pairs, B.con_off, cap, rpc, B.bodies, B.cb1, B.cb2, B.csrc, B.crow, tid, EXS_WG);
+    st_bigflags(B.con_off, B.body_off, cap, rpc, big_rows, B.bg, C, tid, EXS_WG);
+    __syncthreads();
+    block_scan_inclusive<uint64_t>(B.bg, B.binc, cap.inv, wt);
+    st_levels(B.con_off, B.body_off, B.cb1, B.cb2, B.bg, B.binc, cap, rpc, B.big, B.big_list, B.lev_count, B.lev_off, B.lev_rows,
+              B.row_level, B.last, C, tid, EXS_WG);
+    __syncthreads();
+    if (tid == 0) {
+        diag->contacts = 0ull; diag->residual = 0.0;        // the island kernels add to it next
+        publish_counts(C, flags, host_counts, host_flags);
     }
 }
 
@@ -691,6 +848,44 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
                        cap, rpc, B.big, B.big_list, B.lev_count, B.lev_off, B.lev_rows, B.row_level, B.last, B.counts);
     return hipGetLastError();
 }
+
+bool exact_small_fits(int64_t n, uint32_t grid_mask, const ExactCaps &cap)
+{
+    return n <= 8192 && grid_mask < 32768u && cap.entries() <= (uint32_t)(EXS_WG * EXS_ITEMS) && cap.inv <= 8192u;
+}
+
+template <class T>
+hipError_t launch_exact_small_front(T *S, const uint8_t *gtype, int64_t n, int64_t n_active, const GridParams<T> &G, const ExactBuffers<T> &B,
+                                    const ExactCaps &cap, ExactCounts *host_counts, uint32_t *host_flags, hipStream_t st)
+{
+    hipLaunchKernelGGL((ex_small_front<T>), dim3(1), dim3(EXS_WG), 0, st, S, gtype, n, n_active, G, B, cap, host_counts, host_flags);
+    return hipGetLastError();
+}
+
+template <class T>
+hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const GridParams<T> &G, const StepParams<T> &P, const ExactBuffers<T> &B,
+                                    const ExactCaps &cap, int rpc, int big_rows, StepDiag *diag, ExactCounts *host_counts,
+                                    uint32_t *host_flags, hipStream_t st)
+{
+    const size_t ne = (size_t)cap.entries();
+    hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.aabb, P, cap,
+                       B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
+    if (P.hull_n > 0)
+        hipLaunchKernelGGL((ex_narrow_convex<T>), dim3((unsigned)std::min<size_t>((ne + 3) / 4, 65535)), dim3(256), 0, st, S, gtype, B.inv,
+                           B.pairs, G.aabb, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
+    hipLaunchKernelGGL((ex_small_back<T>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, (const uint32_t *)G.flags, diag, host_counts,
+                       host_flags);
+    return hipGetLastError();
+}
+
+#define DMX_EXS_INST(T)                                                                                                                  \
+    template hipError_t launch_exact_small_front<T>(T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, const ExactBuffers<T> &, \
+                                                    const ExactCaps &, ExactCounts *, uint32_t *, hipStream_t);                          \
+    template hipError_t launch_exact_small_group<T>(const T *, const uint8_t *, const GridParams<T> &, const StepParams<T> &,            \
+                                                    const ExactBuffers<T> &, const ExactCaps &, int, int, StepDiag *, ExactCounts *,     \
+                                                    uint32_t *, hipStream_t);
+DMX_EXS_INST(float)
+DMX_EXS_INST(double)
 
 template hipError_t launch_exact_pairs<float>(const float *, const uint8_t *, int64_t, const GridParams<float> &, const ExactBuffers<float> &,
                                               const ExactCaps &, hipStream_t);

@@ -68,4 +68,16 @@ template <class T>
 hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G, const StepParams<T> &P,
                               const ExactBuffers<T> &B, const ExactCaps &cap, int rpc, int big_rows, hipStream_t st);
 
+// Small scenes (exact_small_fits): the same pipeline as two one-workgroup kernels around the narrowphase.  front: also
+// fills the grid (what fill_grid does); group: narrowphase + the rest, zeroes *diag.  A non-null host_counts / host_flags
+// (device-visible pinned memory) receives ExactCounts and the BPF_* flags at the end of that kernel.
+bool exact_small_fits(int64_t n, uint32_t grid_mask, const ExactCaps &cap);
+template <class T>
+hipError_t launch_exact_small_front(T *S, const uint8_t *gtype, int64_t n, int64_t n_active, const GridParams<T> &G, const ExactBuffers<T> &B,
+                                    const ExactCaps &cap, ExactCounts *host_counts, uint32_t *host_flags, hipStream_t st);
+template <class T>
+hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const GridParams<T> &G, const StepParams<T> &P, const ExactBuffers<T> &B,
+                                    const ExactCaps &cap, int rpc, int big_rows, StepDiag *diag, ExactCounts *host_counts,
+                                    uint32_t *host_flags, hipStream_t st);
+
 }  // namespace dmx

@@ -237,6 +237,21 @@ template <class T> int fused_run(dmxBatch *b, double h, int n, bool ends_only, b
 // the tick), then launches the island solve with the exact shape and the fused kernel for everyone else.
 constexpr int kBigIslandRows = 1;        // multi-body islands with at least this many rows get a workgroup (see dmx_joints.cpp)
 
+// scenes of a few thousand bodies run the bookkeeping as two one-workgroup kernels (dmx_exact.hip); DMX_SMALL_EXACT=0: never
+bool small_exact_enabled()
+{
+    static const bool v = [] { const char *e = getenv("DMX_SMALL_EXACT"); return !(e && atoi(e) == 0); }();
+    return v;
+}
+
+// device-visible addresses of the pinned host records the small-scene kernels write themselves
+int host_record_pointers(dmxBatch *b, ExactCounts **counts_dev, uint32_t **flags_dev)
+{
+    HIP_TRY(hipHostGetDevicePointer((void **)counts_dev, b->ex_counts_host, 0));
+    HIP_TRY(hipHostGetDevicePointer((void **)flags_dev, b->bp_flags_host, 0));
+    return DMX_OK;
+}
+
 int big_island_rows_general()
 {
     static const int v = [] { const char *e = getenv("DMX_BIG_ISLAND_ROWS"); return e ? atoi(e) : kBigIslandRows; }();
@@ -311,6 +326,8 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     ExactBuffers<T> B;
     ExactCounts &C = *(ExactCounts *)b->ex_counts_host;
     if (b->ex_cap_pairs == 0) { b->ex_cap_pairs = 1024; b->ex_cap_rows = 16384; }
+    if (!b->bp_flags_host) HIP_TRY(hipHostMalloc((void **)&b->bp_flags_host, 64));
+    bool small = false;
     for (int attempt = 0;; attempt++) {
         if (attempt > 40) return DMX_ECAPACITY;
         ExactCaps cap;
@@ -319,6 +336,18 @@ template <class T> int careful_tick(dmxBatch *b, double h)
         cap.rows = b->ex_cap_rows;
         cap.nstatic = (uint32_t)b->n_static;
         if ((rc = ensure_exact_buffers<T>(b, cap, B)) != DMX_OK) return rc;
+        small = small_exact_enabled() && exact_small_fits(b->n, b->bp_mask, cap);
+        if (small) {
+            // everything between here and the island solve in three launches; the last one leaves the counts and the
+            // flags in host memory: the tick's one wait is all the host does
+            ExactCounts *hc; uint32_t *hf;
+            if ((rc = host_record_pointers(b, &hc, &hf)) != DMX_OK) return rc;
+            const GridParams<T> G = grid_of<T>(b);
+            HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, G, B, cap, nullptr, nullptr, b->stream));
+            HIP_TRY(launch_exact_small_group<T>((const T *)b->slab, b->gtype, G, P, B, cap, rpc, big_island_rows_general(), b->diag_isl,
+                                                hc, hf, b->stream));
+            HIP_TRY(hipStreamSynchronize(b->stream));
+        } else {
         if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
         HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), B, cap, b->stream));
         auto read_back = [&]() -> int {
@@ -338,6 +367,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
             HIP_TRY(launch_exact_group<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), P, B, cap, rpc,
                                           big_island_rows_general(), b->stream));
             if ((rc = read_back()) != DMX_OK) return rc;
+        }
         }
         if (b->bp_flags_host[BPF_OVERFLOW]) {                  // a column holds more bodies than a bucket: widen and search again
             if ((rc = grow_buckets(b)) != DMX_OK) return rc;
@@ -396,7 +426,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     I.rows = (T *)b->jd_rows.p; I.rowjb = (int *)b->jd_rowjb.p; I.bscr = (T *)b->jd_bscr.p; I.local = (int *)b->jd_local.p;
     I.singles = 1;
     // (cmode / cmu / cbounce ... stay null: every contact carries the batch's surface, NearCallback's policy, main.c:684-687)
-    HIP_TRY(hipMemsetAsync(b->diag_isl, 0, sizeof(StepDiag), b->stream));
+    if (!small) HIP_TRY(hipMemsetAsync(b->diag_isl, 0, sizeof(StepDiag), b->stream));       // (the small-scene kernel zeroed it)
     HIP_TRY(launch_islands<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, b->stream));
     ph.reset(new DmxPhase(b, 8));
     // the island step consumed the accumulators of ITS bodies only; everyone else's are still pending for the fused kernel
@@ -591,10 +621,16 @@ template <class T> int find_pairs_t(dmxBatch *b)
         cap.rows = b->ex_cap_rows;
         cap.nstatic = (uint32_t)b->n_static;
         if ((rc = ensure_exact_buffers<T>(b, cap, B)) != DMX_OK) return rc;
-        if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
-        HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), B, cap, b->stream));
-        HIP_TRY(hipMemcpyAsync(b->bp_flags_host, b->bp_flags.p, BPF_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipMemcpyAsync(&C, B.counts, sizeof(ExactCounts), hipMemcpyDeviceToHost, b->stream));
+        if (small_exact_enabled() && exact_small_fits(b->n, b->bp_mask, cap)) {
+            ExactCounts *hc; uint32_t *hf;
+            if ((rc = host_record_pointers(b, &hc, &hf)) != DMX_OK) return rc;
+            HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, grid_of<T>(b), B, cap, hc, hf, b->stream));
+        } else {
+            if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
+            HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), B, cap, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->bp_flags_host, b->bp_flags.p, BPF_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(hipMemcpyAsync(&C, B.counts, sizeof(ExactCounts), hipMemcpyDeviceToHost, b->stream));
+        }
         HIP_TRY(hipStreamSynchronize(b->stream));
         if (b->bp_flags_host[BPF_OVERFLOW]) { if ((rc = grow_buckets(b)) != DMX_OK) return rc; continue; }
         if (C.overflow & 1u) {
