@@ -179,7 +179,9 @@ int dmxBatchCollisionStatsEx(dmxBatchID b, int64_t out[8]);
  *                *exact_only = 1 when the fast path may not be used (crowded bodies, pending external forces),
  *                *ballistic = 1 when bodies move on straight horizontal lines, so checking the chunk's first
  *                and last tick proves the ticks between
- *   ChunkTick    one fused tick of the active bodies, with or without the safe-zone check
+ *   ChunkTick    one fused tick of the active bodies, with or without the safe-zone check.  A checked tick of a scene with
+ *                a ground plane does nothing once the violation flag is up (the chunk will be rolled back whole: the
+ *                only thing a caller may do after a violation)
  *   CheckZonesOnStream  the check alone for slots [first, first+count), on the caller's stream (ghost slots after
  *                their refresh)
  *   RefreshGhostsOnStream  the per-tick ghost refresh in one launch on the caller's stream: the lower neighbour's rows

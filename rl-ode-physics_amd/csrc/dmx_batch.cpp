@@ -133,6 +133,13 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
         fprintf(stderr, "libode_mi355 host profile (exact ticks: %lld):\n", (long long)b->stat_careful_ticks);
         for (int k = 0; k < 9; k++) fprintf(stderr, "  %-32s %9.3f ms total\n", names[k], b->prof[k] * 1e3);
     }
+    if (b->exs_ticks > 0) {          // DMX_EXS_TIMING=1
+        static const char *fn[9] = { "", "zero", "grid insert", "pair count", "scan", "pair write", "union", "flatten", "scan" };
+        static const char *bn[9] = { "", "island keys", "block sort", "sorted lists", "scan", "island bounds", "fill + big flags", "scan", "level schedules" };
+        fprintf(stderr, "libode_mi355 small-scene exact tick, stage averages over %ld ticks:\n", b->exs_ticks);
+        for (int k = 1; k < 9; k++) fprintf(stderr, "  front %-18s %7.2f us\n", fn[k], b->exs_acc[k] / (double)b->exs_ticks / 100.0);
+        for (int k = 1; k < 9; k++) fprintf(stderr, "  back  %-18s %7.2f us\n", bn[k], b->exs_acc[32 + k] / (double)b->exs_ticks / 100.0);
+    }
     if (b->slab) (void)hipFree(b->slab);
     if (b->slab_alt) (void)hipFree(b->slab_alt);
     if (b->gtype) (void)hipFree(b->gtype);

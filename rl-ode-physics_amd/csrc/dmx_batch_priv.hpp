@@ -98,6 +98,10 @@ struct dmxBatch {
     DevBuf jd_int, jd_real, jd_rows, jd_rowjb, jd_bscr, jd_local;   // device staging / scratch
     DevBuf jd_lcp, jd_lcp_off, jd_lcp_int;     // dWorldStep's exact island solve: A, factor, vectors per island; offsets; pivoting state
     std::vector<long long> sc_lcp_off;
+    double exs_acc[64] = { 0 }; long exs_ticks = 0;      // DMX_EXS_TIMING: stage times of the small-scene exact tick, summed
+    bool bp_fresh = false;          // the safe zones were built at exactly the current poses (no tick since)
+    bool snap_fresh = false;        // ... as of the open snapshot
+    bool bp_skip_fast = false;      // the next chunk goes the exact way without trying the fast one (a retry would repeat a failure)
     bool stepper_exact = false;                // dmxBatchSetStepper: dmxBatchStepJoints solves every island's LCP exactly
     bool row_order_ode = false;                // dmxBatchSetRowOrder: ODE's joint-discovery row order + periodic LCG shuffle (QuickStep)
     uint32_t ode_rand = 0;                     // that LCG's state (ODE's is process-global; here it belongs to the batch)

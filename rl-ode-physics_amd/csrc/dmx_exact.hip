@@ -32,44 +32,77 @@ namespace {
 __device__ __forceinline__ uint32_t lo32(uint64_t v) { return (uint32_t)v; }
 __device__ __forceinline__ uint32_t hi32(uint64_t v) { return (uint32_t)(v >> 32); }
 
+// does the body's AABB overlap static box b's?
+template <class T> __device__ __forceinline__ bool rec_meets_static(const GridRec<T> &r, const T *b)
+{
+    return !(r.lo[0] > b[SBOX_HI + 0] || b[SBOX_LO + 0] > r.hi[0] || r.lo[1] > b[SBOX_HI + 1] || b[SBOX_LO + 1] > r.hi[1] ||
+             r.lo[2] > b[SBOX_HI + 2] || b[SBOX_LO + 2] > r.hi[2]);
+}
+
 // Walk the 3x3 columns around body i and call f(j) for every other body whose AABB overlaps i's (each once).
+// Dependent accesses are what this costs (a thread's chain is the kernel's duration in a small scene): a candidate's column
+// and AABB come as one record, a bucket's items four at a time, and the next column's count and first four items are on
+// their way while this column's candidates are tested.  The column loop stays rolled: straight-line code that runs once per
+// launch is paid for in instruction fetches.
 template <class T, class F>
 __device__ __forceinline__ void for_each_partner(const T *S, const uint8_t *gtype, int64_t i, const GridParams<T> &G, F f,
                                                  uint32_t *unsupported = nullptr)
 {
-    const T *bi = G.aabb + 6 * i;            // every body's AABB, left by bp_insert
-    const T lo[3] = { bi[0], bi[1], bi[2] }, hi[3] = { bi[3], bi[4], bi[5] };
-    const int ix = (int)floor((double)(S[slab_ix(C_POS + 0, i)] * G.inv_cell));
-    const int iz = (int)floor((double)(S[slab_ix(C_POS + 2, i)] * G.inv_cell));
-    for (int dz = -1; dz <= 1; dz++)
-        for (int dx = -1; dx <= 1; dx++) {
-            const uint32_t h = cell_hash(ix + dx, iz + dz, G.mask, G.xbits);
-            uint32_t cnt = G.count[h];
-            if (cnt > (uint32_t)G.cap) cnt = (uint32_t)G.cap;
-            for (uint32_t s = 0; s < cnt; s++) {
-                const int64_t j = G.items[(size_t)h * G.cap + s];
-                if (j == i) continue;
-                if (!classes_collide(gtype[i], gtype[j])) {
-                    // no collider for this pair of classes (convex-convex, convex-sphere): not a pair; said once per pair when
-                    // the bounding spheres reach one another
-                    if (j > i && unsupported != nullptr) {
-                        const T dx = S[slab_ix(C_POS + 0, i)] - S[slab_ix(C_POS + 0, j)], dy = S[slab_ix(C_POS + 1, i)] - S[slab_ix(C_POS + 1, j)],
-                                dz = S[slab_ix(C_POS + 2, i)] - S[slab_ix(C_POS + 2, j)];
-                        const T rr = S[slab_ix(C_BPR, i)] + S[slab_ix(C_BPR, j)];
-                        if (dx * dx + dy * dy + dz * dz < rr * rr) atomicAdd(unsupported, 1u);
-                    }
-                    continue;
-                }
-                // hashed buckets can mix columns: keep only true 3x3 neighbours so (i,j) is met in one cell only
-                const int jx = (int)floor((double)(S[slab_ix(C_POS + 0, j)] * G.inv_cell));
-                const int jz = (int)floor((double)(S[slab_ix(C_POS + 2, j)] * G.inv_cell));
-                if (jx != ix + dx || jz != iz + dz) continue;
-                const T *bj = G.aabb + 6 * j;
-                if (bj[0] > hi[0] || lo[0] > bj[3] || bj[1] > hi[1] || lo[1] > bj[4] || bj[2] > hi[2] || lo[2] > bj[5])
-                    continue;
-                f(j);
-            }
+    const GridRec<T> me = G.rec[i];
+    const int gti = gtype[i];
+    auto test4 = [&](const int4 &it, uint32_t s0, uint32_t n, int cx, int cz) {
+        const int32_t js[4] = { it.x, it.y, it.z, it.w };
+        GridRec<T> o[4];
+        int gtj[4];
+        bool live[4];
+        // (fetching all four records unconditionally was tried: in a sparse scene three of four slots are dead, and one
+        //  compute unit's memory pipeline -- which is all a one-workgroup launch has -- is the bound, not the latency)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            live[q] = s0 + q < n && js[q] != (int32_t)i;
+            if (live[q]) { o[q] = G.rec[js[q]]; gtj[q] = gtype[js[q]]; }
         }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (!live[q]) continue;
+            const int64_t j = js[q];
+            // hashed buckets can mix columns: keep only true 3x3 neighbours so (i,j) is met in one cell only
+            if (o[q].ix != cx || o[q].iz != cz) continue;
+            if (!classes_collide(gti, gtj[q])) {
+                // no collider for this pair of classes (convex-convex, convex-sphere): not a pair; said once per pair when
+                // the bounding spheres reach one another
+                if (j > i && unsupported != nullptr) {
+                    const T dx = S[slab_ix(C_POS + 0, i)] - S[slab_ix(C_POS + 0, j)], dy = S[slab_ix(C_POS + 1, i)] - S[slab_ix(C_POS + 1, j)],
+                            dz = S[slab_ix(C_POS + 2, i)] - S[slab_ix(C_POS + 2, j)];
+                    const T rr = S[slab_ix(C_BPR, i)] + S[slab_ix(C_BPR, j)];
+                    if (dx * dx + dy * dy + dz * dz < rr * rr) atomicAdd(unsupported, 1u);
+                }
+                continue;
+            }
+            if (o[q].lo[0] > me.hi[0] || me.lo[0] > o[q].hi[0] || o[q].lo[1] > me.hi[1] || me.lo[1] > o[q].hi[1] ||
+                o[q].lo[2] > me.hi[2] || me.lo[2] > o[q].hi[2])
+                continue;
+            f(j);
+        }
+    };
+    // (bucket capacities are multiples of 4, so a bucket's items are 16-byte aligned and its first four always exist)
+    uint32_t h = cell_hash(me.ix - 1, me.iz - 1, G.mask, G.xbits);
+    uint32_t cnt = G.count[h];
+    int4 it = *reinterpret_cast<const int4 *>(G.items + (size_t)h * G.cap);
+#pragma unroll 1
+    for (int c = 0; c < 9; c++) {
+        const int cx = me.ix + (c % 3) - 1, cz = me.iz + (c / 3) - 1;
+        const uint32_t h0 = h, n = cnt > (uint32_t)G.cap ? (uint32_t)G.cap : cnt;
+        const int4 it0 = it;
+        if (c < 8) {
+            h = cell_hash(me.ix + ((c + 1) % 3) - 1, me.iz + ((c + 1) / 3) - 1, G.mask, G.xbits);
+            cnt = G.count[h];
+            it = *reinterpret_cast<const int4 *>(G.items + (size_t)h * G.cap);
+        }
+        if (n > 0) test4(it0, 0, n, cx, cz);
+        for (uint32_t s0 = 4; s0 < n; s0 += 4)
+            test4(*reinterpret_cast<const int4 *>(G.items + (size_t)h0 * G.cap + s0), s0, n, cx, cz);
+    }
 }
 
 // ---- 1. per active body: partners above it (the pairs it owns) and whether it is in any pair at all ---------------
@@ -92,11 +125,10 @@ __device__ __forceinline__ void st_pair_count(const T *S, const uint8_t *gtype, 
                 else if (j > i) owned++;
             }, &C->unsupported);
             // static box geoms are "big geoms against everyone": a body whose AABB overlaps one goes through the exact path too
-            const T *bi = G.aabb + 6 * i;
-            for (int s = 0; s < G.n_static; s++) {
-                const T *b = G.sbox + s * SBOX_REALS;
-                if (!(bi[0] > b[SBOX_HI + 0] || b[SBOX_LO + 0] > bi[3] || bi[1] > b[SBOX_HI + 1] || b[SBOX_LO + 1] > bi[4] ||
-                      bi[2] > b[SBOX_HI + 2] || b[SBOX_LO + 2] > bi[5])) any = 1;
+            if (G.n_static > 0) {
+                const GridRec<T> me = G.rec[i];
+                for (int s = 0; s < G.n_static; s++)
+                    if (rec_meets_static(me, G.sbox + s * SBOX_REALS)) any = 1;
             }
         }
         pc[i] = ((uint64_t)owned << 32) | any;
@@ -232,7 +264,7 @@ template <class T> __device__ __forceinline__ void put_c(T *gpos, T *gnormal, T 
 // contacts of pair p.  cc[e] = contacts of entry e, 0 for the padding.
 template <class T>
 __global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const uint8_t *__restrict__ gtype, const int32_t *__restrict__ inv,
-                                                const int32_t *__restrict__ pairs, const T *__restrict__ aabb, StepParams<T> P, ExactCaps cap,
+                                                const int32_t *__restrict__ pairs, const GridRec<T> *__restrict__ rec, StepParams<T> P, ExactCaps cap,
                                                 T *__restrict__ gpos, T *__restrict__ gnormal, T *__restrict__ gdepth,
                                                 uint32_t *__restrict__ cc, const ExactCounts *__restrict__ C)
 {
@@ -252,9 +284,8 @@ __global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const u
             const uint32_t s = (e - cap.inv) / cap.inv, k = (e - cap.inv) - s * cap.inv;
             if (k < ninv) {
                 const int64_t i = inv[k];
-                const T *bi = aabb + 6 * i, *sb = P.sbox + s * SBOX_REALS;
-                if (!(bi[0] > sb[SBOX_HI + 0] || sb[SBOX_LO + 0] > bi[3] || bi[1] > sb[SBOX_HI + 1] || sb[SBOX_LO + 1] > bi[4] ||
-                      bi[2] > sb[SBOX_HI + 2] || sb[SBOX_LO + 2] > bi[5])) {
+                const T *sb = P.sbox + s * SBOX_REALS;
+                if (rec_meets_static(rec[i], sb)) {
                     const BodyGeomX<T> Bd = geom_of<T>(S, gtype, i);
                     const V3<T> sx = { sb[SBOX_POS], sb[SBOX_POS + 1], sb[SBOX_POS + 2] };
                     M3<T> sR;
@@ -388,7 +419,7 @@ __device__ __forceinline__ int wave_box_convex(const V3<T> &xb, const M3<T> &Rb,
 template <class T>
 __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S, const uint8_t *__restrict__ gtype,
                                                         const int32_t *__restrict__ inv, const int32_t *__restrict__ pairs,
-                                                        const T *__restrict__ aabb, StepParams<T> P, ExactCaps cap,
+                                                        const GridRec<T> *__restrict__ rec, StepParams<T> P, ExactCaps cap,
                                                         T *__restrict__ gpos, T *__restrict__ gnormal, T *__restrict__ gdepth,
                                                         uint32_t *__restrict__ cc, ExactCounts *__restrict__ C)
 {
@@ -437,9 +468,8 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
             } else {
                 // ---- hull against static box s: dCollide(static box, hull); the joint is attached (0, body): reversed
                 const uint32_t s = (e - cap.inv) / cap.inv;
-                const T *bi = aabb + 6 * i, *sb = P.sbox + s * SBOX_REALS;
-                if (!(bi[0] > sb[SBOX_HI + 0] || sb[SBOX_LO + 0] > bi[3] || bi[1] > sb[SBOX_HI + 1] || sb[SBOX_LO + 1] > bi[4] ||
-                      bi[2] > sb[SBOX_HI + 2] || sb[SBOX_LO + 2] > bi[5]) && P.hull_n > 0) {
+                const T *sb = P.sbox + s * SBOX_REALS;
+                if (rec_meets_static(rec[i], sb) && P.hull_n > 0) {
                     const V3<T> sx = { sb[SBOX_POS], sb[SBOX_POS + 1], sb[SBOX_POS + 2] };
                     M3<T> sR;
                     for (int a = 0; a < 3; a++) for (int c2 = 0; c2 < 3; c2++) sR.m[a][c2] = sb[SBOX_R + 3 * a + c2];
@@ -608,24 +638,31 @@ __device__ __forceinline__ void st_levels(const int *con_off, const int *body_of
         atomicMax(&C->big_max_bodies, (uint32_t)(body_off[i + 1] - body_off[i]));
         if ((uint32_t)(base + m) > cap.rows) continue;          // flagged above; the host grows the capacity
         int *lv_out = row_level + base, *off = lev_off + base + k, *rows_out = lev_rows + base;
-        int nlev = 0, r = 0;
+        // consecutive contacts between the same bodies (a box's four contacts with the plane, a pair's) form one group: its
+        // rows take consecutive levels, and `last` is touched once per group, not once per row
+        int nlev = 0, r = 0, gb1 = -2, gb2 = -2, glast = -1;
         for (int d = con_off[i]; d < con_off[i + 1]; d++) {
             const int b1 = cb1[d], b2 = cb2[d];
-            for (int q = 0; q < rpc; q++, r++) {
+            if (b1 != gb1 || b2 != gb2) {
+                if (gb1 >= 0) { last[gb1] = glast; if (gb2 >= 0) last[gb2] = glast; }
                 int lv = last[b1];
                 if (b2 >= 0 && last[b2] > lv) lv = last[b2];
-                lv += 1;
-                lv_out[r] = lv;
-                last[b1] = lv;
-                if (b2 >= 0) last[b2] = lv;
-                if (lv + 1 > nlev) nlev = lv + 1;
+                glast = lv; gb1 = b1; gb2 = b2;
             }
+            for (int q = 0; q < rpc; q++, r++) lv_out[r] = ++glast;
+            if (glast + 1 > nlev) nlev = glast + 1;
         }
         for (int d = con_off[i]; d < con_off[i + 1]; d++) {       // back to the idle state
             last[cb1[d]] = -1;
             if (cb2[d] >= 0) last[cb2[d]] = -1;
         }
         lev_count[k] = nlev;
+        if (m <= WAVE_ISLAND_ROWS) {
+            // solve_island_wg keeps such an island's rows in one wavefront's registers and reads row_level only (and the
+            // island's extent from the ends of its offsets)
+            off[0] = base; off[nlev] = base + m;
+            continue;
+        }
         for (int q = 0; q <= nlev; q++) off[q] = 0;
         for (int q = 0; q < m; q++) off[lv_out[q] + 1]++;
         int w = 0;
@@ -657,7 +694,7 @@ __global__ __launch_bounds__(64) void ex_levels(const int *__restrict__ con_off,
 // as two one-workgroup kernels around the narrowphase: barriers instead of launches, workgroup scans, one block radix sort
 // of (island << entry bits | entry) keys -- stable by construction.  The back kernel leaves the counts and the broadphase
 // flags in pinned host memory itself, so the tick's one wait on the device is all the host does.
-constexpr int EXS_WG = 1024, EXS_ITEMS = 8;
+constexpr int EXS_WG = 1024;
 
 template <class V> __device__ __forceinline__ V wave_scan_inclusive(V x, int lane)
 {
@@ -694,6 +731,10 @@ __device__ __forceinline__ void publish_counts(const ExactCounts *C, const uint3
     __threadfence_system();
 }
 
+// B.stamps: wall_clock64() (100 MHz) after every stage, front kernel from [0], back kernel from [32]; DMX_EXS_TIMING=1 prints the
+// stage averages when the batch is destroyed
+#define EXS_STAMP() do { if (threadIdx.x == 0) stamps[sk] = wall_clock64(); sk++; } while (0)
+
 // grid fill (fill_grid's memsets + bp_insert) and stages 1-3: pairs, involved bodies, islands' roots
 template <class T>
 __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gtype, int64_t n, int64_t n_active, GridParams<T> G,
@@ -702,68 +743,84 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gt
     __shared__ uint64_t wt[EXS_WG / 64];
     const uint32_t tid = threadIdx.x;
     ExactCounts *C = B.counts;
+    uint64_t *stamps = B.stamps; int sk = 0;
+    EXS_STAMP();
     for (uint32_t k = tid; k <= G.mask; k += EXS_WG) G.count[k] = 0u;
     if (tid < (uint32_t)BPF_COUNT) G.flags[tid] = 0u;
     if (tid < sizeof(ExactCounts) / 4) ((uint32_t *)C)[tid] = 0u;
-    __syncthreads();
+    __syncthreads(); EXS_STAMP();
     for (int64_t i = tid; i < n; i += EXS_WG) grid_insert<T>(S, gtype, i, G);      // ghosts included
-    __syncthreads();
+    __syncthreads(); EXS_STAMP();
     st_pair_count<T>(S, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG);
-    __syncthreads();
-    block_scan_inclusive<uint64_t>(B.pc, B.inc, (uint32_t)n_active, wt);
+    __syncthreads(); EXS_STAMP();
+    block_scan_inclusive<uint64_t>(B.pc, B.inc, (uint32_t)n_active, wt); EXS_STAMP();
     st_pair_write<T>(S, gtype, n_active, G, B.pc, B.inc, B.pairs, B.inv, B.parent, cap, C, tid, EXS_WG);
-    __syncthreads();
+    __syncthreads(); EXS_STAMP();
     st_unite(B.pairs, B.pc, B.inc, B.parent, C, tid, EXS_WG);
-    __syncthreads();
+    __syncthreads(); EXS_STAMP();
     st_flatten(B.parent, B.root, B.rf, cap, C, tid, EXS_WG);
-    __syncthreads();
-    block_scan_inclusive<uint32_t>(B.rf, B.rinc, cap.inv, reinterpret_cast<uint32_t *>(wt));
+    __syncthreads(); EXS_STAMP();
+    block_scan_inclusive<uint32_t>(B.rf, B.rinc, cap.inv, reinterpret_cast<uint32_t *>(wt)); EXS_STAMP();
     if (tid == 0) publish_counts(C, G.flags, host_counts, host_flags);
 }
 
-// stages 5-10 (the narrowphase ran in between): entries sorted by island, joints in creation order, level schedules
-template <class T>
+// stages 5-10 (the narrowphase ran in between): entries sorted by island, joints in creation order, level schedules.
+// ITEMS entries per thread (2, 4 or 8: up to 8192 entries).
+template <class T, int ITEMS>
 __global__ __launch_bounds__(EXS_WG) void ex_small_back(ExactBuffers<T> B, ExactCaps cap, int rpc, int big_rows, const uint32_t *flags,
                                                         StepDiag *diag, ExactCounts *host_counts, uint32_t *host_flags)
 {
-    using sort_t = rocprim::block_radix_sort<uint32_t, EXS_WG, EXS_ITEMS>;
+    using sort_t = rocprim::block_radix_sort<uint32_t, EXS_WG, ITEMS>;
     __shared__ typename sort_t::storage_type sort_storage;
     __shared__ uint64_t wt[EXS_WG / 64];
     const uint32_t tid = threadIdx.x;
     ExactCounts *C = B.counts;
+    uint64_t *stamps = B.stamps + 32; int sk = 0;
+    EXS_STAMP();
     const uint32_t ninv = C->overflow ? 0u : C->ninv, np = C->overflow ? 0u : C->npairs;
     const uint32_t ne = cap.entries();
+    const uint32_t ni = B.rinc[cap.inv - 1];            // islands; the padding sorts behind them all with key ni
     unsigned ebits = 1, kbits = 1;
-    while ((1u << ebits) < ne) ebits++;                 // an entry's index
-    while ((1u << kbits) <= cap.inv) kbits++;           // island numbers < cap.inv and the padding key cap.inv
-    uint32_t keys[EXS_ITEMS];
+    while ((1u << ebits) < ne) ebits++;                 // an entry's index: the low bits, so the keys are in entry order to begin with
+    while ((1u << kbits) <= ni) kbits++;
+    uint32_t keys[ITEMS];
 #pragma unroll
-    for (int j = 0; j < EXS_ITEMS; j++) {
-        const uint32_t e = tid * EXS_ITEMS + j;
-        keys[j] = e < ne ? ((entry_key(e, B.pairs, B.pc, B.inc, B.root, B.rinc, cap, ninv, np) << ebits) | e) : 0xffffffffu;
+    for (int j = 0; j < ITEMS; j++) {
+        const uint32_t e = tid * ITEMS + j;
+        uint32_t key = 0xffffffffu;
+        if (e < ne) {
+            key = entry_key(e, B.pairs, B.pc, B.inc, B.root, B.rinc, cap, ninv, np);
+            key = ((key < ni ? key : ni) << ebits) | e;
+        }
+        keys[j] = key;
     }
-    if (tid == 0) C->ni = B.rinc[cap.inv - 1];
-    sort_t().sort(keys, sort_storage, 0, ebits + kbits);
+    if (tid == 0) C->ni = ni;
+    __syncthreads(); EXS_STAMP();
+    // LSD radix sort is stable: sorting the island bits alone leaves each island's entries in entry (= joint creation) order
+    sort_t().sort(keys, sort_storage, ebits, ebits + kbits);
+    __syncthreads(); EXS_STAMP();
 #pragma unroll
-    for (int j = 0; j < EXS_ITEMS; j++) {
-        const uint32_t t = tid * EXS_ITEMS + j;
+    for (int j = 0; j < ITEMS; j++) {
+        const uint32_t t = tid * ITEMS + j;
         if (t < ne) {
-            const uint32_t key = keys[j] >> ebits, e = keys[j] & ((1u << ebits) - 1u);
+            uint32_t key = (keys[j] >> ebits) & ((1u << kbits) - 1u);
+            const uint32_t e = keys[j] & ((1u << ebits) - 1u);
+            if (key >= ni) key = cap.inv;
             B.keys_s[t] = key; B.vals_s[t] = e;
             B.sc[t] = gathered(key, e, B.cc, cap);
         }
     }
-    __syncthreads();
-    block_scan_inclusive<uint64_t>(B.sc, B.sinc, ne, wt);
+    __syncthreads(); EXS_STAMP();
+    block_scan_inclusive<uint64_t>(B.sc, B.sinc, ne, wt); EXS_STAMP();
     st_bounds(B.keys_s, B.sc, B.sinc, cap, B.body_off, B.con_off, B.row_off, C, tid, EXS_WG);
-    __syncthreads();
+    __syncthreads(); EXS_STAMP();
     st_fill(B.keys_s, B.vals_s, B.sc, B.sinc, B.cc, B.inv, B.pairs, B.con_off, cap, rpc, B.bodies, B.cb1, B.cb2, B.csrc, B.crow, tid, EXS_WG);
     st_bigflags(B.con_off, B.body_off, cap, rpc, big_rows, B.bg, C, tid, EXS_WG);
-    __syncthreads();
-    block_scan_inclusive<uint64_t>(B.bg, B.binc, cap.inv, wt);
+    __syncthreads(); EXS_STAMP();
+    block_scan_inclusive<uint64_t>(B.bg, B.binc, cap.inv, wt); EXS_STAMP();
     st_levels(B.con_off, B.body_off, B.cb1, B.cb2, B.bg, B.binc, cap, rpc, B.big, B.big_list, B.lev_count, B.lev_off, B.lev_rows,
               B.row_level, B.last, C, tid, EXS_WG);
-    __syncthreads();
+    __syncthreads(); EXS_STAMP();
     if (tid == 0) {
         diag->contacts = 0ull; diag->residual = 0.0;        // the island kernels add to it next
         publish_counts(C, flags, host_counts, host_flags);
@@ -825,11 +882,11 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
     hipLaunchKernelGGL(ex_flatten, dim3(grid_for(cap.inv)), dim3(256), 0, st, B.parent, B.root, B.rf, cap, B.counts);
     tb = B.temp_bytes;
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.rf, B.rinc, (size_t)cap.inv, rocprim::plus<uint32_t>(), st));
-    hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.aabb, P, cap,
+    hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.rec, P, cap,
                        B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
     if (P.hull_n > 0)
         hipLaunchKernelGGL((ex_narrow_convex<T>), dim3((unsigned)std::min<size_t>((ne + 3) / 4, 65535)), dim3(256), 0, st, S, gtype, B.inv,
-                           B.pairs, G.aabb, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
+                           B.pairs, G.rec, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
     hipLaunchKernelGGL(ex_keys, dim3(grid_for(ne)), dim3(256), 0, st, B.pairs, B.pc, B.inc, B.root, B.rinc, cap, B.keys, B.vals, B.counts);
     int bits = 1;
     while ((1u << bits) <= cap.inv && bits < 32) bits++;        // keys are island numbers < cap.inv and the padding key cap.inv
@@ -851,7 +908,7 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
 
 bool exact_small_fits(int64_t n, uint32_t grid_mask, const ExactCaps &cap)
 {
-    return n <= 8192 && grid_mask < 32768u && cap.entries() <= (uint32_t)(EXS_WG * EXS_ITEMS) && cap.inv <= 8192u;
+    return n <= 8192 && grid_mask < 32768u && cap.entries() <= (uint32_t)(EXS_WG * 8) && cap.inv <= 8192u;
 }
 
 template <class T>
@@ -868,13 +925,18 @@ hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const Grid
                                     uint32_t *host_flags, hipStream_t st)
 {
     const size_t ne = (size_t)cap.entries();
-    hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.aabb, P, cap,
+    hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.rec, P, cap,
                        B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
     if (P.hull_n > 0)
         hipLaunchKernelGGL((ex_narrow_convex<T>), dim3((unsigned)std::min<size_t>((ne + 3) / 4, 65535)), dim3(256), 0, st, S, gtype, B.inv,
-                           B.pairs, G.aabb, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
-    hipLaunchKernelGGL((ex_small_back<T>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, (const uint32_t *)G.flags, diag, host_counts,
-                       host_flags);
+                           B.pairs, G.rec, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
+    const uint32_t *flags = G.flags;
+    if (ne <= 2 * EXS_WG)
+        hipLaunchKernelGGL((ex_small_back<T, 2>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags);
+    else if (ne <= 4 * EXS_WG)
+        hipLaunchKernelGGL((ex_small_back<T, 4>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags);
+    else
+        hipLaunchKernelGGL((ex_small_back<T, 8>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags);
     return hipGetLastError();
 }
 

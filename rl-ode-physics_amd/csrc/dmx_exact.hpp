@@ -55,6 +55,7 @@ template <class T> struct ExactBuffers {
     int *lev_off;                               // [rows + inv]
     int *lev_rows, *row_level;                  // [rows]
     int32_t *last;                              // [stride] per slot, -1 when idle
+    uint64_t *stamps;                           // [64] stage time stamps of the small-scene kernels (100 MHz ticks)
 };
 
 size_t exact_temp_bytes(const ExactCaps &cap, int64_t n_active);

@@ -41,7 +41,7 @@ template <class T> GridParams<T> grid_of(dmxBatch *b)
     G.count = (uint32_t *)b->bp_count.p;
     G.items = (int32_t *)b->bp_items.p;
     G.flags = (uint32_t *)b->bp_flags.p;
-    G.aabb = (T *)b->ex_aabb.p;             // null until an exact tick has asked for it
+    G.rec = (GridRec<T> *)b->ex_aabb.p;     // null until an exact tick has asked for it
     G.sbox = (const T *)b->sbox.p; G.n_static = b->n_static;
     return G;
 }
@@ -128,6 +128,7 @@ template <class T> int build_safe_zones(dmxBatch *b)
     // zones (and the bounding radii bp_insert refreshed) are constants of the ticks to come: both slabs hold them
     HIP_TRY(launch_copy_components<T>((const T *)b->slab, (T *)b->slab_alt, C_BPX, C_COUNT - C_BPX, 0, b->n, b->stream));
     b->bp_valid = true;
+    b->bp_fresh = true;
     b->stat_rebuilds++;
     return DMX_OK;
 }
@@ -154,6 +155,7 @@ template <class T> int snapshot_begin(dmxBatch *b)
     if (b->snapshot_mode == DMX_SNAPSHOT_COPY) return snapshot_by_copy<T>(b);
     b->flip_armed = true; b->flipped = false;
     b->snap_kind = SNAP_NONE;                   // becomes SNAP_PINGPONG at the first fast launch
+    b->snap_fresh = b->bp_fresh;
     return DMX_OK;
 }
 
@@ -165,6 +167,7 @@ template <class T> int snapshot_restore(dmxBatch *b)
         std::swap(b->slab, b->slab_alt);        // the untouched start state (ghost slots included) is current again
     b->flip_armed = false; b->flipped = false;
     b->snap_kind = SNAP_NONE;
+    b->bp_fresh = b->snap_fresh;
     return DMX_OK;
 }
 
@@ -185,6 +188,7 @@ template <class T> int launch_fast(dmxBatch *b, const StepParams<T> &P, bool ext
         }
     }
     HIP_TRY(launch_step<T>(S, So, b->gtype, b->stride, b->n_active, P, ext, b->diag, b->stream));
+    b->bp_fresh = false;                     // the poses have moved on from the ones the zones were built at
     if (So != S) {
         // ghost slots [n_active, n) are not stepped: their state follows by copy (a few boundary rows)
         HIP_TRY(launch_copy_components<T>(S, So, 0, C_MASS, b->n_active, b->n - b->n_active, b->stream));
@@ -244,6 +248,12 @@ bool small_exact_enabled()
     return v;
 }
 
+bool exs_timing_enabled()
+{
+    static const bool v = [] { const char *e = getenv("DMX_EXS_TIMING"); return e && atoi(e) != 0; }();
+    return v;
+}
+
 // device-visible addresses of the pinned host records the small-scene kernels write themselves
 int host_record_pointers(dmxBatch *b, ExactCounts **counts_dev, uint32_t **flags_dev)
 {
@@ -264,7 +274,7 @@ template <class T> int ensure_exact_buffers(dmxBatch *b, const ExactCaps &cap, E
     const size_t ne = (size_t)cap.entries(), nslots = cap.slots();
     const size_t n = (size_t)b->stride;
     if ((rc = dmx_ensure_dev(b->ex_body, n * (2 * sizeof(uint64_t)))) != DMX_OK) return rc;
-    if ((rc = dmx_ensure_dev(b->ex_aabb, n * 6 * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->ex_aabb, n * sizeof(GridRec<T>))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->bp_inpair, n)) != DMX_OK) return rc;
     if (!b->ex_last.p) {
         if ((rc = dmx_ensure_dev(b->ex_last, n * sizeof(int32_t))) != DMX_OK) return rc;
@@ -274,7 +284,7 @@ template <class T> int ensure_exact_buffers(dmxBatch *b, const ExactCaps &cap, E
     // one arena, carved up in 256-byte steps
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) / 256 * 256; return at; };
-    const size_t o_counts = take(sizeof(ExactCounts)), o_cross = take(2 * EX_CROSS_CAP * sizeof(int32_t)), o_temp = take(temp), o_pairs = take(2 * (size_t)cap.pairs * 4),
+    const size_t o_counts = take(sizeof(ExactCounts)), o_stamps = take(64 * sizeof(uint64_t)), o_cross = take(2 * EX_CROSS_CAP * sizeof(int32_t)), o_temp = take(temp), o_pairs = take(2 * (size_t)cap.pairs * 4),
                  o_inv = take((size_t)cap.inv * 4), o_parent = take((size_t)cap.inv * 4), o_root = take((size_t)cap.inv * 4),
                  o_rf = take((size_t)cap.inv * 4), o_rinc = take((size_t)cap.inv * 4),
                  o_gpos = take(nslots * 3 * sizeof(T)), o_gnormal = take(nslots * 3 * sizeof(T)), o_gdepth = take(nslots * sizeof(T)),
@@ -295,6 +305,7 @@ template <class T> int ensure_exact_buffers(dmxBatch *b, const ExactCaps &cap, E
     char *A = (char *)b->ex_arena.p;
     B.counts = (ExactCounts *)(A + o_counts);
     B.cross_list = (int32_t *)(A + o_cross);
+    B.stamps = (uint64_t *)(A + o_stamps);
     B.temp = A + o_temp; B.temp_bytes = temp;
     B.pc = (uint64_t *)b->ex_body.p; B.inc = B.pc + n;
     B.inpair = (uint8_t *)b->bp_inpair.p;
@@ -347,6 +358,12 @@ template <class T> int careful_tick(dmxBatch *b, double h)
             HIP_TRY(launch_exact_small_group<T>((const T *)b->slab, b->gtype, G, P, B, cap, rpc, big_island_rows_general(), b->diag_isl,
                                                 hc, hf, b->stream));
             HIP_TRY(hipStreamSynchronize(b->stream));
+            if (exs_timing_enabled()) {
+                uint64_t st[64];
+                HIP_TRY(hipMemcpy(st, B.stamps, sizeof(st), hipMemcpyDeviceToHost));
+                for (int k = 1; k < 9; k++) { b->exs_acc[k] += (double)(st[k] - st[k - 1]); b->exs_acc[32 + k] += (double)(st[32 + k] - st[32 + k - 1]); }
+                b->exs_ticks++;
+            }
         } else {
         if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
         HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), B, cap, b->stream));
@@ -457,7 +474,8 @@ template <class T> int step_sync_t(dmxBatch *b, double h, int nsteps)
         if (!b->bp_valid && (rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
         if (b->bp_chunk < kChunk) b->bp_chunk = kChunk;
         int k = std::min(remaining, b->bp_chunk);
-        bool careful = b->bp_crowded > 0;
+        bool careful = b->bp_crowded > 0 || b->bp_skip_fast;
+        b->bp_skip_fast = false;
         // fast chunk: snapshot, k fused ticks with the safe-zone check riding along, one flag read.  If a body
         // left its zone the chunk is rolled back; the first retry only refreshes the zones (a body that has
         // drifted since the last build usually fits again), the second replays the chunk exactly.
@@ -482,9 +500,12 @@ template <class T> int step_sync_t(dmxBatch *b, double h, int nsteps)
             if ((rc = snapshot_restore<T>(b)) != DMX_OK) return rc;
             b->stat_rollbacks++;
             b->bp_chunk = kChunk;
+            const bool same_again = b->bp_fresh && k <= kChunk;    // zones built at these very poses, chunk no longer than the retry's:
             k = std::min(k, kChunk);            // the retry (and an exact replay, if it comes to that) covers a short chunk
-            if (attempt == 0) {
-                if ((rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
+            if (attempt == 0 && same_again) {
+                careful = true;                 // ... the retry would run the same ticks against the same zones
+            } else if (attempt == 0) {
+                if (!b->bp_fresh && (rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
                 careful = b->bp_crowded > 0;
             } else {
                 careful = true;
@@ -532,7 +553,8 @@ template <class T> int close_chunk_t(dmxBatch *b)
     if ((rc = snapshot_restore<T>(b)) != DMX_OK) return rc;
     b->stat_rollbacks++;
     b->bp_chunk = kChunk;
-    b->bp_valid = false;                 // fresh zones first: a body that has drifted since the last build usually fits again
+    if (b->bp_fresh && oc.ticks <= kChunk) b->bp_skip_fast = true;     // same poses, same zones: the replay's first chunk goes the exact way
+    else b->bp_valid = false;            // fresh zones first: a body that has drifted since the last build usually fits again
     std::vector<std::pair<double, int>> segs;
     segs.swap(oc.segs);
     for (auto &sg : segs)

@@ -49,14 +49,14 @@ template <class T> __device__ __forceinline__ void grid_insert(T *S, const uint8
     // (convex bodies take part with their bounding sphere's box: conservative, so only candidates are added)
     if (gtype[i] == GEOM_NONE) return;
     S[slab_ix(C_BPR, i)] = bound_radius<T>(gtype[i], S, i);      // neighbours read this instead of 3 sides + sqrt
-    if (G.aabb != nullptr) {
-        T lo[3], hi[3];
-        body_aabb<T>(S, gtype, i, lo, hi);
-        T *o = G.aabb + 6 * i;
-        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
-    }
     const int ix = (int)floor((double)(S[slab_ix(C_POS + 0, i)] * G.inv_cell));
     const int iz = (int)floor((double)(S[slab_ix(C_POS + 2, i)] * G.inv_cell));
+    if (G.rec != nullptr) {
+        GridRec<T> r;
+        body_aabb<T>(S, gtype, i, r.lo, r.hi);
+        r.ix = ix; r.iz = iz;
+        G.rec[i] = r;
+    }
     const uint32_t h = cell_hash(ix, iz, G.mask, G.xbits);
     const uint32_t slot = atomicAdd(&G.count[h], 1u);
     if (slot < (uint32_t)G.cap) G.items[(size_t)h * G.cap + slot] = (int32_t)i;

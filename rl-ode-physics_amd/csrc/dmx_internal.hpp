@@ -118,6 +118,8 @@ template <class T> struct StepParams {
     // fused kernels also asks that a body's bounding sphere stays clear of every static box's AABB
     const T *sbox; int n_static;
 };
+// islands of up to this many rows: one wavefront of solve_island_wg, rows in registers, only row_level of the schedule read
+constexpr int WAVE_ISLAND_ROWS = 256;
 // layout of one static box in StepParams::sbox / GridParams::sbox
 enum : int { SBOX_POS = 0, SBOX_R = 3, SBOX_SIDE = 12, SBOX_LO = 15, SBOX_HI = 18, SBOX_REALS = 24 };
 constexpr int MAX_STATIC_BOXES = 64;
@@ -126,6 +128,9 @@ constexpr int MAX_STATIC_BOXES = 64;
 enum : int { BPC_ALL = 1, BPC_FIRST = 2, BPC_LAST = 4 };
 // hashed (x,z)-column grid of the body-body broadphase
 enum : int { BPF_OVERFLOW = 0, BPF_CROWDED = 1, BPF_NPAIRS = 2, BPF_VIOLATION = 3, BPF_WARN = 4, BPF_COUNT = 5 };
+// per body, left by grid_insert for the exact pair search: its column and its AABB in one aligned record (32 B f32, 64 B f64),
+// so a candidate costs one access, not eight
+template <class T> struct alignas(16) GridRec { T lo[3], hi[3]; int32_t ix, iz; };
 template <class T> struct GridParams {
     T cell, inv_cell, r_max;
     T r_max_box, r_max_solid;   // largest bounding radius among the boxes / among boxes and spheres (0: none): what a convex hull /
@@ -137,7 +142,7 @@ template <class T> struct GridParams {
     uint32_t *count;       // [mask+1]
     int32_t *items;        // [(mask+1) * cap]
     uint32_t *flags;       // [BPF_COUNT]
-    T *aabb;               // optional [6 per slot]: bp_insert leaves every body's AABB (lo3, hi3) here for the exact pair search
+    GridRec<T> *rec;       // optional [per slot]: bp_insert leaves every body's column and AABB here for the exact pair search
     const T *sbox; int n_static;   // static boxes (StepParams::sbox)
 };
 

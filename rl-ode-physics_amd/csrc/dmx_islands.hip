@@ -13,6 +13,7 @@
 // sweeps and prefetches each lane's next row across the level barrier.  Single bodies resting on the ground plane never come here: they take
 // the fused register-resident path (step_plane).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "dmx_internal.hpp"
 #include "dmx_math.hpp"
 
@@ -607,8 +608,46 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
     }
 }
 
+// The sweeps of a small island by one wavefront: every row is OWNED by a lane (row r by lane r mod 64, the first
+// wavefront's) and stays in that lane's registers, RPL rows per lane; a level step is "lanes whose row is in this level
+// update it"; between two barriers only the bodies' accumulators in LDS are touched.  Returns the lane's share of the
+// last sweep's residual.
+template <class T, int RPL>
+__device__ __forceinline__ double wave_island_sweeps(T *rows, const int *jb, const int *row_level, int m, int nlev, int iters, int tid,
+                                                     T *fc_lds)
+{
+    RowRegs<T> mine[RPL];
+    int my_level[RPL];
+#pragma unroll
+    for (int j = 0; j < RPL; j++) {
+        const int r = tid + 64 * j;
+        my_level[j] = -1;
+        if (tid < 64 && r < m) { row_load(rows, jb, r, mine[j]); my_level[j] = row_level[r]; }
+    }
+    __syncthreads();
+    double resid = 0.0;
+    for (int it = 0; it < iters; it++) {
+        const bool last = (it == iters - 1);
+        for (int lv = 0; lv < nlev; lv++) {
+#pragma unroll
+            for (int j = 0; j < RPL; j++)
+                if (my_level[j] == lv) {
+                    const T d = row_sor_lds<T, false>(rows, mine[j], fc_lds);
+                    if (last) resid += (double)d;
+                }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RPL; j++)
+        if (my_level[j] >= 0) rows[(size_t)mine[j].row * RW_COUNT + RW_LAM] = mine[j].lam;
+    return resid;
+}
+
 // ================================================================================ one workgroup per large island
 constexpr int FC_LDS_BYTES = 48 * 1024;     // islands of up to 2048 (f32) / 1024 (f64) bodies keep their accumulators in LDS
+// (WAVE_ISLAND_ROWS, dmx_internal.hpp: islands of up to that many rows are solved by one wavefront with the rows in registers;
+//  such an island has at most 2 x 256 bodies, which always fit the LDS above)
 
 template <class T, int WG>
 __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const uint8_t *__restrict__ bflags,
@@ -646,38 +685,18 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
     extern __shared__ __align__(16) unsigned char fc_raw[];
     T *fc_lds = reinterpret_cast<T *>(fc_raw);
     const bool use_lds = nb <= lds_bodies && nlev > 0;    // workgroup-uniform
-    constexpr int RPL = 4;      // rows a lane can own in registers (wavefront-per-island form)
-    if (WG == 64 && use_lds && m <= 64 * RPL) {
-        // Small island, one wavefront: every row is OWNED by a lane for the whole solve (row r by lane r mod 64) and stays
-        // in that lane's registers; a level step is "lanes whose row is in this level update it".  Nothing is fetched
-        // between two barriers but the bodies' accumulators in LDS.
+    if (use_lds && m <= WAVE_ISLAND_ROWS) {
+        // Small island, one wavefront (the first, if the launch has four): every row is OWNED by a lane for the whole solve
+        // (row r by lane r mod 64) and stays in that lane's registers; a level step is "lanes whose row is in this level
+        // update it".  Nothing is fetched between two barriers but the bodies' accumulators in LDS.  Only row_level is read
+        // of the schedule: the device-side builder (dmx_exact.hip) leaves the per-level row lists of such islands unbuilt.
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) fc_lds[6 * k + j] = bs[(size_t)k * BW_COUNT + BW_FC + j];
-        RowRegs<T> mine[RPL];
-        int my_level[RPL];
         const int *row_level = I.row_level + lev_off[0];
-#pragma unroll
-        for (int j = 0; j < RPL; j++) {
-            const int r = tid + 64 * j;
-            my_level[j] = -1;
-            if (r < m) { row_load(rows, jb, r, mine[j]); my_level[j] = row_level[r]; }
-        }
-        __syncthreads();
-        for (int it = 0; it < P.iters; it++) {
-            const bool last = (it == P.iters - 1);
-            for (int lv = 0; lv < nlev; lv++) {
-#pragma unroll
-                for (int j = 0; j < RPL; j++)
-                    if (my_level[j] == lv) {
-                        const T d = row_sor_lds<T, false>(rows, mine[j], fc_lds);
-                        if (last) resid += (double)d;
-                    }
-                __syncthreads();
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < RPL; j++)
-            if (my_level[j] >= 0) rows[(size_t)mine[j].row * RW_COUNT + RW_LAM] = mine[j].lam;
+        // (rows per lane as a template parameter: an island of up to 64 rows pays for one row's tests per level, not four)
+        if (m <= 64) resid = wave_island_sweeps<T, 1>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds);
+        else if (m <= 128) resid = wave_island_sweeps<T, 2>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds);
+        else resid = wave_island_sweeps<T, WAVE_ISLAND_ROWS / 64>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds);
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) bs[(size_t)k * BW_COUNT + BW_FC + j] = fc_lds[6 * k + j];
     } else if (use_lds) {
@@ -976,8 +995,8 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
         }
     }
     if (I.n_big > 0) {
-        const size_t want = (size_t)I.big_max_bodies * 6 * sizeof(T);
-        const int lds_bodies = want <= (size_t)FC_LDS_BYTES ? I.big_max_bodies : 0;     // 0: accumulators stay in HBM/L2
+        // islands of up to lds_bodies bodies keep their accumulators in LDS (larger ones: HBM/L2)
+        const int lds_bodies = std::min<int>(std::max(I.big_max_bodies, 1), FC_LDS_BYTES / (int)(6 * sizeof(T)));
         const size_t lds = (size_t)lds_bodies * 6 * sizeof(T);
         if (I.big_max_width <= 64)      // no level has more than 64 rows: one wavefront per island, barriers cost nothing
             hipLaunchKernelGGL((solve_island_wg<T, 64>), dim3((unsigned)I.n_big), dim3(64), lds, st, S, bflags, stride, I, P, diag, lds_bodies);

@@ -234,6 +234,8 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *S, T *So, const uint8
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     int my_contacts = 0;
     double my_resid = 0.0;
+    // a chunk in which a body has left its zone is rolled back whole: once the flag is up, its remaining ticks need no work
+    if (P.bp_check && P.bp_flags[BPF_VIOLATION] != 0u) return;
     if (i < n && !(P.skip != nullptr && P.skip[i])) {
         V3<T> x = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
         if (P.bp_check) {
