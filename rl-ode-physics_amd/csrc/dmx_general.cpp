@@ -264,8 +264,12 @@ bool exs_timing_enabled()
 // device-visible addresses of the pinned host records the small-scene kernels write themselves
 int host_record_pointers(dmxBatch *b, ExactCounts **counts_dev, uint32_t **flags_dev)
 {
-    HIP_TRY(hipHostGetDevicePointer((void **)counts_dev, b->ex_counts_host, 0));
-    HIP_TRY(hipHostGetDevicePointer((void **)flags_dev, b->bp_flags_host, 0));
+    if (!b->ex_counts_dev) {
+        HIP_TRY(hipHostGetDevicePointer(&b->ex_counts_dev, b->ex_counts_host, 0));
+        HIP_TRY(hipHostGetDevicePointer(&b->bp_flags_dev, b->bp_flags_host, 0));
+    }
+    *counts_dev = (ExactCounts *)b->ex_counts_dev;
+    *flags_dev = (uint32_t *)b->bp_flags_dev;
     return DMX_OK;
 }
 

@@ -237,26 +237,41 @@ __device__ __forceinline__ void row_load(const T *rows, const int *jb, int i, Ro
 }
 
 template <class T, bool STORE_LAM = true>
-__device__ __forceinline__ T row_sor_lds(T *rows, RowRegs<T> &r, T *fc)
+__device__ __forceinline__ T row_sor_lds(T *rows, RowRegs<T> &r, T *fc, bool eager = true)
 {
+    // both bodies' accumulators are fetched together, up front, and written back from registers: the row's two bodies differ,
+    // so nothing needs re-reading in between -- one LDS round trip per row instead of three.  eager: a body-less second slot
+    // fetches too (the first body's values, never used), which keeps the two fetches in one straight line of code; launches
+    // of thousands of islands are bound by issue slots, not by latency, and fetch only what they use.
     T *fc1 = fc + 6 * r.l1;
-    T *fc2 = r.l2 >= 0 ? fc + 6 * r.l2 : nullptr;
+    T *fc2 = fc + 6 * (r.l2 >= 0 ? r.l2 : r.l1);
+    const bool two = r.l2 >= 0;
+    T a[6], b[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) a[j] = fc1[j];
+    if (two || eager) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) b[j] = fc2[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) b[j] = T(0);
+    }
     const T *J = r.J;
     const T old = r.lam;
     T delta = fma_(-old, r.ad, r.rhs);
-    delta -= fma_(fc1[5], J[5], fma_(fc1[4], J[4], fma_(fc1[3], J[3], fma_(fc1[2], J[2], fma_(fc1[1], J[1], fc1[0] * J[0])))));
-    if (fc2)
-        delta -= fma_(fc2[5], J[11], fma_(fc2[4], J[10], fma_(fc2[3], J[9], fma_(fc2[2], J[8], fma_(fc2[1], J[7], fc2[0] * J[6])))));
+    delta -= fma_(a[5], J[5], fma_(a[4], J[4], fma_(a[3], J[3], fma_(a[2], J[2], fma_(a[1], J[1], a[0] * J[0])))));
+    if (two)
+        delta -= fma_(b[5], J[11], fma_(b[4], J[10], fma_(b[3], J[9], fma_(b[2], J[8], fma_(b[1], J[7], b[0] * J[6])))));
     const T nl = old + delta;
     if (nl < r.lo) { delta = r.lo - old; r.lam = r.lo; }
     else if (nl > r.hi) { delta = r.hi - old; r.lam = r.hi; }
     else r.lam = nl;
     if (STORE_LAM) rows[(size_t)r.row * RW_COUNT + RW_LAM] = r.lam;
 #pragma unroll
-    for (int j = 0; j < 6; j++) fc1[j] = fma_(delta, r.iMJ[j], fc1[j]);
-    if (fc2) {
+    for (int j = 0; j < 6; j++) fc1[j] = fma_(delta, r.iMJ[j], a[j]);
+    if (two) {
 #pragma unroll
-        for (int j = 0; j < 6; j++) fc2[j] = fma_(delta, r.iMJ[6 + j], fc2[j]);
+        for (int j = 0; j < 6; j++) fc2[j] = fma_(delta, r.iMJ[6 + j], b[j]);
     }
     return tabs(delta);
 }
@@ -614,7 +629,7 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
 // last sweep's residual.
 template <class T, int RPL>
 __device__ __forceinline__ double wave_island_sweeps(T *rows, const int *jb, const int *row_level, int m, int nlev, int iters, int tid,
-                                                     T *fc_lds)
+                                                     T *fc_lds, bool eager)
 {
     RowRegs<T> mine[RPL];
     int my_level[RPL];
@@ -626,18 +641,20 @@ __device__ __forceinline__ double wave_island_sweeps(T *rows, const int *jb, con
     }
     __syncthreads();
     double resid = 0.0;
-    for (int it = 0; it < iters; it++) {
-        const bool last = (it == iters - 1);
+    for (int it = 0; it + 1 < iters; it++)
         for (int lv = 0; lv < nlev; lv++) {
 #pragma unroll
             for (int j = 0; j < RPL; j++)
-                if (my_level[j] == lv) {
-                    const T d = row_sor_lds<T, false>(rows, mine[j], fc_lds);
-                    if (last) resid += (double)d;
-                }
+                if (my_level[j] == lv) (void)row_sor_lds<T, false>(rows, mine[j], fc_lds, eager);
             __syncthreads();
         }
-    }
+    if (iters > 0)                  // the last sweep also sums its |delta lambda|
+        for (int lv = 0; lv < nlev; lv++) {
+#pragma unroll
+            for (int j = 0; j < RPL; j++)
+                if (my_level[j] == lv) resid += (double)row_sor_lds<T, false>(rows, mine[j], fc_lds, eager);
+            __syncthreads();
+        }
 #pragma unroll
     for (int j = 0; j < RPL; j++)
         if (my_level[j] >= 0) rows[(size_t)mine[j].row * RW_COUNT + RW_LAM] = mine[j].lam;
@@ -694,9 +711,10 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
             for (int j = 0; j < 6; j++) fc_lds[6 * k + j] = bs[(size_t)k * BW_COUNT + BW_FC + j];
         const int *row_level = I.row_level + lev_off[0];
         // (rows per lane as a template parameter: an island of up to 64 rows pays for one row's tests per level, not four)
-        if (m <= 64) resid = wave_island_sweeps<T, 1>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds);
-        else if (m <= 128) resid = wave_island_sweeps<T, 2>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds);
-        else resid = wave_island_sweeps<T, WAVE_ISLAND_ROWS / 64>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds);
+        const bool eager = gridDim.x < 2048u;           // few islands: every one waits on its own chain of rows
+        if (m <= 64) resid = wave_island_sweeps<T, 1>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds, eager);
+        else if (m <= 128) resid = wave_island_sweeps<T, 2>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds, eager);
+        else resid = wave_island_sweeps<T, WAVE_ISLAND_ROWS / 64>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds, eager);
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) bs[(size_t)k * BW_COUNT + BW_FC + j] = fc_lds[6 * k + j];
     } else if (use_lds) {
