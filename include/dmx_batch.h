@@ -162,6 +162,14 @@ int dmxBatchSetBodyCollisions(dmxBatchID b, int enable);
  * for callers that replay captured HIP graphs of ticks, which bake the slab's address in.  Not inside a chunk. */
 enum { DMX_SNAPSHOT_PINGPONG = 0, DMX_SNAPSHOT_COPY = 1 };
 int dmxBatchSetSnapshotMode(dmxBatchID b, int mode);
+/* How an exact tick (bodies in pairs / at static boxes) runs its bookkeeping -- pair list, islands, joints by island, level
+ * schedules.  STAGED: a launch per stage over as many compute units as the stage fills.  ONE_WORKGROUP: the same stages, in
+ * the same order, inside two one-workgroup kernels around the narrowphase (barriers instead of ~25 launches), whenever the
+ * tick's arrays fit one workgroup (<= 8192 slots and entries); AUTO (default; DMX_SMALL_EXACT=0/2 in the environment picks
+ * one of the others): ONE_WORKGROUP for scenes of up to 2048 slots whose last tick had at most 512 pairs.  Same results,
+ * bit for bit, either way. */
+enum { DMX_EXACT_AUTO = 0, DMX_EXACT_STAGED = 1, DMX_EXACT_ONE_WORKGROUP = 2 };
+int dmxBatchSetExactPipeline(dmxBatchID b, int mode);
 /* Contact-free ticks (no ground plane) may be taken `ticks` at a time inside one kernel launch, the bodies' state held
  * in registers between them: same arithmetic per tick, same results bit for bit, one read and one write of the state
  * per launch instead of per tick.  Default 1 (one launch per tick); 1..64. */

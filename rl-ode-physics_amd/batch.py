@@ -18,6 +18,7 @@ GEOM_NONE, GEOM_SPHERE, GEOM_BOX = 0, 1, 2
 GYRO_OFF, GYRO_EXPLICIT, GYRO_IMPLICIT = 0, 1, 2
 CONTACT_BOUNCE = 0x004
 SNAPSHOT_PINGPONG, SNAPSHOT_COPY = 0, 1
+EXACT_AUTO, EXACT_STAGED, EXACT_ONE_WORKGROUP = 0, 1, 2
 
 
 class DmxError(RuntimeError):
@@ -200,6 +201,10 @@ class BatchWorld:
     def set_snapshot_mode(self, mode):
         """SNAPSHOT_PINGPONG (default) / SNAPSHOT_COPY: how a chunk keeps its start state (include/dmx_batch.h)"""
         _check(self.lib.dmxBatchSetSnapshotMode(self.h, mode), "dmxBatchSetSnapshotMode")
+
+    def set_exact_pipeline(self, mode):
+        """EXACT_AUTO (default) / EXACT_STAGED / EXACT_ONE_WORKGROUP: how an exact tick runs its bookkeeping (include/dmx_batch.h)"""
+        _check(self.lib.dmxBatchSetExactPipeline(self.h, mode), "dmxBatchSetExactPipeline")
 
     def set_ticks_per_launch(self, ticks):
         _check(self.lib.dmxBatchSetTicksPerLaunch(self.h, ticks), "dmxBatchSetTicksPerLaunch")

@@ -383,6 +383,14 @@ extern "C" int dmxBatchSetSnapshotMode(dmxBatchID b, int mode)
     return DMX_OK;
 }
 
+extern "C" int dmxBatchSetExactPipeline(dmxBatchID b, int mode)
+{
+    if (!b || mode < DMX_EXACT_AUTO || mode > DMX_EXACT_ONE_WORKGROUP) return DMX_EINVAL;
+    SETTLE(b);
+    b->exact_pipeline = mode;
+    return DMX_OK;
+}
+
 extern "C" int dmxBatchSetBodyCollisions(dmxBatchID b, int enable)
 {
     if (!b) return DMX_EINVAL;

@@ -242,17 +242,23 @@ template <class T> int fused_run(dmxBatch *b, double h, int n, bool ends_only, b
 constexpr int kBigIslandRows = 1;        // multi-body islands with at least this many rows get a workgroup (see dmx_joints.cpp)
 
 constexpr int64_t kSmallExactBodies = 2048, kSmallExactPairs = 512;
-// scenes of up to kSmallExactBodies slots whose last tick had at most kSmallExactPairs body pairs run the bookkeeping as two
-// one-workgroup kernels (dmx_exact.hip); DMX_SMALL_EXACT=0: never, DMX_SMALL_EXACT=2: whenever the arrays fit
-bool small_exact_enabled()
+// Does this exact tick run its bookkeeping as the two one-workgroup kernels (dmx_exact.hip)?  dmxBatchSetExactPipeline; AUTO:
+// scenes of up to kSmallExactBodies slots whose last tick had at most kSmallExactPairs body pairs (one workgroup has one
+// compute unit's memory pipeline: past that the stage-per-launch pipeline over many compute units is the faster one again).
+int default_exact_pipeline()
 {
-    static const bool v = [] { const char *e = getenv("DMX_SMALL_EXACT"); return !(e && atoi(e) == 0); }();
+    static const int v = [] {
+        const char *e = getenv("DMX_SMALL_EXACT");
+        return !e ? DMX_EXACT_AUTO : atoi(e) == 0 ? DMX_EXACT_STAGED : atoi(e) == 2 ? DMX_EXACT_ONE_WORKGROUP : DMX_EXACT_AUTO;
+    }();
     return v;
 }
-bool small_exact_always()
+bool use_small_exact(const dmxBatch *b, const ExactCaps &cap, bool pairs_matter)
 {
-    static const bool v = [] { const char *e = getenv("DMX_SMALL_EXACT"); return e && atoi(e) == 2; }();
-    return v;
+    const int mode = b->exact_pipeline != DMX_EXACT_AUTO ? b->exact_pipeline : default_exact_pipeline();
+    if (mode == DMX_EXACT_STAGED || !exact_small_fits(b->n, b->bp_mask, cap)) return false;
+    if (mode == DMX_EXACT_ONE_WORKGROUP) return true;
+    return b->n <= kSmallExactBodies && (!pairs_matter || b->last_pairs <= (unsigned long long)kSmallExactPairs);
 }
 
 bool exs_timing_enabled()
@@ -358,9 +364,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
         cap.rows = b->ex_cap_rows;
         cap.nstatic = (uint32_t)b->n_static;
         if ((rc = ensure_exact_buffers<T>(b, cap, B)) != DMX_OK) return rc;
-        // (one workgroup has one compute unit's memory pipeline: past a couple of thousand bodies, or with hundreds of
-        //  pairs to walk and sort, the stage-per-launch pipeline over many compute units is the faster one again)
-        small = small_exact_enabled() && exact_small_fits(b->n, b->bp_mask, cap) && (small_exact_always() || (b->n <= kSmallExactBodies && b->last_pairs <= kSmallExactPairs));
+        small = use_small_exact(b, cap, true);
         if (small) {
             // everything between here and the island solve in three launches; the last one leaves the counts and the
             // flags in host memory: the tick's one wait is all the host does
@@ -656,7 +660,7 @@ template <class T> int find_pairs_t(dmxBatch *b)
         cap.rows = b->ex_cap_rows;
         cap.nstatic = (uint32_t)b->n_static;
         if ((rc = ensure_exact_buffers<T>(b, cap, B)) != DMX_OK) return rc;
-        if (small_exact_enabled() && exact_small_fits(b->n, b->bp_mask, cap) && (small_exact_always() || b->n <= kSmallExactBodies)) {
+        if (use_small_exact(b, cap, false)) {
             ExactCounts *hc; uint32_t *hf;
             if ((rc = host_record_pointers(b, &hc, &hf)) != DMX_OK) return rc;
             HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, grid_of<T>(b), B, cap, hc, hf, b->stream));

@@ -189,6 +189,32 @@ def test_mixed_spheres_and_boxes_pile_up():
     assert w.collision_stats()["pair_ticks"] > 100
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_exact_tick_pipelines_agree(dtype):
+    """The exact tick's bookkeeping as a launch per stage and as two one-workgroup kernels (dmxBatchSetExactPipeline): the
+    same pairs, islands, joints and level schedules, so the same state bit for bit -- and the oracle's.  1 296 bodies in
+    144 piles (every tick exact, ~600 body pairs, islands of ~9 bodies) and the tumbling-box scene (mostly one-body islands,
+    a few pairs: what the one-workgroup form is for)."""
+    piles = pkg.scenes.box_grid(36, 36, seed=5, y_range=(0.6, 6.0), spin=True, box_mass=True).astype(dtype)
+    ix, iz = np.arange(piles.n) % 36, np.arange(piles.n) // 36
+    piles.pos[:, 0] = (ix // 3) * 7.5 + (ix % 3) * 0.6
+    piles.pos[:, 2] = (iz // 3) * 7.5 + (iz % 3) * 0.6
+    tumble = pkg.scenes.box_grid(24, 24, seed=11, y_range=(0.8, 4.0), spin=True, box_mass=True).astype(dtype)
+    tumble.avel[:] *= 3.0
+    for scene, steps in ((piles, 90), (tumble, 240)):
+        runs = {}
+        for mode in (pkg.batch.EXACT_STAGED, pkg.batch.EXACT_ONE_WORKGROUP):
+            w = _gpu_run(scene, dtype, steps, setup=lambda w, m=mode: w.set_exact_pipeline(m))
+            runs[mode] = (w.state(), w.last_contact_count(), w.collision_stats())
+        a, b = runs[pkg.batch.EXACT_STAGED], runs[pkg.batch.EXACT_ONE_WORKGROUP]
+        for x, y in zip(a[0], b[0]):
+            assert np.array_equal(x, y)
+        assert a[1] == b[1] and a[2]["pair_ticks"] == b[2]["pair_ticks"] > 0 and a[2]["last_pairs"] == b[2]["last_pairs"]
+        ow = _oracle_run(_orc(dtype), scene, steps, allow_pairs=True)
+        _compare(b[0], ow.state())
+        assert b[1] == ow.n_contacts() > 0
+
+
 def test_body_collisions_off_is_the_plain_fused_path():
     scene = pkg.scenes.box_grid(32, 32, seed=1, spin=True, plane=False).astype("float32")
     a = _gpu_run(scene, "float32", 100).state()
