@@ -215,6 +215,22 @@ def test_exact_tick_pipelines_agree(dtype):
         assert b[1] == ow.n_contacts() > 0
 
 
+def test_thousands_of_piles_several_islands_per_wavefront():
+    """36 864 bodies in 4 096 piles: every tick exact, 4 096+ multi-body islands -- the launch shape in which a wavefront
+    solves several small islands together (solve_islands_packed).  Bit-identical to the sequential oracle."""
+    side = 64
+    scene = pkg.scenes.box_grid(3 * side, 3 * side, seed=5, y_range=(0.6, 6.0), spin=True, box_mass=True).astype("float32")
+    ix, iz = np.arange(scene.n) % (3 * side), np.arange(scene.n) // (3 * side)
+    scene.pos[:, 0] = (ix // 3) * 7.5 + (ix % 3) * 0.6
+    scene.pos[:, 2] = (iz // 3) * 7.5 + (iz % 3) * 0.6
+    steps = 45
+    w = _gpu_run(scene, "float32", steps)
+    ow = _oracle_run(_orc("float32"), scene, steps, allow_pairs=True)
+    _compare(w.state(), ow.state())
+    assert w.last_contact_count() == ow.n_contacts() > 10000
+    assert w.collision_stats()["last_pairs"] > 4096
+
+
 def test_body_collisions_off_is_the_plain_fused_path():
     scene = pkg.scenes.box_grid(32, 32, seed=1, spin=True, plane=False).astype("float32")
     a = _gpu_run(scene, "float32", 100).state()
