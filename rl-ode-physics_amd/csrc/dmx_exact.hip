@@ -636,7 +636,6 @@ __device__ __forceinline__ void st_levels(const int *con_off, const int *body_of
         big[i] = base + k;
         big_list[k] = (int)i;
         atomicMax(&C->big_max_bodies, (uint32_t)(body_off[i + 1] - body_off[i]));
-        atomicMax(&C->big_max_rows, (uint32_t)m);
         if ((uint32_t)(base + m) > cap.rows) continue;          // flagged above; the host grows the capacity
         int *lv_out = row_level + base, *off = lev_off + base + k, *rows_out = lev_rows + base;
         // consecutive contacts between the same bodies (a box's four contacts with the plane, a pair's) form one group: its

@@ -29,8 +29,7 @@ struct ExactCounts {
     uint32_t cross_a, cross_b;
     uint32_t unsupported;   // AABB pairs of this tick that have no collider (convex-convex, convex-sphere)
     uint32_t ncross;        // pairs (own body, ghost slot) met; the first EX_CROSS_CAP of them are in ExactBuffers::cross_list
-    uint32_t big_max_rows;  // most rows of any island that gets a workgroup
-    uint32_t pad[1];
+    uint32_t pad[2];
 };
 
 constexpr uint32_t EX_CROSS_CAP = 256;

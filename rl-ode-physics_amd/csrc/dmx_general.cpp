@@ -456,7 +456,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     I.gpos = B.gpos; I.gnormal = B.gnormal; I.gdepth = B.gdepth;
     I.big = B.big; I.n_big = (int)C.nbig; I.big_list = B.big_list; I.lev_count = B.lev_count;
     I.lev_off = B.lev_off; I.lev_rows = B.lev_rows; I.row_level = B.row_level;
-    I.big_max_bodies = (int)C.big_max_bodies; I.big_max_width = (int)C.big_max_width; I.big_max_rows = (int)C.big_max_rows;
+    I.big_max_bodies = (int)C.big_max_bodies; I.big_max_width = (int)C.big_max_width;
     I.rows = (T *)b->jd_rows.p; I.rowjb = (int *)b->jd_rowjb.p; I.bscr = (T *)b->jd_bscr.p; I.local = (int *)b->jd_local.p;
     I.singles = 1;
     // (cmode / cmu / cbounce ... stay null: every contact carries the batch's surface, NearCallback's policy, main.c:684-687)

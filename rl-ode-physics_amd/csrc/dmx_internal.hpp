@@ -82,7 +82,6 @@ template <class T> struct IslandSet {
     // launch shape of solve_island_wg: bodies of the largest such island (its accumulators go to LDS when they fit) and
     // the widest level of any schedule (64 lanes per island are enough when no level is wider)
     int big_max_bodies, big_max_width;
-    int big_max_rows;      // most rows of any big island (0 = unknown): with at most WAVE_ISLAND_ROWS, a packed launch leaves nothing over
     const int *row_level;  // level of every scheduled row, laid out like lev_rows (an island's rows start at its lev_off[0])
     const int *order;      // optional (dmxBatchSetRowOrder, DMX_ORDER_ODE): sweep `it` visits row order[(it / 8) * order_stride +
     int order_stride;      //   row_off[island] + i] at its i-th step; null: rows in creation order (solve_islands only)

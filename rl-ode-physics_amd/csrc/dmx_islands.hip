@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64) void solve_islands(T *__restrict__ S, const uin
 // A lane has RPL slots of one row each.  Laid out plainly (row v in slot v / 64 of lane v % 64) the rows of one level sit in
 // any slot, so every level step tests all RPL slots of every lane, and rows of one level that sit in different slots are
 // updated one slot after the other.  Laid out BY LEVEL CLASS -- a row of level L in slot L mod RPL, lanes filled in row
-// order -- a level step concerns one slot only: one test, one pass, however many islands share the wavefront.  tab[c * 64 +
+// order -- a level step concerns one slot only: one test, one pass.  tab[c * 64 +
 // t] = the row lane t holds in slot c (-1: none).  Returns false (and the plain layout) when a class has more than 64 rows.
 // Called by the wavefront's 64 lanes; the caller synchronises before reading tab.
 template <int RPL, class LevelOf>
@@ -725,6 +725,134 @@ __device__ __forceinline__ double wave_island_sweeps(T *rows, const int *jb, con
     return resid;
 }
 
+// ---- the same sweeps with a CONTACT (its normal and two friction rows) as the unit a lane owns -----------------------------
+// The three rows of a contact are consecutive in creation order and share both bodies, so they sit on three consecutive levels
+// and nothing else touches those bodies in between: a lane that owns all three fetches the two bodies' accumulators once,
+// updates them in registers through the three rows, and writes them back once -- one LDS round trip per contact instead of
+// per row, with exactly the row-by-row arithmetic.  Contact level = (level of its first row) / 3: two contacts sharing a body
+// are at least three row levels apart, so they never get the same contact level and keep their order.  For islands whose
+// contacts all carry the batch's surface with friction (three rows each).
+template <class T> struct ContactRegs { T J[3][12], iMJ[3][12], rhs[3], ad[3], lo[3], hi[3], lam[3]; int l1, l2, row0; };
+
+template <class T>
+__device__ __forceinline__ void contact_load(const T *rows, const int *jb, int r0, ContactRegs<T> &c)
+{
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const T *row = rows + (size_t)(r0 + d) * RW_COUNT;
+#pragma unroll
+        for (int j = 0; j < 12; j++) { c.J[d][j] = row[RW_J + j]; c.iMJ[d][j] = row[RW_IMJ + j]; }
+        c.rhs[d] = row[RW_RHS]; c.ad[d] = row[RW_AD]; c.lo[d] = row[RW_LO]; c.hi[d] = row[RW_HI]; c.lam[d] = row[RW_LAM];
+    }
+    c.l1 = jb[2 * r0]; c.l2 = jb[2 * r0 + 1];
+    c.row0 = r0;
+}
+
+template <class T, bool LAST>
+__device__ __forceinline__ void contact_sor_lds(ContactRegs<T> &c, T *fc, bool eager, double &resid)
+{
+    T *fc1 = fc + 6 * c.l1;
+    T *fc2 = fc + 6 * (c.l2 >= 0 ? c.l2 : c.l1);
+    const bool two = c.l2 >= 0;
+    T a[6], b[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) a[j] = fc1[j];
+    if (two || eager) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) b[j] = fc2[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) b[j] = T(0);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const T *J = c.J[d];
+        const T old = c.lam[d];
+        T delta = fma_(-old, c.ad[d], c.rhs[d]);
+        delta -= fma_(a[5], J[5], fma_(a[4], J[4], fma_(a[3], J[3], fma_(a[2], J[2], fma_(a[1], J[1], a[0] * J[0])))));
+        if (two)
+            delta -= fma_(b[5], J[11], fma_(b[4], J[10], fma_(b[3], J[9], fma_(b[2], J[8], fma_(b[1], J[7], b[0] * J[6])))));
+        const T nl = old + delta;
+        if (nl < c.lo[d]) { delta = c.lo[d] - old; c.lam[d] = c.lo[d]; }
+        else if (nl > c.hi[d]) { delta = c.hi[d] - old; c.lam[d] = c.hi[d]; }
+        else c.lam[d] = nl;
+#pragma unroll
+        for (int j = 0; j < 6; j++) a[j] = fma_(delta, c.iMJ[d][j], a[j]);
+        if (two) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) b[j] = fma_(delta, c.iMJ[d][6 + j], b[j]);
+        }
+        if (LAST) resid += (double)tabs(delta);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) fc1[j] = a[j];
+    if (two) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) fc2[j] = b[j];
+    }
+}
+
+// one sweep over the wavefront's contacts; slot cl mod CPL holds every contact of contact level cl when classed
+template <class T, int CPL, bool LAST>
+__device__ __forceinline__ void wave_contact_sweep(ContactRegs<T> (&mine)[CPL], const int (&my_cl)[CPL], int n_clev, bool classed, T *fc_lds,
+                                                   bool eager, double &resid)
+{
+    if (classed) {
+        for (int cl0 = 0; cl0 < n_clev; cl0 += CPL) {
+#pragma unroll
+            for (int j = 0; j < CPL; j++) {
+                if (cl0 + j < n_clev) {
+                    if (my_cl[j] == cl0 + j) contact_sor_lds<T, LAST>(mine[j], fc_lds, eager, resid);
+                    __syncthreads();
+                }
+            }
+        }
+    } else {
+        for (int cl = 0; cl < n_clev; cl++) {
+#pragma unroll
+            for (int j = 0; j < CPL; j++)
+                if (my_cl[j] == cl) contact_sor_lds<T, LAST>(mine[j], fc_lds, eager, resid);
+            __syncthreads();
+        }
+    }
+}
+
+// one island's sweeps with contacts as units (crow: the island's contacts' first rows, island-relative)
+template <class T, int CPL>
+__device__ __forceinline__ double wave_island_contact_sweeps(T *rows, const int *jb, const int *row_level, const int *crow, int nc, int nlev,
+                                                             int iters, int tid, T *fc_lds, bool eager)
+{
+    __shared__ short tab[CPL * 64];
+    __shared__ int tab_classed;
+    if (tid < 64) {
+        const bool ok = CPL > 1 ? assign_row_slots<CPL>(nc, tid, tab, [&](int v) { return row_level[crow[v]] / 3; }) : false;
+        if (CPL == 1) tab[tid] = (short)(tid < nc ? tid : -1);
+        if (tid == 0) tab_classed = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const bool classed = tab_classed != 0;
+    ContactRegs<T> mine[CPL];
+    int my_cl[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; j++) {
+        const int v = tid < 64 ? (int)tab[j * 64 + tid] : -1;
+        my_cl[j] = -1;
+        if (v >= 0) { const int r0 = crow[v]; contact_load(rows, jb, r0, mine[j]); my_cl[j] = row_level[r0] / 3; }
+    }
+    __syncthreads();
+    const int n_clev = (nlev + 2) / 3;
+    double resid = 0.0;
+    for (int it = 0; it + 1 < iters; it++) wave_contact_sweep<T, CPL, false>(mine, my_cl, n_clev, classed, fc_lds, eager, resid);
+    if (iters > 0) wave_contact_sweep<T, CPL, true>(mine, my_cl, n_clev, classed, fc_lds, eager, resid);
+#pragma unroll
+    for (int j = 0; j < CPL; j++)
+        if (my_cl[j] >= 0) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) rows[(size_t)(mine[j].row0 + d) * RW_COUNT + RW_LAM] = mine[j].lam[d];
+        }
+    return resid;
+}
+
 // ================================================================================ one workgroup per large island
 constexpr int FC_LDS_BYTES = 48 * 1024;     // islands of up to 2048 (f32) / 1024 (f64) bodies keep their accumulators in LDS
 // (WAVE_ISLAND_ROWS, dmx_internal.hpp: islands of up to that many rows are solved by one wavefront with the rows in registers;
@@ -733,7 +861,7 @@ constexpr int FC_LDS_BYTES = 48 * 1024;     // islands of up to 2048 (f32) / 102
 template <class T, int WG>
 __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const uint8_t *__restrict__ bflags,
                                                       int64_t stride, IslandSet<T> I, StepParams<T> P,
-                                                      StepDiag *__restrict__ diag, int lds_bodies, int packed_bodies)
+                                                      StepDiag *__restrict__ diag, int lds_bodies)
 {
     const int isl = I.big_list[blockIdx.x];
     const int tid = threadIdx.x;
@@ -748,9 +876,6 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
     const int nlev = I.lev_count[blockIdx.x];
     const int *lev_off = I.lev_off + lv0;                     // [nlev+1], offsets into lev_rows (island-relative rows)
     const int m = lev_off[nlev] - lev_off[0];
-    // (packed_bodies > 0: solve_islands_packed ran before this launch and has taken every island of up to WAVE_ISLAND_ROWS
-    //  rows and packed_bodies bodies)
-    if (packed_bodies > 0 && m <= WAVE_ISLAND_ROWS && nb <= packed_bodies) return;
 
     for (int k = tid; k < nb; k += WG) stage_body(S, bflags, stride, I, P, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], k);
     __syncthreads();
@@ -779,7 +904,11 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
         const int *row_level = I.row_level + lev_off[0];
         // (rows per lane as a template parameter: an island of up to 64 rows pays for one row's tests per level, not four)
         const bool eager = gridDim.x < 2048u;           // few islands: every one waits on its own chain of rows
-        if (m <= 64) resid = wave_island_sweeps<T, 1>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds, eager);
+        const bool by_contact = I.cmu == nullptr && P.mu > 0;     // three rows per contact throughout: a lane owns a contact
+        // (a contact's rows are 90 reals of registers: two contacts per lane in f32, one in f64)
+        if (by_contact && nc <= 64) resid = wave_island_contact_sweeps<T, 1>(rows, jb, row_level, I.crow + c0, nc, nlev, P.iters, tid, fc_lds, eager);
+        else if (by_contact && sizeof(T) == 4) resid = wave_island_contact_sweeps<T, sizeof(T) == 4 ? 2 : 1>(rows, jb, row_level, I.crow + c0, nc, nlev, P.iters, tid, fc_lds, eager);
+        else if (m <= 64) resid = wave_island_sweeps<T, 1>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds, eager);
         else if (m <= 128) resid = wave_island_sweeps<T, 2>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds, eager);
         else resid = wave_island_sweeps<T, WAVE_ISLAND_ROWS / 64>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds, eager);
         for (int k = tid; k < nb; k += WG)
@@ -836,132 +965,6 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
     for (int o = 32; o > 0; o >>= 1) resid += __shfl_xor(resid, o, 64);
     if ((tid & 63) == 0) atomicAdd(&diag->residual, resid);
     if (tid == 0) atomicAdd(&diag->contacts, (unsigned long long)nc);
-}
-
-// ================================================================================ several small islands per wavefront
-// One wavefront per island leaves most of it idle: a level of a small island has one or two rows, so one or two live lanes
-// per instruction, and with thousands of islands in flight the compute units' issue slots -- not any island's chain of rows
-// -- are the bound (16 384 piles of 9 boxes: 760 us of a 1.5 ms tick).  Here a wavefront takes up to `pack` consecutive
-// entries of the big-island list and solves as many of them TOGETHER as fit its registers and LDS (rows of all of them on
-// its lanes, up to WAVE_ISLAND_ROWS; their bodies' accumulators side by side in LDS): every level step serves all of them.
-// Islands own disjoint bodies and rows, every island's rows keep their levels, so each island's arithmetic is exactly what
-// solve_island_wg does for it alone.  Islands that do not qualify (more than WAVE_ISLAND_ROWS rows or than lds_bodies
-// bodies) are left to solve_island_wg, launched behind with packed_bodies = lds_bodies.
-constexpr int PACK_MAX = 8;
-
-template <class T>
-__global__ __launch_bounds__(64) void solve_islands_packed(T *__restrict__ S, const uint8_t *__restrict__ bflags, int64_t stride,
-                                                           IslandSet<T> I, StepParams<T> P, StepDiag *__restrict__ diag,
-                                                           int lds_bodies, int pack)
-{
-    extern __shared__ __align__(16) unsigned char fc_raw[];
-    T *fc_lds = reinterpret_cast<T *>(fc_raw);
-    // the batch: island q has bodies [pb[q], pb[q+1]) of the batch's body numbering, contacts [pc[q], ..), row slots [pr[q], ..)
-    __shared__ int q_isl[PACK_MAX], q_lv0[PACK_MAX], q_nlev[PACK_MAX], pb[PACK_MAX + 1], pc[PACK_MAX + 1], pr[PACK_MAX + 1];
-    constexpr int RPL = WAVE_ISLAND_ROWS / 64;
-    __shared__ short tab[RPL * 64];
-    const int tid = threadIdx.x;
-    const T h = P.h, hinv = T(1) / h;
-    double resid = 0.0;
-    unsigned long long contacts = 0;
-    const int k_end = min(I.n_big, ((int)blockIdx.x + 1) * pack);
-    for (int k = (int)blockIdx.x * pack; k < k_end;) {
-        // ---- form a batch: consecutive qualifying entries while rows, the span of their bodies and the slots last
-        int cnt = 0, rows = 0, b_first = 0;
-        for (; k + cnt < k_end && cnt < PACK_MAX; cnt++) {
-            const int isl = I.big_list[k + cnt];
-            const int lv0 = I.big[isl], nlev = I.lev_count[k + cnt];
-            const int m = I.lev_off[lv0 + nlev] - I.lev_off[lv0];
-            const int b0 = I.body_off[isl], nb = I.body_off[isl + 1] - b0;
-            if (m > WAVE_ISLAND_ROWS || nb > lds_bodies) break;                 // not a wave island: solve_island_wg's
-            if (cnt > 0 && (rows + m > WAVE_ISLAND_ROWS || b0 + nb - b_first > lds_bodies)) break;
-            if (cnt == 0) b_first = b0;
-            rows += m;
-            if (tid == 0) {
-                q_isl[cnt] = isl; q_lv0[cnt] = lv0; q_nlev[cnt] = nlev;
-                if (cnt == 0) { pb[0] = 0; pc[0] = 0; pr[0] = 0; }
-                pb[cnt + 1] = pb[cnt] + nb;
-                pc[cnt + 1] = pc[cnt] + (I.con_off[isl + 1] - I.con_off[isl]);
-                pr[cnt + 1] = pr[cnt] + m;
-            }
-        }
-        if (cnt == 0) { k++; continue; }
-        __syncthreads();
-        const int nbod = pb[cnt], ncon = pc[cnt], nrow = pr[cnt];
-        int nlev_max = 0;
-        for (int q = 0; q < cnt; q++) nlev_max = max(nlev_max, q_nlev[q]);
-        T *bs = I.bscr + (size_t)b_first * BW_COUNT;               // body at position p of I.bodies: bs + (p - b_first) * BW_COUNT
-        auto which = [&](const int *pre, int t) { int q = 0; while (q + 1 < cnt && t >= pre[q + 1]) q++; return q; };
-
-        for (int t = tid; t < nbod; t += 64) {
-            const int q = which(pb, t), pos = I.body_off[q_isl[q]] + (t - pb[q]);
-            stage_body(S, bflags, stride, I, P, I.bscr + (size_t)pos * BW_COUNT, I.bodies[pos], pos - b_first);
-        }
-        __syncthreads();
-        for (int t = tid; t < ncon; t += 64) {
-            const int q = which(pc, t), isl = q_isl[q], ci = I.con_off[isl] + (t - pc[q]);
-            const int r0 = I.row_off[isl];
-            contact_rows(S, stride, I, P, I.rows + (size_t)r0 * RW_COUNT, I.rowjb + 2 * (size_t)r0, ci, I.crow[ci], hinv);
-        }
-        for (int t = tid; t < nbod; t += 64) {
-            const int q = which(pb, t), pos = I.body_off[q_isl[q]] + (t - pb[q]);
-            body_tmp(S, stride, I.bscr + (size_t)pos * BW_COUNT, I.bodies[pos], hinv);
-        }
-        __syncthreads();
-        for (int t = tid; t < nrow; t += 64) {
-            const int q = which(pr, t), r0 = I.row_off[q_isl[q]];
-            row_setup(I.rows + (size_t)r0 * RW_COUNT, I.rowjb + 2 * (size_t)r0, bs, t - pr[q], hinv, P.sor_w);
-        }
-        for (int t = tid; t < nbod; t += 64) {                     // accumulators start at zero (stage_body): LDS, by batch position
-            const int q = which(pb, t), L = I.body_off[q_isl[q]] + (t - pb[q]) - b_first;
-#pragma unroll
-            for (int j = 0; j < 6; j++) fc_lds[6 * L + j] = T(0);
-        }
-        __syncthreads();
-
-        // ---- the sweeps: the batch's rows (v = pr[q] + r) in the wavefront's slots, by level class
-        const bool classed = assign_row_slots<RPL>(nrow, tid, tab, [&](int v) {
-            const int q = which(pr, v);
-            return I.row_level[I.lev_off[q_lv0[q]] + (v - pr[q])];
-        });
-        __syncthreads();
-        RowRegs<T> mine[RPL];
-        int my_level[RPL];
-        T *my_lam[RPL];
-#pragma unroll
-        for (int j = 0; j < RPL; j++) {
-            const int v = (int)tab[j * 64 + tid];
-            my_level[j] = -1;
-            my_lam[j] = nullptr;
-            if (v >= 0) {
-                const int q = which(pr, v), r = v - pr[q], r0 = I.row_off[q_isl[q]];
-                row_load(I.rows + (size_t)r0 * RW_COUNT, I.rowjb + 2 * (size_t)r0, r, mine[j]);
-                my_level[j] = I.row_level[I.lev_off[q_lv0[q]] + r];
-                my_lam[j] = I.rows + ((size_t)r0 + r) * RW_COUNT + RW_LAM;
-            }
-        }
-        for (int it = 0; it + 1 < P.iters; it++) wave_sweep<T, RPL, false>(mine, my_level, nlev_max, classed, fc_lds, false, resid);
-        if (P.iters > 0) wave_sweep<T, RPL, true>(mine, my_level, nlev_max, classed, fc_lds, false, resid);
-#pragma unroll
-        for (int j = 0; j < RPL; j++)
-            if (my_level[j] >= 0) *my_lam[j] = mine[j].lam;
-        for (int t = tid; t < nbod; t += 64) {
-            const int q = which(pb, t), pos = I.body_off[q_isl[q]] + (t - pb[q]);
-            T *b = I.bscr + (size_t)pos * BW_COUNT;
-#pragma unroll
-            for (int j = 0; j < 6; j++) b[BW_FC + j] = fc_lds[6 * (pos - b_first) + j];
-            finish_body(S, bflags, stride, b, I.bodies[pos], pr[q + 1] > pr[q], h);
-        }
-        contacts += (unsigned long long)ncon;
-        __syncthreads();                                           // the next batch reuses the header and the LDS
-        k += cnt;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) resid += __shfl_xor(resid, o, 64);
-    if (tid == 0) {
-        if (resid != 0.0) atomicAdd(&diag->residual, resid);
-        if (contacts) atomicAdd(&diag->contacts, contacts);
-    }
 }
 
 // ================================================================================ dWorldStep: the island's LCP solved exactly
@@ -1182,21 +1185,6 @@ hipError_t launch_islands_exact(T *S, const uint8_t *bflags, int64_t stride, con
     return hipGetLastError();
 }
 
-// big-island list entries per wavefront (DMX_PACK_ISLANDS, default 2; 1 = never) in launches of at least pack_min_islands()
-// big islands (DMX_PACK_MIN_ISLANDS, default 4096: below that every island has a compute unit's issue slots to itself anyway).
-// Measured, 16 384 piles of 9 boxes (108 rows each: two fit a wavefront's 256 row slots): 1.50 ms/tick unpacked, 1.25 with 2,
-// 1.23 with 4 (the same two per batch, half the workgroups), 1.39 with 8; 4 096 piles: 0.70 / 0.64 / 0.77 / 0.95.
-static int pack_islands()
-{
-    static const int v = [] { const char *e = getenv("DMX_PACK_ISLANDS"); const int p = e ? atoi(e) : 2; return p < 1 ? 1 : (p > PACK_MAX ? PACK_MAX : p); }();
-    return v;
-}
-static int pack_min_islands()
-{
-    static const int v = [] { const char *e = getenv("DMX_PACK_MIN_ISLANDS"); return e ? atoi(e) : 4096; }();
-    return v;
-}
-
 template <class T>
 hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
                           StepDiag *diag, hipStream_t st)
@@ -1225,20 +1213,10 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
         const int lds_cap = FC_LDS_BYTES / (int)(6 * sizeof(T));
         const int lds_bodies = std::min<int>(std::max(I.big_max_bodies, 1), lds_cap);
         const size_t lds = (size_t)lds_bodies * 6 * sizeof(T);
-        // thousands of islands: issue slots are the bound, not any island's chain of rows -- several small islands per wavefront
-        int packed_bodies = 0;
-        const int pack = pack_islands();
-        if (pack > 1 && I.n_big >= pack_min_islands() && I.order == nullptr) {
-            packed_bodies = std::min<int>(std::max(pack * std::max(I.big_max_bodies, 1), 64), lds_cap);
-            hipLaunchKernelGGL((solve_islands_packed<T>), dim3((unsigned)((I.n_big + pack - 1) / pack)), dim3(64),
-                               (size_t)packed_bodies * 6 * sizeof(T), st, S, bflags, stride, I, P, diag, packed_bodies, pack);
-        }
-        const bool all_packed = packed_bodies > 0 && I.big_max_rows > 0 && I.big_max_rows <= WAVE_ISLAND_ROWS && I.big_max_bodies <= packed_bodies;
-        if (all_packed) { /* nothing left for a workgroup of its own */ }
-        else if (I.big_max_width <= 64)      // no level has more than 64 rows: one wavefront per island, barriers cost nothing
-            hipLaunchKernelGGL((solve_island_wg<T, 64>), dim3((unsigned)I.n_big), dim3(64), lds, st, S, bflags, stride, I, P, diag, lds_bodies, packed_bodies);
+        if (I.big_max_width <= 64)      // no level has more than 64 rows: one wavefront per island, barriers cost nothing
+            hipLaunchKernelGGL((solve_island_wg<T, 64>), dim3((unsigned)I.n_big), dim3(64), lds, st, S, bflags, stride, I, P, diag, lds_bodies);
         else
-            hipLaunchKernelGGL((solve_island_wg<T, 256>), dim3((unsigned)I.n_big), dim3(256), lds, st, S, bflags, stride, I, P, diag, lds_bodies, packed_bodies);
+            hipLaunchKernelGGL((solve_island_wg<T, 256>), dim3((unsigned)I.n_big), dim3(256), lds, st, S, bflags, stride, I, P, diag, lds_bodies);
     }
     return hipGetLastError();
 }

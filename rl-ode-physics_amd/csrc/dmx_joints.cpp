@@ -164,7 +164,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     std::vector<int> &big_h = b->sc_iv[3], &big_list_h = b->sc_iv[4], &lev_count_h = b->sc_iv[5], &lev_off_h = b->sc_iv[6],
                      &lev_rows_h = b->sc_iv[7], &lvl_all = b->sc_iv[8];
     big_h.assign((size_t)ni, -1); big_list_h.clear(); lev_count_h.clear(); lev_off_h.clear(); lev_rows_h.clear(); lvl_all.clear();
-    int big_max_bodies = 0, big_max_width = 0, big_max_rows = 0;
+    int big_max_bodies = 0, big_max_width = 0;
     std::vector<int> &island_bodies = b->sc_iv[9];
     island_bodies.assign((size_t)ni, 0);
     for (int s : slots) island_bodies[(size_t)island_of[(size_t)s]]++;
@@ -206,7 +206,6 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
             row_base.push_back(rows_total);
             rows_total += m_of[(size_t)i];
             big_max_bodies = std::max(big_max_bodies, island_bodies[(size_t)i]);
-            big_max_rows = std::max(big_max_rows, m_of[(size_t)i]);
         }
         const int nbig = (int)big_list_h.size();
         if (exact) {
@@ -366,7 +365,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     I.crow = I.cmode + 2 * (size_t)nc;
     I.big = I.crow + nc; I.n_big = n_big; I.big_list = I.big + ni; I.lev_count = I.big_list + n_big;
     I.lev_off = I.lev_count + n_big; I.lev_rows = I.lev_off + lev_off_h.size();
-    I.big_max_bodies = big_max_bodies; I.big_max_width = big_max_width; I.big_max_rows = big_max_rows;
+    I.big_max_bodies = big_max_bodies; I.big_max_width = big_max_width;
     I.row_level = I.lev_rows + lev_rows_h.size();
     I.gpos = geo ? (const T *)geo->pos : nullptr; I.gnormal = geo ? (const T *)geo->normal : nullptr;
     I.gdepth = geo ? (const T *)geo->depth : nullptr;

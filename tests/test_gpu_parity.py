@@ -215,9 +215,9 @@ def test_exact_tick_pipelines_agree(dtype):
         assert b[1] == ow.n_contacts() > 0
 
 
-def test_thousands_of_piles_several_islands_per_wavefront():
-    """36 864 bodies in 4 096 piles: every tick exact, 4 096+ multi-body islands -- the launch shape in which a wavefront
-    solves several small islands together (solve_islands_packed).  Bit-identical to the sequential oracle."""
+def test_thousands_of_piles():
+    """36 864 bodies in 4 096 piles: every tick exact, 4 096+ multi-body islands of ~100 rows each (a wavefront per island,
+    a lane per contact), the stage-per-launch bookkeeping at scale.  Bit-identical to the sequential oracle."""
     side = 64
     scene = pkg.scenes.box_grid(3 * side, 3 * side, seed=5, y_range=(0.6, 6.0), spin=True, box_mass=True).astype("float32")
     ix, iz = np.arange(scene.n) % (3 * side), np.arange(scene.n) // (3 * side)
