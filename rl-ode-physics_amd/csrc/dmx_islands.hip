@@ -904,7 +904,14 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
         const int *row_level = I.row_level + lev_off[0];
         // (rows per lane as a template parameter: an island of up to 64 rows pays for one row's tests per level, not four)
         const bool eager = gridDim.x < 2048u;           // few islands: every one waits on its own chain of rows
-        const bool by_contact = I.cmu == nullptr && P.mu > 0;     // three rows per contact throughout: a lane owns a contact
+        // three rows per contact throughout (the batch's surface with friction, or per-contact surfaces that all have it): a
+        // lane owns a contact
+        bool by_contact = I.cmu == nullptr && P.mu > 0;
+        if (I.cmu != nullptr) {
+            int all3 = 1;
+            for (int c = tid; c < nc; c += WG) all3 &= I.cmu[c0 + c] > 0 ? 1 : 0;
+            by_contact = __syncthreads_and(all3) != 0;
+        }
         // (a contact's rows are 90 reals of registers: two contacts per lane in f32, one in f64)
         if (by_contact && nc <= 64) resid = wave_island_contact_sweeps<T, 1>(rows, jb, row_level, I.crow + c0, nc, nlev, P.iters, tid, fc_lds, eager);
         else if (by_contact && sizeof(T) == 4) resid = wave_island_contact_sweeps<T, sizeof(T) == 4 ? 2 : 1>(rows, jb, row_level, I.crow + c0, nc, nlev, P.iters, tid, fc_lds, eager);
