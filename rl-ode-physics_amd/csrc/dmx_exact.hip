@@ -723,12 +723,16 @@ template <class V> __device__ __forceinline__ void block_scan_inclusive(const V 
     __syncthreads();
 }
 
+// the count record and the broadphase flags into pinned host memory: one lane per word, so the record crosses the bus as one
+// 64-byte write and one of 20 bytes, not as 21 writes one after the other.  Called by the whole workgroup after a barrier.
 __device__ __forceinline__ void publish_counts(const ExactCounts *C, const uint32_t *flags, ExactCounts *host_counts, uint32_t *host_flags)
 {
     if (host_counts == nullptr) return;
-    for (int k = 0; k < (int)(sizeof(ExactCounts) / 4); k++) ((volatile uint32_t *)host_counts)[k] = ((const volatile uint32_t *)C)[k];
-    for (int k = 0; k < BPF_COUNT; k++) ((volatile uint32_t *)host_flags)[k] = ((const volatile uint32_t *)flags)[k];
-    __threadfence_system();
+    const uint32_t t = threadIdx.x;
+    constexpr uint32_t NW = sizeof(ExactCounts) / 4;
+    if (t < NW) ((volatile uint32_t *)host_counts)[t] = ((const volatile uint32_t *)C)[t];
+    else if (t < NW + (uint32_t)BPF_COUNT) ((volatile uint32_t *)host_flags)[t - NW] = ((const volatile uint32_t *)flags)[t - NW];
+    if (t < NW + (uint32_t)BPF_COUNT) __threadfence_system();
 }
 
 // B.stamps: wall_clock64() (100 MHz) after every stage, front kernel from [0], back kernel from [32]; DMX_EXS_TIMING=1 prints the
@@ -761,7 +765,7 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gt
     st_flatten(B.parent, B.root, B.rf, cap, C, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
     block_scan_inclusive<uint32_t>(B.rf, B.rinc, cap.inv, reinterpret_cast<uint32_t *>(wt)); EXS_STAMP();
-    if (tid == 0) publish_counts(C, G.flags, host_counts, host_flags);
+    publish_counts(C, G.flags, host_counts, host_flags);         // (the scan above ended on a barrier)
 }
 
 // stages 5-10 (the narrowphase ran in between): entries sorted by island, joints in creation order, level schedules.
@@ -821,10 +825,8 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_back(ExactBuffers<T> B, Exact
     st_levels(B.con_off, B.body_off, B.cb1, B.cb2, B.bg, B.binc, cap, rpc, B.big, B.big_list, B.lev_count, B.lev_off, B.lev_rows,
               B.row_level, B.last, C, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
-    if (tid == 0) {
-        diag->contacts = 0ull; diag->residual = 0.0;        // the island kernels add to it next
-        publish_counts(C, flags, host_counts, host_flags);
-    }
+    if (tid == 0) { diag->contacts = 0ull; diag->residual = 0.0; }       // the island kernels add to it next
+    publish_counts(C, flags, host_counts, host_flags);
 }
 
 __global__ void ex_fill_i32(int32_t *p, int32_t v, size_t n)
