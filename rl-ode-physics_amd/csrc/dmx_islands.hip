@@ -74,7 +74,9 @@ template <class T> __device__ __forceinline__ int contact_rpc(const IslandSet<T>
 }
 
 // ---- rows of contact ci (normal + 2 friction when mu > 0), written at island-relative row m -----------------
-template <class T>
+// RPCK = 3: the caller knows the contact has friction rows (constant trip counts: a caller that hands in thread-local
+// arrays gets them in registers)
+template <class T, int RPCK = 0>
 __device__ __forceinline__ void contact_rows(const T *S, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
                                              T *rows, int *jb, int ci, int m, T hinv)
 {
@@ -95,10 +97,11 @@ __device__ __forceinline__ void contact_rows(const T *S, int64_t stride, const I
     const int mode = own_surface ? I.cmode[ci] : P.surf_mode;
     T mu = own_surface ? I.cmu[ci] : P.mu;
     if (mu < 0) mu = 0;
-    const int rpc = mu > 0 ? 3 : 1;
+    const int rpc = RPCK ? RPCK : (mu > 0 ? 3 : 1);
     V3<T> dir[3];
     dir[0] = normal;
     if (rpc == 3) plane_space(normal, dir[1], dir[2]);
+#pragma unroll
     for (int dnum = 0; dnum < rpc; dnum++) {
         T *row = rows + (size_t)(m + dnum) * RW_COUNT;
         jb[2 * (m + dnum)] = l1; jb[2 * (m + dnum) + 1] = l2;
@@ -748,6 +751,20 @@ __device__ __forceinline__ void contact_load(const T *rows, const int *jb, int r
     c.row0 = r0;
 }
 
+// the same three rows made in registers, never stored: contact_rows + row_setup on thread-local arrays (the functions the
+// other paths run on the row arrays in HBM, so the same bits), then straight into the lane's ContactRegs
+template <class T>
+__device__ __forceinline__ void contact_build(const T *S, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P, const T *bs, int ci,
+                                              T hinv, ContactRegs<T> &c)
+{
+    T lrows[3 * RW_COUNT];
+    int ljb[6];
+    contact_rows<T, 3>(S, stride, I, P, lrows, ljb, ci, 0, hinv);
+#pragma unroll
+    for (int d = 0; d < 3; d++) row_setup(lrows, ljb, bs, d, hinv, P.sor_w);
+    contact_load(lrows, ljb, 0, c);
+}
+
 template <class T, bool LAST>
 __device__ __forceinline__ void contact_sor_lds(ContactRegs<T> &c, T *fc, bool eager, double &resid)
 {
@@ -817,10 +834,11 @@ __device__ __forceinline__ void wave_contact_sweep(ContactRegs<T> (&mine)[CPL], 
     }
 }
 
-// one island's sweeps with contacts as units (crow: the island's contacts' first rows, island-relative)
-template <class T, int CPL>
-__device__ __forceinline__ double wave_island_contact_sweeps(T *rows, const int *jb, const int *row_level, const int *crow, int nc, int nlev,
-                                                             int iters, int tid, T *fc_lds, bool eager)
+// one island's sweeps with contacts as units (crow: the island's contacts' first rows, island-relative).  load(v, c): contact
+// v's rows into c -- from the row arrays, or made on the spot (contact_build: then nothing is written back either).
+template <class T, int CPL, class Load>
+__device__ __forceinline__ double wave_island_contact_sweeps(T *rows, const int *row_level, const int *crow, int nc, int nlev,
+                                                             int iters, int tid, T *fc_lds, bool eager, bool write_back, Load load)
 {
     __shared__ short tab[CPL * 64];
     __shared__ int tab_classed;
@@ -837,19 +855,21 @@ __device__ __forceinline__ double wave_island_contact_sweeps(T *rows, const int 
     for (int j = 0; j < CPL; j++) {
         const int v = tid < 64 ? (int)tab[j * 64 + tid] : -1;
         my_cl[j] = -1;
-        if (v >= 0) { const int r0 = crow[v]; contact_load(rows, jb, r0, mine[j]); my_cl[j] = row_level[r0] / 3; }
+        if (v >= 0) { load(v, mine[j]); mine[j].row0 = crow[v]; my_cl[j] = row_level[crow[v]] / 3; }
     }
     __syncthreads();
     const int n_clev = (nlev + 2) / 3;
     double resid = 0.0;
     for (int it = 0; it + 1 < iters; it++) wave_contact_sweep<T, CPL, false>(mine, my_cl, n_clev, classed, fc_lds, eager, resid);
     if (iters > 0) wave_contact_sweep<T, CPL, true>(mine, my_cl, n_clev, classed, fc_lds, eager, resid);
+    if (write_back) {
 #pragma unroll
-    for (int j = 0; j < CPL; j++)
-        if (my_cl[j] >= 0) {
+        for (int j = 0; j < CPL; j++)
+            if (my_cl[j] >= 0) {
 #pragma unroll
-            for (int d = 0; d < 3; d++) rows[(size_t)(mine[j].row0 + d) * RW_COUNT + RW_LAM] = mine[j].lam[d];
-        }
+                for (int d = 0; d < 3; d++) rows[(size_t)(mine[j].row0 + d) * RW_COUNT + RW_LAM] = mine[j].lam[d];
+            }
+    }
     return resid;
 }
 
@@ -877,13 +897,30 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
     const int *lev_off = I.lev_off + lv0;                     // [nlev+1], offsets into lev_rows (island-relative rows)
     const int m = lev_off[nlev] - lev_off[0];
 
+    // Small island, three rows per contact throughout (the batch's surface with friction, or per-contact surfaces that all
+    // have it): one wavefront, a lane owns a contact and makes its rows in its own registers -- they never go to HBM.
+    const bool wave = nb <= lds_bodies && nlev > 0 && m <= WAVE_ISLAND_ROWS;         // (workgroup-uniform, like all of this)
+    bool by_contact = false;
+    if (wave) {
+        by_contact = I.cmu == nullptr && P.mu > 0;
+        if (I.cmu != nullptr) {
+            int all3 = 1;
+            for (int c = tid; c < nc; c += WG) all3 &= I.cmu[c0 + c] > 0 ? 1 : 0;
+            by_contact = __syncthreads_and(all3) != 0;
+        }
+        by_contact = by_contact && (nc <= 64 || sizeof(T) == 4);      // (a contact's rows are 90 reals of registers: two per lane in f32)
+    }
+
     for (int k = tid; k < nb; k += WG) stage_body(S, bflags, stride, I, P, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], k);
     __syncthreads();
-    for (int c = tid; c < nc; c += WG) contact_rows(S, stride, I, P, rows, jb, c0 + c, I.crow[c0 + c], hinv);
+    if (!by_contact)
+        for (int c = tid; c < nc; c += WG) contact_rows(S, stride, I, P, rows, jb, c0 + c, I.crow[c0 + c], hinv);
     for (int k = tid; k < nb; k += WG) body_tmp(S, stride, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], hinv);
     __syncthreads();
-    for (int i = tid; i < m; i += WG) row_setup(rows, jb, bs, i, hinv, P.sor_w);
-    __syncthreads();
+    if (!by_contact) {
+        for (int i = tid; i < m; i += WG) row_setup(rows, jb, bs, i, hinv, P.sor_w);
+        __syncthreads();
+    }
 
     double resid = 0.0;
     // LDS staging: the only data one level hands to the next is the bodies' constraint-force accumulators (6 reals per
@@ -904,17 +941,9 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
         const int *row_level = I.row_level + lev_off[0];
         // (rows per lane as a template parameter: an island of up to 64 rows pays for one row's tests per level, not four)
         const bool eager = gridDim.x < 2048u;           // few islands: every one waits on its own chain of rows
-        // three rows per contact throughout (the batch's surface with friction, or per-contact surfaces that all have it): a
-        // lane owns a contact
-        bool by_contact = I.cmu == nullptr && P.mu > 0;
-        if (I.cmu != nullptr) {
-            int all3 = 1;
-            for (int c = tid; c < nc; c += WG) all3 &= I.cmu[c0 + c] > 0 ? 1 : 0;
-            by_contact = __syncthreads_and(all3) != 0;
-        }
-        // (a contact's rows are 90 reals of registers: two contacts per lane in f32, one in f64)
-        if (by_contact && nc <= 64) resid = wave_island_contact_sweeps<T, 1>(rows, jb, row_level, I.crow + c0, nc, nlev, P.iters, tid, fc_lds, eager);
-        else if (by_contact && sizeof(T) == 4) resid = wave_island_contact_sweeps<T, sizeof(T) == 4 ? 2 : 1>(rows, jb, row_level, I.crow + c0, nc, nlev, P.iters, tid, fc_lds, eager);
+        auto build = [&](int v, ContactRegs<T> &c) { contact_build(S, stride, I, P, bs, c0 + v, hinv, c); };
+        if (by_contact && nc <= 64) resid = wave_island_contact_sweeps<T, 1>(rows, row_level, I.crow + c0, nc, nlev, P.iters, tid, fc_lds, eager, false, build);
+        else if (by_contact) resid = wave_island_contact_sweeps<T, sizeof(T) == 4 ? 2 : 1>(rows, row_level, I.crow + c0, nc, nlev, P.iters, tid, fc_lds, eager, false, build);
         else if (m <= 64) resid = wave_island_sweeps<T, 1>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds, eager);
         else if (m <= 128) resid = wave_island_sweeps<T, 2>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds, eager);
         else resid = wave_island_sweeps<T, WAVE_ISLAND_ROWS / 64>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds, eager);
