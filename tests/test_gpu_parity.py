@@ -274,6 +274,29 @@ def test_solver_parameters_are_honoured():
     _compare(w.state(), ow.state())
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("mu", [0.0, 0.4, float("inf")])
+def test_piles_with_and_without_friction(dtype, mu):
+    """Multi-body islands under the three shapes of a contact: one row (mu = 0: the island solve's row-per-lane form), three
+    rows with bounded friction, three with unbounded (a lane per contact, its rows made in registers).  36 piles of 9 boxes,
+    some of them more than 64 contacts (two contacts per lane in f32, the row form in f64)."""
+    scene = pkg.scenes.box_grid(18, 18, seed=9, y_range=(0.6, 6.0), spin=True, box_mass=True).astype(dtype)
+    ix, iz = np.arange(scene.n) % 18, np.arange(scene.n) // 18
+    scene.pos[:, 0] = (ix // 3) * 7.5 + (ix % 3) * 0.6
+    scene.pos[:, 2] = (iz // 3) * 7.5 + (iz % 3) * 0.6
+
+    def gs(w):
+        w.set_surface(mu=mu, bounce=0.2, bounce_vel=0.1)
+
+    def os_(orc, ow):
+        orc.lib.orc_world_set_surface(ow.w, 0x004, mu, 0.2, 0.1)
+    steps = 100
+    w = _gpu_run(scene, dtype, steps, setup=gs)
+    ow = _oracle_run(_orc(dtype), scene, steps, setup=os_, allow_pairs=True)
+    _compare(w.state(), ow.state())
+    assert w.last_contact_count() == ow.n_contacts() > scene.n
+
+
 def test_tilted_plane():
     scene = pkg.scenes.box_grid(16, 16, seed=6, y_range=(3.0, 5.0), spin=True, box_mass=True).astype("float64")
     scene.plane = (0.1, 1.0, -0.2, -0.5)
