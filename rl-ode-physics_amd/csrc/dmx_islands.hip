@@ -553,30 +553,45 @@ __global__ __launch_bounds__(64) void solve_singles_lds(T *__restrict__ S, const
     }
     double resid = 0.0;
     T *fc = b + BW_FC;
-    for (int it = 0; it < P.iters; it++) {                    // the sweeps (row_sor), rows in creation order
-        const bool last = (it == P.iters - 1);
+    // One sweep (row_sor, rows in creation order).  A row's twelve LDS words do not depend on the rows before it: they are
+    // fetched, in one batch of independent reads, while the row before is being updated -- the chain of updates never waits
+    // for LDS.  (Slots without a row are fetched too and not used.)  LAST: the final sweep also sums |delta lambda|.
+    auto sweep = [&](auto LAST) {
+        T rw[RS_FIELDS], nx[RS_FIELDS];
+#pragma unroll
+        for (int f = 0; f < RS_FIELDS; f++) rw[f] = at(0, f);
 #pragma unroll
         for (int i = 0; i < MAXR; i++) {
-            if (!(valid >> i & 1u)) continue;
-            // the row's twelve LDS words in one batch of independent reads (one wait), then arithmetic only
-            T rw[RS_FIELDS];
+            if (i + 1 < MAXR) {
 #pragma unroll
-            for (int f = 0; f < RS_FIELDS; f++) rw[f] = at(i, f);
-            const T old = lamr[i];
-            T delta = fma_(-old, adr[i], rhsr[i]);
-            delta -= fma_(fc[5], rw[RS_J + 5], fma_(fc[4], rw[RS_J + 4], fma_(fc[3], rw[RS_J + 3],
-                     fma_(fc[2], rw[RS_J + 2], fma_(fc[1], rw[RS_J + 1], fc[0] * rw[RS_J + 0])))));
-            const T lo = (i % 3 == 0) ? T(0) : lo_f[i / 3], hi = (i % 3 == 0) ? Limits<T>::inf() : hi_f[i / 3];
-            const T nl = old + delta;
-            T lam = nl;
-            if (nl < lo) { delta = lo - old; lam = lo; }
-            else if (nl > hi) { delta = hi - old; lam = hi; }
-            lamr[i] = lam;
+                for (int f = 0; f < RS_FIELDS; f++) nx[f] = at(i + 1, f);
+            }
+            if (valid >> i & 1u) {
+                const T old = lamr[i];
+                T delta = fma_(-old, adr[i], rhsr[i]);
+                delta -= fma_(fc[5], rw[RS_J + 5], fma_(fc[4], rw[RS_J + 4], fma_(fc[3], rw[RS_J + 3],
+                         fma_(fc[2], rw[RS_J + 2], fma_(fc[1], rw[RS_J + 1], fc[0] * rw[RS_J + 0])))));
+                const T lo = (i % 3 == 0) ? T(0) : lo_f[i / 3], hi = (i % 3 == 0) ? Limits<T>::inf() : hi_f[i / 3];
+                const T nl = old + delta;
+                T lam = nl;
+                if (nl < lo) { delta = lo - old; lam = lo; }
+                else if (nl > hi) { delta = hi - old; lam = hi; }
+                lamr[i] = lam;
 #pragma unroll
-            for (int j = 0; j < 6; j++) fc[j] = fma_(delta, rw[RS_IMJ + j], fc[j]);
-            if (last) resid += (double)tabs(delta);
+                for (int j = 0; j < 6; j++) fc[j] = fma_(delta, rw[RS_IMJ + j], fc[j]);
+                if (decltype(LAST)::value) resid += (double)tabs(delta);
+            }
+            if (i + 1 < MAXR) {
+#pragma unroll
+                for (int f = 0; f < RS_FIELDS; f++) rw[f] = nx[f];
+            }
+            // (one row ahead and no further: left to itself the scheduler hoists every fetch of the unrolled sweep to its top,
+            //  288 registers of them)
+            __builtin_amdgcn_sched_barrier(0);
         }
-    }
+    };
+    for (int it = 0; it + 1 < P.iters; it++) sweep(std::false_type{});
+    if (P.iters > 0) sweep(std::true_type{});
     finish_body(S, bflags, stride, b, s, true, h);
     atomicAdd(&diag->contacts, (unsigned long long)nc);
     atomicAdd(&diag->residual, resid);
