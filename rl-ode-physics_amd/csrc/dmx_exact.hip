@@ -260,17 +260,34 @@ template <class T> __device__ __forceinline__ void put_c(T *gpos, T *gnormal, T 
     gdepth[slot] = d;
 }
 
+__device__ __forceinline__ uint32_t entry_key(uint32_t e, const int32_t *pairs, const uint64_t *pc, const uint64_t *inc, const int32_t *root,
+                                              const uint32_t *rinc, const ExactCaps &cap, uint32_t ninv, uint32_t np)
+{
+    const uint32_t e_pairs = cap.pair_entry0();
+    if (e < e_pairs) { const uint32_t k = e % cap.inv; if (k < ninv) return rinc[root[k]] - 1u; }
+    else if (e - e_pairs < np) return rinc[root[kidx_of(pc, inc, pairs[2 * (e - e_pairs)])]] - 1u;
+    return cap.inv;                                     // padding sorts behind every island
+}
+
+// stage 5's arrays (the sort keys: entry -> island, rinc = inclusive scan of the root flags: island of root r = rinc[r] - 1);
+// keys == nullptr: not wanted (the one-workgroup form makes its keys itself)
+struct SortKeyArgs { const uint64_t *pc, *inc; const int32_t *root; const uint32_t *rinc; uint32_t *keys, *vals; };
+
 // Entries as ExactCaps lays them out: ground-plane contacts of involved body k, contacts of body k with static box s,
 // contacts of pair p.  cc[e] = contacts of entry e, 0 for the padding.
 template <class T>
 __global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const uint8_t *__restrict__ gtype, const int32_t *__restrict__ inv,
                                                 const int32_t *__restrict__ pairs, const GridRec<T> *__restrict__ rec, StepParams<T> P, ExactCaps cap,
                                                 T *__restrict__ gpos, T *__restrict__ gnormal, T *__restrict__ gdepth,
-                                                uint32_t *__restrict__ cc, const ExactCounts *__restrict__ C)
+                                                uint32_t *__restrict__ cc, ExactCounts *C, SortKeyArgs K)
 {
     const uint32_t ninv = C->overflow ? 0u : C->ninv, np = C->overflow ? 0u : C->npairs;
     const uint32_t ne = cap.entries(), e_pairs = cap.pair_entry0();
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
+        if (K.keys != nullptr) {       // stage 5 rides along (one launch fewer): entry e -> its island
+            K.keys[e] = entry_key(e, pairs, K.pc, K.inc, K.root, K.rinc, cap, ninv, np); K.vals[e] = e;
+            if (e == 0) C->ni = K.rinc[cap.inv - 1];
+        }
         int nc = 0;
         if (P.hull_n > 0) {   // entries with a convex body in them belong to ex_narrow_convex (one wavefront each; not launched without a hull)
             bool convex = false;
@@ -497,28 +514,7 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
     }
 }
 
-// ---- 5. sort keys: entry e -> its island (rinc = inclusive scan of the root flags: island of root r = rinc[r] - 1) ---
-__device__ __forceinline__ uint32_t entry_key(uint32_t e, const int32_t *pairs, const uint64_t *pc, const uint64_t *inc, const int32_t *root,
-                                              const uint32_t *rinc, const ExactCaps &cap, uint32_t ninv, uint32_t np)
-{
-    const uint32_t e_pairs = cap.pair_entry0();
-    if (e < e_pairs) { const uint32_t k = e % cap.inv; if (k < ninv) return rinc[root[k]] - 1u; }
-    else if (e - e_pairs < np) return rinc[root[kidx_of(pc, inc, pairs[2 * (e - e_pairs)])]] - 1u;
-    return cap.inv;                                     // padding sorts behind every island
-}
-__global__ __launch_bounds__(256) void ex_keys(const int32_t *__restrict__ pairs, const uint64_t *__restrict__ pc,
-                                               const uint64_t *__restrict__ inc, const int32_t *__restrict__ root,
-                                               const uint32_t *__restrict__ rinc, ExactCaps cap, uint32_t *__restrict__ keys,
-                                               uint32_t *__restrict__ vals, ExactCounts *C)
-{
-    const uint32_t ninv = C->overflow ? 0u : C->ninv, np = C->overflow ? 0u : C->npairs;
-    const uint32_t ne = cap.entries();
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
-        keys[e] = entry_key(e, pairs, pc, inc, root, rinc, cap, ninv, np); vals[e] = e;
-        if (e == 0) C->ni = rinc[cap.inv - 1];
-    }
-}
-
+// ---- 5. sort keys: written by ex_narrow (entry_key, above) --------------------------------------------------------------
 // ---- 6. sorted entries -> (contacts << 32 | is-body-entry), scanned next ------------------------------------------
 __device__ __forceinline__ uint64_t gathered(uint32_t key, uint32_t e, const uint32_t *cc, const ExactCaps &cap)
 {
@@ -558,6 +554,9 @@ __global__ __launch_bounds__(256) void ex_bounds(const uint32_t *__restrict__ ke
     st_bounds(keys_s, sc, sinc, cap, body_off, con_off, row_off, C, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
+__device__ __forceinline__ void st_bigflags(const int *con_off, const int *body_off, const ExactCaps &cap, int rpc, int big_rows,
+                                            uint64_t *bg, const ExactCounts *C, uint32_t first, uint32_t step);
+
 // ---- 8. the island-grouped body list and contact arrays -------------------------------------------------------------
 __device__ __forceinline__ void st_fill(const uint32_t *keys_s, const uint32_t *vals_s, const uint64_t *sc, const uint64_t *sinc,
                                         const uint32_t *cc, const int32_t *inv, const int32_t *pairs, const int *con_off,
@@ -587,10 +586,13 @@ __global__ __launch_bounds__(256) void ex_fill(const uint32_t *__restrict__ keys
                                                const uint32_t *__restrict__ cc, const int32_t *__restrict__ inv,
                                                const int32_t *__restrict__ pairs, const int *__restrict__ con_off, ExactCaps cap, int rpc,
                                                int *__restrict__ bodies, int *__restrict__ cb1, int *__restrict__ cb2,
-                                               int *__restrict__ csrc, int *__restrict__ crow)
+                                               int *__restrict__ csrc, int *__restrict__ crow, const int *__restrict__ body_off,
+                                               int big_rows, uint64_t *__restrict__ bg, const ExactCounts *__restrict__ C)
 {
     st_fill(keys_s, vals_s, sc, sinc, cc, inv, pairs, con_off, cap, rpc, bodies, cb1, cb2, csrc, crow,
             blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    // stage 9 needs the island offsets only, like this one: same launch
+    st_bigflags(con_off, body_off, cap, rpc, big_rows, bg, C, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // ---- 9. which islands get a workgroup: bg[isl] = (rows << 32 | 1) for those, 0 otherwise and for the padding -------
@@ -607,11 +609,6 @@ __device__ __forceinline__ void st_bigflags(const int *con_off, const int *body_
         }
         bg[i] = v;
     }
-}
-__global__ __launch_bounds__(256) void ex_bigflags(const int *__restrict__ con_off, const int *__restrict__ body_off, ExactCaps cap,
-                                                   int rpc, int big_rows, uint64_t *__restrict__ bg, const ExactCounts *__restrict__ C)
-{
-    st_bigflags(con_off, body_off, cap, rpc, big_rows, bg, C, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // ---- 10. level schedules.  One lane per island; islands own disjoint bodies, so `last` (per slot, -1 when idle) is
@@ -885,11 +882,10 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
     tb = B.temp_bytes;
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.rf, B.rinc, (size_t)cap.inv, rocprim::plus<uint32_t>(), st));
     hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.rec, P, cap,
-                       B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
+                       B.gpos, B.gnormal, B.gdepth, B.cc, B.counts, SortKeyArgs{ B.pc, B.inc, B.root, B.rinc, B.keys, B.vals });
     if (P.hull_n > 0)
         hipLaunchKernelGGL((ex_narrow_convex<T>), dim3((unsigned)std::min<size_t>((ne + 3) / 4, 65535)), dim3(256), 0, st, S, gtype, B.inv,
                            B.pairs, G.rec, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
-    hipLaunchKernelGGL(ex_keys, dim3(grid_for(ne)), dim3(256), 0, st, B.pairs, B.pc, B.inc, B.root, B.rinc, cap, B.keys, B.vals, B.counts);
     int bits = 1;
     while ((1u << bits) <= cap.inv && bits < 32) bits++;        // keys are island numbers < cap.inv and the padding key cap.inv
     tb = B.temp_bytes;
@@ -898,9 +894,8 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
     tb = B.temp_bytes;
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.sc, B.sinc, ne, rocprim::plus<uint64_t>(), st));
     hipLaunchKernelGGL(ex_bounds, dim3(grid_for(ne)), dim3(256), 0, st, B.keys_s, B.sc, B.sinc, cap, B.body_off, B.con_off, B.row_off, B.counts);
-    hipLaunchKernelGGL(ex_fill, dim3(grid_for(ne)), dim3(256), 0, st, B.keys_s, B.vals_s, B.sc, B.sinc, B.cc, B.inv, B.pairs, B.con_off, cap, rpc,
-                       B.bodies, B.cb1, B.cb2, B.csrc, B.crow);
-    hipLaunchKernelGGL(ex_bigflags, dim3(grid_for(cap.inv)), dim3(256), 0, st, B.con_off, B.body_off, cap, rpc, big_rows, B.bg, B.counts);
+    hipLaunchKernelGGL(ex_fill, dim3(grid_for(std::max<size_t>(ne, cap.inv))), dim3(256), 0, st, B.keys_s, B.vals_s, B.sc, B.sinc, B.cc, B.inv,
+                       B.pairs, B.con_off, cap, rpc, B.bodies, B.cb1, B.cb2, B.csrc, B.crow, B.body_off, big_rows, B.bg, B.counts);
     tb = B.temp_bytes;
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.bg, B.binc, (size_t)cap.inv, rocprim::plus<uint64_t>(), st));
     hipLaunchKernelGGL(ex_levels, dim3((unsigned)(((size_t)cap.inv + 63) / 64)), dim3(64), 0, st, B.con_off, B.body_off, B.cb1, B.cb2, B.bg, B.binc,
@@ -928,7 +923,7 @@ hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const Grid
 {
     const size_t ne = (size_t)cap.entries();
     hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.rec, P, cap,
-                       B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
+                       B.gpos, B.gnormal, B.gdepth, B.cc, B.counts, SortKeyArgs{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr });
     if (P.hull_n > 0)
         hipLaunchKernelGGL((ex_narrow_convex<T>), dim3((unsigned)std::min<size_t>((ne + 3) / 4, 65535)), dim3(256), 0, st, S, gtype, B.inv,
                            B.pairs, G.rec, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
