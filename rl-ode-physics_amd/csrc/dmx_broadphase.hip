@@ -72,6 +72,27 @@ __global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uin
     S[slab_ix(C_BPSAFE, i)] = safe;
 }
 
+// the grid's bucket counts and flags to zero, and up to two small records with them (the exact tick's count record and the
+// island solve's diagnostics): one launch where four memsets went
+__global__ __launch_bounds__(256) void bp_clear(uint32_t *__restrict__ count, size_t n_count, uint32_t *__restrict__ flags,
+                                                uint32_t *__restrict__ rec_a, int words_a, uint32_t *__restrict__ rec_b, int words_b)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t k = t; k < n_count; k += (size_t)gridDim.x * blockDim.x) count[k] = 0u;
+    if (t < (size_t)BPF_COUNT) flags[t] = 0u;
+    if (rec_a != nullptr && t < (size_t)words_a) rec_a[t] = 0u;
+    if (rec_b != nullptr && t < (size_t)words_b) rec_b[t] = 0u;
+}
+
+hipError_t launch_bp_clear(uint32_t *count, size_t n_count, uint32_t *flags, void *rec_a, size_t bytes_a, void *rec_b, size_t bytes_b,
+                           hipStream_t st)
+{
+    const size_t g = (n_count + 255) / 256;
+    hipLaunchKernelGGL(bp_clear, dim3((unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g))), dim3(256), 0, st, count, n_count, flags,
+                       (uint32_t *)rec_a, (int)(bytes_a / 4), (uint32_t *)rec_b, (int)(bytes_b / 4));
+    return hipGetLastError();
+}
+
 static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 template <class T>

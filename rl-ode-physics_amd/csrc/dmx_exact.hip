@@ -862,8 +862,7 @@ template <class T>
 hipError_t launch_exact_pairs(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G,
                               const ExactBuffers<T> &B, const ExactCaps &cap, hipStream_t st)
 {
-    size_t tb = B.temp_bytes;
-    EX_TRY(hipMemsetAsync(B.counts, 0, sizeof(ExactCounts), st));
+    size_t tb = B.temp_bytes;          // (B.counts was zeroed by the caller, with the grid)
     hipLaunchKernelGGL((ex_pair_count<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inpair, B.counts, B.cross_list);
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.pc, B.inc, (size_t)n_active, rocprim::plus<uint64_t>(), st));
     hipLaunchKernelGGL((ex_pair_write<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inc,

@@ -60,8 +60,8 @@ template <class T> struct ExactBuffers {
 
 size_t exact_temp_bytes(const ExactCaps &cap, int64_t n_active);
 hipError_t exact_init_last(int32_t *last, int64_t n, hipStream_t st);
-// The pipeline on `st` in two parts; the grid G (with its AABB array) must have been filled (bp_insert) on the same stream
-// before.  pairs: canonical pair list, involved bodies, union-find initialised, counts.npairs / ninv.  group: everything else.
+// The pipeline on `st` in two parts; the grid G (with its records) must have been filled (bp_insert) and B.counts zeroed on
+// the same stream before.  pairs: canonical pair list, involved bodies, union-find initialised, counts.npairs / ninv.  group: everything else.
 template <class T>
 hipError_t launch_exact_pairs(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G,
                               const ExactBuffers<T> &B, const ExactCaps &cap, hipStream_t st);

@@ -102,11 +102,12 @@ int grow_buckets(dmxBatch *b)
     return dmx_ensure_dev(b->bp_items, ((size_t)b->bp_mask + 1) * (size_t)b->bp_cap * sizeof(int32_t));
 }
 
-template <class T> int fill_grid(dmxBatch *b)
+// (rec_a / rec_b: small records of the caller's to zero in the same launch)
+template <class T> int fill_grid(dmxBatch *b, void *rec_a = nullptr, size_t bytes_a = 0, void *rec_b = nullptr, size_t bytes_b = 0)
 {
     const GridParams<T> G = grid_of<T>(b);
-    HIP_TRY(hipMemsetAsync(b->bp_count.p, 0, ((size_t)b->bp_mask + 1) * sizeof(uint32_t), b->stream));
-    HIP_TRY(hipMemsetAsync(b->bp_flags.p, 0, BPF_COUNT * sizeof(uint32_t), b->stream));
+    HIP_TRY(launch_bp_clear((uint32_t *)b->bp_count.p, (size_t)b->bp_mask + 1, (uint32_t *)b->bp_flags.p, rec_a, bytes_a, rec_b, bytes_b,
+                            b->stream));
     HIP_TRY(launch_bp_insert<T>((T *)b->slab, b->gtype, b->stride, b->n, G, b->stream));   // ghosts included
     return DMX_OK;
 }
@@ -382,7 +383,8 @@ template <class T> int careful_tick(dmxBatch *b, double h)
                 b->exs_ticks++;
             }
         } else {
-        if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
+        // (the count record and the island solve's diagnostics are zeroed with the grid: one launch)
+        if ((rc = fill_grid<T>(b, B.counts, sizeof(ExactCounts), b->diag_isl, sizeof(StepDiag))) != DMX_OK) return rc;
         HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), B, cap, b->stream));
         auto read_back = [&]() -> int {
             HIP_TRY(hipMemcpyAsync(b->bp_flags_host, b->bp_flags.p, BPF_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
@@ -460,7 +462,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     I.rows = (T *)b->jd_rows.p; I.rowjb = (int *)b->jd_rowjb.p; I.bscr = (T *)b->jd_bscr.p; I.local = (int *)b->jd_local.p;
     I.singles = 1;
     // (cmode / cmu / cbounce ... stay null: every contact carries the batch's surface, NearCallback's policy, main.c:684-687)
-    if (!small) HIP_TRY(hipMemsetAsync(b->diag_isl, 0, sizeof(StepDiag), b->stream));       // (the small-scene kernel zeroed it)
+    // (diag_isl was zeroed with the grid / by the small-scene kernel)
     HIP_TRY(launch_islands<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, b->stream));
     ph.reset(new DmxPhase(b, 8));
     // the island step consumed the accumulators of ITS bodies only; everyone else's are still pending for the fused kernel
@@ -665,7 +667,7 @@ template <class T> int find_pairs_t(dmxBatch *b)
             if ((rc = host_record_pointers(b, &hc, &hf)) != DMX_OK) return rc;
             HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, grid_of<T>(b), B, cap, hc, hf, b->stream));
         } else {
-            if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
+            if ((rc = fill_grid<T>(b, B.counts, sizeof(ExactCounts))) != DMX_OK) return rc;
             HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), B, cap, b->stream));
             HIP_TRY(hipMemcpyAsync(b->bp_flags_host, b->bp_flags.p, BPF_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
             HIP_TRY(hipMemcpyAsync(&C, B.counts, sizeof(ExactCounts), hipMemcpyDeviceToHost, b->stream));

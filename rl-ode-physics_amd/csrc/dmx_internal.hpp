@@ -165,6 +165,9 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
 template <class T>
 hipError_t launch_islands_exact(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
                                 StepDiag *diag, T *scratch, const long long *scratch_off, int *iscratch, int max_rows, hipStream_t st);
+// bucket counts and flags to zero, and two optional small records (each at most 256 words) with them
+hipError_t launch_bp_clear(uint32_t *count, size_t n_count, uint32_t *flags, void *rec_a, size_t bytes_a, void *rec_b, size_t bytes_b,
+                           hipStream_t st);
 template <class T>
 hipError_t launch_bp_insert(T *S, const uint8_t *gtype, int64_t stride, int64_t n, const GridParams<T> &G, hipStream_t st);
 template <class T>
