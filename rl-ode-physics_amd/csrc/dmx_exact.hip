@@ -18,6 +18,8 @@
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 #include <rocprim/block/block_radix_sort.hpp>
 #include "dmx_internal.hpp"
 #include "dmx_math.hpp"
@@ -153,6 +155,7 @@ __device__ __forceinline__ void st_pair_write(const T *S, const uint8_t *gtype, 
 {
     const uint64_t tot = inc[n_active - 1];
     if (first == 0) {
+        C->bp_overflow = G.flags[BPF_OVERFLOW];          // (bp_insert has finished)
         C->npairs = hi32(tot); C->ninv = lo32(tot);
         if (hi32(tot) > cap.pairs || lo32(tot) > cap.inv) atomicOr(&C->overflow, 1u);
     }
@@ -520,23 +523,23 @@ __device__ __forceinline__ uint64_t gathered(uint32_t key, uint32_t e, const uin
 {
     return key < cap.inv ? (((uint64_t)cc[e] << 32) | (e < cap.inv ? 1u : 0u)) : 0ull;
 }
-__global__ __launch_bounds__(256) void ex_gather(const uint32_t *__restrict__ keys_s, const uint32_t *__restrict__ vals_s,
-                                                 const uint32_t *__restrict__ cc, ExactCaps cap, uint64_t *__restrict__ sc)
-{
-    const uint32_t ne = cap.entries();
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ne; t += gridDim.x * blockDim.x)
-        sc[t] = gathered(keys_s[t], vals_s[t], cc, cap);
-}
+// (the stage-per-launch form scans this through a transform iterator: no array, no launch of its own)
+struct GatherOp {
+    const uint32_t *keys_s, *vals_s, *cc;
+    ExactCaps cap;
+    __device__ uint64_t operator()(uint32_t t) const { return gathered(keys_s[t], vals_s[t], cc, cap); }
+};
 
 // ---- 7. island boundaries: first sorted entry of each island gives its offsets ------------------------------------
-__device__ __forceinline__ void st_bounds(const uint32_t *keys_s, const uint64_t *sc, const uint64_t *sinc, const ExactCaps &cap,
-                                          int *body_off, int *con_off, int *row_off, ExactCounts *C, uint32_t first, uint32_t step)
+__device__ __forceinline__ void st_bounds(const uint32_t *keys_s, const uint32_t *vals_s, const uint32_t *cc, const uint64_t *sinc,
+                                          const ExactCaps &cap, int *body_off, int *con_off, int *row_off, ExactCounts *C, uint32_t first,
+                                          uint32_t step)
 {
     const uint32_t ne = cap.entries();
     for (uint32_t t = first; t < ne; t += step) {
         const uint32_t key = keys_s[t];
         if (key < cap.inv && (t == 0 || keys_s[t - 1] != key)) {
-            const uint64_t exc = sinc[t] - sc[t];
+            const uint64_t exc = sinc[t] - gathered(key, vals_s[t], cc, cap);
             body_off[key] = (int)lo32(exc); con_off[key] = (int)hi32(exc); row_off[key] = 3 * (int)hi32(exc);
         }
         if (t == ne - 1) {
@@ -547,18 +550,19 @@ __device__ __forceinline__ void st_bounds(const uint32_t *keys_s, const uint64_t
         }
     }
 }
-__global__ __launch_bounds__(256) void ex_bounds(const uint32_t *__restrict__ keys_s, const uint64_t *__restrict__ sc,
-                                                 const uint64_t *__restrict__ sinc, ExactCaps cap, int *__restrict__ body_off,
-                                                 int *__restrict__ con_off, int *__restrict__ row_off, ExactCounts *C)
+__global__ __launch_bounds__(256) void ex_bounds(const uint32_t *__restrict__ keys_s, const uint32_t *__restrict__ vals_s,
+                                                 const uint32_t *__restrict__ cc, const uint64_t *__restrict__ sinc, ExactCaps cap,
+                                                 int *__restrict__ body_off, int *__restrict__ con_off, int *__restrict__ row_off,
+                                                 ExactCounts *C)
 {
-    st_bounds(keys_s, sc, sinc, cap, body_off, con_off, row_off, C, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    st_bounds(keys_s, vals_s, cc, sinc, cap, body_off, con_off, row_off, C, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 __device__ __forceinline__ void st_bigflags(const int *con_off, const int *body_off, const ExactCaps &cap, int rpc, int big_rows,
                                             uint64_t *bg, const ExactCounts *C, uint32_t first, uint32_t step);
 
 // ---- 8. the island-grouped body list and contact arrays -------------------------------------------------------------
-__device__ __forceinline__ void st_fill(const uint32_t *keys_s, const uint32_t *vals_s, const uint64_t *sc, const uint64_t *sinc,
+__device__ __forceinline__ void st_fill(const uint32_t *keys_s, const uint32_t *vals_s, const uint64_t *sinc,
                                         const uint32_t *cc, const int32_t *inv, const int32_t *pairs, const int *con_off,
                                         const ExactCaps &cap, int rpc, int *bodies, int *cb1, int *cb2, int *csrc, int *crow,
                                         uint32_t first, uint32_t step)
@@ -568,7 +572,7 @@ __device__ __forceinline__ void st_fill(const uint32_t *keys_s, const uint32_t *
         const uint32_t key = keys_s[t];
         if (key >= cap.inv) continue;
         const uint32_t e = vals_s[t];
-        const uint64_t exc = sinc[t] - sc[t];
+        const uint64_t exc = sinc[t] - gathered(key, e, cc, cap);
         const int d0 = (int)hi32(exc), c0 = con_off[key];
         int b1, b2, src0;
         if (e < cap.inv) { b1 = inv[e]; b2 = -1; src0 = 8 * (int)e; bodies[lo32(exc)] = b1; }
@@ -582,14 +586,14 @@ __device__ __forceinline__ void st_fill(const uint32_t *keys_s, const uint32_t *
     }
 }
 __global__ __launch_bounds__(256) void ex_fill(const uint32_t *__restrict__ keys_s, const uint32_t *__restrict__ vals_s,
-                                               const uint64_t *__restrict__ sc, const uint64_t *__restrict__ sinc,
+                                               const uint64_t *__restrict__ sinc,
                                                const uint32_t *__restrict__ cc, const int32_t *__restrict__ inv,
                                                const int32_t *__restrict__ pairs, const int *__restrict__ con_off, ExactCaps cap, int rpc,
                                                int *__restrict__ bodies, int *__restrict__ cb1, int *__restrict__ cb2,
                                                int *__restrict__ csrc, int *__restrict__ crow, const int *__restrict__ body_off,
                                                int big_rows, uint64_t *__restrict__ bg, const ExactCounts *__restrict__ C)
 {
-    st_fill(keys_s, vals_s, sc, sinc, cc, inv, pairs, con_off, cap, rpc, bodies, cb1, cb2, csrc, crow,
+    st_fill(keys_s, vals_s, sinc, cc, inv, pairs, con_off, cap, rpc, bodies, cb1, cb2, csrc, crow,
             blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
     // stage 9 needs the island offsets only, like this one: same launch
     st_bigflags(con_off, body_off, cap, rpc, big_rows, bg, C, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
@@ -813,9 +817,9 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_back(ExactBuffers<T> B, Exact
     }
     __syncthreads(); EXS_STAMP();
     block_scan_inclusive<uint64_t>(B.sc, B.sinc, ne, wt); EXS_STAMP();
-    st_bounds(B.keys_s, B.sc, B.sinc, cap, B.body_off, B.con_off, B.row_off, C, tid, EXS_WG);
+    st_bounds(B.keys_s, B.vals_s, B.cc, B.sinc, cap, B.body_off, B.con_off, B.row_off, C, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
-    st_fill(B.keys_s, B.vals_s, B.sc, B.sinc, B.cc, B.inv, B.pairs, B.con_off, cap, rpc, B.bodies, B.cb1, B.cb2, B.csrc, B.crow, tid, EXS_WG);
+    st_fill(B.keys_s, B.vals_s, B.sinc, B.cc, B.inv, B.pairs, B.con_off, cap, rpc, B.bodies, B.cb1, B.cb2, B.csrc, B.crow, tid, EXS_WG);
     st_bigflags(B.con_off, B.body_off, cap, rpc, big_rows, B.bg, C, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
     block_scan_inclusive<uint64_t>(B.bg, B.binc, cap.inv, wt); EXS_STAMP();
@@ -842,7 +846,10 @@ size_t exact_temp_bytes(const ExactCaps &cap, int64_t n_active)
     const size_t ne = (size_t)cap.entries();
     (void)rocprim::inclusive_scan(nullptr, a, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)n_active, rocprim::plus<uint64_t>());
     (void)rocprim::inclusive_scan(nullptr, b, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)cap.inv, rocprim::plus<uint32_t>());
-    (void)rocprim::inclusive_scan(nullptr, c, (uint64_t *)nullptr, (uint64_t *)nullptr, ne, rocprim::plus<uint64_t>());
+    (void)rocprim::inclusive_scan(nullptr, c,
+                                  rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u),
+                                                                   GatherOp{ nullptr, nullptr, nullptr, cap }),
+                                  (uint64_t *)nullptr, ne, rocprim::plus<uint64_t>());
     (void)rocprim::radix_sort_pairs(nullptr, d, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, ne, 0, 32);
     size_t m = a > b ? a : b;
     m = m > c ? m : c;
@@ -889,11 +896,14 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
     while ((1u << bits) <= cap.inv && bits < 32) bits++;        // keys are island numbers < cap.inv and the padding key cap.inv
     tb = B.temp_bytes;
     EX_TRY(rocprim::radix_sort_pairs(B.temp, tb, B.keys, B.keys_s, B.vals, B.vals_s, ne, 0, (unsigned)bits, st));
-    hipLaunchKernelGGL(ex_gather, dim3(grid_for(ne)), dim3(256), 0, st, B.keys_s, B.vals_s, B.cc, cap, B.sc);
     tb = B.temp_bytes;
-    EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.sc, B.sinc, ne, rocprim::plus<uint64_t>(), st));
-    hipLaunchKernelGGL(ex_bounds, dim3(grid_for(ne)), dim3(256), 0, st, B.keys_s, B.sc, B.sinc, cap, B.body_off, B.con_off, B.row_off, B.counts);
-    hipLaunchKernelGGL(ex_fill, dim3(grid_for(std::max<size_t>(ne, cap.inv))), dim3(256), 0, st, B.keys_s, B.vals_s, B.sc, B.sinc, B.cc, B.inv,
+    EX_TRY(rocprim::inclusive_scan(B.temp, tb,
+                                   rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u),
+                                                                    GatherOp{ B.keys_s, B.vals_s, B.cc, cap }),
+                                   B.sinc, ne, rocprim::plus<uint64_t>(), st));
+    hipLaunchKernelGGL(ex_bounds, dim3(grid_for(ne)), dim3(256), 0, st, B.keys_s, B.vals_s, B.cc, B.sinc, cap, B.body_off, B.con_off, B.row_off,
+                       B.counts);
+    hipLaunchKernelGGL(ex_fill, dim3(grid_for(std::max<size_t>(ne, cap.inv))), dim3(256), 0, st, B.keys_s, B.vals_s, B.sinc, B.cc, B.inv,
                        B.pairs, B.con_off, cap, rpc, B.bodies, B.cb1, B.cb2, B.csrc, B.crow, B.body_off, big_rows, B.bg, B.counts);
     tb = B.temp_bytes;
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.bg, B.binc, (size_t)cap.inv, rocprim::plus<uint64_t>(), st));

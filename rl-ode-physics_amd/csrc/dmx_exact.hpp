@@ -29,7 +29,9 @@ struct ExactCounts {
     uint32_t cross_a, cross_b;
     uint32_t unsupported;   // AABB pairs of this tick that have no collider (convex-convex, convex-sphere)
     uint32_t ncross;        // pairs (own body, ghost slot) met; the first EX_CROSS_CAP of them are in ExactBuffers::cross_list
-    uint32_t pad[2];
+    uint32_t bp_overflow;   // the grid's BPF_OVERFLOW flag as of the pair search (a bucket overflowed: the host widens them and searches
+                            // again), carried here so that one read-back brings everything
+    uint32_t pad[1];
 };
 
 constexpr uint32_t EX_CROSS_CAP = 256;

@@ -386,10 +386,10 @@ template <class T> int careful_tick(dmxBatch *b, double h)
         // (the count record and the island solve's diagnostics are zeroed with the grid: one launch)
         if ((rc = fill_grid<T>(b, B.counts, sizeof(ExactCounts), b->diag_isl, sizeof(StepDiag))) != DMX_OK) return rc;
         HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), B, cap, b->stream));
-        auto read_back = [&]() -> int {
-            HIP_TRY(hipMemcpyAsync(b->bp_flags_host, b->bp_flags.p, BPF_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+        auto read_back = [&]() -> int {          // (the record carries the grid's overflow flag too: one copy)
             HIP_TRY(hipMemcpyAsync(&C, B.counts, sizeof(ExactCounts), hipMemcpyDeviceToHost, b->stream));
             HIP_TRY(hipStreamSynchronize(b->stream));
+            b->bp_flags_host[BPF_OVERFLOW] = C.bp_overflow;
             return DMX_OK;
         };
         // The last exact tick found no body involved (crowded bounding spheres, nothing touching): most likely this one
@@ -662,6 +662,7 @@ template <class T> int find_pairs_t(dmxBatch *b)
         cap.rows = b->ex_cap_rows;
         cap.nstatic = (uint32_t)b->n_static;
         if ((rc = ensure_exact_buffers<T>(b, cap, B)) != DMX_OK) return rc;
+        bool staged = false;
         if (use_small_exact(b, cap, false)) {
             ExactCounts *hc; uint32_t *hf;
             if ((rc = host_record_pointers(b, &hc, &hf)) != DMX_OK) return rc;
@@ -669,10 +670,11 @@ template <class T> int find_pairs_t(dmxBatch *b)
         } else {
             if ((rc = fill_grid<T>(b, B.counts, sizeof(ExactCounts))) != DMX_OK) return rc;
             HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), B, cap, b->stream));
-            HIP_TRY(hipMemcpyAsync(b->bp_flags_host, b->bp_flags.p, BPF_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
             HIP_TRY(hipMemcpyAsync(&C, B.counts, sizeof(ExactCounts), hipMemcpyDeviceToHost, b->stream));
+            staged = true;
         }
         HIP_TRY(hipStreamSynchronize(b->stream));
+        if (staged) b->bp_flags_host[BPF_OVERFLOW] = C.bp_overflow;
         if (b->bp_flags_host[BPF_OVERFLOW]) { if ((rc = grow_buckets(b)) != DMX_OK) return rc; continue; }
         if (C.overflow & 1u) {
             const uint64_t need = std::max<uint64_t>(C.npairs, (uint64_t)(C.ninv + 1) / 2);
