@@ -101,6 +101,7 @@ struct dmxBatch {
     double exs_acc[64] = { 0 }; long exs_ticks = 0;      // DMX_EXS_TIMING: stage times of the small-scene exact tick, summed
     void *ex_counts_dev = nullptr, *bp_flags_dev = nullptr;    // device-visible addresses of ex_counts_host / bp_flags_host
     int exact_pipeline = 0;         // dmxBatchSetExactPipeline (DMX_EXACT_*); the environment's DMX_SMALL_EXACT is the default
+    uint32_t ex_seq = 0;            // sequence number of the small-scene kernels' host record (await_host_record)
     bool bp_fresh = false;          // the safe zones were built at exactly the current poses (no tick since)
     bool snap_fresh = false;        // ... as of the open snapshot
     bool bp_skip_fast = false;      // the next chunk goes the exact way without trying the fast one (a retry would repeat a failure)

@@ -726,14 +726,20 @@ template <class V> __device__ __forceinline__ void block_scan_inclusive(const V 
 
 // the count record and the broadphase flags into pinned host memory: one lane per word, so the record crosses the bus as one
 // 64-byte write and one of 20 bytes, not as 21 writes one after the other.  Called by the whole workgroup after a barrier.
-__device__ __forceinline__ void publish_counts(const ExactCounts *C, const uint32_t *flags, ExactCounts *host_counts, uint32_t *host_flags)
+// The record's last word is the caller's sequence number and goes out after everything else has been fenced to the system:
+// the host may watch for it instead of waiting for the stream (a stream synchronisation costs it 10-20 us to wake up).
+__device__ __forceinline__ void publish_counts(const ExactCounts *C, const uint32_t *flags, ExactCounts *host_counts, uint32_t *host_flags,
+                                               uint32_t seq)
 {
     if (host_counts == nullptr) return;
     const uint32_t t = threadIdx.x;
     constexpr uint32_t NW = sizeof(ExactCounts) / 4;
-    if (t < NW) ((volatile uint32_t *)host_counts)[t] = ((const volatile uint32_t *)C)[t];
-    else if (t < NW + (uint32_t)BPF_COUNT) ((volatile uint32_t *)host_flags)[t - NW] = ((const volatile uint32_t *)flags)[t - NW];
+    static_assert(offsetof(ExactCounts, seq) == (NW - 1) * 4, "seq is the record's last word");
+    if (t < NW - 1) ((volatile uint32_t *)host_counts)[t] = ((const volatile uint32_t *)C)[t];
+    else if (t >= NW && t < NW + (uint32_t)BPF_COUNT) ((volatile uint32_t *)host_flags)[t - NW] = ((const volatile uint32_t *)flags)[t - NW];
     if (t < NW + (uint32_t)BPF_COUNT) __threadfence_system();
+    __syncthreads();
+    if (t == 0) { ((volatile uint32_t *)host_counts)[NW - 1] = seq; __threadfence_system(); }
 }
 
 // B.stamps: wall_clock64() (100 MHz) after every stage, front kernel from [0], back kernel from [32]; DMX_EXS_TIMING=1 prints the
@@ -743,7 +749,8 @@ __device__ __forceinline__ void publish_counts(const ExactCounts *C, const uint3
 // grid fill (fill_grid's memsets + bp_insert) and stages 1-3: pairs, involved bodies, islands' roots
 template <class T>
 __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gtype, int64_t n, int64_t n_active, GridParams<T> G,
-                                                         ExactBuffers<T> B, ExactCaps cap, ExactCounts *host_counts, uint32_t *host_flags)
+                                                         ExactBuffers<T> B, ExactCaps cap, ExactCounts *host_counts, uint32_t *host_flags,
+                                                         uint32_t seq)
 {
     __shared__ uint64_t wt[EXS_WG / 64];
     const uint32_t tid = threadIdx.x;
@@ -766,14 +773,14 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gt
     st_flatten(B.parent, B.root, B.rf, cap, C, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
     block_scan_inclusive<uint32_t>(B.rf, B.rinc, cap.inv, reinterpret_cast<uint32_t *>(wt)); EXS_STAMP();
-    publish_counts(C, G.flags, host_counts, host_flags);         // (the scan above ended on a barrier)
+    publish_counts(C, G.flags, host_counts, host_flags, seq);    // (the scan above ended on a barrier)
 }
 
 // stages 5-10 (the narrowphase ran in between): entries sorted by island, joints in creation order, level schedules.
 // ITEMS entries per thread (2, 4 or 8: up to 8192 entries).
 template <class T, int ITEMS>
 __global__ __launch_bounds__(EXS_WG) void ex_small_back(ExactBuffers<T> B, ExactCaps cap, int rpc, int big_rows, const uint32_t *flags,
-                                                        StepDiag *diag, ExactCounts *host_counts, uint32_t *host_flags)
+                                                        StepDiag *diag, ExactCounts *host_counts, uint32_t *host_flags, uint32_t seq)
 {
     using sort_t = rocprim::block_radix_sort<uint32_t, EXS_WG, ITEMS>;
     __shared__ typename sort_t::storage_type sort_storage;
@@ -827,7 +834,7 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_back(ExactBuffers<T> B, Exact
               B.row_level, B.last, C, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
     if (tid == 0) { diag->contacts = 0ull; diag->residual = 0.0; }       // the island kernels add to it next
-    publish_counts(C, flags, host_counts, host_flags);
+    publish_counts(C, flags, host_counts, host_flags, seq);
 }
 
 __global__ void ex_fill_i32(int32_t *p, int32_t v, size_t n)
@@ -919,16 +926,16 @@ bool exact_small_fits(int64_t n, uint32_t grid_mask, const ExactCaps &cap)
 
 template <class T>
 hipError_t launch_exact_small_front(T *S, const uint8_t *gtype, int64_t n, int64_t n_active, const GridParams<T> &G, const ExactBuffers<T> &B,
-                                    const ExactCaps &cap, ExactCounts *host_counts, uint32_t *host_flags, hipStream_t st)
+                                    const ExactCaps &cap, ExactCounts *host_counts, uint32_t *host_flags, uint32_t seq, hipStream_t st)
 {
-    hipLaunchKernelGGL((ex_small_front<T>), dim3(1), dim3(EXS_WG), 0, st, S, gtype, n, n_active, G, B, cap, host_counts, host_flags);
+    hipLaunchKernelGGL((ex_small_front<T>), dim3(1), dim3(EXS_WG), 0, st, S, gtype, n, n_active, G, B, cap, host_counts, host_flags, seq);
     return hipGetLastError();
 }
 
 template <class T>
 hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const GridParams<T> &G, const StepParams<T> &P, const ExactBuffers<T> &B,
                                     const ExactCaps &cap, int rpc, int big_rows, StepDiag *diag, ExactCounts *host_counts,
-                                    uint32_t *host_flags, hipStream_t st)
+                                    uint32_t *host_flags, uint32_t seq, hipStream_t st)
 {
     const size_t ne = (size_t)cap.entries();
     hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.rec, P, cap,
@@ -938,20 +945,20 @@ hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const Grid
                            B.pairs, G.rec, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
     const uint32_t *flags = G.flags;
     if (ne <= 2 * EXS_WG)
-        hipLaunchKernelGGL((ex_small_back<T, 2>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags);
+        hipLaunchKernelGGL((ex_small_back<T, 2>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq);
     else if (ne <= 4 * EXS_WG)
-        hipLaunchKernelGGL((ex_small_back<T, 4>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags);
+        hipLaunchKernelGGL((ex_small_back<T, 4>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq);
     else
-        hipLaunchKernelGGL((ex_small_back<T, 8>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags);
+        hipLaunchKernelGGL((ex_small_back<T, 8>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq);
     return hipGetLastError();
 }
 
 #define DMX_EXS_INST(T)                                                                                                                  \
     template hipError_t launch_exact_small_front<T>(T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, const ExactBuffers<T> &, \
-                                                    const ExactCaps &, ExactCounts *, uint32_t *, hipStream_t);                          \
+                                                    const ExactCaps &, ExactCounts *, uint32_t *, uint32_t, hipStream_t);                \
     template hipError_t launch_exact_small_group<T>(const T *, const uint8_t *, const GridParams<T> &, const StepParams<T> &,            \
                                                     const ExactBuffers<T> &, const ExactCaps &, int, int, StepDiag *, ExactCounts *,     \
-                                                    uint32_t *, hipStream_t);
+                                                    uint32_t *, uint32_t, hipStream_t);
 DMX_EXS_INST(float)
 DMX_EXS_INST(double)
 

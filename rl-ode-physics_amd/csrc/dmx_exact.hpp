@@ -31,7 +31,8 @@ struct ExactCounts {
     uint32_t ncross;        // pairs (own body, ghost slot) met; the first EX_CROSS_CAP of them are in ExactBuffers::cross_list
     uint32_t bp_overflow;   // the grid's BPF_OVERFLOW flag as of the pair search (a bucket overflowed: the host widens them and searches
                             // again), carried here so that one read-back brings everything
-    uint32_t pad[1];
+    uint32_t seq;           // small-scene kernels: the caller's sequence number, written to the host copy LAST: a host that watches
+                            // for it has the whole record (and the flags) without waiting for the stream
 };
 
 constexpr uint32_t EX_CROSS_CAP = 256;
@@ -77,10 +78,10 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
 bool exact_small_fits(int64_t n, uint32_t grid_mask, const ExactCaps &cap);
 template <class T>
 hipError_t launch_exact_small_front(T *S, const uint8_t *gtype, int64_t n, int64_t n_active, const GridParams<T> &G, const ExactBuffers<T> &B,
-                                    const ExactCaps &cap, ExactCounts *host_counts, uint32_t *host_flags, hipStream_t st);
+                                    const ExactCaps &cap, ExactCounts *host_counts, uint32_t *host_flags, uint32_t seq, hipStream_t st);
 template <class T>
 hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const GridParams<T> &G, const StepParams<T> &P, const ExactBuffers<T> &B,
                                     const ExactCaps &cap, int rpc, int big_rows, StepDiag *diag, ExactCounts *host_counts,
-                                    uint32_t *host_flags, hipStream_t st);
+                                    uint32_t *host_flags, uint32_t seq, hipStream_t st);
 
 }  // namespace dmx

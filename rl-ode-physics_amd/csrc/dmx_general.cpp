@@ -16,6 +16,8 @@
 #include <string.h>
 #include <algorithm>
 #include <memory>
+#include <chrono>
+#include <atomic>
 #include <cmath>
 
 #include "dmx_batch_priv.hpp"
@@ -83,7 +85,7 @@ int ensure_buffers(dmxBatch *b)
     if ((rc = dmx_ensure_dev(b->bp_items, tbl * (size_t)b->bp_cap * sizeof(int32_t))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->bp_flags, 64)) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->bp_inpair, (size_t)b->stride)) != DMX_OK) return rc;
-    if (!b->bp_flags_host) HIP_TRY(hipHostMalloc((void **)&b->bp_flags_host, 64));
+    if (!b->bp_flags_host) HIP_TRY(hipHostMalloc((void **)&b->bp_flags_host, 64, hipHostMallocCoherent | hipHostMallocMapped));
     return DMX_OK;
 }
 
@@ -269,6 +271,24 @@ bool exs_timing_enabled()
 }
 
 // device-visible addresses of the pinned host records the small-scene kernels write themselves
+// Wait for the small-scene kernels' host record: watch for the sequence number (the record's last word, written after a
+// system-scope fence) rather than synchronise the stream -- the device keeps running, the host has its numbers a
+// microsecond or two after they were written.  Falls back to the stream after 2 ms (a faulted kernel never writes).
+int await_host_record(dmxBatch *b, uint32_t seq)
+{
+    static const bool spin = [] { const char *e = getenv("DMX_RECORD_SPIN"); return !(e && atoi(e) == 0); }();
+    volatile uint32_t *word = &((volatile ExactCounts *)b->ex_counts_host)->seq;
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int it = 0;; it++) {
+            if (*word == seq) { std::atomic_thread_fence(std::memory_order_acquire); return DMX_OK; }
+            if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return *word == seq ? DMX_OK : DMX_EHIP;
+}
+
 int host_record_pointers(dmxBatch *b, ExactCounts **counts_dev, uint32_t **flags_dev)
 {
     if (!b->ex_counts_dev) {
@@ -349,13 +369,13 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     int rc;
     snapshot_drop(b);           // exact ticks run in place and are never rolled back
     std::unique_ptr<DmxPhase> ph(new DmxPhase(b, 0));
-    if (!b->ex_counts_host) HIP_TRY(hipHostMalloc((void **)&b->ex_counts_host, sizeof(ExactCounts)));
+    if (!b->ex_counts_host) HIP_TRY(hipHostMalloc((void **)&b->ex_counts_host, sizeof(ExactCounts), hipHostMallocCoherent | hipHostMallocMapped));
     const StepParams<T> P = dmx_make_params<T>(b, h);
     const int rpc = b->mu > 0 ? 3 : 1;
     ExactBuffers<T> B;
     ExactCounts &C = *(ExactCounts *)b->ex_counts_host;
     if (b->ex_cap_pairs == 0) { b->ex_cap_pairs = 1024; b->ex_cap_rows = 16384; }
-    if (!b->bp_flags_host) HIP_TRY(hipHostMalloc((void **)&b->bp_flags_host, 64));
+    if (!b->bp_flags_host) HIP_TRY(hipHostMalloc((void **)&b->bp_flags_host, 64, hipHostMallocCoherent | hipHostMallocMapped));
     bool small = false;
     for (int attempt = 0;; attempt++) {
         if (attempt > 40) return DMX_ECAPACITY;
@@ -372,10 +392,11 @@ template <class T> int careful_tick(dmxBatch *b, double h)
             ExactCounts *hc; uint32_t *hf;
             if ((rc = host_record_pointers(b, &hc, &hf)) != DMX_OK) return rc;
             const GridParams<T> G = grid_of<T>(b);
-            HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, G, B, cap, nullptr, nullptr, b->stream));
+            const uint32_t seq = ++b->ex_seq;
+            HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, G, B, cap, nullptr, nullptr, 0u, b->stream));
             HIP_TRY(launch_exact_small_group<T>((const T *)b->slab, b->gtype, G, P, B, cap, rpc, big_island_rows_general(), b->diag_isl,
-                                                hc, hf, b->stream));
-            HIP_TRY(hipStreamSynchronize(b->stream));
+                                                hc, hf, seq, b->stream));
+            if ((rc = await_host_record(b, seq)) != DMX_OK) return rc;
             if (exs_timing_enabled()) {
                 uint64_t st[64];
                 HIP_TRY(hipMemcpy(st, B.stamps, sizeof(st), hipMemcpyDeviceToHost));
@@ -650,7 +671,7 @@ template <class T> int find_pairs_t(dmxBatch *b)
 {
     int rc;
     if ((rc = ensure_buffers(b)) != DMX_OK) return rc;
-    if (!b->ex_counts_host) HIP_TRY(hipHostMalloc((void **)&b->ex_counts_host, sizeof(ExactCounts)));
+    if (!b->ex_counts_host) HIP_TRY(hipHostMalloc((void **)&b->ex_counts_host, sizeof(ExactCounts), hipHostMallocCoherent | hipHostMallocMapped));
     ExactBuffers<T> B;
     ExactCounts &C = *(ExactCounts *)b->ex_counts_host;
     if (b->ex_cap_pairs == 0) { b->ex_cap_pairs = 1024; b->ex_cap_rows = 16384; }
@@ -663,18 +684,22 @@ template <class T> int find_pairs_t(dmxBatch *b)
         cap.nstatic = (uint32_t)b->n_static;
         if ((rc = ensure_exact_buffers<T>(b, cap, B)) != DMX_OK) return rc;
         bool staged = false;
+        uint32_t small_seq = 0;
         if (use_small_exact(b, cap, false)) {
             ExactCounts *hc; uint32_t *hf;
             if ((rc = host_record_pointers(b, &hc, &hf)) != DMX_OK) return rc;
-            HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, grid_of<T>(b), B, cap, hc, hf, b->stream));
+            small_seq = ++b->ex_seq;
+            HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, grid_of<T>(b), B, cap, hc, hf, small_seq, b->stream));
         } else {
             if ((rc = fill_grid<T>(b, B.counts, sizeof(ExactCounts))) != DMX_OK) return rc;
             HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), B, cap, b->stream));
             HIP_TRY(hipMemcpyAsync(&C, B.counts, sizeof(ExactCounts), hipMemcpyDeviceToHost, b->stream));
             staged = true;
         }
-        HIP_TRY(hipStreamSynchronize(b->stream));
-        if (staged) b->bp_flags_host[BPF_OVERFLOW] = C.bp_overflow;
+        if (staged) {
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            b->bp_flags_host[BPF_OVERFLOW] = C.bp_overflow;
+        } else if ((rc = await_host_record(b, small_seq)) != DMX_OK) return rc;
         if (b->bp_flags_host[BPF_OVERFLOW]) { if ((rc = grow_buckets(b)) != DMX_OK) return rc; continue; }
         if (C.overflow & 1u) {
             const uint64_t need = std::max<uint64_t>(C.npairs, (uint64_t)(C.ninv + 1) / 2);
