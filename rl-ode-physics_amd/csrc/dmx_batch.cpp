@@ -89,6 +89,7 @@ extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int dev
     if (const char *v = getenv("DMX_OOP")) b->oop = atoi(v);
     b->prof_on = getenv("DMX_HOST_PROFILE") != nullptr;
     if (const char *v = getenv("DMX_LAZY_CHUNKS")) b->lazy_chunks = atoi(v) != 0;
+    if (const char *v = getenv("DMX_STATIC_FAST")) b->static_fast = atoi(v) != 0;
     int rc = DMX_OK;
     do {
         if (hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = DMX_EHIP; break; }
@@ -321,9 +322,10 @@ template <class T> static int step_t(dmxBatch *b, double h, int nsteps, int64_t 
     StepParams<T> P = dmx_make_params<T>(b, h);
     if (first != 0) P.pack_out = nullptr;      // the boundary pack is defined on whole-slab launches only
     if (P.cbuf != nullptr) { P.cbuf += (size_t)first * CONVEX_MAXC * 4; P.ccount += first; }   // per-body contact slots follow the range
+    if (P.sbuf != nullptr) { P.sbuf += sc_ix(0, 0, first); P.scount += first; }                 // (first is a multiple of the tile)
     // contact-free ticks go ticks_per_launch at a time (state in registers between ticks); the first tick alone when
     // external force accumulators are pending (they act once)
-    const int per = (b->plane_on || first != 0) ? 1 : std::max(1, b->ticks_per_launch);
+    const int per = (b->plane_on || b->n_static > 0 || first != 0) ? 1 : std::max(1, b->ticks_per_launch);
     for (int s = 0; s < nsteps;) {
         (void)reset_diag;   // every wave overwrites its own slot each tick: nothing to clear
         const bool ext = b->ext_pending && s == 0;
@@ -338,7 +340,7 @@ template <class T> static int step_t(dmxBatch *b, double h, int nsteps, int64_t 
         }
         s += P.ticks;
     }
-    b->stepped_with_plane = b->plane_on != 0;
+    b->stepped_with_plane = dmx_fused_contacts(b);
     b->last_islands = false;
     return DMX_OK;
 }
@@ -423,6 +425,10 @@ template <class T> static int set_static_boxes_t(dmxBatch *b, int32_t n, const d
         if ((rc = dmx_ensure_dev(b->sbox, h.size() * sizeof(T))) != DMX_OK) return rc;
         HIP_TRY(hipMemcpyAsync(b->sbox.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));
+        // the fused path's contact buffer: SC_MAXC contacts of SC_REALS reals per slot, tiled like the slab
+        if ((rc = dmx_ensure_dev(b->sbuf, (size_t)b->stride * SC_MAXC * SC_REALS * sizeof(T))) != DMX_OK) return rc;
+        if ((rc = dmx_ensure_dev(b->scount, (size_t)b->stride * sizeof(int))) != DMX_OK) return rc;
+        HIP_TRY(hipMemset(b->scount.p, 0, (size_t)b->stride * sizeof(int)));
     }
     b->n_static = n;
     b->bp_valid = false;

@@ -101,7 +101,6 @@ struct dmxBatch {
     double exs_acc[64] = { 0 }; long exs_ticks = 0;      // DMX_EXS_TIMING: stage times of the small-scene exact tick, summed
     void *ex_counts_dev = nullptr, *bp_flags_dev = nullptr;    // device-visible addresses of ex_counts_host / bp_flags_host
     int exact_pipeline = 0;         // dmxBatchSetExactPipeline (DMX_EXACT_*); the environment's DMX_SMALL_EXACT is the default
-    uint32_t ex_seq = 0;            // sequence number of the small-scene kernels' host record (await_host_record)
     bool bp_fresh = false;          // the safe zones were built at exactly the current poses (no tick since)
     bool snap_fresh = false;        // ... as of the open snapshot
     bool bp_skip_fast = false;      // the next chunk goes the exact way without trying the fast one (a retry would repeat a failure)
@@ -135,6 +134,11 @@ struct dmxBatch {
     DevBuf hull_planes; int hull_nf = 0;       // the hull's faces (dmxBatchSetConvexHullFaces): 4 reals each
     int64_t stat_unsupported = 0;              // AABB pairs met that have no collider (convex-convex, convex-sphere)
     DevBuf sbox; int n_static = 0;             // static box geoms (dmxBatchSetStaticBoxes), SBOX_REALS reals each
+    // the fused path of bodies at static geometry (np_static -> step_contacts): per-body contact buffer and counts
+    DevBuf sbuf, scount;
+    bool static_fast = true;                   // DMX_STATIC_FAST=0: every body at a static box goes through the exact tick (round 2's way)
+    bool static_need8 = false;                 // a body with 5..8 static contacts has been met: the second step_contacts launch rides along
+    int nofast_hold = 0, nofast_level = 0;     // chunks to go the exact way after a body overflowed the contact buffer (backs off)
     int hull_n = 0;
     int64_t stat_rollbacks = 0;
     int64_t stat_fast_ticks = 0, stat_careful_ticks = 0, stat_rebuilds = 0, stat_pair_ticks = 0;
@@ -144,6 +148,8 @@ struct dmxBatch {
 };
 
 int dmx_ensure_dev(dmxBatch::DevBuf &d, size_t bytes);
+// do the fused kernels make contacts (and so leave contact diagnostics behind)?  The ground plane, or static boxes on the fused path
+inline bool dmx_fused_contacts(const dmxBatch *b) { return b->plane_on != 0 || (b->n_static > 0 && b->static_fast); }
 // f(begin, end, thread) over contiguous chunks of [0, n) on up to DMX_HOST_THREADS (default: the host's cores, at most 16)
 // threads of a persistent pool (dmx_host_pool.cpp); runs inline when n is below two grains.  The chunks must touch
 // disjoint data.
@@ -225,6 +231,8 @@ template <class T> inline StepParams<T> dmx_make_params(dmxBatch *b, double h)
     P.skip = nullptr;
     P.pack_out = (T *)b->pack_out; P.pack_lo = b->pack_lo; P.pack_hi = b->pack_hi;
     P.sbox = (const T *)b->sbox.p; P.n_static = b->n_static;
+    P.sbuf = b->static_fast ? (T *)b->sbuf.p : nullptr; P.scount = (int *)b->scount.p;
+    P.have8 = 1;             // (a collision-checked launch may leave the 5..8-contact launch out: fused_tick, dmx_general.cpp)
     P.hull = (const T *)b->hull.p; P.hull_n = b->hull_n;
     P.hull_planes = (const T *)b->hull_planes.p; P.hull_nf = b->hull_nf;
     P.cbuf = (T *)b->cbuf.p; P.ccount = (int *)b->ccount.p;

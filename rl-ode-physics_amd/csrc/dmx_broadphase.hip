@@ -58,9 +58,11 @@ __global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uin
                 }
             }
         safe = T(0.5) * gap;
-        bool near_static = false;            // bounding sphere reaches into a static box's AABB: only the exact path can step it
+        // bounding sphere reaches into a static box's AABB: without the static fused path (G.static_fast) only the exact path
+        // can step it; with it, step_contacts does, and says so itself (BPF_NOFAST) when a body's contacts overflow its buffer
+        bool near_static = false;
         const T y = S[slab_ix(C_POS + 1, i)];
-        for (int s = 0; s < G.n_static; s++) {
+        for (int s = 0; s < (G.static_fast ? 0 : G.n_static); s++) {
             const T *b = G.sbox + s * SBOX_REALS;
             if (!(x - ri > b[SBOX_HI + 0] || x + ri < b[SBOX_LO + 0] || y - ri > b[SBOX_HI + 1] || y + ri < b[SBOX_LO + 1] ||
                   z - ri > b[SBOX_HI + 2] || z + ri < b[SBOX_LO + 2])) near_static = true;

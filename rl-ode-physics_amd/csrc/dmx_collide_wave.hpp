@@ -1,0 +1,127 @@
+// dmx_collide_wave.hpp -- the convex-hull colliders of dCollide (/root/reference/src/main.c:678), one WAVEFRONT per
+// geom pair: lane l tests hull point / face 64 j + l, ballots give every hit its rank in array order, so the contacts kept
+// are the ones a sequential walk keeps (oracle/orc_collide.c).  Shared by the exact tick's narrowphase (dmx_exact.hip)
+// and the fused path of bodies at static geometry (dmx_narrow.hip).  The caller says where a contact goes:
+// emit(rank, pos, normal, depth) runs on the one lane that holds contact `rank` of this geom pair.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include "dmx_internal.hpp"
+#include "dmx_math.hpp"
+
+namespace dmx {
+
+// ---- convex hull against the ground plane (dCollideConvexPlane [ODE-recall]) ----------------------------------------
+// ODE walks the hull's points in array order: a point on or below the plane becomes a contact (position = the point,
+// depth = distance below) until max_contacts are taken, and the result counts only if the hull has points on both
+// sides of the plane (or on it).  ODE's early exit (max_contacts reached and both signs seen) only skips points that can
+// change neither the contact set nor the both-sides test, so the wave may stop at the same condition.
+template <class T, class Emit>
+__device__ __forceinline__ int wave_convex_plane(const V3<T> &x, const M3<T> &R, const StepParams<T> &P, int maxc, int lane, Emit emit)
+{
+    int contacts = 0;
+    bool any_le = false, any_ge = false;
+    for (int base = 0; base < P.hull_n; base += 64) {
+        const int k = base + lane;
+        bool below = false, le = false, ge = false;
+        V3<T> v2 = { T(0), T(0), T(0) };
+        T distance2 = T(0);
+        if (k < P.hull_n) {
+            v2 = mulv(R, V3<T>{ P.hull[3 * k], P.hull[3 * k + 1], P.hull[3 * k + 2] });
+            v2.x += x.x; v2.y += x.y; v2.z += x.z;
+            distance2 = dot(P.pn, v2) - P.pd;
+            le = distance2 <= T(0);
+            ge = distance2 >= T(0);
+            below = le;
+        }
+        const unsigned long long mb = __ballot(below);
+        any_le = any_le || (__ballot(le) != 0ull);
+        any_ge = any_ge || (__ballot(ge) != 0ull);
+        if (below) {
+            const int rank = contacts + __popcll(mb & ((1ull << lane) - 1ull));
+            if (rank < maxc) emit(rank, v2, P.pn, -distance2);
+        }
+        contacts += __popcll(mb);
+        if (contacts >= maxc && any_le && any_ge) break;
+    }
+    return (any_le && any_ge) ? (contacts < maxc ? contacts : maxc) : 0;
+}
+
+// ---- box against convex hull: this library's collider (ODE's dCollideConvexBox is an empty stub; include/dmx_batch.h,
+// dmxBatchSetConvexHullFaces): (1) hull vertices inside the box, in array order, each along the box face it is nearest to;
+// (2) box corners inside the hull (corner order = bits), each along the hull face it is nearest to.  The normal points
+// into the box; `negate` flips it (hull first in dCollide's order, or a reversed joint).
+template <class T, class Emit>
+__device__ __forceinline__ int wave_box_convex(const V3<T> &xb, const M3<T> &Rb, const T *side, const V3<T> &xh, const M3<T> &Rh,
+                                               T hull_radius, const StepParams<T> &P, int maxc, bool negate, int lane, Emit emit)
+{
+    const T half[3] = { T(0.5) * side[0], T(0.5) * side[1], T(0.5) * side[2] };
+    int contacts = 0;
+    for (int base = 0; base < P.hull_n && contacts < maxc; base += 64) {
+        const int k = base + lane;
+        bool inside = false;
+        V3<T> v = { T(0), T(0), T(0) }, n = { T(0), T(0), T(0) };
+        T dep = T(0);
+        if (k < P.hull_n) {
+            v = mulv(Rh, V3<T>{ P.hull[3 * k], P.hull[3 * k + 1], P.hull[3 * k + 2] });
+            v.x += xh.x; v.y += xh.y; v.z += xh.z;
+            const V3<T> d = { v.x - xb.x, v.y - xb.y, v.z - xb.z };
+            T q[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) q[a] = fma_(Rb.m[2][a], d.z, fma_(Rb.m[1][a], d.y, Rb.m[0][a] * d.x));     // box frame
+            inside = !(tabs(q[0]) > half[0] || tabs(q[1]) > half[1] || tabs(q[2]) > half[2]);
+            int best = 0;
+            dep = half[0] - tabs(q[0]);
+#pragma unroll
+            for (int a = 1; a < 3; a++) { const T e = half[a] - tabs(q[a]); if (e < dep) { dep = e; best = a; } }
+            const T sg = q[best] < T(0) ? T(-1) : T(1);
+            n = { -(sg * Rb.m[0][best]), -(sg * Rb.m[1][best]), -(sg * Rb.m[2][best]) };      // into the box
+        }
+        const unsigned long long mb = __ballot(inside);
+        if (inside) {
+            const int rank = contacts + __popcll(mb & ((1ull << lane) - 1ull));
+            if (rank < maxc) emit(rank, v, negate ? V3<T>{ -n.x, -n.y, -n.z } : n, dep);
+        }
+        contacts += __popcll(mb);
+    }
+    if (contacts > maxc) contacts = maxc;
+    for (int cn = 0; cn < 8 && contacts < maxc && P.hull_nf > 0; cn++) {
+        const V3<T> l = { (cn & 1) ? half[0] : -half[0], (cn & 2) ? half[1] : -half[1], (cn & 4) ? half[2] : -half[2] };
+        V3<T> cw = mulv(Rb, l);
+        cw.x += xb.x; cw.y += xb.y; cw.z += xb.z;
+        const V3<T> d = { cw.x - xh.x, cw.y - xh.y, cw.z - xh.z };
+        // a corner inside the hull is inside the hull's bounding sphere (slack for rounding): most corners of a floor-sized
+        // box are nowhere near it and skip the walk over the faces
+        if (d.x * d.x + d.y * d.y + d.z * d.z > hull_radius * hull_radius * T(1.0001)) continue;
+        V3<T> r;
+        r.x = fma_(Rh.m[2][0], d.z, fma_(Rh.m[1][0], d.y, Rh.m[0][0] * d.x));
+        r.y = fma_(Rh.m[2][1], d.z, fma_(Rh.m[1][1], d.y, Rh.m[0][1] * d.x));
+        r.z = fma_(Rh.m[2][2], d.z, fma_(Rh.m[1][2], d.y, Rh.m[0][2] * d.x));
+        T dep = Limits<T>::inf();
+        int fbest = 0x7fffffff;
+        bool neg = false;
+        for (int f = lane; f < P.hull_nf; f += 64) {
+            const T *pl = P.hull_planes + 4 * f;
+            const T e = pl[3] - dot(V3<T>{ pl[0], pl[1], pl[2] }, r);
+            if (e < T(0)) neg = true;
+            if (e < dep) { dep = e; fbest = f; }             // (f ascends within a lane: the first minimum is kept)
+        }
+        if (__ballot(neg) != 0ull) continue;                 // outside some face
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {                   // lexicographic (depth, face) minimum over the wave
+            const T od = __shfl_xor(dep, o, 64);
+            const int of = __shfl_xor(fbest, o, 64);
+            if (od < dep || (od == dep && of < fbest)) { dep = od; fbest = of; }
+        }
+        if (fbest == 0x7fffffff) continue;
+        if (lane == 0) {
+            const T *pl = P.hull_planes + 4 * fbest;
+            const V3<T> nw = mulv(Rh, V3<T>{ pl[0], pl[1], pl[2] });     // the hull's outward normal points into the box
+            emit(contacts, cw, negate ? V3<T>{ -nw.x, -nw.y, -nw.z } : nw, dep);
+        }
+        contacts++;
+    }
+    return contacts;
+}
+
+}  // namespace dmx

@@ -24,6 +24,7 @@
 #include "dmx_internal.hpp"
 #include "dmx_math.hpp"
 #include "dmx_collide.hpp"
+#include "dmx_collide_wave.hpp"
 #include "dmx_grid.hpp"
 #include "dmx_exact.hpp"
 
@@ -126,11 +127,16 @@ __device__ __forceinline__ void st_pair_count(const T *S, const uint8_t *gtype, 
                 }
                 else if (j > i) owned++;
             }, &C->unsupported);
-            // static box geoms are "big geoms against everyone": a body whose AABB overlaps one goes through the exact path too
+            // static box geoms are "big geoms against everyone".  A body whose AABB overlaps static boxes but no other body's
+            // is a one-body island: the fused path (np_static -> step_contacts) steps it -- unless its contacts might not fit
+            // that path's buffer of SC_MAXC: AABB over two or more static boxes, or over one with a ground plane present
+            // (<= 8 contacts per geom pair).  Those, and every such body when the fused path is off, are involved here.
             if (G.n_static > 0) {
                 const GridRec<T> me = G.rec[i];
+                int ns = 0;
                 for (int s = 0; s < G.n_static; s++)
-                    if (rec_meets_static(me, G.sbox + s * SBOX_REALS)) any = 1;
+                    if (rec_meets_static(me, G.sbox + s * SBOX_REALS)) ns++;
+                if (G.static_fast ? (ns >= 2 || (ns >= 1 && G.plane_on)) : ns >= 1) any = 1;
             }
         }
         pc[i] = ((uint64_t)owned << 32) | any;
@@ -363,80 +369,6 @@ __global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const u
 // the hull.  Lane l tests point / face 64 j + l; ballots give array-order ranks, so the contacts are the ones a sequential
 // walk keeps.
 template <class T>
-__device__ __forceinline__ int wave_box_convex(const V3<T> &xb, const M3<T> &Rb, const T *side, const V3<T> &xh, const M3<T> &Rh,
-                                               T hull_radius, const StepParams<T> &P, int maxc, bool negate, int lane, T *gpos,
-                                               T *gnormal, T *gdepth, size_t slot0)
-{
-    const T half[3] = { T(0.5) * side[0], T(0.5) * side[1], T(0.5) * side[2] };
-    int contacts = 0;
-    for (int base = 0; base < P.hull_n && contacts < maxc; base += 64) {
-        const int k = base + lane;
-        bool inside = false;
-        V3<T> v = { T(0), T(0), T(0) }, n = { T(0), T(0), T(0) };
-        T dep = T(0);
-        if (k < P.hull_n) {
-            v = mulv(Rh, V3<T>{ P.hull[3 * k], P.hull[3 * k + 1], P.hull[3 * k + 2] });
-            v.x += xh.x; v.y += xh.y; v.z += xh.z;
-            const V3<T> d = { v.x - xb.x, v.y - xb.y, v.z - xb.z };
-            T q[3];
-#pragma unroll
-            for (int a = 0; a < 3; a++) q[a] = fma_(Rb.m[2][a], d.z, fma_(Rb.m[1][a], d.y, Rb.m[0][a] * d.x));     // box frame
-            inside = !(tabs(q[0]) > half[0] || tabs(q[1]) > half[1] || tabs(q[2]) > half[2]);
-            int best = 0;
-            dep = half[0] - tabs(q[0]);
-#pragma unroll
-            for (int a = 1; a < 3; a++) { const T e = half[a] - tabs(q[a]); if (e < dep) { dep = e; best = a; } }
-            const T sg = q[best] < T(0) ? T(-1) : T(1);
-            n = { -(sg * Rb.m[0][best]), -(sg * Rb.m[1][best]), -(sg * Rb.m[2][best]) };      // into the box
-        }
-        const unsigned long long mb = __ballot(inside);
-        if (inside) {
-            const int rank = contacts + __popcll(mb & ((1ull << lane) - 1ull));
-            if (rank < maxc) put_c(gpos, gnormal, gdepth, slot0 + rank, v, negate ? V3<T>{ -n.x, -n.y, -n.z } : n, dep);
-        }
-        contacts += __popcll(mb);
-    }
-    if (contacts > maxc) contacts = maxc;
-    for (int cn = 0; cn < 8 && contacts < maxc && P.hull_nf > 0; cn++) {
-        const V3<T> l = { (cn & 1) ? half[0] : -half[0], (cn & 2) ? half[1] : -half[1], (cn & 4) ? half[2] : -half[2] };
-        V3<T> cw = mulv(Rb, l);
-        cw.x += xb.x; cw.y += xb.y; cw.z += xb.z;
-        const V3<T> d = { cw.x - xh.x, cw.y - xh.y, cw.z - xh.z };
-        // a corner inside the hull is inside the hull's bounding sphere (slack for rounding): most corners of a floor-sized
-        // box are nowhere near it and skip the walk over the faces
-        if (d.x * d.x + d.y * d.y + d.z * d.z > hull_radius * hull_radius * T(1.0001)) continue;
-        V3<T> r;
-        r.x = fma_(Rh.m[2][0], d.z, fma_(Rh.m[1][0], d.y, Rh.m[0][0] * d.x));
-        r.y = fma_(Rh.m[2][1], d.z, fma_(Rh.m[1][1], d.y, Rh.m[0][1] * d.x));
-        r.z = fma_(Rh.m[2][2], d.z, fma_(Rh.m[1][2], d.y, Rh.m[0][2] * d.x));
-        T dep = Limits<T>::inf();
-        int fbest = 0x7fffffff;
-        bool neg = false;
-        for (int f = lane; f < P.hull_nf; f += 64) {
-            const T *pl = P.hull_planes + 4 * f;
-            const T e = pl[3] - dot(V3<T>{ pl[0], pl[1], pl[2] }, r);
-            if (e < T(0)) neg = true;
-            if (e < dep) { dep = e; fbest = f; }             // (f ascends within a lane: the first minimum is kept)
-        }
-        if (__ballot(neg) != 0ull) continue;                 // outside some face
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {                   // lexicographic (depth, face) minimum over the wave
-            const T od = __shfl_xor(dep, o, 64);
-            const int of = __shfl_xor(fbest, o, 64);
-            if (od < dep || (od == dep && of < fbest)) { dep = od; fbest = of; }
-        }
-        if (fbest == 0x7fffffff) continue;
-        if (lane == 0) {
-            const T *pl = P.hull_planes + 4 * fbest;
-            const V3<T> nw = mulv(Rh, V3<T>{ pl[0], pl[1], pl[2] });     // the hull's outward normal points into the box
-            put_c(gpos, gnormal, gdepth, slot0 + contacts, cw, negate ? V3<T>{ -nw.x, -nw.y, -nw.z } : nw, dep);
-        }
-        contacts++;
-    }
-    return contacts;
-}
-
-template <class T>
 __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S, const uint8_t *__restrict__ gtype,
                                                         const int32_t *__restrict__ inv, const int32_t *__restrict__ pairs,
                                                         const GridRec<T> *__restrict__ rec, StepParams<T> P, ExactCaps cap,
@@ -457,34 +389,9 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
             const BodyGeomX<T> H = geom_of<T>(S, gtype, i);
             if (e < cap.inv) {
                 // ---- hull against the ground plane
-                if (P.plane_on && P.hull_n > 0) {
-                    int contacts = 0;
-                    bool any_le = false, any_ge = false;
-                    for (int base = 0; base < P.hull_n; base += 64) {
-                        const int q = base + lane;
-                        bool below = false, le = false, ge = false;
-                        V3<T> v2 = { T(0), T(0), T(0) };
-                        T distance2 = T(0);
-                        if (q < P.hull_n) {
-                            v2 = mulv(H.R, V3<T>{ P.hull[3 * q], P.hull[3 * q + 1], P.hull[3 * q + 2] });
-                            v2.x += H.x.x; v2.y += H.x.y; v2.z += H.x.z;
-                            distance2 = dot(P.pn, v2) - P.pd;
-                            le = distance2 <= T(0);
-                            ge = distance2 >= T(0);
-                            below = le;
-                        }
-                        const unsigned long long mb = __ballot(below);
-                        any_le = any_le || (__ballot(le) != 0ull);
-                        any_ge = any_ge || (__ballot(ge) != 0ull);
-                        if (below) {
-                            const int rank = contacts + __popcll(mb & ((1ull << lane) - 1ull));
-                            if (rank < maxc) put_c(gpos, gnormal, gdepth, (size_t)8 * e + rank, v2, P.pn, -distance2);
-                        }
-                        contacts += __popcll(mb);
-                        if (contacts >= maxc && any_le && any_ge) break;
-                    }
-                    nc = (any_le && any_ge) ? (contacts < maxc ? contacts : maxc) : 0;
-                }
+                if (P.plane_on && P.hull_n > 0)
+                    nc = wave_convex_plane<T>(H.x, H.R, P, maxc, lane, [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) {
+                        put_c(gpos, gnormal, gdepth, (size_t)8 * e + rank, p, nn, dep); });
             } else {
                 // ---- hull against static box s: dCollide(static box, hull); the joint is attached (0, body): reversed
                 const uint32_t s = (e - cap.inv) / cap.inv;
@@ -494,8 +401,9 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
                     M3<T> sR;
                     for (int a = 0; a < 3; a++) for (int c2 = 0; c2 < 3; c2++) sR.m[a][c2] = sb[SBOX_R + 3 * a + c2];
                     const T sside[3] = { sb[SBOX_SIDE], sb[SBOX_SIDE + 1], sb[SBOX_SIDE + 2] };
-                    nc = wave_box_convex<T>(sx, sR, sside, H.x, H.R, H.side[0], P, maxc, true, lane, gpos, gnormal, gdepth,
-                                            cap.static_slot0() + (size_t)8 * (e - cap.inv));
+                    const size_t slot0 = cap.static_slot0() + (size_t)8 * (e - cap.inv);
+                    nc = wave_box_convex<T>(sx, sR, sside, H.x, H.R, H.side[0], P, maxc, true, lane,
+                                            [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) { put_c(gpos, gnormal, gdepth, slot0 + rank, p, nn, dep); });
                 }
             }
         } else {
@@ -508,9 +416,10 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
                 // (box i, hull j): the collider's own order, normal into i.  (hull i, box j): dCollide swaps and flips.
                 const BodyGeomX<T> Bx = geom_of<T>(S, gtype, gi == GEOM_BOX ? i : j);
                 const BodyGeomX<T> H = geom_of<T>(S, gtype, gi == GEOM_BOX ? j : i);
+                const size_t slot0 = cap.pair_slot0() + (size_t)8 * p;
                 if (P.hull_n > 0)
-                    nc = wave_box_convex<T>(Bx.x, Bx.R, Bx.side, H.x, H.R, H.side[0], P, maxc, gi != GEOM_BOX, lane, gpos, gnormal, gdepth,
-                                            cap.pair_slot0() + (size_t)8 * p);
+                    nc = wave_box_convex<T>(Bx.x, Bx.R, Bx.side, H.x, H.R, H.side[0], P, maxc, gi != GEOM_BOX, lane,
+                                            [&](int rank, const V3<T> &pp, const V3<T> &nn, T dep) { put_c(gpos, gnormal, gdepth, slot0 + rank, pp, nn, dep); });
             }       // (pairs of classes without a collider never reach the pair list: for_each_partner)
         }
         if (lane == 0) cc[e] = (uint32_t)nc;

@@ -45,7 +45,26 @@ template <class T> GridParams<T> grid_of(dmxBatch *b)
     G.flags = (uint32_t *)b->bp_flags.p;
     G.rec = (GridRec<T> *)b->ex_aabb.p;     // null until an exact tick has asked for it
     G.sbox = (const T *)b->sbox.p; G.n_static = b->n_static;
+    G.static_fast = b->static_fast ? 1 : 0; G.plane_on = b->plane_on;
     return G;
+}
+
+// Pinned, device-visible host records (the chunk flags, the exact tick's count record).  Zeroed: a recycled pinned page may
+// hold a previous owner's record, and await_host_record trusts the sequence number it finds there.
+int alloc_host_record(void **p, size_t bytes)
+{
+    HIP_TRY(hipHostMalloc(p, bytes, hipHostMallocCoherent | hipHostMallocMapped));
+    memset(*p, 0, bytes);
+    return DMX_OK;
+}
+// Sequence numbers of the small-scene kernels' host records: process-wide and never 0, so no record left in memory by an
+// earlier batch -- or by this batch's zeroed allocation -- can be taken for the one a launch is about to write.
+uint32_t next_record_seq()
+{
+    static std::atomic<uint32_t> g{ 0 };
+    uint32_t s;
+    do { s = g.fetch_add(1u, std::memory_order_relaxed) + 1u; } while (s == 0u);
+    return s;
 }
 
 int read_flags(dmxBatch *b)
@@ -85,7 +104,7 @@ int ensure_buffers(dmxBatch *b)
     if ((rc = dmx_ensure_dev(b->bp_items, tbl * (size_t)b->bp_cap * sizeof(int32_t))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->bp_flags, 64)) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->bp_inpair, (size_t)b->stride)) != DMX_OK) return rc;
-    if (!b->bp_flags_host) HIP_TRY(hipHostMalloc((void **)&b->bp_flags_host, 64, hipHostMallocCoherent | hipHostMallocMapped));
+    if (!b->bp_flags_host && (rc = alloc_host_record((void **)&b->bp_flags_host, 64)) != DMX_OK) return rc;
     return DMX_OK;
 }
 
@@ -208,6 +227,9 @@ template <class T> int fused_tick(dmxBatch *b, double h, bool check, const uint8
     P.bp_check = check ? BPC_ALL : 0;
     P.bp_flags = (uint32_t *)b->bp_flags.p;
     P.skip = skip;
+    // static fused path: the launch for bodies with 5..8 contacts rides along once such a body has been met; a checked tick
+    // that meets one without it says so (BPF_NEED8) and its chunk is run again, an unchecked tick cannot be
+    P.have8 = (b->static_need8 || !check) ? 1 : 0;
     int rc = launch_fast<T>(b, P, b->ext_pending);
     if (rc != DMX_OK) return rc;
     b->ext_pending = false;
@@ -220,7 +242,7 @@ template <class T> int fused_tick(dmxBatch *b, double h, bool check, const uint8
 template <class T> int fused_run(dmxBatch *b, double h, int n, bool ends_only, bool check_first, bool check_last)
 {
     int rc;
-    const int per = (b->plane_on || b->ext_pending) ? 1 : std::max(1, b->ticks_per_launch);
+    const int per = (b->plane_on || b->n_static > 0 || b->ext_pending) ? 1 : std::max(1, b->ticks_per_launch);
     for (int s = 0; s < n; s += per) {
         const int kk = std::min(per, n - s);
         if (kk == 1) {
@@ -270,10 +292,11 @@ bool exs_timing_enabled()
     return v;
 }
 
-// device-visible addresses of the pinned host records the small-scene kernels write themselves
 // Wait for the small-scene kernels' host record: watch for the sequence number (the record's last word, written after a
 // system-scope fence) rather than synchronise the stream -- the device keeps running, the host has its numbers a
 // microsecond or two after they were written.  Falls back to the stream after 2 ms (a faulted kernel never writes).
+// NOTE for callers: on return the record is complete but the STREAM MAY STILL BE BUSY (the kernel that wrote the record has
+// not necessarily retired); whatever follows must be stream-ordered behind it or synchronise itself.
 int await_host_record(dmxBatch *b, uint32_t seq)
 {
     static const bool spin = [] { const char *e = getenv("DMX_RECORD_SPIN"); return !(e && atoi(e) == 0); }();
@@ -282,6 +305,7 @@ int await_host_record(dmxBatch *b, uint32_t seq)
         const auto t0 = std::chrono::steady_clock::now();
         for (int it = 0;; it++) {
             if (*word == seq) { std::atomic_thread_fence(std::memory_order_acquire); return DMX_OK; }
+            __builtin_ia32_pause();
             if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
         }
     }
@@ -289,6 +313,7 @@ int await_host_record(dmxBatch *b, uint32_t seq)
     return *word == seq ? DMX_OK : DMX_EHIP;
 }
 
+// device-visible addresses of the pinned host records the small-scene kernels write themselves
 int host_record_pointers(dmxBatch *b, ExactCounts **counts_dev, uint32_t **flags_dev)
 {
     if (!b->ex_counts_dev) {
@@ -369,13 +394,13 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     int rc;
     snapshot_drop(b);           // exact ticks run in place and are never rolled back
     std::unique_ptr<DmxPhase> ph(new DmxPhase(b, 0));
-    if (!b->ex_counts_host) HIP_TRY(hipHostMalloc((void **)&b->ex_counts_host, sizeof(ExactCounts), hipHostMallocCoherent | hipHostMallocMapped));
+    if (!b->ex_counts_host && (rc = alloc_host_record(&b->ex_counts_host, sizeof(ExactCounts))) != DMX_OK) return rc;
     const StepParams<T> P = dmx_make_params<T>(b, h);
     const int rpc = b->mu > 0 ? 3 : 1;
     ExactBuffers<T> B;
     ExactCounts &C = *(ExactCounts *)b->ex_counts_host;
     if (b->ex_cap_pairs == 0) { b->ex_cap_pairs = 1024; b->ex_cap_rows = 16384; }
-    if (!b->bp_flags_host) HIP_TRY(hipHostMalloc((void **)&b->bp_flags_host, 64, hipHostMallocCoherent | hipHostMallocMapped));
+    if (!b->bp_flags_host && (rc = alloc_host_record((void **)&b->bp_flags_host, 64)) != DMX_OK) return rc;
     bool small = false;
     for (int attempt = 0;; attempt++) {
         if (attempt > 40) return DMX_ECAPACITY;
@@ -392,7 +417,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
             ExactCounts *hc; uint32_t *hf;
             if ((rc = host_record_pointers(b, &hc, &hf)) != DMX_OK) return rc;
             const GridParams<T> G = grid_of<T>(b);
-            const uint32_t seq = ++b->ex_seq;
+            const uint32_t seq = next_record_seq();
             HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, G, B, cap, nullptr, nullptr, 0u, b->stream));
             HIP_TRY(launch_exact_small_group<T>((const T *)b->slab, b->gtype, G, P, B, cap, rpc, big_island_rows_general(), b->diag_isl,
                                                 hc, hf, seq, b->stream));
@@ -495,6 +520,25 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     return DMX_OK;
 }
 
+// What the static fused path reported about the chunk just rolled back.  BPF_NEED8: a body has 5..8 contacts with static
+// geometry and the launch for those was left out -- from now on it rides along, and the chunk can simply run again.
+// BPF_NOFAST: a body has more contacts than the fused path's buffer holds -- the exact path steps the chunk, and the next
+// 1, 2, 4 .. 64 chunks too (a body wedged in a corner stays there; a clean fast chunk walks the hold back down).
+// Returns true if either was up.
+bool static_flags_say(dmxBatch *b, bool *go_exact)
+{
+    const uint32_t *f = b->bp_flags_host;
+    if (f[BPF_NOFAST]) {
+        b->static_need8 = b->static_need8 || f[BPF_NEED8];
+        b->nofast_hold = 1 << b->nofast_level;
+        if (b->nofast_level < 6) b->nofast_level++;
+        *go_exact = true;
+        return true;
+    }
+    if (f[BPF_NEED8] && !b->static_need8) { b->static_need8 = true; *go_exact = false; return true; }
+    return false;
+}
+
 // The collision-checked loop, synchronous form: every chunk's flag is read (one stream synchronisation) before the
 // call returns.  The lazy form below defers that read; this one is what it falls back to after a violation.
 template <class T> int step_sync_t(dmxBatch *b, double h, int nsteps)
@@ -514,14 +558,15 @@ template <class T> int step_sync_t(dmxBatch *b, double h, int nsteps)
         if (!b->bp_valid && (rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
         if (b->bp_chunk < kChunk) b->bp_chunk = kChunk;
         int k = std::min(remaining, b->bp_chunk);
-        bool careful = b->bp_crowded > 0 || b->bp_skip_fast;
+        bool careful = b->bp_crowded > 0 || b->bp_skip_fast || b->nofast_hold > 0;
         b->bp_skip_fast = false;
+        if (b->nofast_hold > 0) b->nofast_hold--;
         // fast chunk: snapshot, k fused ticks with the safe-zone check riding along, one flag read.  If a body
         // left its zone the chunk is rolled back; the first retry only refreshes the zones (a body that has
         // drifted since the last build usually fits again), the second replays the chunk exactly.
         for (int attempt = 0; !careful; attempt++) {
             if ((rc = snapshot_begin<T>(b)) != DMX_OK) return rc;
-            HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, 2 * sizeof(uint32_t), b->stream));
+            HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, BPF_CHUNK_FLAGS * sizeof(uint32_t), b->stream));
             // Without a ground plane and with gravity along y nothing acts horizontally: every body's (x,z) moves on a
             // straight line during the chunk, and a disc is convex, so a body inside its zone at the chunk's first and
             // last tick is inside it at every tick between -- two checks per chunk prove all of them.
@@ -535,10 +580,16 @@ template <class T> int step_sync_t(dmxBatch *b, double h, int nsteps)
                 b->last_mixed = false;
                 if (b->bp_flags_host[BPF_WARN]) b->bp_valid = false;     // zones are getting used up: refresh before the next chunk
                 else if (k == b->bp_chunk) b->bp_chunk = std::min(2 * b->bp_chunk, kChunkMax);   // quiet scene: snapshot and read the flag less often
+                if (b->nofast_level > 0) b->nofast_level--;
                 break;
             }
             if ((rc = snapshot_restore<T>(b)) != DMX_OK) return rc;
             b->stat_rollbacks++;
+            if (static_flags_say(b, &careful)) {
+                if (careful) { b->bp_chunk = kChunk; k = std::min(k, kChunk); }
+                else attempt--;                 // the same chunk again, now with the launch for 5..8-contact bodies
+                continue;
+            }
             b->bp_chunk = kChunk;
             const bool same_again = b->bp_fresh && k <= kChunk;    // zones built at these very poses, chunk no longer than the retry's:
             k = std::min(k, kChunk);            // the retry (and an exact replay, if it comes to that) covers a short chunk
@@ -557,7 +608,7 @@ template <class T> int step_sync_t(dmxBatch *b, double h, int nsteps)
         b->bp_valid = false;           // poses moved: new safe zones before the next fast chunk
         remaining -= k;
     }
-    b->stepped_with_plane = b->plane_on != 0 || b->last_mixed;
+    b->stepped_with_plane = dmx_fused_contacts(b) || b->last_mixed;
     b->last_islands = false;
     return DMX_OK;
 }
@@ -587,14 +638,20 @@ template <class T> int close_chunk_t(dmxBatch *b)
         b->last_mixed = false;
         if (b->bp_flags_host[BPF_WARN]) b->bp_valid = false;
         else if (oc.ticks >= b->bp_chunk) b->bp_chunk = std::min(2 * b->bp_chunk, kChunkMax);
+        if (b->nofast_level > 0) b->nofast_level--;
         oc.segs.clear();
         return DMX_OK;
     }
     if ((rc = snapshot_restore<T>(b)) != DMX_OK) return rc;
     b->stat_rollbacks++;
+    bool go_exact = false;
+    if (static_flags_say(b, &go_exact)) {
+        if (go_exact) b->bp_chunk = kChunk;      // (nofast_hold sends the replay the exact way; otherwise it runs fast again as it was)
+    } else {
     b->bp_chunk = kChunk;
     if (b->bp_fresh && oc.ticks <= kChunk) b->bp_skip_fast = true;     // same poses, same zones: the replay's first chunk goes the exact way
     else b->bp_valid = false;            // fresh zones first: a body that has drifted since the last build usually fits again
+    }
     std::vector<std::pair<double, int>> segs;
     segs.swap(oc.segs);
     for (auto &sg : segs)
@@ -611,10 +668,10 @@ template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
         if (!oc.open) {
             if (b->ext_pending || !b->lazy_chunks) return step_sync_t<T>(b, h, remaining);
             if (!b->bp_valid && (rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
-            if (b->bp_crowded > 0) return step_sync_t<T>(b, h, remaining);
+            if (b->bp_crowded > 0 || b->nofast_hold > 0) return step_sync_t<T>(b, h, remaining);
             if (b->bp_chunk < kChunk) b->bp_chunk = kChunk;
             if ((rc = snapshot_begin<T>(b)) != DMX_OK) return rc;
-            HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, 2 * sizeof(uint32_t), b->stream));
+            HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, BPF_CHUNK_FLAGS * sizeof(uint32_t), b->stream));
             oc.open = true; oc.ticks = 0; oc.budget = b->bp_chunk; oc.last_checked = false;
             oc.ballistic = !b->plane_on && b->n_static == 0 && b->g[0] == 0.0 && b->g[2] == 0.0;
             oc.segs.clear();
@@ -623,7 +680,7 @@ template <class T> int step_collide_t(dmxBatch *b, double h, int nsteps)
         const bool closes = oc.ticks + k >= oc.budget;         // the chunk's last tick is in this run: test it there
         if ((rc = fused_run<T>(b, h, k, oc.ballistic, oc.ticks == 0, closes)) != DMX_OK) return rc;
         oc.last_checked = closes;
-        b->stepped_with_plane = b->plane_on != 0;
+        b->stepped_with_plane = dmx_fused_contacts(b);
         b->last_islands = false;
         b->last_mixed = false;
         b->last_pairs = 0;
@@ -642,10 +699,11 @@ template <class T> int chunk_begin_t(dmxBatch *b, int *exact_only, int *ballisti
     int rc;
     if ((rc = ensure_buffers(b)) != DMX_OK) return rc;
     if (!b->bp_valid && (rc = build_safe_zones<T>(b)) != DMX_OK) return rc;
-    *exact_only = (b->bp_crowded > 0 || b->ext_pending) ? 1 : 0;
+    *exact_only = (b->bp_crowded > 0 || b->ext_pending || b->nofast_hold > 0) ? 1 : 0;
+    if (b->nofast_hold > 0) b->nofast_hold--;
     *ballistic = (!b->plane_on && b->n_static == 0 && b->g[0] == 0.0 && b->g[2] == 0.0) ? 1 : 0;
     if ((rc = snapshot_begin<T>(b)) != DMX_OK) return rc;
-    HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, 2 * sizeof(uint32_t), b->stream));
+    HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, BPF_CHUNK_FLAGS * sizeof(uint32_t), b->stream));
     return DMX_OK;
 }
 
@@ -671,28 +729,34 @@ template <class T> int find_pairs_t(dmxBatch *b)
 {
     int rc;
     if ((rc = ensure_buffers(b)) != DMX_OK) return rc;
-    if (!b->ex_counts_host) HIP_TRY(hipHostMalloc((void **)&b->ex_counts_host, sizeof(ExactCounts), hipHostMallocCoherent | hipHostMallocMapped));
+    if (!b->ex_counts_host && (rc = alloc_host_record(&b->ex_counts_host, sizeof(ExactCounts))) != DMX_OK) return rc;
     ExactBuffers<T> B;
     ExactCounts &C = *(ExactCounts *)b->ex_counts_host;
     if (b->ex_cap_pairs == 0) { b->ex_cap_pairs = 1024; b->ex_cap_rows = 16384; }
     for (int attempt = 0;; attempt++) {
         if (attempt > 40) return DMX_ECAPACITY;
+
         ExactCaps cap;
         cap.pairs = b->ex_cap_pairs;
         cap.inv = (uint32_t)std::min<int64_t>(2 * (int64_t)cap.pairs, b->n_active);
         cap.rows = b->ex_cap_rows;
         cap.nstatic = (uint32_t)b->n_static;
         if ((rc = ensure_exact_buffers<T>(b, cap, B)) != DMX_OK) return rc;
+        // dmxBatchFindPairs' contract (include/dmx_batch.h): EVERY body whose AABB overlaps a static box is involved -- the
+        // caller (dSpaceCollide of the ODE API) hands those pairs to the user's callback itself.  (After the buffers: the
+        // grid's per-body records are one of them.)
+        GridParams<T> Gfp = grid_of<T>(b);
+        Gfp.static_fast = 0;
         bool staged = false;
         uint32_t small_seq = 0;
         if (use_small_exact(b, cap, false)) {
             ExactCounts *hc; uint32_t *hf;
             if ((rc = host_record_pointers(b, &hc, &hf)) != DMX_OK) return rc;
-            small_seq = ++b->ex_seq;
-            HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, grid_of<T>(b), B, cap, hc, hf, small_seq, b->stream));
+            small_seq = next_record_seq();
+            HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, Gfp, B, cap, hc, hf, small_seq, b->stream));
         } else {
             if ((rc = fill_grid<T>(b, B.counts, sizeof(ExactCounts))) != DMX_OK) return rc;
-            HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), B, cap, b->stream));
+            HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, Gfp, B, cap, b->stream));
             HIP_TRY(hipMemcpyAsync(&C, B.counts, sizeof(ExactCounts), hipMemcpyDeviceToHost, b->stream));
             staged = true;
         }
@@ -746,7 +810,7 @@ int dmx_chunk_tick(dmxBatch *b, double h, int check)
 {
     if (!b->bp_flags.p) return DMX_EINVAL;          // no chunk begun
     const int rc = b->precision == DMX_F32 ? fused_tick<float>(b, h, check != 0, nullptr) : fused_tick<double>(b, h, check != 0, nullptr);
-    b->stepped_with_plane = b->plane_on != 0;
+    b->stepped_with_plane = dmx_fused_contacts(b);
     b->last_islands = false;
     b->last_mixed = false;
     b->last_pairs = 0;
@@ -758,7 +822,7 @@ int dmx_chunk_ticks(dmxBatch *b, double h, int n, int check_first, int check_las
     if (!b->bp_flags.p) return DMX_EINVAL;          // no chunk begun
     const int rc = b->precision == DMX_F32 ? fused_run<float>(b, h, n, true, check_first != 0, check_last != 0)
                                            : fused_run<double>(b, h, n, true, check_first != 0, check_last != 0);
-    b->stepped_with_plane = b->plane_on != 0;
+    b->stepped_with_plane = dmx_fused_contacts(b);
     b->last_islands = false;
     b->last_mixed = false;
     b->last_pairs = 0;
@@ -778,6 +842,7 @@ int dmx_chunk_end(dmxBatch *b, int *violated, int *warn)
     if (rc != DMX_OK) return rc;
     *violated = b->bp_flags_host[BPF_VIOLATION] ? 1 : 0;
     *warn = b->bp_flags_host[BPF_WARN] ? 1 : 0;
+    if (*violated) { bool go_exact; (void)static_flags_say(b, &go_exact); }     // (the caller's replay finds need8 / the hold set)
     return DMX_OK;
 }
 
@@ -801,7 +866,7 @@ int dmx_exact_tick(dmxBatch *b, double h)
     if (rc != DMX_OK) return rc;
     rc = b->precision == DMX_F32 ? careful_tick<float>(b, h) : careful_tick<double>(b, h);
     b->bp_valid = false;
-    b->stepped_with_plane = b->plane_on != 0 || b->last_mixed;
+    b->stepped_with_plane = dmx_fused_contacts(b) || b->last_mixed;
     b->last_islands = false;
     return rc;
 }

@@ -117,7 +117,20 @@ template <class T> struct StepParams {
     // static (body-less) box geoms, AddBodyMap main.c:735-761: SBOX_REALS reals each (see SBOX_*); the safe-zone test of the
     // fused kernels also asks that a body's bounding sphere stays clear of every static box's AABB
     const T *sbox; int n_static;
+    // the fused path of bodies at static boxes (np_static / np_convex_static -> step_contacts, dmx_kernels.hip): every body's
+    // contacts with the ground plane and the static boxes, creation order, canonical form (normal into the body), in tiles
+    // like the slab's (sc_ix); scount[i] = their number, SC_MAXC + 1 = more than the buffer holds.  have8: the launch
+    // for bodies with 5..8 contacts follows the one for 0..4 (otherwise the latter reports BPF_NEED8 when it meets one)
+    T *sbuf; int *scount; int have8;
 };
+// contact buffer of the static fused path: SC_MAXC contacts of SC_REALS reals per body, field f of contact k of body i at
+// sbuf[sc_ix(k, f, i)] -- tiles of 64 bodies, so a wavefront's access to one field of one contact is one contiguous run
+constexpr int SC_MAXC = 8;
+enum : int { SC_POS = 0, SC_NORMAL = 3, SC_DEPTH = 6, SC_REALS = 7 };
+__host__ __device__ __forceinline__ int64_t sc_ix(int k, int f, int64_t i)
+{
+    return ((i >> SLAB_TILE_LOG2) * (int64_t)(SC_MAXC * SC_REALS) + (int64_t)(k * SC_REALS + f)) * SLAB_TILE + (i & (SLAB_TILE - 1));
+}
 // islands of up to this many rows: one wavefront of solve_island_wg, rows in registers, only row_level of the schedule read
 constexpr int WAVE_ISLAND_ROWS = 256;
 // layout of one static box in StepParams::sbox / GridParams::sbox
@@ -127,7 +140,11 @@ constexpr int MAX_STATIC_BOXES = 64;
 // StepParams::bp_check for a launch of `ticks` ticks: test at every tick, or only at the launch's first / last tick
 enum : int { BPC_ALL = 1, BPC_FIRST = 2, BPC_LAST = 4 };
 // hashed (x,z)-column grid of the body-body broadphase
-enum : int { BPF_OVERFLOW = 0, BPF_CROWDED = 1, BPF_NPAIRS = 2, BPF_VIOLATION = 3, BPF_WARN = 4, BPF_COUNT = 5 };
+// (BPF_VIOLATION .. BPF_NEED8 are the chunk's flags, cleared together when a chunk begins.  BPF_NOFAST: a body has more contacts
+// with static geometry than the fused path's buffer holds -- only the exact path can step it; BPF_NEED8: a body has 5..8 and
+// the launch for those was not enqueued.  Both come with BPF_VIOLATION.)
+enum : int { BPF_OVERFLOW = 0, BPF_CROWDED = 1, BPF_NPAIRS = 2, BPF_VIOLATION = 3, BPF_WARN = 4, BPF_NOFAST = 5, BPF_NEED8 = 6, BPF_COUNT = 7 };
+constexpr int BPF_CHUNK_FLAGS = 4;      // VIOLATION, WARN, NOFAST, NEED8
 // per body, left by grid_insert for the exact pair search: its column and its AABB in one aligned record (32 B f32, 64 B f64),
 // so a candidate costs one access, not eight
 template <class T> struct alignas(16) GridRec { T lo[3], hi[3]; int32_t ix, iz; };
@@ -144,6 +161,10 @@ template <class T> struct GridParams {
     uint32_t *flags;       // [BPF_COUNT]
     GridRec<T> *rec;       // optional [per slot]: bp_insert leaves every body's column and AABB here for the exact pair search
     const T *sbox; int n_static;   // static boxes (StepParams::sbox)
+    // 1: bodies at static boxes take the fused path (step_contacts) unless their contacts might not fit its buffer -- AABB
+    // over two or more static boxes, or over one with a ground plane present: only those are "involved" in an exact tick,
+    // and being near a static box does not make a body crowded.  0 (DMX_STATIC_FAST=0): every body at a static box is.
+    int static_fast, plane_on;
 };
 
 struct StepDiag {
@@ -175,6 +196,10 @@ hipError_t launch_bp_safe_zone(T *S, const uint8_t *gtype, int64_t stride, int64
 // ground-plane contacts of the convex bodies among [0, n): one wavefront per body walks the hull (dCollideConvexPlane)
 template <class T>
 hipError_t launch_np_convex_plane(const T *S, const uint8_t *gtype, int64_t n, const StepParams<T> &P, hipStream_t st);
+// contacts of bodies [0, n) with the ground plane and the static boxes -> P.sbuf / P.scount (boxes and spheres one lane each,
+// convex hulls one wavefront each); bodies masked by P.skip are left alone
+template <class T>
+hipError_t launch_np_static(const T *S, const uint8_t *gtype, int64_t n, const StepParams<T> &P, hipStream_t st);
 template <class T>
 hipError_t launch_pack_transforms(const T *S, int64_t stride, int64_t first, int64_t count, T *out, hipStream_t st);
 template <class T>

@@ -457,6 +457,222 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *S, T *So, const uint8
 }
 
 // ---------------------------------------------------------------------------------------------
+// step_contacts: fused tick for single-body islands at STATIC GEOMETRY -- the ground plane and the static boxes
+// (AddBodyMap, main.c:735-761; the reference's floor is one, main.c:115).  The contacts come from np_static /
+// np_convex_static (dmx_narrow.hip) in joint creation order and canonical form; here: rows (normal + 2 friction per
+// contact, every contact with its own normal) -> SOR-PGS sweeps -> velocity update -> integrate, one lane per body, rows in
+// registers, the arithmetic of step_plane / solve_singles operation for operation (same bits as the oracle).
+// Two instantiations share a tick: NC = 4 steps the bodies with 0..4 contacts (free bodies included), NC = 8 -- launched
+// behind it when the batch may have such bodies (P.have8) -- those with 5..8; each leaves the other's lanes alone.  A body
+// with more contacts than the buffer holds raises BPF_NOFAST (the exact path steps it: the chunk is rolled back).
+// Algorithmic traffic per body-step: 13 + 4 read, 13 written, + 7 reals per contact written and read.
+// ---------------------------------------------------------------------------------------------
+template <class T, bool EXT, int MINW, int NC>
+__global__ __launch_bounds__(256, MINW) void step_contacts(T *S, T *So, int64_t n, StepParams<T> P, StepDiag *__restrict__ diag)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int my_contacts = 0;
+    double my_resid = 0.0;
+    if (P.bp_check && P.bp_flags[BPF_VIOLATION] != 0u) return;      // the chunk will be rolled back whole
+    const int cnt = (i < n && !(P.skip != nullptr && P.skip[i])) ? P.scount[i] : -1;
+    // (a body with more contacts than the buffer holds is flagged, and stepped with the first SC_MAXC of them: what a caller
+    //  who has switched the collision proof off -- nobody reads the flag then -- gets, and says so in include/dmx_batch.h)
+    const bool mine = NC == 4 ? (cnt >= 0 && cnt <= 4) : (cnt > 4);
+    if (NC == 4) {
+        const unsigned long long over = __ballot(cnt > SC_MAXC), need8 = __ballot(cnt > 4 && cnt <= SC_MAXC && !P.have8);
+        if ((over | need8) != 0ull && (threadIdx.x & 63) == 0 && P.bp_flags != nullptr) {
+            if (over != 0ull) atomicOr(&P.bp_flags[BPF_NOFAST], 1u);
+            if (need8 != 0ull) atomicOr(&P.bp_flags[BPF_NEED8], 1u);
+            atomicOr(&P.bp_flags[BPF_VIOLATION], 1u);
+        }
+    } else if (__ballot(mine) == 0ull) return;                      // nobody here has 5..8 contacts
+    if (mine) {
+        V3<T> x = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
+        if (P.bp_check) report_zone(zone_state(x.x - S[slab_ix(C_BPX, i)], x.z - S[slab_ix(C_BPZ, i)], S[slab_ix(C_BPSAFE, i)]), P.bp_flags);
+        Q4<T> q = { S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)],
+                    S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] };
+        V3<T> v = { S[slab_ix(C_LVEL + 0, i)], S[slab_ix(C_LVEL + 1, i)], S[slab_ix(C_LVEL + 2, i)] };
+        V3<T> w = { S[slab_ix(C_AVEL + 0, i)], S[slab_ix(C_AVEL + 1, i)], S[slab_ix(C_AVEL + 2, i)] };
+        const T mass = S[slab_ix(C_MASS, i)];
+        const V3<T> Ib = { S[slab_ix(C_INERTIA + 0, i)], S[slab_ix(C_INERTIA + 1, i)],
+                           S[slab_ix(C_INERTIA + 2, i)] };
+        V3<T> facc = { T(0), T(0), T(0) }, tacc = { T(0), T(0), T(0) };
+        if (EXT) {
+            facc = { S[slab_ix(C_FORCE + 0, i)], S[slab_ix(C_FORCE + 1, i)], S[slab_ix(C_FORCE + 2, i)] };
+            tacc = { S[slab_ix(C_TORQUE + 0, i)], S[slab_ix(C_TORQUE + 1, i)], S[slab_ix(C_TORQUE + 2, i)] };
+        }
+
+        const T h = P.h;
+        const M3<T> R = quat_to_R(q);
+        const T invMass = T(1) / mass;
+        const V3<T> invIb = { T(1) / Ib.x, T(1) / Ib.y, T(1) / Ib.z };
+        facc.x = fma_(mass, P.g.x, facc.x); facc.y = fma_(mass, P.g.y, facc.y); facc.z = fma_(mass, P.g.z, facc.z);
+        const M3<T> invIw = rotate_diag(R, invIb);
+        if (P.gyro != 0) {
+            const M3<T> Iw = rotate_diag(R, Ib);
+            add_gyro_torque(tacc, Iw, w, h, P.gyro);
+        }
+        const int nc = cnt > SC_MAXC ? SC_MAXC : cnt;
+        my_contacts = nc;
+        int ncu = 0;     // largest contact count among the wave's lanes stepped here (wave-uniform by construction)
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            if (__ballot(nc > k) != 0ull) ncu = k + 1;
+
+        if (ncu > 0) {
+            constexpr int MAXR = 3 * NC;
+            const int rpc = P.mu > 0 ? 3 : 1;
+            const T hinv = T(1) / h;
+            // v/h + M^-1 f
+            const V3<T> tl = { fma_(facc.x, invMass, v.x * hinv), fma_(facc.y, invMass, v.y * hinv),
+                               fma_(facc.z, invMass, v.z * hinv) };
+            V3<T> ta = mulv(invIw, tacc);
+            ta.x = fma_(w.x, hinv, ta.x); ta.y = fma_(w.y, hinv, ta.y); ta.z = fma_(w.z, hinv, ta.z);
+            const T cfm = P.cfm * hinv;
+            T rhs[MAXR], adcfm[MAXR], lam[MAXR];
+            const T lo_f = -P.mu, hi_f = P.mu, hi_n = Limits<T>::inf();
+            V3<T> Ja[MAXR], iMa[MAXR], Jl[MAXR], iMl[MAXR];      // J (angular, linear) times Ad, as J *= Ad leaves it; M^-1 J^T
+#pragma unroll
+            for (int r = 0; r < MAXR; r++) {      // rows of absent contacts stay zero
+                rhs[r] = adcfm[r] = lam[r] = T(0);
+                Ja[r] = { T(0), T(0), T(0) }; iMa[r] = { T(0), T(0), T(0) }; Jl[r] = { T(0), T(0), T(0) }; iMl[r] = { T(0), T(0), T(0) };
+            }
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                if (k < ncu) {                    // (scalar branch; lanes with fewer contacts keep zero rows)
+                    if (k < nc) {
+                        const V3<T> cp = { P.sbuf[sc_ix(k, SC_POS + 0, i)], P.sbuf[sc_ix(k, SC_POS + 1, i)], P.sbuf[sc_ix(k, SC_POS + 2, i)] };
+                        V3<T> dir[3];
+                        dir[0] = { P.sbuf[sc_ix(k, SC_NORMAL + 0, i)], P.sbuf[sc_ix(k, SC_NORMAL + 1, i)], P.sbuf[sc_ix(k, SC_NORMAL + 2, i)] };
+                        dir[1] = dir[2] = { T(0), T(0), T(0) };
+                        if (rpc == 3) plane_space(dir[0], dir[1], dir[2]);
+                        const V3<T> c1 = { cp.x - x.x, cp.y - x.y, cp.z - x.z };
+#pragma unroll
+                        for (int dnum = 0; dnum < 3; dnum++) {
+                            const int r = 3 * k + dnum;
+                            if (dnum < rpc) {
+                                const V3<T> ja = cross(c1, dir[dnum]);
+                                T c = T(0);
+                                if (dnum == 0) {
+                                    T depth = P.sbuf[sc_ix(k, SC_DEPTH, i)];
+                                    if (depth < 0) depth = 0;
+                                    c = (hinv * P.erp) * depth;
+                                    if (P.surf_mode & SURF_BOUNCE) {
+                                        const T outgoing = dot(dir[0], v) + dot(ja, w);
+                                        if (P.bounce_vel >= 0 && (-outgoing) > P.bounce_vel) {
+                                            const T newc = -P.bounce * outgoing;
+                                            if (newc > c) c = newc;
+                                        }
+                                    }
+                                }
+                                T sum = dir[dnum].x * tl.x;
+                                sum = fma_(dir[dnum].y, tl.y, sum); sum = fma_(dir[dnum].z, tl.z, sum);
+                                sum = fma_(ja.x, ta.x, sum); sum = fma_(ja.y, ta.y, sum); sum = fma_(ja.z, ta.z, sum);
+                                const T b = fma_(c, hinv, -sum);
+                                const V3<T> iml = { invMass * dir[dnum].x, invMass * dir[dnum].y, invMass * dir[dnum].z };
+                                const V3<T> ima = mulv(invIw, ja);
+                                T s2 = iml.x * dir[dnum].x;
+                                s2 = fma_(iml.y, dir[dnum].y, s2); s2 = fma_(iml.z, dir[dnum].z, s2);
+                                s2 = fma_(ima.x, ja.x, s2); s2 = fma_(ima.y, ja.y, s2); s2 = fma_(ima.z, ja.z, s2);
+                                const T ad = P.sor_w / (s2 + cfm);
+                                Ja[r] = { ja.x * ad, ja.y * ad, ja.z * ad };
+                                Jl[r] = { dir[dnum].x * ad, dir[dnum].y * ad, dir[dnum].z * ad };
+                                iMa[r] = ima; iMl[r] = iml;
+                                rhs[r] = b * ad;
+                                adcfm[r] = ad * cfm;
+                            }
+                        }
+                    }
+                }
+            }
+
+            // ---- SOR-PGS: lambda = 0 start, rows in creation order; branch-free row update as in step_plane ----
+            V3<T> fl = { T(0), T(0), T(0) }, fa = { T(0), T(0), T(0) };
+            T rsum = T(0);
+            auto sweep = [&](auto FAST, auto LAST) {
+#pragma unroll
+                for (int k = 0; k < NC; k++) {
+                    if (k < ncu) {
+                        const bool act = decltype(FAST)::value ? true : (k < nc);
+#pragma unroll
+                        for (int dnum = 0; dnum < 3; dnum++) {
+                            const int r = 3 * k + dnum;
+                            if (dnum < rpc) {
+                                const T old = lam[r];
+                                T delta = fma_(-old, adcfm[r], rhs[r]);
+                                delta -= fma_(fa.z, Ja[r].z, fma_(fa.y, Ja[r].y, fma_(fa.x, Ja[r].x,
+                                         fma_(fl.z, Jl[r].z, fma_(fl.y, Jl[r].y, fl.x * Jl[r].x)))));
+                                const T nl = old + delta;
+                                T nlam = nl;
+                                if (dnum == 0 || !decltype(FAST)::value) {
+                                    const T lo = dnum == 0 ? T(0) : lo_f, hi = dnum == 0 ? hi_n : hi_f;
+                                    const bool below = nl < lo, above = nl > hi;
+                                    nlam = below ? lo : (above ? hi : nl);
+                                    delta = below ? lo - old : (above ? hi - old : delta);
+                                }
+                                if (!decltype(FAST)::value) {
+                                    delta = act ? delta : T(0);
+                                    nlam = act ? nlam : old;
+                                }
+                                lam[r] = nlam;
+                                fl.x = fma_(delta, iMl[r].x, fl.x); fl.y = fma_(delta, iMl[r].y, fl.y);
+                                fl.z = fma_(delta, iMl[r].z, fl.z);
+                                fa.x = fma_(delta, iMa[r].x, fa.x); fa.y = fma_(delta, iMa[r].y, fa.y);
+                                fa.z = fma_(delta, iMa[r].z, fa.z);
+                                if (decltype(LAST)::value) rsum += tabs(delta);
+                            }
+                        }
+                    }
+                }
+            };
+            using std::true_type;
+            using std::false_type;
+            const bool fast = (__ballot(nc != ncu) == 0ull) && !(P.mu < Limits<T>::inf());   // wave-uniform
+            if (fast) {
+                for (int it = 0; it + 1 < P.iters; it++) sweep(true_type{}, false_type{});
+                if (P.iters > 0) sweep(true_type{}, true_type{});
+            } else {
+                for (int it = 0; it + 1 < P.iters; it++) sweep(false_type{}, false_type{});
+                if (P.iters > 0) sweep(false_type{}, true_type{});
+            }
+            my_resid = (double)rsum;
+            if (nc > 0) {        // v += h * (M^-1 J^T lambda)
+                v.x = fma_(h, fl.x, v.x); v.y = fma_(h, fl.y, v.y); v.z = fma_(h, fl.z, v.z);
+                w.x = fma_(h, fa.x, w.x); w.y = fma_(h, fa.y, w.y); w.z = fma_(h, fa.z, w.z);
+            }
+        }
+
+        // ---- v += h M^-1 f_ext ; integrate ----------------------------------------------------
+        const T hm = h * invMass;
+        v.x = fma_(hm, facc.x, v.x); v.y = fma_(hm, facc.y, v.y); v.z = fma_(hm, facc.z, v.z);
+        tacc.x *= h; tacc.y *= h; tacc.z *= h;
+        const V3<T> dw = mulv(invIw, tacc);
+        w.x += dw.x; w.y += dw.y; w.z += dw.z;
+        x.x = fma_(h, v.x, x.x); x.y = fma_(h, v.y, x.y); x.z = fma_(h, v.z, x.z);
+        integrate_quat(q, w, h);
+        pack_boundary(P, i, x, q, v, w);
+
+        So[slab_ix(C_POS + 0, i)] = x.x; So[slab_ix(C_POS + 1, i)] = x.y; So[slab_ix(C_POS + 2, i)] = x.z;
+        So[slab_ix(C_QUAT + 0, i)] = q.w; So[slab_ix(C_QUAT + 1, i)] = q.x;
+        So[slab_ix(C_QUAT + 2, i)] = q.y; So[slab_ix(C_QUAT + 3, i)] = q.z;
+        So[slab_ix(C_LVEL + 0, i)] = v.x; So[slab_ix(C_LVEL + 1, i)] = v.y; So[slab_ix(C_LVEL + 2, i)] = v.z;
+        So[slab_ix(C_AVEL + 0, i)] = w.x; So[slab_ix(C_AVEL + 1, i)] = w.y; So[slab_ix(C_AVEL + 2, i)] = w.z;
+        if (EXT) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) S[slab_ix(C_FORCE + k, i)] = T(0);
+        }
+    }
+    // ---- diagnostics: one slot per wave; the NC = 4 launch writes it, the NC = 8 launch behind it adds its lanes' share
+    const int wc = wave_sum<int>(my_contacts);
+    const double wr = wave_sum<double>(my_resid);
+    if ((threadIdx.x & 63) == 0 && i < n) {
+        StepDiag *d = &diag[(blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6];
+        if (NC == 4) { d->contacts = (unsigned long long)wc; d->residual = wr; }
+        else { d->contacts += (unsigned long long)wc; d->residual += wr; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // pack_transforms: GetTransformMat (main.c:602-622) per body: column-major 4x4 from pos + R(q).
 // ---------------------------------------------------------------------------------------------
 template <class T>
@@ -602,7 +818,19 @@ template <class T>
 hipError_t launch_step(T *S, T *So, const uint8_t *gtype, int64_t stride, int64_t n, const StepParams<T> &P, bool ext,
                        StepDiag *diag, hipStream_t st)
 {
-    if (!P.plane_on) {
+    if (P.n_static > 0 && P.sbuf != nullptr) {
+        // bodies at static geometry: narrowphase against the plane and the static boxes, then the fused solve + integrate
+        const hipError_t e = launch_np_static<T>(S, gtype, n, P, st);
+        if (e != hipSuccess) return e;
+        const unsigned grid = blocks_for(n, 256);
+        if (ext) hipLaunchKernelGGL((step_contacts<T, true, 1, 4>), dim3(grid), dim3(256), 0, st, S, So, n, P, diag);
+        else if (sizeof(T) == 4) hipLaunchKernelGGL((step_contacts<T, false, 2, 4>), dim3(grid), dim3(256), 0, st, S, So, n, P, diag);
+        else hipLaunchKernelGGL((step_contacts<T, false, 1, 4>), dim3(grid), dim3(256), 0, st, S, So, n, P, diag);
+        if (P.have8) {
+            if (ext) hipLaunchKernelGGL((step_contacts<T, true, 1, 8>), dim3(grid), dim3(256), 0, st, S, So, n, P, diag);
+            else     hipLaunchKernelGGL((step_contacts<T, false, 1, 8>), dim3(grid), dim3(256), 0, st, S, So, n, P, diag);
+        }
+    } else if (!P.plane_on) {
         constexpr int VMAX = 16 / sizeof(T);
         // default: one body per lane.  On the tiled slab a wave's 17 loads already cover one contiguous run, so wider
         // per-lane loads buy nothing, and V = 1 keeps the kernel at 67 VGPRs (7 waves/SIMD): measured 21.1 / 22.2 / 22.4 us
