@@ -93,10 +93,21 @@ int dmxBatchSetPlane(dmxBatchID b, double a, double bb, double c, double d, int 
  * Every body collides with every static box (the category / collide bits the reference ends up with, main.c:724-725,
  * 751-752); static boxes do not link dynamics islands and static-static pairs are ignored.  Contacts are dCollide(static
  * geom, body geom) in creation order: ground plane, static boxes in order, then body pairs.  n = 0 removes them;
- * at most DMX_MAX_STATIC_BOXES.  Bodies near a static box are stepped by the exact path (pair search, narrowphase, island
- * solve); the fused kernels keep everyone else and test, per tick, that their bounding spheres stay clear of the boxes. */
+ * at most DMX_MAX_STATIC_BOXES.
+ * A body touching static geometry only (the ground plane, static boxes) is a dynamics island of its own; such bodies are
+ * stepped by a fused path -- narrowphase against the plane and the static boxes, then rows + 20 sweeps + integration in
+ * registers, one lane per body -- inside the same collision-proof chunks as free bodies (dmxBatchStep).  The path holds
+ * 8 contacts per body (the reference's MAX_CONTACTS for ONE geom pair, main.c:675): a body with more (wedged between the
+ * floor and two walls, say) sends its chunk through the exact path (pair search, narrowphase, island solve), which has no
+ * such limit; with the collision proof switched off (dmxBatchSetBodyCollisions(b, 0)) nobody can, and such a body is
+ * stepped with its first 8 contacts.  Same results as the exact path, bit for bit. */
 #define DMX_MAX_STATIC_BOXES 64
 int dmxBatchSetStaticBoxes(dmxBatchID b, int32_t n, const double *sides, const double *pos, const double *rot3x4);
+/* DMX_STATIC_FUSED (default; DMX_STATIC_FAST=0 in the environment picks the other): as described above.  DMX_STATIC_EXACT:
+ * every body whose bounding sphere reaches a static box goes through the exact path every tick (how round 2 did it; kept
+ * for A/B runs and for the tests that hold the two against each other). */
+enum { DMX_STATIC_EXACT = 0, DMX_STATIC_FUSED = 1 };
+int dmxBatchSetStaticPath(dmxBatchID b, int mode);
 
 /* ---- body data: replaces the AddBody loop (main.c:695-733) and the read-back loop (main.c:221-237) */
 int dmxBatchUpload(dmxBatchID b, int field, const void *host_aos, int64_t first, int64_t count);

@@ -8,8 +8,10 @@
  * contact rows, SOR, integration -- runs on the MI355X.  Each declaration
  * cites the reference call site it serves.
  *
- * Deviation: dWorldStep steps with QuickStep (SOR) semantics, not
- * the Dantzig LCP; both names are exported and behave identically.
+ * dWorldStep (main.c:213) solves every island's boxed LCP to the end -- the
+ * solution ODE's Dantzig solver reaches, by block principal pivoting on the
+ * device -- and dWorldQuickStep runs QuickStep's 20 SOR sweeps: the two names
+ * behave as ODE's two steppers do.
  * Errors: no call site checks a return value (main.c:94-98, 212-214); failures
  * print to stderr and return 0 / NULL, HIP failures abort like ODE's dError.
  */

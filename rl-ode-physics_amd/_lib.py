@@ -24,7 +24,7 @@ BATCH_SYMBOLS = [
     "dmxBatchChunkBegin", "dmxBatchChunkTick", "dmxBatchCheckZonesOnStream", "dmxBatchChunkEnd",
     "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream", "dmxBatchSetConvexHull", "dmxBatchChunkTicks", "dmxBatchSetTicksPerLaunch",
     "dmxBatchSetSnapshotMode", "dmxBatchSetStaticBoxes", "dmxBatchSetStepper", "dmxBatchSetConvexHullFaces",
-    "dmxBatchCollisionStatsEx", "dmxBatchFindPairs", "dmxBatchCrossPairs", "dmxBatchSetRowOrder", "dmxBatchSetExactPipeline",
+    "dmxBatchCollisionStatsEx", "dmxBatchFindPairs", "dmxBatchCrossPairs", "dmxBatchSetRowOrder", "dmxBatchSetExactPipeline", "dmxBatchSetStaticPath",
 ]
 
 _lib = None
@@ -104,6 +104,7 @@ def load():
     sig("dmxBatchSetTicksPerLaunch", I, P, I)
     sig("dmxBatchSetSnapshotMode", I, P, I)
     sig("dmxBatchSetExactPipeline", I, P, I)
+    sig("dmxBatchSetStaticPath", I, P, I)
     sig("dmxBatchSetStaticBoxes", I, P, C.c_int32, P, P, P)
     sig("dmxBatchSetStepper", I, P, I)
     sig("dmxBatchSetConvexHullFaces", I, P, C.c_int32, P)

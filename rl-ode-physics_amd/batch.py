@@ -206,6 +206,10 @@ class BatchWorld:
         """EXACT_AUTO (default) / EXACT_STAGED / EXACT_ONE_WORKGROUP: how an exact tick runs its bookkeeping (include/dmx_batch.h)"""
         _check(self.lib.dmxBatchSetExactPipeline(self.h, mode), "dmxBatchSetExactPipeline")
 
+    def set_static_path(self, fused=True):
+        """bodies at static boxes: the fused path (default) or the exact tick for every one of them (include/dmx_batch.h)"""
+        _check(self.lib.dmxBatchSetStaticPath(self.h, 1 if fused else 0), "dmxBatchSetStaticPath")
+
     def set_ticks_per_launch(self, ticks):
         _check(self.lib.dmxBatchSetTicksPerLaunch(self.h, ticks), "dmxBatchSetTicksPerLaunch")
 

@@ -393,6 +393,15 @@ extern "C" int dmxBatchSetExactPipeline(dmxBatchID b, int mode)
     return DMX_OK;
 }
 
+extern "C" int dmxBatchSetStaticPath(dmxBatchID b, int mode)
+{
+    if (!b || (mode != DMX_STATIC_EXACT && mode != DMX_STATIC_FUSED)) return DMX_EINVAL;
+    SETTLE(b);
+    b->static_fast = mode == DMX_STATIC_FUSED;
+    b->bp_valid = false;            // who counts as crowded depends on it
+    return DMX_OK;
+}
+
 extern "C" int dmxBatchSetBodyCollisions(dmxBatchID b, int enable)
 {
     if (!b) return DMX_EINVAL;

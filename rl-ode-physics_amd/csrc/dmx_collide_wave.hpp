@@ -1,6 +1,6 @@
 // dmx_collide_wave.hpp -- the convex-hull colliders of dCollide (/root/reference/src/main.c:678), one WAVEFRONT per
 // geom pair: lane l tests hull point / face 64 j + l, ballots give every hit its rank in array order, so the contacts kept
-// are the ones a sequential walk keeps (oracle/orc_collide.c).  Shared by the exact tick's narrowphase (dmx_exact.hip)
+// are the ones a sequential walk keeps (the CPU restatement the tests compare with).  Shared by the exact tick's narrowphase (dmx_exact.hip)
 // and the fused path of bodies at static geometry (dmx_narrow.hip).  The caller says where a contact goes:
 // emit(rank, pos, normal, depth) runs on the one lane that holds contact `rank` of this geom pair.
 #pragma once

@@ -467,9 +467,12 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *S, T *So, const uint8
 // with more contacts than the buffer holds raises BPF_NOFAST (the exact path steps it: the chunk is rolled back).
 // Algorithmic traffic per body-step: 13 + 4 read, 13 written, + 7 reals per contact written and read.
 // ---------------------------------------------------------------------------------------------
-template <class T, bool EXT, int MINW, int NC>
+// ALL (with NC = 8): this one launch steps every body, whatever its contact count -- a scene of a few ten thousand bodies is one
+// wave per SIMD or less, where the tick costs the longest lane's chain once per LAUNCH: one launch beats two.
+template <class T, bool EXT, int MINW, int NC, bool ALL = false>
 __global__ __launch_bounds__(256, MINW) void step_contacts(T *S, T *So, int64_t n, StepParams<T> P, StepDiag *__restrict__ diag)
 {
+    static_assert(!ALL || NC == SC_MAXC, "the one-launch form holds every contact count");
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     int my_contacts = 0;
     double my_resid = 0.0;
@@ -477,9 +480,9 @@ __global__ __launch_bounds__(256, MINW) void step_contacts(T *S, T *So, int64_t 
     const int cnt = (i < n && !(P.skip != nullptr && P.skip[i])) ? P.scount[i] : -1;
     // (a body with more contacts than the buffer holds is flagged, and stepped with the first SC_MAXC of them: what a caller
     //  who has switched the collision proof off -- nobody reads the flag then -- gets, and says so in include/dmx_batch.h)
-    const bool mine = NC == 4 ? (cnt >= 0 && cnt <= 4) : (cnt > 4);
-    if (NC == 4) {
-        const unsigned long long over = __ballot(cnt > SC_MAXC), need8 = __ballot(cnt > 4 && cnt <= SC_MAXC && !P.have8);
+    const bool mine = ALL ? cnt >= 0 : NC == 4 ? (cnt >= 0 && cnt <= 4) : (cnt > 4);
+    if (NC == 4 || ALL) {
+        const unsigned long long over = __ballot(cnt > SC_MAXC), need8 = __ballot(!ALL && cnt > 4 && cnt <= SC_MAXC && !P.have8);
         if ((over | need8) != 0ull && (threadIdx.x & 63) == 0 && P.bp_flags != nullptr) {
             if (over != 0ull) atomicOr(&P.bp_flags[BPF_NOFAST], 1u);
             if (need8 != 0ull) atomicOr(&P.bp_flags[BPF_NEED8], 1u);
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(256, MINW) void step_contacts(T *S, T *So, int64_t 
     const double wr = wave_sum<double>(my_resid);
     if ((threadIdx.x & 63) == 0 && i < n) {
         StepDiag *d = &diag[(blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6];
-        if (NC == 4) { d->contacts = (unsigned long long)wc; d->residual = wr; }
+        if (NC == 4 || ALL) { d->contacts = (unsigned long long)wc; d->residual = wr; }
         else { d->contacts += (unsigned long long)wc; d->residual += wr; }
     }
 }
@@ -813,6 +816,7 @@ __global__ __launch_bounds__(256) void soa_to_aos(const T *__restrict__ S, int64
 // launchers
 // ---------------------------------------------------------------------------------------------
 static inline unsigned blocks_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+constexpr int64_t kOneLaunchBodies = 256 * 4 * 64;
 
 template <class T>
 hipError_t launch_step(T *S, T *So, const uint8_t *gtype, int64_t stride, int64_t n, const StepParams<T> &P, bool ext,
@@ -823,6 +827,12 @@ hipError_t launch_step(T *S, T *So, const uint8_t *gtype, int64_t stride, int64_
         const hipError_t e = launch_np_static<T>(S, gtype, n, P, st);
         if (e != hipSuccess) return e;
         const unsigned grid = blocks_for(n, 256);
+        // up to one wave per SIMD of the chip (256 CUs x 4 SIMDs x 64 lanes): the tick is the longest lane's chain per launch
+        if (P.have8 && n <= kOneLaunchBodies && sizeof(T) == 4) {
+            if (ext) hipLaunchKernelGGL((step_contacts<T, true, 1, 8, true>), dim3(grid), dim3(256), 0, st, S, So, n, P, diag);
+            else     hipLaunchKernelGGL((step_contacts<T, false, 1, 8, true>), dim3(grid), dim3(256), 0, st, S, So, n, P, diag);
+            return hipGetLastError();
+        }
         if (ext) hipLaunchKernelGGL((step_contacts<T, true, 1, 4>), dim3(grid), dim3(256), 0, st, S, So, n, P, diag);
         else if (sizeof(T) == 4) hipLaunchKernelGGL((step_contacts<T, false, 2, 4>), dim3(grid), dim3(256), 0, st, S, So, n, P, diag);
         else hipLaunchKernelGGL((step_contacts<T, false, 1, 4>), dim3(grid), dim3(256), 0, st, S, So, n, P, diag);

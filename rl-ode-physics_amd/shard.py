@@ -26,7 +26,9 @@ carries a broadphase safe zone; the step kernel checks the rank's own bodies, a 
 the ghost slots right after their refresh.  Ticks run in chunks; at a chunk's end the ranks OR their violation flags
 (one tiny all-reduce) and either all commit or all roll back to the chunk's snapshot and replay it -- first with fresh
 zones, then tick by tick on the exact path (pair search, narrowphase, island solve).  A pair of bodies owned by two
-different ranks is reported (DMX_ECROSS): migrating an island to one owner is not built yet.
+different ranks makes an island that spans them: before an exact tick the ranks probe for such pairs and migrate the island
+to the lower rank (`_migrate`: the boundary body is adopted into a spare slot, the upper rank retires its copy); what
+migration cannot cover is reported on every rank at once (DMX_ECROSS).
 
 The exchange is written against a tiny `ops` interface (gather / scatter / buffers / streams) so the index
 logic and the collective run unchanged on CPU tensors with the gloo backend (tests/test_shard_gloo.py).
