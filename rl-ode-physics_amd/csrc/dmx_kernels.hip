@@ -362,25 +362,25 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *S, T *So, const uint8
 
             // ---- SOR-PGS: lambda = 0 start, rows in creation order --------------------------
             // Branch-free row update: the contact loop bound is the wave's maximum contact count (a scalar
-            // branch), lanes with fewer contacts carry zeroed rows and a zero delta; clamping is by select.
+            // branch), lanes with fewer contacts carry zeroed rows -- whose delta is exactly zero; clamping is by select.
             V3<T> fl = { T(0), T(0), T(0) }, fa = { T(0), T(0), T(0) };
             int ncu = 0;     // largest contact count among the wave's active lanes (wave-uniform by construction)
 #pragma unroll
             for (int k = 0; k < MAXC; k++)
                 if (__ballot(nc > k) != 0ull) ncu = k + 1;
             T rsum = T(0);
-            // One sweep over the wave's rows.  FAST: every active lane has the wave's contact count and the friction
-            // rows are unbounded (mu = inf, the reference's surface): no lane masking, no friction clamp.
-            // LAST: only the final sweep tallies |delta lambda|.  Same arithmetic in every variant.
-            auto sweep = [&](auto FAST, auto LAST) {
+            // One sweep over the wave's rows.  FAST: the friction rows are unbounded (mu = inf, the reference's surface): no
+            // friction clamp.  LAST: only the final sweep tallies |delta lambda|.  Same arithmetic in every variant.
+            // FULL: every contact slot of every active lane is taken and friction rows exist (a box resting on the plane: four
+            // contacts x three rows) -- the sweep is one straight line of 3 MAXC row updates, no scalar branch per contact / row
+            auto sweep = [&](auto FAST, auto LAST, auto FULL) {
 #pragma unroll
                 for (int k = 0; k < MAXC; k++) {
-                    if (k < ncu) {
-                        const bool act = decltype(FAST)::value ? true : (k < nc);
+                    if (decltype(FULL)::value || k < ncu) {
 #pragma unroll
                         for (int dnum = 0; dnum < 3; dnum++) {
                             const int r = 3 * k + dnum;
-                            if (dnum < rpc) {
+                            if (decltype(FULL)::value || dnum < rpc) {
                                 const T old = lam[r];
                                 T delta = fma_(-old, adcfm[r], rhs[r]);
                                 delta -= fma_(fa.z, Ja[r].z, fma_(fa.y, Ja[r].y, fma_(fa.x, Ja[r].x,
@@ -392,10 +392,6 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *S, T *So, const uint8
                                     const bool below = nl < lo, above = nl > hi;
                                     nlam = below ? lo : (above ? hi : nl);
                                     delta = below ? lo - old : (above ? hi - old : delta);
-                                }
-                                if (!decltype(FAST)::value) {
-                                    delta = act ? delta : T(0);
-                                    nlam = act ? nlam : old;
                                 }
                                 lam[r] = nlam;
                                 fl.x = fma_(delta, iml[dnum].x, fl.x); fl.y = fma_(delta, iml[dnum].y, fl.y);
@@ -410,13 +406,19 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *S, T *So, const uint8
             };
             using std::true_type;
             using std::false_type;
-            const bool fast = (__ballot(nc != ncu) == 0ull) && !(P.mu < Limits<T>::inf());   // wave-uniform
-            if (fast) {
-                for (int it = 0; it + 1 < P.iters; it++) sweep(true_type{}, false_type{});
-                if (P.iters > 0) sweep(true_type{}, true_type{});
+            // FAST: friction rows are unbounded (mu = inf, the reference's surface, main.c:687): no friction clamp.  Lanes with
+            // fewer contacts than the wave's count need no masking either way: their surplus rows are all zero, a zero row's
+            // delta is exactly zero and leaves lambda and the accumulators as they are.
+            const bool fast = !(P.mu < Limits<T>::inf());   // wave-uniform
+            if (fast && ncu == MAXC && rpc == 3) {
+                for (int it = 0; it + 1 < P.iters; it++) sweep(true_type{}, false_type{}, true_type{});
+                if (P.iters > 0) sweep(true_type{}, true_type{}, true_type{});
+            } else if (fast) {
+                for (int it = 0; it + 1 < P.iters; it++) sweep(true_type{}, false_type{}, false_type{});
+                if (P.iters > 0) sweep(true_type{}, true_type{}, false_type{});
             } else {
-                for (int it = 0; it + 1 < P.iters; it++) sweep(false_type{}, false_type{});
-                if (P.iters > 0) sweep(false_type{}, true_type{});
+                for (int it = 0; it + 1 < P.iters; it++) sweep(false_type{}, false_type{}, false_type{});
+                if (P.iters > 0) sweep(false_type{}, true_type{}, false_type{});
             }
             my_resid = (double)rsum;      // |delta lambda| summed over the last sweep
             // v += h * (M^-1 J^T lambda)
@@ -592,15 +594,15 @@ __global__ __launch_bounds__(256, MINW) void step_contacts(T *S, T *So, int64_t 
             // ---- SOR-PGS: lambda = 0 start, rows in creation order; branch-free row update as in step_plane ----
             V3<T> fl = { T(0), T(0), T(0) }, fa = { T(0), T(0), T(0) };
             T rsum = T(0);
-            auto sweep = [&](auto FAST, auto LAST) {
+            // (FULL: as in step_plane -- every contact slot taken in every lane stepped here, friction rows present)
+            auto sweep = [&](auto FAST, auto LAST, auto FULL) {
 #pragma unroll
                 for (int k = 0; k < NC; k++) {
-                    if (k < ncu) {
-                        const bool act = decltype(FAST)::value ? true : (k < nc);
+                    if (decltype(FULL)::value || k < ncu) {
 #pragma unroll
                         for (int dnum = 0; dnum < 3; dnum++) {
                             const int r = 3 * k + dnum;
-                            if (dnum < rpc) {
+                            if (decltype(FULL)::value || dnum < rpc) {
                                 const T old = lam[r];
                                 T delta = fma_(-old, adcfm[r], rhs[r]);
                                 delta -= fma_(fa.z, Ja[r].z, fma_(fa.y, Ja[r].y, fma_(fa.x, Ja[r].x,
@@ -612,10 +614,6 @@ __global__ __launch_bounds__(256, MINW) void step_contacts(T *S, T *So, int64_t 
                                     const bool below = nl < lo, above = nl > hi;
                                     nlam = below ? lo : (above ? hi : nl);
                                     delta = below ? lo - old : (above ? hi - old : delta);
-                                }
-                                if (!decltype(FAST)::value) {
-                                    delta = act ? delta : T(0);
-                                    nlam = act ? nlam : old;
                                 }
                                 lam[r] = nlam;
                                 fl.x = fma_(delta, iMl[r].x, fl.x); fl.y = fma_(delta, iMl[r].y, fl.y);
@@ -630,13 +628,19 @@ __global__ __launch_bounds__(256, MINW) void step_contacts(T *S, T *So, int64_t 
             };
             using std::true_type;
             using std::false_type;
-            const bool fast = (__ballot(nc != ncu) == 0ull) && !(P.mu < Limits<T>::inf());   // wave-uniform
-            if (fast) {
-                for (int it = 0; it + 1 < P.iters; it++) sweep(true_type{}, false_type{});
-                if (P.iters > 0) sweep(true_type{}, true_type{});
+            // FAST: friction rows are unbounded (mu = inf, the reference's surface, main.c:687): no friction clamp.  Lanes with
+            // fewer contacts than the wave's count need no masking either way: their surplus rows are all zero, a zero row's
+            // delta is exactly zero and leaves lambda and the accumulators as they are.
+            const bool fast = !(P.mu < Limits<T>::inf());   // wave-uniform
+            if (fast && ncu == NC && rpc == 3) {
+                for (int it = 0; it + 1 < P.iters; it++) sweep(true_type{}, false_type{}, true_type{});
+                if (P.iters > 0) sweep(true_type{}, true_type{}, true_type{});
+            } else if (fast) {
+                for (int it = 0; it + 1 < P.iters; it++) sweep(true_type{}, false_type{}, false_type{});
+                if (P.iters > 0) sweep(true_type{}, true_type{}, false_type{});
             } else {
-                for (int it = 0; it + 1 < P.iters; it++) sweep(false_type{}, false_type{});
-                if (P.iters > 0) sweep(false_type{}, true_type{});
+                for (int it = 0; it + 1 < P.iters; it++) sweep(false_type{}, false_type{}, false_type{});
+                if (P.iters > 0) sweep(false_type{}, true_type{}, false_type{});
             }
             my_resid = (double)rsum;
             if (nc > 0) {        // v += h * (M^-1 J^T lambda)
