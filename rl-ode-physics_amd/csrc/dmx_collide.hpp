@@ -193,41 +193,81 @@ DMX_HD void line_closest_approach(const V3<T> &pa, const V3<T> &ua, const V3<T> 
     }
 }
 
-// clip the quad p[8] (4 xy pairs) against |x| <= h[0], |y| <= h[1]; result in ret[16], returns point count
-template <class T> DMX_HD int intersect_rect_quad(const T h[2], const T p[8], T ret[16])
+// ---- the incident face clipped against the reference face's rectangle, in REGISTERS ------------------------------------
+// ODE's intersectRectQuad is a Sutherland-Hodgman pass per rectangle side over point arrays indexed by running counters; on a
+// GPU such arrays live in scratch memory and every step of the walk is a round trip through the memory pipeline (one lane per
+// box pair: a chain of them).  Here a polygon is eight points held in named registers -- every index below is a compile-time
+// constant after unrolling -- and "append at position n" is a chain of selects.  Same arithmetic, same order of points, same
+// early stop at eight points as the sequential walk (the CPU restatement the tests compare with), operation for operation.
+template <class T> struct Poly8 { T x[8], y[8]; };
+
+// point (px, py) to slot `at` (0 <= at < 8); slots above `hi` cannot be meant (at <= hi by construction; hi is a constant
+// once the caller's loop is unrolled, so the surplus selects fold away)
+template <class T> DMX_HD void poly_put(Poly8<T> &p, int at, int hi, T px, T py)
 {
-    T bufA[16], bufB[16];
-    for (int i = 0; i < 8; i++) bufA[i] = p[i];
-    T *q = bufA, *r = bufB;
-    int nq = 4, nr = 0;
-    bool full = false;
-    for (int dir = 0; dir <= 1 && !full; dir++) {
-        for (int sign = -1; sign <= 1 && !full; sign += 2) {
-            nr = 0;
-            for (int i = 0; i < nq && !full; i++) {
-                const T *pq = q + 2 * i;
-                const T *nextq = (i + 1 < nq) ? pq + 2 : q;
-                const bool in0 = sign * pq[dir] < h[dir];
-                const bool in1 = sign * nextq[dir] < h[dir];
-                if (in0) {
-                    r[2 * nr] = pq[0]; r[2 * nr + 1] = pq[1];
-                    nr++;
-                    if (nr & 8) { full = true; break; }
-                }
-                if (in0 != in1) {
-                    r[2 * nr + (1 - dir)] = pq[1 - dir] + (nextq[1 - dir] - pq[1 - dir]) / (nextq[dir] - pq[dir]) *
-                                                             (sign * h[dir] - pq[dir]);
-                    r[2 * nr + dir] = sign * h[dir];
-                    nr++;
-                    if (nr & 8) { full = true; break; }
-                }
-            }
-            T *t = q; q = r; r = t;
-            nq = nr;
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        if (s <= hi) {
+            const bool here = s == at;
+            p.x[s] = here ? px : p.x[s];
+            p.y[s] = here ? py : p.y[s];
         }
     }
-    for (int i = 0; i < 2 * nr; i++) ret[i] = q[i];
+}
+
+// one side of the rectangle: keep what lies on the inner side of  sign * coord[DIR] < h, cut the crossing edges.
+// NQMAX = the most points the input can hold at this stage (4 for the quad itself); returns the output count, `full` once
+// eight points are out (the walk stops there, as ODE's does).
+template <class T, int DIR, int NQMAX>
+DMX_HD int clip_side(const Poly8<T> &q, int nq, int sign, T h, Poly8<T> &r, bool &full)
+{
+    int nr = 0;
+    const T sh = (T)sign * h;
+#pragma unroll
+    for (int i = 0; i < NQMAX; i++) {
+        if (i < nq && !full) {
+            const T px = q.x[i], py = q.y[i];
+            // the next point, cyclically: q[i + 1], or q[0] behind the last one
+            const bool wrap = !(i + 1 < nq);
+            const T nx = (i + 1 < NQMAX) ? (wrap ? q.x[0] : q.x[i + 1 < 8 ? i + 1 : 7]) : q.x[0];
+            const T ny = (i + 1 < NQMAX) ? (wrap ? q.y[0] : q.y[i + 1 < 8 ? i + 1 : 7]) : q.y[0];
+            const T pd = DIR == 0 ? px : py, po = DIR == 0 ? py : px;      // along the clipped axis / the other one
+            const T nd = DIR == 0 ? nx : ny, no = DIR == 0 ? ny : nx;
+            const bool in0 = (T)sign * pd < h;
+            const bool in1 = (T)sign * nd < h;
+            if (in0) {
+                poly_put<T>(r, nr, 2 * i, px, py);
+                nr++;
+                if (nr & 8) full = true;
+            }
+            if (in0 != in1 && !full) {
+                const T cut = po + (no - po) / (nd - pd) * (sh - pd);
+                poly_put<T>(r, nr, 2 * i + 1, DIR == 0 ? sh : cut, DIR == 0 ? cut : sh);
+                nr++;
+                if (nr & 8) full = true;
+            }
+        }
+    }
     return nr;
+}
+
+// clip the quad p[8] (4 xy pairs) against |x| <= h[0], |y| <= h[1]; result in `out`, returns the point count
+template <class T> DMX_HD int intersect_rect_quad(const T h[2], const T p[8], Poly8<T> &out)
+{
+    Poly8<T> a, b;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { a.x[i] = a.y[i] = b.x[i] = b.y[i] = T(0); }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { a.x[i] = p[2 * i]; a.y[i] = p[2 * i + 1]; }
+    bool full = false;
+    int n = clip_side<T, 0, 4>(a, 4, -1, h[0], b, full);                 // (a side clipped after `full` is skipped whole,
+    if (!full) { n = clip_side<T, 0, 8>(b, n, +1, h[0], a, full);        //  as the sequential walk's loops end there)
+        if (!full) { n = clip_side<T, 1, 8>(a, n, -1, h[1], b, full);
+            if (!full) { n = clip_side<T, 1, 8>(b, n, +1, h[1], a, full); out = a; }
+            else out = b; }
+        else out = a; }
+    else out = b;
+    return n;
 }
 
 }  // namespace detail
@@ -279,9 +319,30 @@ template <class T> DMX_HD void cull_points(int n, const T p[], int m, int i0, in
     }
 }
 
+// static-index selects (a runtime index into a register array would send the array to scratch memory on the device)
+template <class T> DMX_HD V3<T> colv_sel(const M3<T> &R, int j)
+{
+    return { j == 0 ? R.m[0][0] : (j == 1 ? R.m[0][1] : R.m[0][2]), j == 0 ? R.m[1][0] : (j == 1 ? R.m[1][1] : R.m[1][2]),
+             j == 0 ? R.m[2][0] : (j == 1 ? R.m[2][1] : R.m[2][2]) };
+}
+template <class T> DMX_HD M3<T> m3_sel(bool first, const M3<T> &A, const M3<T> &B)
+{
+    M3<T> r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = first ? A.m[i][j] : B.m[i][j];
+    return r;
+}
+
 // Returns the contact count; contacts' normal = -(box1 -> box2 separating axis).  maxc >= 8 returns every
 // clipped point (the reference asks for 8, main.c:675); with a smaller maxc the surplus points are culled as ODE does
 // (cullPoints: the deepest one, then the ones nearest to evenly spaced directions about the centroid).
+// Written for one lane per box pair with everything in registers: all array indices are compile-time constants after
+// unrolling (selects pick the reference box, its face axes and the clipped points), the face clipping is
+// detail::intersect_rect_quad above.  Only the culling branch (maxc below the clipped count: never with the reference's
+// MAX_CONTACTS = 8) keeps indexed arrays.  The arithmetic is the sequential dBoxBox's [ODE-recall box.cpp], operation for
+// operation, so host, device and the CPU restatement agree bit for bit (tests/test_collider_equivalence.py).
 template <class T>
 DMX_HD int box_box(const V3<T> &p1, const M3<T> &R1, const T side1[3], const V3<T> &p2, const M3<T> &R2,
                    const T side2[3], int maxc_in, ContactPoint<T> *out)
@@ -290,8 +351,11 @@ DMX_HD int box_box(const V3<T> &p1, const M3<T> &R1, const T side1[3], const V3<
     const V3<T> p = { p2.x - p1.x, p2.y - p1.y, p2.z - p1.z };
     const T pp[3] = { dot(colv(R1, 0), p), dot(colv(R1, 1), p), dot(colv(R1, 2), p) };
     T A[3], B[3], Rr[3][3], Q[3][3];
+#pragma unroll
     for (int i = 0; i < 3; i++) { A[i] = side1[i] * T(0.5); B[i] = side2[i] * T(0.5); }
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) { Rr[i][j] = dot(colv(R1, i), colv(R2, j)); Q[i][j] = tabs(Rr[i][j]); }
 
     T s = -Limits<T>::inf(), s2, l, e;
@@ -340,8 +404,8 @@ DMX_HD int box_box(const V3<T> &p1, const M3<T> &R1, const T side1[3], const V3<
     if (!code) return 0;
 
     V3<T> normal;
-    if (normalR_box == 1) normal = colv(R1, normalR_col);
-    else if (normalR_box == 2) normal = colv(R2, normalR_col);
+    if (normalR_box == 1) normal = colv_sel(R1, normalR_col);
+    else if (normalR_box == 2) normal = colv_sel(R2, normalR_col);
     else normal = mulv(R1, normalC);
     if (invert_normal) normal = { -normal.x, -normal.y, -normal.z };
     const T depth = -s;
@@ -349,17 +413,19 @@ DMX_HD int box_box(const V3<T> &p1, const M3<T> &R1, const T side1[3], const V3<
 
     if (code > 6) {
         V3<T> pa = p1, pb = p2;
+#pragma unroll
         for (int j = 0; j < 3; j++) {
             const V3<T> cj = colv(R1, j);
             const T sign = (dot(normal, cj) > 0) ? T(1) : T(-1);
             pa.x += sign * A[j] * cj.x; pa.y += sign * A[j] * cj.y; pa.z += sign * A[j] * cj.z;
         }
+#pragma unroll
         for (int j = 0; j < 3; j++) {
             const V3<T> cj = colv(R2, j);
             const T sign = (dot(normal, cj) > 0) ? T(-1) : T(1);
             pb.x += sign * B[j] * cj.x; pb.y += sign * B[j] * cj.y; pb.z += sign * B[j] * cj.z;
         }
-        const V3<T> ua = colv(R1, (code - 7) / 3), ub = colv(R2, (code - 7) % 3);
+        const V3<T> ua = colv_sel(R1, (code - 7) / 3), ub = colv_sel(R2, (code - 7) % 3);
         T alpha, beta;
         detail::line_closest_approach(pa, ua, pb, ub, alpha, beta);
         pa.x += ua.x * alpha; pa.y += ua.y * alpha; pa.z += ua.z * alpha;
@@ -372,9 +438,10 @@ DMX_HD int box_box(const V3<T> &p1, const M3<T> &R1, const T side1[3], const V3<
 
     // face contact: 'a' = box owning the reference face, 'b' = incident box
     const bool ref1 = code <= 3;
-    const M3<T> &Ra = ref1 ? R1 : R2, &Rb = ref1 ? R2 : R1;
-    const V3<T> &pa = ref1 ? p1 : p2, &pb = ref1 ? p2 : p1;
-    const T *Sa = ref1 ? A : B, *Sb = ref1 ? B : A;
+    const M3<T> Ra = m3_sel(ref1, R1, R2), Rb = m3_sel(ref1, R2, R1);
+    const V3<T> pa = ref1 ? p1 : p2, pb = ref1 ? p2 : p1;
+    const T Sa[3] = { ref1 ? A[0] : B[0], ref1 ? A[1] : B[1], ref1 ? A[2] : B[2] };
+    const T Sb[3] = { ref1 ? B[0] : A[0], ref1 ? B[1] : A[1], ref1 ? B[2] : A[2] };
     const V3<T> normal2 = ref1 ? normal : V3<T>{ -normal.x, -normal.y, -normal.z };
     const T nr[3] = { dot(colv(Rb, 0), normal2), dot(colv(Rb, 1), normal2), dot(colv(Rb, 2), normal2) };
     const T anr[3] = { tabs(nr[0]), tabs(nr[1]), tabs(nr[2]) };
@@ -386,47 +453,63 @@ DMX_HD int box_box(const V3<T> &p1, const M3<T> &R1, const T side1[3], const V3<
         if (anr[0] > anr[2]) { lanr = 0; a1 = 1; a2 = 2; }
         else { a1 = 0; a2 = 1; lanr = 2; }
     }
-    const V3<T> bl = colv(Rb, lanr);
+    const V3<T> bl = colv_sel(Rb, lanr);
+    const T Sbl = pick(Sb, lanr), nrl = pick(nr, lanr);
     V3<T> center;
-    if (nr[lanr] < 0)
-        center = { pb.x - pa.x + Sb[lanr] * bl.x, pb.y - pa.y + Sb[lanr] * bl.y, pb.z - pa.z + Sb[lanr] * bl.z };
+    if (nrl < 0)
+        center = { pb.x - pa.x + Sbl * bl.x, pb.y - pa.y + Sbl * bl.y, pb.z - pa.z + Sbl * bl.z };
     else
-        center = { pb.x - pa.x - Sb[lanr] * bl.x, pb.y - pa.y - Sb[lanr] * bl.y, pb.z - pa.z - Sb[lanr] * bl.z };
+        center = { pb.x - pa.x - Sbl * bl.x, pb.y - pa.y - Sbl * bl.y, pb.z - pa.z - Sbl * bl.z };
     const int codeN = ref1 ? code - 1 : code - 4;
     const int code1 = codeN == 0 ? 1 : 0;
     const int code2 = codeN == 2 ? 1 : 2;
 
-    const V3<T> ra1 = colv(Ra, code1), ra2 = colv(Ra, code2), rb1 = colv(Rb, a1), rb2 = colv(Rb, a2);
+    const V3<T> ra1 = colv_sel(Ra, code1), ra2 = colv_sel(Ra, code2), rb1 = colv_sel(Rb, a1), rb2 = colv_sel(Rb, a2);
     const T c1 = dot(center, ra1), c2 = dot(center, ra2);
     T m11 = dot(ra1, rb1), m12 = dot(ra1, rb2), m21 = dot(ra2, rb1), m22 = dot(ra2, rb2);
     T quad[8];
     {
-        const T k1 = m11 * Sb[a1], k2 = m21 * Sb[a1], k3 = m12 * Sb[a2], k4 = m22 * Sb[a2];
+        const T Sb1 = pick(Sb, a1), Sb2 = pick(Sb, a2);
+        const T k1 = m11 * Sb1, k2 = m21 * Sb1, k3 = m12 * Sb2, k4 = m22 * Sb2;
         quad[0] = c1 - k1 - k3; quad[1] = c2 - k2 - k4;
         quad[2] = c1 - k1 + k3; quad[3] = c2 - k2 + k4;
         quad[4] = c1 + k1 + k3; quad[5] = c2 + k2 + k4;
         quad[6] = c1 + k1 - k3; quad[7] = c2 + k2 - k4;
     }
-    const T rect[2] = { Sa[code1], Sa[code2] };
-    T ret[16];
+    const T rect[2] = { pick(Sa, code1), pick(Sa, code2) };
+    detail::Poly8<T> ret;
     const int n = detail::intersect_rect_quad(rect, quad, ret);
     if (n < 1) return 0;
 
+    // clipped 2-D points -> 3-D points on the incident face and their depths; the ones not below the reference face are kept,
+    // in order (slot `cnum` is a running count: select chains again)
     V3<T> point[8];
     T dep[8];
+    detail::Poly8<T> kept;      // the 2-D points of the kept contacts (cullPoints reads them)
+#pragma unroll
+    for (int j = 0; j < 8; j++) { point[j] = { T(0), T(0), T(0) }; dep[j] = T(0); kept.x[j] = kept.y[j] = T(0); }
     const T det1 = T(1) / (m11 * m22 - m12 * m21);
     m11 *= det1; m12 *= det1; m21 *= det1; m22 *= det1;
+    const T Sn = pick(Sa, codeN);
     int cnum = 0;
-    for (int j = 0; j < n; j++) {
-        const T k1 = m22 * (ret[j * 2] - c1) - m12 * (ret[j * 2 + 1] - c2);
-        const T k2 = -m21 * (ret[j * 2] - c1) + m11 * (ret[j * 2 + 1] - c2);
-        point[cnum] = { center.x + k1 * rb1.x + k2 * rb2.x, center.y + k1 * rb1.y + k2 * rb2.y,
-                        center.z + k1 * rb1.z + k2 * rb2.z };
-        dep[cnum] = Sa[codeN] - dot(normal2, point[cnum]);
-        if (dep[cnum] >= 0) {
-            ret[cnum * 2] = ret[j * 2];              // keep the 2-D point with its contact: cull_points reads them
-            ret[cnum * 2 + 1] = ret[j * 2 + 1];
-            cnum++;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (j < n) {
+            const T k1 = m22 * (ret.x[j] - c1) - m12 * (ret.y[j] - c2);
+            const T k2 = -m21 * (ret.x[j] - c1) + m11 * (ret.y[j] - c2);
+            const V3<T> pt = { center.x + k1 * rb1.x + k2 * rb2.x, center.y + k1 * rb1.y + k2 * rb2.y,
+                               center.z + k1 * rb1.z + k2 * rb2.z };
+            const T dj = Sn - dot(normal2, pt);
+            if (dj >= 0) {
+#pragma unroll
+                for (int q = 0; q <= j; q++) {              // (cnum <= j)
+                    const bool here = q == cnum;
+                    point[q].x = here ? pt.x : point[q].x; point[q].y = here ? pt.y : point[q].y; point[q].z = here ? pt.z : point[q].z;
+                    dep[q] = here ? dj : dep[q];
+                    kept.x[q] = here ? ret.x[j] : kept.x[q]; kept.y[q] = here ? ret.y[j] : kept.y[q];
+                }
+                cnum++;
+            }
         }
     }
     if (cnum < 1) return 0;
@@ -435,26 +518,40 @@ DMX_HD int box_box(const V3<T> &p1, const M3<T> &R1, const T side1[3], const V3<
     if (maxc > cnum) maxc = cnum;
     if (maxc < 1) maxc = 1;
     if (cnum <= maxc) {
-        for (int j = 0; j < cnum; j++) {
-            out[j].pos = { point[j].x + pa.x, point[j].y + pa.y, point[j].z + pa.z };
-            if (!ref1) {
-                out[j].pos.x -= normal.x * dep[j]; out[j].pos.y -= normal.y * dep[j]; out[j].pos.z -= normal.z * dep[j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j < cnum) {
+                V3<T> o = { point[j].x + pa.x, point[j].y + pa.y, point[j].z + pa.z };
+                if (!ref1) { o.x -= normal.x * dep[j]; o.y -= normal.y * dep[j]; o.z -= normal.z * dep[j]; }
+                out[j].pos = o;
+                out[j].depth = dep[j];
+                out[j].normal = cn;
             }
-            out[j].depth = dep[j];
-            out[j].normal = cn;
         }
         return cnum;
     }
-    // fewer contacts wanted than found: the deepest point, then cullPoints' angular selection
+    // fewer contacts wanted than found: the deepest point, then cullPoints' angular selection (its arrays are walked with
+    // running indices: the one place that stays in memory on the device; never reached with the reference's MAX_CONTACTS = 8)
+    T p2d[16];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { p2d[2 * j] = kept.x[j]; p2d[2 * j + 1] = kept.y[j]; }
     int i1 = 0;
     T maxdepth = dep[0];
-    for (int i = 1; i < cnum; i++) if (dep[i] > maxdepth) { maxdepth = dep[i]; i1 = i; }
+#pragma unroll
+    for (int i = 1; i < 8; i++) if (i < cnum && dep[i] > maxdepth) { maxdepth = dep[i]; i1 = i; }
     int iret[8];
-    cull_points<T>(cnum, ret, maxc, i1, iret);
-    for (int j = 0; j < maxc; j++) {
-        const int k = iret[j];
-        out[j].pos = { point[k].x + pa.x, point[k].y + pa.y, point[k].z + pa.z };
-        out[j].depth = dep[k]; out[j].normal = cn;
+    cull_points<T>(cnum, p2d, maxc, i1, iret);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (j < maxc) {
+            const int k = iret[j];
+            V3<T> pt = point[0];
+            T dk = dep[0];
+#pragma unroll
+            for (int q = 1; q < 8; q++) { const bool h = q == k; pt.x = h ? point[q].x : pt.x; pt.y = h ? point[q].y : pt.y; pt.z = h ? point[q].z : pt.z; dk = h ? dep[q] : dk; }
+            out[j].pos = { pt.x + pa.x, pt.y + pa.y, pt.z + pa.z };
+            out[j].depth = dk; out[j].normal = cn;
+        }
     }
     return maxc;
 }

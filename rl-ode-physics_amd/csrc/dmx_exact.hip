@@ -324,9 +324,12 @@ __global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const u
                     else if (Bd.gt == GEOM_SPHERE) { nc = sphere_box(Bd.x, Bd.side[0], sx, sR, sside, c); negate = false; }   // swapped collider: flipped twice
                     if (nc > mc) nc = mc;
                     const size_t base = cap.static_slot0() + (size_t)8 * ((size_t)s * cap.inv + k);
-                    for (int q = 0; q < nc; q++) {
-                        const V3<T> n = negate ? V3<T>{ -c[q].normal.x, -c[q].normal.y, -c[q].normal.z } : c[q].normal;
-                        put_c(gpos, gnormal, gdepth, base + q, c[q].pos, n, c[q].depth);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {           // (static indices: the contacts stay in registers)
+                        if (q < nc) {
+                            const V3<T> n = negate ? V3<T>{ -c[q].normal.x, -c[q].normal.y, -c[q].normal.z } : c[q].normal;
+                            put_c(gpos, gnormal, gdepth, base + q, c[q].pos, n, c[q].depth);
+                        }
                     }
                 }
             }
@@ -352,9 +355,12 @@ __global__ __launch_bounds__(64) void ex_narrow(const T *__restrict__ S, const u
                 else if (A.gt == GEOM_BOX && B.gt == GEOM_SPHERE) { nc = sphere_box(B.x, B.side[0], A.x, A.R, A.side, c); flip = true; }
                 if (nc > mc) nc = mc;
                 const size_t base = cap.pair_slot0() + (size_t)8 * p;
-                for (int k = 0; k < nc; k++) {
-                    const V3<T> n = flip ? V3<T>{ -c[k].normal.x, -c[k].normal.y, -c[k].normal.z } : c[k].normal;
-                    put_c(gpos, gnormal, gdepth, base + k, c[k].pos, n, c[k].depth);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (k < nc) {
+                        const V3<T> n = flip ? V3<T>{ -c[k].normal.x, -c[k].normal.y, -c[k].normal.z } : c[k].normal;
+                        put_c(gpos, gnormal, gdepth, base + k, c[k].pos, n, c[k].depth);
+                    }
                 }
             }
         }

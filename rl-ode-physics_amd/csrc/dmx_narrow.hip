@@ -94,10 +94,12 @@ __global__ __launch_bounds__(256) void np_static(const T *__restrict__ S, const 
             if (gt == GEOM_BOX) k = box_box(sx, sR, sside, x, R, side, mc, c);
             else { k = sphere_box(x, side[0], sx, sR, sside, c); negate = false; }
             if (k > mc) k = mc;
-            for (int q = 0; q < k; q++) {
-                if (nc + q >= SC_MAXC) break;
-                const V3<T> nn = negate ? V3<T>{ -c[q].normal.x, -c[q].normal.y, -c[q].normal.z } : c[q].normal;
-                put_sc(P.sbuf, i, nc + q, c[q].pos, nn, c[q].depth);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {               // (static indices: the contacts stay in registers)
+                if (q < k && nc + q < SC_MAXC) {
+                    const V3<T> nn = negate ? V3<T>{ -c[q].normal.x, -c[q].normal.y, -c[q].normal.z } : c[q].normal;
+                    put_sc(P.sbuf, i, nc + q, c[q].pos, nn, c[q].depth);
+                }
             }
             nc += k;
         }
