@@ -253,21 +253,27 @@ def measure(cx, a, scene, layout, kind, dtype, *, exchanging, every_tick=False, 
         if not collide:
             w.set_body_collisions(False)
         w.set_stream(cx.stream.cuda_stream)
-        ops = None
-        if exchanging and cx.rehearse:
-            ops = pkg.shard.StagedDeviceOps(w, cx.device, cx.stream)
-        elif exchanging and cx.world == 1:
-            ops = pkg.shard.DeviceOps(w, cx.device, cx.stream)      # --force-exchange: the collective degenerates to a copy
-        st = pkg.shard.ShardedStepper(w, layout, cx.rank, cx.world, exchange="boundary" if exchanging else "none",
-                                      device=cx.device, stream=cx.stream, collide=collide and exchanging,
-                                      geometry=(scene.sides, scene.gtype, scene.mass[:, 0], scene.inertia), ops=ops,
-                                      exchange_every_tick=every_tick,
-                                      lazy=True)
+        c_loop = exchanging and not every_tick          # the sharded loop behind the C ABI (include/dmx_shard.h): the product path
+        if c_loop:
+            # collectives: the library's own RCCL binding (ncclAllGather on its side stream), or -- ranks sharing one GPU, which
+            # RCCL does not allow -- callbacks that stage through host memory over the gloo group (REHEARSAL, flagged in `data`)
+            st = pkg.shard.CShardedStepper(w, layout, cx.rank, cx.world, collectives="staged" if cx.rehearse else "rccl")
+        else:
+            ops = None
+            if exchanging and cx.rehearse:
+                ops = pkg.shard.StagedDeviceOps(w, cx.device, cx.stream)
+            elif exchanging and cx.world == 1:
+                ops = pkg.shard.DeviceOps(w, cx.device, cx.stream)      # --force-exchange: the collective degenerates to a copy
+            st = pkg.shard.ShardedStepper(w, layout, cx.rank, cx.world, exchange="boundary" if exchanging else "none",
+                                          device=cx.device, stream=cx.stream, collide=collide and exchanging,
+                                          geometry=(scene.sides, scene.gtype, scene.mass[:, 0], scene.inertia), ops=ops,
+                                          exchange_every_tick=every_tick,
+                                          lazy=True)
         if settle_steps:
             st.run(H, settle_steps)             # let the bodies land: timed steps are all in contact
         st.run(H, warmup)
         graphed = False
-        if st.exchange is not None and every_tick and a.graph_steps > 0:
+        if not c_loop and st.exchange is not None and every_tick and a.graph_steps > 0:
             torch.cuda.synchronize()
             graphed = st.capture(H, a.graph_steps, cx.stream)
             st.run(H, a.graph_steps)            # one replay outside the timed region
@@ -285,16 +291,23 @@ def measure(cx, a, scene, layout, kind, dtype, *, exchanging, every_tick=False, 
             cx.barrier()
             return dt, e0.elapsed_time(e1) * 1e-3
 
-        ex0 = st.exchange.count if st.exchange is not None else 0
+        def exchanges():
+            if c_loop:
+                return st.stats()["exchanges"]
+            return st.exchange.count if st.exchange is not None else 0
+        ex0 = exchanges()
         first = block()
         est = cx.max_over_ranks([first[0]])[0]
         nblocks = 1 if est >= MIN_REGION_S else min(MAX_BLOCKS, int(math.ceil(MIN_REGION_S / max(est, 1e-6))) | 1)
         blocks = [first] + [block() for _ in range(nblocks - 1)]
         t_close = time.perf_counter()
-        st.close()                              # the chunk the loop may have left open: validated before anything is reported
+        if c_loop:
+            st.settle()                         # the chunk the loop may have left open: validated before anything is reported
+        else:
+            st.close()
         torch.cuda.synchronize()
         t_close = cx.max_over_ranks([time.perf_counter() - t_close])[0]
-        n_ex = (st.exchange.count - ex0) if st.exchange is not None else 0
+        n_ex = exchanges() - ex0
         if graphed:
             n_ex = nblocks * steps              # a captured graph counts its exchanges once, at capture
         wall = cx.max_over_ranks([b[0] for b in blocks])
@@ -307,11 +320,16 @@ def measure(cx, a, scene, layout, kind, dtype, *, exchanging, every_tick=False, 
         return {"dt": dt, "mean_dt": mean_dt, "contacts": contacts,
                 "dev_s": statistics.median(dev), "blocks": nblocks, "wall_min": min(wall), "wall_max": max(wall),
                 "steps": steps, "n_exchanges": n_ex, "ticks_timed": nblocks * steps, "graphed": graphed, "stats": stats,
-                "exchanging": st.exchange is not None, "tpl": ticks_per_launch if kind == "free" else 1,
-                "bodies": scene.n}
+                "exchanging": c_loop or st.exchange is not None, "tpl": ticks_per_launch if kind == "free" else 1,
+                "bodies": scene.n, "c_loop": c_loop}
     finally:
-        if st is not None and st.exchange is not None and st.exchange.fused:
+        if st is not None and getattr(st, "exchange", None) is not None and st.exchange.fused:
             st.exchange.ops.disarm_pack()       # the send buffers die with the stepper: the batch must not keep aiming at them
+        if st is not None and isinstance(st, pkg.shard.CShardedStepper):
+            try:
+                st.close()                      # (dmxShardDestroy detaches the batch from its send buffers)
+            except Exception:       # noqa: BLE001 -- a failed run is already on its way out
+                pass
         w.close()
 
 
@@ -502,7 +520,11 @@ def rank_main(a):
         if not m["exchanging"]:
             return f"islands sharded over {world} GPU(s), one slab per rank; no exchange" + (" (one rank)" if world == 1 else " (--exchange none)")
         every = m["n_exchanges"] >= m["ticks_timed"]
-        return (f"islands sharded over {world} GPU(s), one slab of {bodies_per_gpu} bodies per rank; torch.distributed backend "
+        loop = ("the rank loop behind the C ABI (dmxShardRun, include/dmx_shard.h) with " +
+                ("its own RCCL communicator (ncclAllGather on the side stream, ncclAllReduce for the chunk flags)" if backend == "nccl"
+                 else "collectives injected as host-staged callbacks: REHEARSAL")) if m.get("c_loop") else \
+               f"the Python rank loop (rl-ode-physics_amd/shard.py) over torch.distributed backend {backend}"
+        return (f"islands sharded over {world} GPU(s), one slab of {bodies_per_gpu} bodies per rank; {loop}; process group backend "
                 f"{backend} ({'RCCL over xGMI' if backend == 'nccl' else 'gloo, staged through host memory: REHEARSAL'}), world size "
                 f"{dist.get_world_size()}; boundary rows (2 x {layout.side} bodies x 13 reals per rank) all-gathered on a side stream"
                 f"{', HIP-graph replay' if m['graphed'] else ''}: {m['n_exchanges']} exchanges issued in the {m['ticks_timed']} timed ticks "

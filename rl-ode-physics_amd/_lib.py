@@ -26,6 +26,7 @@ BATCH_SYMBOLS = [
     "dmxBatchSetSnapshotMode", "dmxBatchSetStaticBoxes", "dmxBatchSetStepper", "dmxBatchSetConvexHullFaces",
     "dmxBatchCollisionStatsEx", "dmxBatchFindPairs", "dmxBatchCrossPairs", "dmxBatchSetRowOrder", "dmxBatchSetExactPipeline", "dmxBatchSetStaticPath",
 ]
+SHARD_SYMBOLS = ["dmxShardRcclUniqueId", "dmxShardCreateRccl", "dmxShardCreate", "dmxShardRun", "dmxShardSettle", "dmxShardStats", "dmxShardDestroy"]
 
 _lib = None
 
@@ -105,6 +106,14 @@ def load():
     sig("dmxBatchSetSnapshotMode", I, P, I)
     sig("dmxBatchSetExactPipeline", I, P, I)
     sig("dmxBatchSetStaticPath", I, P, I)
+    # include/dmx_shard.h
+    sig("dmxShardRcclUniqueId", I, P)
+    sig("dmxShardCreateRccl", I, C.POINTER(P), P, L, L, L, I, I, P)
+    sig("dmxShardCreate", I, C.POINTER(P), P, L, L, L, I, I, P)
+    sig("dmxShardRun", I, P, D, I)
+    sig("dmxShardSettle", I, P)
+    sig("dmxShardStats", I, P, C.POINTER(L))
+    sig("dmxShardDestroy", I, P)
     sig("dmxBatchSetStaticBoxes", I, P, C.c_int32, P, P, P)
     sig("dmxBatchSetStepper", I, P, I)
     sig("dmxBatchSetConvexHullFaces", I, P, C.c_int32, P)

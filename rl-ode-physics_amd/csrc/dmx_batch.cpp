@@ -84,6 +84,10 @@ extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int dev
     b->rsize = precision == DMX_F32 ? 4 : 8;
     b->cfm = precision == DMX_F32 ? 1e-5 : 1e-10;      // dWorldCreate default per precision [ODE]
     if (const char *v = getenv("DMX_VEC")) b->vec = atoi(v);
+    if (const char *v = getenv("DMX_WIDE")) {            // 1: integrate_free_wide; 2: integrate_free_dma (DMX_WIDE_BLOCKS per CU, default 4)
+        if (atoi(v) == 1) b->vec = -16;
+        if (atoi(v) == 2) { const char *k = getenv("DMX_WIDE_BLOCKS"); const int pc = k ? atoi(k) : 4; b->vec = -(32 + (pc > 0 && pc < 32 ? pc : 4)); }
+    }
     if (const char *v = getenv("DMX_MIN_WAVES")) b->min_waves = atoi(v);
     if (const char *v = getenv("DMX_NT")) b->nt = atoi(v);
     if (const char *v = getenv("DMX_OOP")) b->oop = atoi(v);

@@ -211,6 +211,157 @@ __global__ __launch_bounds__(256, MINW) void integrate_free(T *S, T *So, int64_t
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// integrate_free_wide: the same contact-free tick with the tile moved in 16-byte pieces.  integrate_free's lanes load and store
+// one real each (a wavefront's request is 256 B); here a wavefront streams its tile's 17 input components as ONE flat run in
+// dwordx4 pieces (1 KiB per request) into LDS, every lane picks its body's components out of LDS, steps it, and the 13 new
+// state components go back through LDS and out as dwordx4 stores.  Same arithmetic (free_body_step), same bits; an experiment
+// on the memory system's request granularity (DMX_WIDE=1; DESIGN.md section 4, HBM-resident sizes).
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void integrate_free_wide(T *S, T *So, int64_t ntiles, StepParams<T> P)
+{
+    constexpr int W16 = 16 / sizeof(T);                       // reals per 16-byte piece
+    constexpr int IN = C_SIDES * SLAB_TILE, OUT = C_MASS * SLAB_TILE;      // reals in, reals out per tile
+    __shared__ __align__(16) T stage[4][IN];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+    const bool live = tile < ntiles;
+    T *ls = stage[wv];
+    const int64_t base = tile * (int64_t)(C_COUNT * SLAB_TILE);
+    if (live) {
+#pragma unroll
+        for (int k = 0; k * 64 * W16 < IN; k++) {
+            const int f = (k * 64 + lane) * W16;
+            if (f < IN) *reinterpret_cast<Pack<T, W16> *>(ls + f) = *reinterpret_cast<const Pack<T, W16> *>(S + base + f);
+        }
+    }
+    __syncthreads();
+    T c[C_SIDES];
+#pragma unroll
+    for (int k = 0; k < C_SIDES; k++) c[k] = ls[k * SLAB_TILE + lane];
+    __syncthreads();
+    const int64_t i = tile * SLAB_TILE + lane;
+    if (live) {
+        if (P.bp_check) {
+            int z = zone_state(c[C_POS] - S[slab_ix(C_BPX, i)], c[C_POS + 2] - S[slab_ix(C_BPZ, i)], S[slab_ix(C_BPSAFE, i)]);
+            if (P.n_static > 0) {
+                const int z2 = static_state(P, c[C_POS], c[C_POS + 1], c[C_POS + 2], S[slab_ix(C_BPR, i)]);
+                z = z2 > z ? z2 : z;
+            }
+            report_zone(z, P.bp_flags);
+        }
+        V3<T> x = { c[C_POS], c[C_POS + 1], c[C_POS + 2] };
+        Q4<T> q = { c[C_QUAT], c[C_QUAT + 1], c[C_QUAT + 2], c[C_QUAT + 3] };
+        V3<T> v = { c[C_LVEL], c[C_LVEL + 1], c[C_LVEL + 2] };
+        V3<T> w = { c[C_AVEL], c[C_AVEL + 1], c[C_AVEL + 2] };
+        const V3<T> Ib = { c[C_INERTIA], c[C_INERTIA + 1], c[C_INERTIA + 2] };
+        free_body_step(x, q, v, w, c[C_MASS], Ib, V3<T>{ T(0), T(0), T(0) }, V3<T>{ T(0), T(0), T(0) }, P.g, P.h, P.gyro);
+        pack_boundary(P, i, x, q, v, w);
+        ls[(C_POS + 0) * SLAB_TILE + lane] = x.x; ls[(C_POS + 1) * SLAB_TILE + lane] = x.y; ls[(C_POS + 2) * SLAB_TILE + lane] = x.z;
+        ls[(C_QUAT + 0) * SLAB_TILE + lane] = q.w; ls[(C_QUAT + 1) * SLAB_TILE + lane] = q.x;
+        ls[(C_QUAT + 2) * SLAB_TILE + lane] = q.y; ls[(C_QUAT + 3) * SLAB_TILE + lane] = q.z;
+        ls[(C_LVEL + 0) * SLAB_TILE + lane] = v.x; ls[(C_LVEL + 1) * SLAB_TILE + lane] = v.y; ls[(C_LVEL + 2) * SLAB_TILE + lane] = v.z;
+        ls[(C_AVEL + 0) * SLAB_TILE + lane] = w.x; ls[(C_AVEL + 1) * SLAB_TILE + lane] = w.y; ls[(C_AVEL + 2) * SLAB_TILE + lane] = w.z;
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int k = 0; k * 64 * W16 < OUT; k++) {
+            const int f = (k * 64 + lane) * W16;
+            if (f < OUT) *reinterpret_cast<Pack<T, W16> *>(So + base + f) = *reinterpret_cast<const Pack<T, W16> *>(ls + f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// integrate_free_dma: the contact-free tick with its READS taken off the register path.  A persistent grid; every wavefront walks
+// tiles, and a tile's 17 input components -- one flat run of the slab -- arrive by LDS-DMA (global_load_lds_dwordx4: 1 KiB per
+// request, no VGPR held while in flight) into one of the wave's two LDS buffers while the wave steps the tile before it: two
+// tiles of reads in flight per wave.  The counters behind this (profiles/r03_tcc_counters_16Mi.txt): at HBM-resident sizes the
+// pass is bound by how many read requests a compute unit keeps in flight (about 110-125 of 128 B through the vector L1), not by
+// DRAM credits or by request size.  Same arithmetic (free_body_step), same bits (DMX_WIDE=2).
+// ---------------------------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ void dma_tile_in(const T *src, T *lds, int lane)
+{
+    constexpr int BYTES = C_SIDES * SLAB_TILE * (int)sizeof(T), FULL = BYTES / 1024, REM4 = (BYTES - FULL * 1024) / 256;
+    const char *g = reinterpret_cast<const char *>(src);
+    char *l = reinterpret_cast<char *>(lds);
+#pragma unroll
+    for (int k = 0; k < FULL; k++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + k * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(l + k * 1024), 16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < REM4; k++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + FULL * 1024 + k * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void *)(l + FULL * 1024 + k * 256), 4, 0, 0);
+}
+template <class T> constexpr int dma_loads_per_tile()
+{
+    return (C_SIDES * SLAB_TILE * (int)sizeof(T)) / 1024 + ((C_SIDES * SLAB_TILE * (int)sizeof(T)) % 1024) / 256;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void integrate_free_dma(T *S, T *So, int64_t ntiles, StepParams<T> P)
+{
+    constexpr int IN = C_SIDES * SLAB_TILE;
+    extern __shared__ __align__(16) unsigned char dma_raw[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    T *buf0 = reinterpret_cast<T *>(dma_raw) + (size_t)(2 * wv) * IN, *buf1 = buf0 + IN;
+    const int64_t step = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+    if (tile >= ntiles) return;
+    constexpr int TILE_REALS = C_COUNT * SLAB_TILE;
+    // counted waits need every vector-memory operation between two waits to be known: the 13 state stores and the next tile's
+    // loads.  Ticks that also test zones or pack boundary rows (chunk ends, exchange ticks) wait for everything instead.
+    const bool counted = !P.bp_check && P.pack_out == nullptr;
+    dma_tile_in<T>(S + tile * TILE_REALS, buf0, lane);
+    int cur = 0;
+    bool first = true;
+    for (; tile < ntiles; tile += step, cur ^= 1) {
+        T *ls = cur ? buf1 : buf0;
+        const int64_t next = tile + step;
+        if (next < ntiles) dma_tile_in<T>(S + next * TILE_REALS, cur ? buf0 : buf1, lane);
+        // this tile's loads are older than: the tile before's 13 stores and the next tile's loads (vmcnt counts them all, in order)
+        // (the wave's first tile has no stores before it)
+        if (!counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (first) {
+            if (next >= ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (sizeof(T) == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        } else if (next < ntiles) {
+            if (sizeof(T) == 4) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");      // 13 + 5
+            else                asm volatile("s_waitcnt vmcnt(23)" ::: "memory");      // 13 + 10
+        } else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        first = false;
+        T c[C_SIDES];
+#pragma unroll
+        for (int k = 0; k < C_SIDES; k++) c[k] = ls[k * SLAB_TILE + lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // in registers before the buffer is handed to the tile after next
+        const int64_t i = tile * SLAB_TILE + lane;
+        if (P.bp_check) {
+            int z = zone_state(c[C_POS] - S[slab_ix(C_BPX, i)], c[C_POS + 2] - S[slab_ix(C_BPZ, i)], S[slab_ix(C_BPSAFE, i)]);
+            if (P.n_static > 0) {
+                const int z2 = static_state(P, c[C_POS], c[C_POS + 1], c[C_POS + 2], S[slab_ix(C_BPR, i)]);
+                z = z2 > z ? z2 : z;
+            }
+            report_zone(z, P.bp_flags);
+        }
+        V3<T> x = { c[C_POS], c[C_POS + 1], c[C_POS + 2] };
+        Q4<T> q = { c[C_QUAT], c[C_QUAT + 1], c[C_QUAT + 2], c[C_QUAT + 3] };
+        V3<T> v = { c[C_LVEL], c[C_LVEL + 1], c[C_LVEL + 2] };
+        V3<T> w = { c[C_AVEL], c[C_AVEL + 1], c[C_AVEL + 2] };
+        const V3<T> Ib = { c[C_INERTIA], c[C_INERTIA + 1], c[C_INERTIA + 2] };
+        free_body_step(x, q, v, w, c[C_MASS], Ib, V3<T>{ T(0), T(0), T(0) }, V3<T>{ T(0), T(0), T(0) }, P.g, P.h, P.gyro);
+        pack_boundary(P, i, x, q, v, w);
+        So[slab_ix(C_POS + 0, i)] = x.x; So[slab_ix(C_POS + 1, i)] = x.y; So[slab_ix(C_POS + 2, i)] = x.z;
+        So[slab_ix(C_QUAT + 0, i)] = q.w; So[slab_ix(C_QUAT + 1, i)] = q.x;
+        So[slab_ix(C_QUAT + 2, i)] = q.y; So[slab_ix(C_QUAT + 3, i)] = q.z;
+        So[slab_ix(C_LVEL + 0, i)] = v.x; So[slab_ix(C_LVEL + 1, i)] = v.y; So[slab_ix(C_LVEL + 2, i)] = v.z;
+        So[slab_ix(C_AVEL + 0, i)] = w.x; So[slab_ix(C_AVEL + 1, i)] = w.y; So[slab_ix(C_AVEL + 2, i)] = w.z;
+    }
+}
+
 template <class T> __device__ __forceinline__ T wave_sum(T x)
 {
 #pragma unroll
@@ -853,6 +1004,25 @@ hipError_t launch_step(T *S, T *So, const uint8_t *gtype, int64_t stride, int64_
         const int V = P.skip != nullptr ? 1 : (P.vec == 1 || P.vec == 2 || P.vec == VMAX) ? P.vec : VDEF;
         const int64_t nvec = (n + V - 1) / V;     // pad bodies up to `stride` are valid memory
         const unsigned grid = blocks_for(nvec, 256);
+        if (P.vec <= -32 && P.ticks == 1 && !ext && P.skip == nullptr) {      // DMX_WIDE=2[:blocks per CU]: reads by LDS-DMA, persistent grid
+            const int64_t ntiles = (n + SLAB_TILE - 1) / SLAB_TILE;
+            const int per_cu = (-P.vec) / 32 > 0 ? ((-P.vec) % 32 == 0 ? 4 : (-P.vec) % 32) : 4;
+            const size_t lds = (size_t)4 * 2 * C_SIDES * SLAB_TILE * sizeof(T);
+            static bool attr_done[2] = { false, false };
+            if (!attr_done[sizeof(T) == 8]) {
+                (void)hipFuncSetAttribute((const void *)integrate_free_dma<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_done[sizeof(T) == 8] = true;
+            }
+            int64_t blocks = (ntiles + 3) / 4;
+            if (blocks > (int64_t)256 * per_cu) blocks = (int64_t)256 * per_cu;
+            hipLaunchKernelGGL((integrate_free_dma<T>), dim3((unsigned)blocks), dim3(256), lds, st, S, So, ntiles, P);
+            return hipGetLastError();
+        }
+        if (P.vec == -16 && P.ticks == 1 && !ext && P.skip == nullptr) {      // DMX_WIDE=1: the tile in 16-byte pieces through LDS
+            const int64_t ntiles = (n + SLAB_TILE - 1) / SLAB_TILE;
+            hipLaunchKernelGGL((integrate_free_wide<T>), dim3(blocks_for(ntiles, 4)), dim3(256), 0, st, S, So, ntiles, P);
+            return hipGetLastError();
+        }
 #define DMX_LAUNCH_FREE(VV, MW)                                                                                      \
     do {                                                                                                             \
         if (P.ticks > 1) hipLaunchKernelGGL((integrate_free<T, VV, false, MW, true>), dim3(grid), dim3(256), 0, st, S, So, stride, nvec, P);   \

@@ -627,3 +627,108 @@ class ShardedStepper:
                 torch.cuda.synchronize()
             print(f"[shard] graph capture unavailable ({type(e).__name__}: {e}); running eagerly", flush=True)
             return False
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same loop behind the C ABI (include/dmx_shard.h, csrc/dmx_shard.cpp): what a C host calls, and what bench.py's N > 1
+# runs use.  This class only binds it.  The classes above stay as the index-logic reference that the CPU tests drive over
+# gloo with host arrays standing in for the device batch (tests/test_shard_gloo.py); on a GPU the two are held against each
+# other and against the oracle (tests/test_gpu_shard_abi.py).
+# ---------------------------------------------------------------------------------------------------------------------
+class CShardedStepper:
+    """dmxShardCreate* / dmxShardRun / dmxShardSettle / dmxShardDestroy.
+
+    collectives="rccl": the library's own RCCL binding (ncclAllGather on the side stream); the unique id comes from rank 0
+    through the torch.distributed group that is already up (any backend).  collectives="staged": the two collectives are
+    injected as callbacks that stage through host memory over that group -- several ranks can then share one GPU, which RCCL
+    does not allow (rehearsals and tests; never a measurement)."""
+
+    def __init__(self, world_batch, layout, rank, world_size, collectives="rccl", group=None):
+        import ctypes as C
+        self.w, self.L, self.rank, self.world, self.group = world_batch, layout, rank, world_size, group
+        self.lib = world_batch.lib
+        self.h = C.c_void_p()
+        self._keep = None
+        if collectives == "rccl":
+            ident = (C.c_char * 128)()
+            if rank == 0:
+                _check_rc(self.lib.dmxShardRcclUniqueId(ident), "dmxShardRcclUniqueId")
+            if world_size > 1:
+                t = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8).clone()
+                if dist.get_backend(group) == "nccl":
+                    t = t.cuda()
+                dist.broadcast(t, src=0, group=group)
+                ident = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+            _check_rc(self.lib.dmxShardCreateRccl(C.byref(self.h), world_batch.h, layout.side, layout.rows, layout.spare, rank, world_size,
+                                                  ident), "dmxShardCreateRccl")
+        else:
+            self._keep = self._staged_collectives()
+            _check_rc(self.lib.dmxShardCreate(C.byref(self.h), world_batch.h, layout.side, layout.rows, layout.spare, rank, world_size,
+                                              C.byref(self._keep[0])), "dmxShardCreate")
+
+    def _staged_collectives(self):
+        """(dmxCollectives struct, callbacks kept alive): all-gather and max-all-reduce through host memory over the group"""
+        import ctypes as C
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_int)
+        hip = C.CDLL(None)              # the HIP runtime is already in the process (torch / the library)
+        world, group = self.world, self.group
+
+        def all_gather(_ctx, send, recv, nbytes, stream):
+            try:
+                if hip.hipStreamSynchronize(C.c_void_p(stream)) != 0:
+                    return 1
+                mine = (C.c_ubyte * nbytes)()
+                if hip.hipMemcpy(mine, C.c_void_p(send), C.c_size_t(nbytes), 2) != 0:      # device to host
+                    return 1
+                h = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+                o = torch.empty(world * nbytes, dtype=torch.uint8)
+                dist.all_gather_into_tensor(o, h, group=group)
+                buf = o.numpy().tobytes()
+                return 0 if hip.hipMemcpy(C.c_void_p(recv), buf, C.c_size_t(len(buf)), 1) == 0 else 1      # host to device
+            except Exception as e:      # noqa: BLE001 -- an exception must not unwind through the C caller
+                print(f"[shard] staged all-gather failed: {type(e).__name__}: {e}", flush=True)
+                return 1
+
+        def all_reduce_max(_ctx, vals, n):
+            try:
+                t = torch.tensor([vals[i] for i in range(n)], dtype=torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+                for i in range(n):
+                    vals[i] = int(t[i])
+                return 0
+            except Exception as e:      # noqa: BLE001
+                print(f"[shard] staged all-reduce failed: {type(e).__name__}: {e}", flush=True)
+                return 1
+
+        class Coll(C.Structure):
+            _fields_ = [("ctx", C.c_void_p), ("all_gather", AG), ("all_reduce_max", AR)]
+        ag, ar = AG(all_gather), AR(all_reduce_max)
+        return Coll(None, ag, ar), ag, ar
+
+    def run(self, h, nsteps):
+        _check_rc(self.lib.dmxShardRun(self.h, float(h), int(nsteps)), "dmxShardRun")
+
+    def settle(self):
+        _check_rc(self.lib.dmxShardSettle(self.h), "dmxShardSettle")
+
+    def drain(self):
+        self.settle()
+
+    def stats(self):
+        import ctypes as C
+        out = (C.c_int64 * 6)()
+        _check_rc(self.lib.dmxShardStats(self.h, out), "dmxShardStats")
+        return dict(zip(("exchanges", "committed", "rolled_back", "exact_ticks", "adopted", "retired"), [int(v) for v in out]))
+
+    def close(self):
+        if self.h:
+            self.settle()
+            _check_rc(self.lib.dmxShardDestroy(self.h), "dmxShardDestroy")
+            self.h = None
+
+
+def _check_rc(rc, what):
+    if rc != 0:
+        from .batch import DmxError
+        raise DmxError(f"{what} failed with code {rc}", rc)

@@ -13,6 +13,28 @@ __global__ void k_copy(const float4 *a, float4 *b, size_t n4)
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) b[i] = a[i];
 }
+// pure streams: what the memory system gives reads alone and writes alone (the pass is 57 % reads)
+__global__ void k_read(const float4 *a, float *out, size_t n4)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float4 v = i < n4 ? a[i] : make_float4(0, 0, 0, 0);
+    float s = v.x + v.y + v.z + v.w;
+    if (s == 12345.678f) out[i & 1023] = s;                 // (never true: keeps the load alive without a store stream)
+}
+__global__ void k_write(float4 *b, size_t n4)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) b[i] = make_float4(1.f, 2.f, 3.f, (float)i);
+}
+// r of every 8 float4 are read-modify-written, the rest only read: a read share between 50 % and 100 %
+template <int W> __global__ void k_mix(float4 *a, size_t n4)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = a[i];
+    if ((blockIdx.x & 7) < W) { v.x *= 1.0000001f; a[i] = v; }
+    else if (v.x == 12345.678f) a[i] = v;
+}
 __global__ void k_scale_inplace(float4 *a, size_t n4)      // read X, write X
 {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -135,6 +157,15 @@ int main(int argc, char **argv)
     report("split layout, in place (Y = X)", n, time_us([&] { k_split<<<g, 256>>>(A, Cn, A, (int)n); }, reps));
     report("17-comp dense tiles -> 13-comp dense slab (out of place)", n, time_us([&] { k_dense17<<<g, 256>>>(A, B, (int)n, 13); }, reps));
     report("17-comp dense tiles in place", n, time_us([&] { k_dense17<<<g, 256>>>(A, A, (int)n, 17); }, reps));
+    {
+        auto rep2 = [&](const char *name, double bytes, double us) { printf("  %-58s %9.2f us  %7.0f GB/s  frac %.3f\n", name, us, bytes / us * 1e-3, bytes / us * 1e-3 / 8000.0); fflush(stdout); };
+        const double b60 = (double)n * 60.0;
+        rep2("pure read  (float4, 60 B / body)", b60, time_us([&] { k_read<<<(n4 + 255) / 256, 256>>>((float4 *)A, B, n4); }, reps));
+        rep2("pure write (float4, 60 B / body)", b60, time_us([&] { k_write<<<(n4 + 255) / 256, 256>>>((float4 *)B, n4); }, reps));
+        rep2("in place, 2 of 8 blocks written back (read share 80 %)", b60 * 1.25, time_us([&] { k_mix<2><<<(n4 + 255) / 256, 256>>>((float4 *)A, n4); }, reps));
+        rep2("in place, 4 of 8 blocks written back (read share 67 %)", b60 * 1.5, time_us([&] { k_mix<4><<<(n4 + 255) / 256, 256>>>((float4 *)A, n4); }, reps));
+        rep2("in place, 6 of 8 blocks written back (read share 57 %)", b60 * 1.75, time_us([&] { k_mix<6><<<(n4 + 255) / 256, 256>>>((float4 *)A, n4); }, reps));
+    }
     report("float4 copy again", n, time_us([&] { k_copy<<<(n4 + 255) / 256, 256>>>((float4 *)A, (float4 *)B, n4); }, reps));
     return 0;
 }

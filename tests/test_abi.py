@@ -30,8 +30,9 @@ def test_library_loads_and_exports_batch_abi():
 def test_every_header_symbol_is_exported():
     lib = pkg._lib.load()
     headers = sorted(h for h in os.listdir(os.path.join(ROOT, "include")) if h.endswith(".h"))
-    assert headers == ["dmx_batch.h", "dmx_hull.h"]
+    assert headers == ["dmx_batch.h", "dmx_hull.h", "dmx_shard.h"]
     assert _declared("dmx_hull.h") == ["dmxHullBuild", "dmxHullPlanes", "dmxObjReadVertices"]
+    assert _declared("dmx_shard.h") == sorted(pkg._lib.SHARD_SYMBOLS)
     for h in headers:
         for n in _declared(h):
             assert hasattr(lib, n), f"{n} declared in include/{h} but not exported"
