@@ -11,11 +11,14 @@
  *            dmxShardSettle(s); dmxBatchDownload...    whenever poses are wanted
  *     dmxShardDestroy(s)
  *
- * Slab layout (the batch must have side * rows + spare + 2 * side slots): [0, n) the rank's own bodies, n = side * rows,
+ * Slab layout (the batch must have side * rows + spare + 2 * side + spare slots): [0, n) the rank's own bodies, n = side * rows,
  * row r = slots [r * side, (r + 1) * side), rows ordered along the sharding axis; [n, n + spare) empty slots that take bodies
  * adopted from the upper neighbour when an island spans the shared face; then `side` ghost slots for the lower neighbour's
- * last row and `side` for the upper neighbour's first row.  dmxShardCreate* calls dmxBatchSetActiveCount itself, shares the
- * boundary rows' geometry (extents, classes, mass properties) with the neighbours and primes the ghost slots.
+ * last row, `side` for the upper neighbour's first row, and `spare` for the lower neighbour's spare slots -- a body that
+ * neighbour adopted from this rank stays visible here as a ghost, so this rank's bodies behind the boundary row still see it:
+ * they either follow it down (first-row bodies) or the contact is reported on every rank (DMX_ECROSS), never missed.
+ * dmxShardCreate* calls dmxBatchSetActiveCount itself, shares the boundary rows' geometry (extents, classes, mass properties)
+ * with the neighbours and primes the ghost slots.
  *
  * What a tick does is what rl-ode-physics_amd/shard.py documents (the same loop, which that module now binds): ticks run in
  * collision-proof chunks; the step kernel packs the boundary rows' new state itself; a side stream all-gathers them and one

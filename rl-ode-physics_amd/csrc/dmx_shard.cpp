@@ -184,7 +184,11 @@ int ex_before_step(dmxShard *s, bool fused)
 }
 int ex_pack(dmxShard *s, bool fused)
 {
+    // (the step kernel packs the two boundary rows itself; the spare slots -- bodies adopted from the upper neighbour, which that
+    //  neighbour must keep seeing -- follow by a small gather)
     if (!fused) SH_TRY(dmxBatchGatherBodies(s->b, s->send_idx, s->n_send, s->send[s->k % 2]));
+    else if (s->spare > 0)
+        SH_TRY(dmxBatchGatherBodies(s->b, s->send_idx + 2 * s->side, s->spare, (char *)s->send[s->k % 2] + (size_t)(2 * s->side) * STATE_REALS * s->rsize));
     HIP_TRY(hipEventRecord(s->packed, main_stream(s)));
     HIP_TRY(hipStreamWaitEvent(s->side_stream, s->packed, 0));
     return DMX_OK;
@@ -192,12 +196,17 @@ int ex_pack(dmxShard *s, bool fused)
 int ex_exchange(dmxShard *s, bool check_ghosts)
 {
     const int slot = (int)(s->k % 2);
-    const size_t row_bytes = (size_t)s->side * STATE_REALS * s->rsize, bytes = 2 * row_bytes;
+    const size_t row_bytes = (size_t)s->side * STATE_REALS * s->rsize, bytes = (size_t)s->n_send * STATE_REALS * s->rsize;
     if (s->coll.all_gather(s->coll.ctx, s->send[slot], s->recv, bytes, s->side_stream) != 0) return DMX_EHIP;
     const char *r = (const char *)s->recv;
     const void *lo = s->rank > 0 ? r + (size_t)(s->rank - 1) * bytes + row_bytes : nullptr;            // lower neighbour's upper row
     const void *hi = s->rank < s->world - 1 ? r + (size_t)(s->rank + 1) * bytes : nullptr;            // upper neighbour's lower row
     if (lo || hi) SH_TRY(dmxBatchRefreshGhostsOnStream(s->b, s->side_stream, s->n_active, s->side, lo, s->side, hi, check_ghosts ? 1 : 0));
+    // the lower neighbour's spare slots: the bodies it adopted from THIS rank come back as ghosts, so that this rank's bodies
+    // behind the boundary row still see them (zones, pair search); slots of bodies not adopted are class NONE and inert
+    if (s->rank > 0 && s->spare > 0)
+        SH_TRY(dmxBatchRefreshGhostsOnStream(s->b, s->side_stream, s->n_active + 2 * s->side, s->spare,
+                                             r + (size_t)(s->rank - 1) * bytes + 2 * row_bytes, 0, nullptr, check_ghosts ? 1 : 0));
     HIP_TRY(hipEventRecord(s->done[slot], s->side_stream));
     s->have_done[slot] = true;
     s->last = slot;
@@ -218,7 +227,7 @@ int shard_tick(dmxShard *s, double h, bool check)
 int migrate(dmxShard *s)
 {
     dmxBatch *b = s->b;
-    const int64_t side = s->side, hi0 = s->n_active + side, lo0 = s->n_active;
+    const int64_t side = s->side, hi0 = s->n_active + side;
     for (int round = 0; round < 8; round++) {
         const int32_t *pairs, *inv; int64_t np, ninv;
         SH_TRY(dmxBatchFindPairs(b, &pairs, &np, &inv, &ninv));
@@ -231,40 +240,53 @@ int migrate(dmxShard *s)
         int64_t stuck = 0;
         for (int64_t c = 0; c < ncross; c++) {
             const int64_t i = cross[2 * c], g = cross[2 * c + 1];
-            if (g >= hi0) adopt.push_back(g);
-            else if (g >= lo0 && i >= side) stuck++;           // reaches the lower neighbour from behind the boundary row
+            if (g >= hi0 && g < hi0 + side) adopt.push_back(g);            // the upper neighbour's first row: this rank adopts
+            else if (i >= side) stuck++;           // a body behind my boundary row reaches the lower neighbour's row, or a body the
+                                                   // lower neighbour adopted from me: only first-row bodies can follow it down
         }
         std::sort(adopt.begin(), adopt.end());
         adopt.erase(std::unique(adopt.begin(), adopt.end()), adopt.end());
         if ((int64_t)adopt.size() > kNoticeCap || s->spare_used + (int64_t)adopt.size() > s->spare) { stuck++; adopt.clear(); }
-        std::vector<double> mine((size_t)kNoticeCap + 2, 0.0), all;
+        // notice: [count, stuck, (index in the upper neighbour's first row, my spare slot) ...]
+        std::vector<double> mine((size_t)2 * kNoticeCap + 2, 0.0), all;
         mine[0] = (double)adopt.size(); mine[1] = (double)stuck;
-        for (size_t a = 0; a < adopt.size(); a++) mine[2 + a] = (double)(adopt[a] - hi0);
+        for (size_t a = 0; a < adopt.size(); a++) { mine[2 + 2 * a] = (double)(adopt[a] - hi0); mine[3 + 2 * a] = (double)(s->spare_used + (int64_t)a); }
         SH_TRY(gather_host(s, mine, all));
+        const size_t nw = (size_t)2 * kNoticeCap + 2;
         double stuck_all = 0;
-        for (int r = 0; r < s->world; r++) stuck_all += all[(size_t)r * (kNoticeCap + 2) + 1];
+        for (int r = 0; r < s->world; r++) stuck_all += all[(size_t)r * nw + 1];
         if (stuck_all > 0) {
             fprintf(stderr, "libode_mi355: rank %d: an island spans two ranks and cannot be migrated (a body beyond the boundary row "
                             "reaches across the face, or the spare slots are used up)\n", s->rank);
             return DMX_ECROSS;
         }
         std::vector<char> tmp((size_t)STATE_REALS * 8);
+        auto copy_body = [&](int64_t from, int64_t to) -> int {
+            for (int field : { DMX_STATE, DMX_MASS, DMX_INERTIA, DMX_SIDES }) {
+                SH_TRY(dmxBatchDownload(b, field, tmp.data(), from, 1));
+                SH_TRY(dmxBatchUpload(b, field, tmp.data(), to, 1));
+            }
+            return DMX_OK;
+        };
+        const uint8_t none = DMX_GEOM_NONE;
         for (int64_t g : adopt) {                              // the ghost becomes a body of this rank's own, in a spare slot
             const int64_t slot = s->n + s->spare_used++;
-            for (int field : { DMX_STATE, DMX_MASS, DMX_INERTIA, DMX_SIDES }) {
-                SH_TRY(dmxBatchDownload(b, field, tmp.data(), g, 1));
-                SH_TRY(dmxBatchUpload(b, field, tmp.data(), slot, 1));
-            }
-            const uint8_t cls = s->ghost_gtype[(size_t)(g - s->n_active)], none = DMX_GEOM_NONE;
+            SH_TRY(copy_body(g, slot));
+            const uint8_t cls = s->ghost_gtype[(size_t)(g - s->n_active)];
             SH_TRY(dmxBatchUploadGeomType(b, &cls, slot, 1));
             SH_TRY(dmxBatchUploadGeomType(b, &none, g, 1));    // the ghost is switched off for good
             s->stat[4]++;
         }
         if (s->rank > 0) {                                     // the lower neighbour adopted these bodies of my first row
-            const double *nb = all.data() + (size_t)(s->rank - 1) * (kNoticeCap + 2);
+            const double *nb = all.data() + (size_t)(s->rank - 1) * nw;
             for (int a = 0; a < (int)nb[0]; a++) {
-                const int64_t j = (int64_t)nb[2 + a];
-                const uint8_t none = DMX_GEOM_NONE;
+                const int64_t j = (int64_t)nb[2 + 2 * a], kslot = (int64_t)nb[3 + 2 * a];
+                // it stays visible here as a ghost: the slot that mirrors the neighbour's spare slot takes its geometry and, until
+                // the next exchange brings the neighbour's copy, its state
+                const int64_t ret = s->n_active + 2 * side + kslot;
+                SH_TRY(copy_body(j, ret));
+                const uint8_t cls = b->h_gtype[(size_t)j];
+                SH_TRY(dmxBatchUploadGeomType(b, &cls, ret, 1));
                 SH_TRY(dmxBatchUploadGeomType(b, &none, j, 1));
                 double park[3] = { 0.0, -1.0e6 - (double)j, 0.0 }, zero[3] = { 0, 0, 0 };
                 float parkf[3] = { 0.f, (float)park[1], 0.f }, zerof[3] = { 0, 0, 0 };
@@ -478,9 +500,9 @@ int create_common(dmxShard **out, dmxBatch *b, int64_t side, int64_t rows, int64
                   RcclCtx *own)
 {
     if (!out || !b || side < 4 || side % 4 || rows < 2 || spare < 0 || spare % 4 || world < 1 || rank < 0 || rank >= world) return DMX_EINVAL;
-    const int64_t n = side * rows, n_active = n + spare, n_total = n_active + 2 * side;
+    const int64_t n = side * rows, n_active = n + spare, n_total = n_active + 2 * side + spare;
     if (b->n != n_total) {
-        fprintf(stderr, "libode_mi355: dmxShardCreate: the batch has %lld slots, the layout needs side * rows + spare + 2 * side = %lld\n",
+        fprintf(stderr, "libode_mi355: dmxShardCreate: the batch has %lld slots, the layout needs side * rows + 2 * spare + 2 * side = %lld\n",
                 (long long)b->n, (long long)n_total);
         return DMX_EINVAL;
     }
@@ -489,7 +511,7 @@ int create_common(dmxShard **out, dmxBatch *b, int64_t side, int64_t rows, int64
     dmxShard *s = new (std::nothrow) dmxShard();
     if (!s) return DMX_ENOMEM;
     s->b = b; s->side = side; s->rows = rows; s->spare = spare; s->n = n; s->n_active = n_active; s->n_total = n_total;
-    s->n_send = 2 * side; s->rank = rank; s->world = world; s->rsize = b->rsize; s->coll = coll; s->own = own;
+    s->n_send = 2 * side + spare; s->rank = rank; s->world = world; s->rsize = b->rsize; s->coll = coll; s->own = own;
     int rc = DMX_OK;
     do {
         if ((rc = dmxBatchSetActiveCount(b, n_active)) != DMX_OK) break;
@@ -501,6 +523,7 @@ int create_common(dmxShard **out, dmxBatch *b, int64_t side, int64_t rows, int64
             hipMalloc(&s->recv, buf * (size_t)world) != hipSuccess || hipMalloc((void **)&s->send_idx, (size_t)s->n_send * sizeof(int32_t)) != hipSuccess) { rc = DMX_ENOMEM; break; }
         std::vector<int32_t> idx((size_t)s->n_send);
         for (int64_t t = 0; t < side; t++) { idx[(size_t)t] = (int32_t)t; idx[(size_t)(side + t)] = (int32_t)(n - side + t); }
+        for (int64_t t = 0; t < spare; t++) idx[(size_t)(2 * side + t)] = (int32_t)(n + t);       // the spare slots: bodies adopted from above
         if (hipMemcpy(s->send_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { rc = DMX_EHIP; break; }
         if ((rc = share_geometry(s)) != DMX_OK) break;
         // prime: one exchange of the boundary rows as they stand, so the ghost slots hold the neighbours' bodies where they are

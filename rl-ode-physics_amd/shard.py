@@ -26,9 +26,10 @@ carries a broadphase safe zone; the step kernel checks the rank's own bodies, a 
 the ghost slots right after their refresh.  Ticks run in chunks; at a chunk's end the ranks OR their violation flags
 (one tiny all-reduce) and either all commit or all roll back to the chunk's snapshot and replay it -- first with fresh
 zones, then tick by tick on the exact path (pair search, narrowphase, island solve).  A pair of bodies owned by two
-different ranks makes an island that spans them: before an exact tick the ranks probe for such pairs and migrate the island
-to the lower rank (`_migrate`: the boundary body is adopted into a spare slot, the upper rank retires its copy); what
-migration cannot cover is reported on every rank at once (DMX_ECROSS).
+different ranks makes an island that spans them: the product loop -- the same loop behind the C ABI, include/dmx_shard.h,
+bound by CShardedStepper at the end of this module -- probes for such pairs before an exact tick and migrates the island to
+the lower rank (the boundary body is adopted into a spare slot, the upper rank retires its copy and keeps seeing the body as a
+ghost); the classes below, kept as the index-logic reference the CPU tests drive over gloo, report it (DMX_ECROSS).
 
 The exchange is written against a tiny `ops` interface (gather / scatter / buffers / streams) so the index
 logic and the collective run unchanged on CPU tensors with the gloo backend (tests/test_shard_gloo.py).
@@ -46,8 +47,9 @@ class SlabLayout:
     """Row-major slab: body i sits in grid row i // side (z) and column i % side (x).
 
     Slots: [0, n) the rank's own bodies; [n, n_active) `spare` empty slots (stepped, geometry class NONE) that take bodies
-    adopted from the upper neighbour when an island spans the shared face; [n_active, n_total) ghost copies of the
-    neighbours' boundary rows."""
+    adopted from the upper neighbour when an island spans the shared face; then ghost copies of the neighbours' boundary rows
+    (2 x side) and of the lower neighbour's spare slots (`spare`: a body that neighbour adopted from this rank stays visible
+    here) -- include/dmx_shard.h."""
 
     def __init__(self, side, rows, spare=0):
         self.side, self.rows, self.spare = int(side), int(rows), int(spare)
@@ -61,7 +63,7 @@ class SlabLayout:
         # ghost slots behind the active bodies: rank-1's upper row, then rank+1's lower row
         self.ghost_lo = np.arange(self.n_active, self.n_active + self.side, dtype=np.int32)
         self.ghost_hi = np.arange(self.n_active + self.side, self.n_active + 2 * self.side, dtype=np.int32)
-        self.n_total = self.n_active + 2 * self.side
+        self.n_total = self.n_active + 2 * self.side + self.spare
 
     @property
     def interior(self):
@@ -302,14 +304,10 @@ class ShardedStepper:
 
     CHUNK_MIN, CHUNK_MAX = 32, 256
 
-    NOTICE_CAP = 64        # bodies one rank can adopt in one migration round
-
     def __init__(self, world_batch, layout, rank, world_size, exchange="boundary", device=None, stream=None,
                  collide=False, geometry=None, ops=None, group=None, exchange_every_tick=False, lazy=False):
         self.w, self.L = world_batch, layout
         self.rank, self.world = rank, world_size
-        self.spare_used = 0
-        self.adopted, self.retired = [], []      # (spare slot, index in the upper neighbour's lower row); own slots given away
         # lazy: ballistic chunks stay open across run() calls (a caller that issues a few ticks per call does not pay a
         # chunk's exchange, flag read and flag all-reduce per call); settle() closes the open chunk
         self.lazy = bool(lazy)
@@ -359,69 +357,12 @@ class ShardedStepper:
         kernels, so the boundary rows are gathered after the tick instead of packed inside the step kernel"""
         ex = self.exchange
         ex.drain()
-        self._migrate()
+        # (an island that spans two ranks is reported by the exact tick, DMX_ECROSS; migrating it to one owner is the C loop's
+        #  job -- csrc/dmx_shard.cpp, bound by CShardedStepper below)
         ex.before_step(fused=False)
         self.w.exact_tick(h)
         ex.pack(fused=False)
         ex.exchange()
-
-    # -- islands that span two ranks -------------------------------------------------------------------------
-    def _migrate(self):
-        """Before an exact tick: if a body of some rank touches a neighbour's boundary body (an (own, ghost) AABB pair),
-        their island spans two ranks and has to be stepped by one.  The LOWER rank adopts: it copies the upper
-        neighbour's boundary body out of its ghost slot (state as of the last exchange, extents and mass properties shared
-        at set-up) into a spare slot, switches the ghost off, and tells the upper rank, which retires its copy (geometry
-        class NONE, parked far below).  One small all-gather of notices per round; rounds repeat until no rank sees a
-        crossing pair (an adopted body may reach further boundary bodies).  A rank's body touching the LOWER neighbour's
-        ghost is adopted by that neighbour when it is in this rank's boundary row -- the neighbour sees the same pair --
-        and is reported (DMX_ECROSS) otherwise: bodies that reach across the face from behind the boundary row are not
-        handled."""
-        from .batch import STATE, MASS, INERTIA, SIDES, POS, LVEL, AVEL, DmxError
-        ex, w, L, ops = self.exchange, self.w, self.L, self.exchange.ops
-        if not hasattr(w, "find_pairs") or not hasattr(ex, "ghost_gtype"):
-            return                                         # (host doubles of the batch in the CPU tests: nothing to probe)
-        side = L.side
-        for _round in range(8):
-            cross = w.find_pairs()[2]
-            (any_cross,) = ops.any_rank([len(cross) > 0], ex.group)
-            if not any_cross:
-                return
-            hi0, lo0 = int(L.ghost_hi[0]), int(L.ghost_lo[0])
-            adopt = sorted({int(g) for _i, g in cross if g >= hi0})
-            stuck = [(int(i), int(g)) for i, g in cross if lo0 <= g < hi0 and int(i) >= side]
-            notice = np.zeros(self.NOTICE_CAP + 2)
-            notice[0] = len(adopt); notice[1] = len(stuck)
-            if len(adopt) > self.NOTICE_CAP or self.spare_used + len(adopt) > L.spare:
-                notice[1] += 1                             # out of spare slots: reported like a stuck pair, on every rank
-                adopt = []
-                notice[0] = 0
-            notice[2:2 + len(adopt)] = [g - hi0 for g in adopt]
-            mine = ops.empty(self.NOTICE_CAP + 2)
-            mine.copy_(torch.from_numpy(notice).to(mine.dtype))
-            flat = ops.empty(self.world * (self.NOTICE_CAP + 2))
-            ex._all_gather(flat, mine)
-            got = flat.view(self.world, self.NOTICE_CAP + 2).cpu().numpy()
-            if got[:, 1].sum() > 0:
-                raise DmxError(f"rank {self.rank}: an island spans two ranks and cannot be migrated (a body beyond the boundary "
-                               f"row reaches across the face, or the spare slots are used up): {stuck}", -6)
-            for g in adopt:                                # this rank is the lower one: the ghost becomes a body of its own
-                slot = L.n + self.spare_used
-                self.spare_used += 1
-                for field in (STATE, MASS, INERTIA, SIDES):
-                    w.upload(field, w.download(field, g, 1), first=slot)
-                w.upload_geom_type(ex.ghost_gtype[g - L.n_active:g - L.n_active + 1], first=slot)
-                w.upload_geom_type(np.zeros(1, np.uint8), first=g)          # the ghost is switched off for good
-                self.adopted.append((slot, g - hi0))
-            if self.rank > 0:                              # notices of the lower neighbour: it adopted these bodies of my first row
-                cnt = int(got[self.rank - 1, 0])
-                for idx in got[self.rank - 1, 2:2 + cnt].astype(int):
-                    j = int(idx)                           # my lower row is slots [0, side)
-                    w.upload_geom_type(np.zeros(1, np.uint8), first=j)
-                    w.upload(POS, np.array([[0.0, -1.0e6 - j, 0.0]]), first=j)
-                    w.upload(LVEL, np.zeros((1, 3)), first=j)
-                    w.upload(AVEL, np.zeros((1, 3)), first=j)
-                    self.retired.append(j)
-        raise DmxError(f"rank {self.rank}: islands spanning two ranks keep growing after 8 migration rounds", -6)
 
     # -- the loop ------------------------------------------------------------------------------------------
     def run(self, h, nsteps):

@@ -1145,86 +1145,3 @@ def test_config5_full_size_teapots_on_the_box_floor():
     w.close()
 
 
-# ----------------------------------------------------------------- an island that spans two ranks is migrated to one owner
-def _migration_scene(p, nx, rows):
-    scene = p.scenes.box_grid(nx, 2 * rows, seed=31, y_range=(10.0, 10.0), spin=False, box_mass=True, plane=False).astype("float64")
-    scene.sides[:] = 0.8
-    scene.mass[:] = 0.8 ** 3
-    scene.inertia[:] = (0.8 ** 3) / 12.0 * 2 * 0.64
-    thrown = (rows - 1) * nx + 3                       # lower rank's last row, column 3: heads for the upper rank's first row
-    scene.lvel[thrown, 2] = 4.0
-    return scene, thrown
-
-
-def _migration_worker(rank, port, steps, out_q):
-    import os
-    import torch
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=2)
-    try:
-        from __graft_entry__ import load_package
-        p = load_package()
-        nx, rows = 8, 4
-        full, _ = _migration_scene(p, nx, rows)
-        scene = full.slice(rank * nx * rows, (rank + 1) * nx * rows)
-        L = p.shard.SlabLayout(nx, rows, spare=8)
-        w = p.BatchWorld(L.n_total, dtype="float64")
-        w.load_scene(scene)
-        w.set_active_count(L.n_active)
-        stream = torch.cuda.Stream()
-        with torch.cuda.stream(stream):
-            w.set_stream(stream.cuda_stream)
-            ops = p.shard.StagedDeviceOps(w, torch.device("cuda", 0), stream)
-            st = p.shard.ShardedStepper(w, L, rank, 2, collide=True, ops=ops,
-                                        geometry=(scene.sides, scene.gtype, scene.mass[:, 0], scene.inertia))
-            st.run(H, steps)
-            st.drain()
-            w.synchronize()
-            state = [a.copy() for a in w.state()]
-        out_q.put((rank, state, list(st.adopted), list(st.retired), w.collision_stats()))
-        w.close()
-    finally:
-        dist.destroy_process_group()
-
-
-def test_island_spanning_two_ranks_is_migrated_to_the_lower_rank():
-    """A body of rank 0's last row is thrown across the shared face into rank 1's first row.  Their island spans two ranks:
-    rank 0 adopts rank 1's body (out of its ghost slot into a spare slot), rank 1 retires its copy, and from then on the
-    collision is rank 0's to solve -- every body ends where the oracle stepping the whole scene in one world puts it."""
-    import socket
-    import torch.multiprocessing as mp
-    steps, nx, rows = 50, 8, 4
-    full, thrown = _migration_scene(pkg, nx, rows)
-    ow = _oracle_build(_orc("float64"), full)
-    pairs = 0
-    for _ in range(steps):
-        ow.tick(H)
-        pairs += ow.n_contacts()
-    assert pairs > 0                                       # the thrown body does hit its neighbour across the face
-    ref = ow.state()
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_migration_worker, args=(r, port, steps, q)) for r in range(2)]
-    for pr in procs:
-        pr.start()
-    got = {}
-    try:
-        for _ in range(2):
-            r, state, adopted, retired, stats = q.get(timeout=150)
-            got[r] = (state, adopted, retired, stats)
-        for pr in procs:
-            pr.join(timeout=60)
-            assert pr.exitcode == 0
-    finally:
-        for pr in procs:
-            if pr.is_alive():
-                pr.terminate()
-    n = nx * rows
-    hit = n + 3                                            # global index of the body that was struck: rank 1's row 0, column 3
-    assert got[0][1] == [(n, 3)] and got[1][2] == [3] and got[0][2] == [] and got[1][1] == []
-    _compare([a[:n] for a in got[0][0]], [a[:n] for a in ref])                       # rank 0's own bodies, the thrown one included
-    _compare([a[n:n + 1] for a in got[0][0]], [a[hit:hit + 1] for a in ref])         # the adopted body lives in rank 0's first spare slot
-    keep = np.array([i for i in range(n) if i != 3])
-    _compare([a[keep] for a in got[1][0]], [a[n + keep] for a in ref])               # rank 1's bodies but the one it retired

@@ -77,9 +77,13 @@ def _worker(rank, port, steps, thrown, out_q):
         w = p.BatchWorld(L.n_total, dtype="float64")
         w.load_scene(scene)
         st = p.shard.CShardedStepper(w, L, rank, 2, collectives="staged")
-        for k in (1, 6, steps - 7):
-            st.run(H, k)
-        st.settle()
+        try:
+            for k in (1, 6, steps - 7):
+                st.run(H, k)
+            st.settle()
+        except p.batch.DmxError as e:
+            out_q.put((rank, "error", e.code))
+            return
         state = [a.copy() for a in w.state()]
         stats = st.stats()
         st.close()
@@ -94,20 +98,20 @@ def _two_rank_scene(p, nx, rows, thrown):
     scene.sides[:] = 0.8
     scene.mass[:] = 0.8 ** 3
     scene.inertia[:] = (0.8 ** 3) / 12.0 * 2 * 0.64
-    if thrown:
+    if thrown == "chain":
+        # A (lower rank's last row) is thrown at B (upper rank's first row); B, once adopted by the lower rank, is driven on into
+        # C, the body BEHIND it in the upper rank's second row -- out of reach of the migration, which must say so
+        scene.lvel[(rows - 1) * nx + 3, 2] = 9.0
+        scene.mass[(rows - 1) * nx + 3] *= 8.0
+    elif thrown:
         scene.lvel[(rows - 1) * nx + 3, 2] = 4.0          # lower rank's last row, column 3: heads for the upper rank's first row
     else:
         scene.lvel[5, 0] = 0.9                              # a body of rank 0 drifts out of its zone: both ranks roll back
     return scene
 
 
-@pytest.mark.parametrize("thrown", [False, True])
-def test_two_ranks_sharing_the_gpu_through_the_c_loop(thrown):
+def _run_two_ranks(steps, thrown):
     import torch.multiprocessing as mp
-    steps, nx, rows = 50, 8, 4
-    full = _two_rank_scene(pkg, nx, rows, thrown)
-    ref, contacts = _oracle_state("float64", full, steps)
-    assert (contacts > 0) == thrown or contacts >= 0
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -126,6 +130,39 @@ def test_two_ranks_sharing_the_gpu_through_the_c_loop(thrown):
         for pr in procs:
             if pr.is_alive():
                 pr.terminate()
+    return got
+
+
+def test_a_body_adopted_by_the_lower_rank_stays_visible_to_the_rank_it_came_from():
+    """an island of three bodies across the face -- A on rank 0, B in rank 1's first row, C in rank 1's second row.
+    After rank 0 has adopted B, rank 1 no longer owns it; it must still SEE it (a ghost fed by rank 0's spare slots), or B would
+    pass through C unnoticed.  C is behind the boundary row and cannot follow B down: every rank reports DMX_ECROSS."""
+    steps, nx, rows = 150, 8, 4
+    full = _two_rank_scene(pkg, nx, rows, "chain")
+    ow = _orc("float64").world()
+    ow.add_boxes(full.pos, full.quat, full.lvel, full.avel, full.mass[:, 0], full.inertia, full.sides)
+    n = nx * rows
+    a, b_, c = (rows - 1) * nx + 3, n + 3, n + nx + 3
+    seen = set()
+    for _ in range(steps):
+        ow.tick(H)
+        for j in ow.joints():
+            seen.add((min(j[0], j[1]), max(j[0], j[1])))
+    assert (a, b_) in seen and (b_, c) in seen              # in one world: A strikes B, B then strikes C
+    got = _run_two_ranks(steps, "chain")
+    assert got[0][0] == "error" and got[1][0] == "error" and got[0][1] == -6 and got[1][1] == -6
+
+
+@pytest.mark.parametrize("thrown", [False, True])
+def test_two_ranks_sharing_the_gpu_through_the_c_loop(thrown):
+    steps, nx, rows = 50, 8, 4
+    full = _two_rank_scene(pkg, nx, rows, thrown)
+    ref, contacts = _oracle_state("float64", full, steps)
+    got = _run_two_ranks(steps, thrown)
+    _check_two_ranks(got, ref, nx, rows, thrown)
+
+
+def _check_two_ranks(got, ref, nx, rows, thrown):
     n = nx * rows
     if thrown:
         hit = n + 3
