@@ -285,6 +285,11 @@ extern "C" int dmxBatchUploadGeomType(dmxBatchID b, const uint8_t *types, int64_
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemcpyAsync(b->gtype + first, types, (size_t)count, hipMemcpyHostToDevice, b->stream));
     memcpy(b->h_gtype.data() + first, types, (size_t)count);
+    if (b->scount.p)        // a slot that changes class must not keep its old class's contact count (np_static / np_convex_static
+                            // write the counts of the slots they serve; nobody serves a slot of no class in a hulls-only batch)
+        HIP_TRY(hipMemsetAsync((int *)b->scount.p + first, 0, (size_t)count * sizeof(int), b->stream));
+    b->has_simple = false;
+    for (int64_t i = 0; i < b->n && !b->has_simple; i++) b->has_simple = b->h_gtype[(size_t)i] == GEOM_BOX || b->h_gtype[(size_t)i] == GEOM_SPHERE;
     b->bp_rmax = 0; b->bp_valid = false;
     HIP_TRY(hipStreamSynchronize(b->stream));
     return DMX_OK;

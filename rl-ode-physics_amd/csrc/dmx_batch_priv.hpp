@@ -136,6 +136,7 @@ struct dmxBatch {
     DevBuf sbox; int n_static = 0;             // static box geoms (dmxBatchSetStaticBoxes), SBOX_REALS reals each
     // the fused path of bodies at static geometry (np_static -> step_contacts): per-body contact buffer and counts
     DevBuf sbuf, scount;
+    bool has_simple = true;                    // some slot is a box or a sphere (kept by dmxBatchUploadGeomType)
     bool static_fast = true;                   // DMX_STATIC_FAST=0: every body at a static box goes through the exact tick (round 2's way)
     bool static_need8 = false;                 // a body with 5..8 static contacts has been met: the second step_contacts launch rides along
     int nofast_hold = 0, nofast_level = 0;     // chunks to go the exact way after a body overflowed the contact buffer (backs off)
@@ -232,6 +233,7 @@ template <class T> inline StepParams<T> dmx_make_params(dmxBatch *b, double h)
     P.pack_out = (T *)b->pack_out; P.pack_lo = b->pack_lo; P.pack_hi = b->pack_hi;
     P.sbox = (const T *)b->sbox.p; P.n_static = b->n_static;
     P.sbuf = b->static_fast ? (T *)b->sbuf.p : nullptr; P.scount = (int *)b->scount.p;
+    P.has_simple = b->has_simple ? 1 : 0;
     P.have8 = 1;             // (a collision-checked launch may leave the 5..8-contact launch out: fused_tick, dmx_general.cpp)
     P.hull = (const T *)b->hull.p; P.hull_n = b->hull_n;
     P.hull_planes = (const T *)b->hull_planes.p; P.hull_nf = b->hull_nf;

@@ -70,12 +70,18 @@ __device__ __forceinline__ int wave_box_convex(const V3<T> &xb, const M3<T> &Rb,
 #pragma unroll
             for (int a = 0; a < 3; a++) q[a] = fma_(Rb.m[2][a], d.z, fma_(Rb.m[1][a], d.y, Rb.m[0][a] * d.x));     // box frame
             inside = !(tabs(q[0]) > half[0] || tabs(q[1]) > half[1] || tabs(q[2]) > half[2]);
-            int best = 0;
-            dep = half[0] - tabs(q[0]);
+            if (inside) {        // (the face it is nearest to: only the handful of points inside the box pay for this)
+                int best = 0;
+                dep = half[0] - tabs(q[0]);
 #pragma unroll
-            for (int a = 1; a < 3; a++) { const T e = half[a] - tabs(q[a]); if (e < dep) { dep = e; best = a; } }
-            const T sg = q[best] < T(0) ? T(-1) : T(1);
-            n = { -(sg * Rb.m[0][best]), -(sg * Rb.m[1][best]), -(sg * Rb.m[2][best]) };      // into the box
+                for (int a = 1; a < 3; a++) { const T e = half[a] - tabs(q[a]); if (e < dep) { dep = e; best = a; } }
+                const T qb = best == 0 ? q[0] : (best == 1 ? q[1] : q[2]);
+                const T sg = qb < T(0) ? T(-1) : T(1);
+                const V3<T> col = { best == 0 ? Rb.m[0][0] : (best == 1 ? Rb.m[0][1] : Rb.m[0][2]),
+                                    best == 0 ? Rb.m[1][0] : (best == 1 ? Rb.m[1][1] : Rb.m[1][2]),
+                                    best == 0 ? Rb.m[2][0] : (best == 1 ? Rb.m[2][1] : Rb.m[2][2]) };
+                n = { -(sg * col.x), -(sg * col.y), -(sg * col.z) };      // into the box
+            }
         }
         const unsigned long long mb = __ballot(inside);
         if (inside) {

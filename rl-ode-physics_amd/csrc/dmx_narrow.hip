@@ -151,7 +151,9 @@ template <class T>
 hipError_t launch_np_static(const T *S, const uint8_t *gtype, int64_t n, const StepParams<T> &P, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL((np_static<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, gtype, n, P);
+    // (np_static serves boxes and spheres and writes a zero count for slots of no class; a batch of hulls only does not need the
+    //  launch: slots of no class keep the zero count dmxBatchSetStaticBoxes / dmxBatchUploadGeomType left there)
+    if (P.has_simple || P.hull_n <= 0) hipLaunchKernelGGL((np_static<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, gtype, n, P);
     if (P.hull_n > 0) hipLaunchKernelGGL((np_convex_static<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, S, gtype, n, P);
     return hipGetLastError();
 }
