@@ -234,7 +234,7 @@ def tile_scene(np, base, reps_x):
 
 
 def measure(cx, a, scene, layout, kind, dtype, *, exchanging, every_tick=False, ticks_per_launch=1, settle_steps=0,
-            steps=None, warmup=None):
+            steps=None, warmup=None, setup=None):
     """Build the batch and the tick loop for `scene`, warm up, time blocks of `steps` ticks.  Any failure raises: a run
     that could not exchange is no run (there is no substitute path)."""
     torch, dist, pkg, np = cx.torch, cx.dist, cx.pkg, cx.np
@@ -247,6 +247,8 @@ def measure(cx, a, scene, layout, kind, dtype, *, exchanging, every_tick=False, 
         if exchanging:
             w.set_active_count(layout.n_active)     # the slots behind are ghosts of the neighbours' boundary rows
         w.set_gyro_mode(a.gyro)
+        if setup is not None:
+            setup(w)
         if ticks_per_launch > 1:
             w.set_ticks_per_launch(ticks_per_launch)
         collide = not a.no_body_collisions
@@ -481,8 +483,10 @@ def rank_main(a):
             side = side_arg or 128
             kind = "convex"
             workload = (f"configs[4]: {side * side} convex hulls of res/teapot.obj (1 265 points, 2 526 faces, scale 0.01) per GPU resting on a "
-                        f"static box floor (the reference's floor is one, main.c:115): box-convex contacts (<= 8 per hull), 20 SOR "
-                        f"iterations, dt=1/60")
+                        f"static box floor (the reference's floor is one, main.c:115): box-trimesh contacts (<= 8 per hull) and those only, as "
+                        f"BASELINE names them -- the hull geoms' collide bits name the map, not one another (dGeomSetCollideBits, main.c:725: "
+                        f"dmxBatchSetClassPairs(CONVEX, CONVEX, 0)); 20 SOR iterations, dt=1/60.  The same scene with the teapots colliding "
+                        f"with one another too (hull-hull collider; tipped teapots roll into their neighbours) is `hull_pairs_on`")
             gold = np.load(os.path.join(ROOT, "tests", "golden", "teapot_hull.npz"))     # the hull's vertices (data fixture)
             hull = pkg.hull.build(gold["points"], 0.01)
             hull_points = int(hull.points.shape[0])
@@ -514,7 +518,8 @@ def rank_main(a):
 
     head = measure(cx, a, scene, layout, kind, dtype, exchanging=use_exchange, every_tick=a.exchange_every_tick,
                    ticks_per_launch=a.ticks_per_launch if kind == "free" else 1, settle_steps=settle, steps=steps_override,
-                   warmup=10 if steps_override else None)
+                   warmup=10 if steps_override else None,
+                   setup=(lambda w: w.set_class_pairs(pkg.scenes.GEOM_CONVEX, pkg.scenes.GEOM_CONVEX, False)) if kind == "convex" else None)
 
     def parallelism_text(m, bodies_per_gpu):
         if not m["exchanging"]:
@@ -563,15 +568,24 @@ def rank_main(a):
             "observes, since it reads poses every other physics tick (main.c:208, 218) -- and is the variant expected past 6x. Both are "
             "reported; neither is substituted for the other.")
 
+    def hulls_map_only(w):
+        w.set_class_pairs(pkg.scenes.GEOM_CONVEX, pkg.scenes.GEOM_CONVEX, False)
+
     def config_leg(cfg):
         """one BASELINE config timed beside the headline: a short leg of the same measure()"""
         sc, lay, kd, wl, stl, stp, hp = build_config(cfg, 0)
         m = measure(cx, a, sc, lay, kd, dtype, exchanging=False, settle_steps=stl, steps=stp or min(a.steps, 200),
-                    warmup=10 if stp else min(a.warmup, 20))
+                    warmup=10 if stp else min(a.warmup, 20), setup=hulls_map_only if kd == "convex" else None)
         leg = {"workload": wl, "bodies": sc.n, "dtype": a.dtype, "value": sc.n * m["steps"] / m["dt"], "unit": "body-steps/s",
                "ms_per_step": m["dt"] * 1e3 / m["steps"], "ms_per_step_mean": m["mean_dt"] * 1e3 / m["steps"], "steps": m["steps"],
                "blocks": m["blocks"], "contacts_last_tick": m["contacts"], "collide": collide_text(m, a, kd),
                "roofline": roofline_of(m, kd, rsize, profile_evidence(kd, a.dtype, sc.n), hp)}
+        if kd == "convex":
+            m2 = measure(cx, a, sc, lay, kd, dtype, exchanging=False, settle_steps=stl, steps=min(a.steps, 100), warmup=min(a.warmup, 20))
+            leg["hull_pairs_on"] = {"ms_per_step": m2["dt"] * 1e3 / m2["steps"], "value": sc.n * m2["steps"] / m2["dt"], "unit": "body-steps/s",
+                                    "contacts_last_tick": m2["contacts"], "collide": collide_text(m2, a, kd),
+                                    "note": "every class collides with every class (the default): teapots that have rolled into one another "
+                                            "are body pairs, every tick runs the pair search and the islands"}
         return leg
 
     extras = not a.no_extras

@@ -103,6 +103,12 @@ int dmxBatchSetPlane(dmxBatchID b, double a, double bb, double c, double d, int 
  * stepped with its first 8 contacts.  Same results as the exact path, bit for bit. */
 #define DMX_MAX_STATIC_BOXES 64
 int dmxBatchSetStaticBoxes(dmxBatchID b, int32_t n, const double *sides, const double *pos, const double *rot3x4);
+/* dGeomSetCategoryBits / dGeomSetCollideBits (main.c:724-725, 751-752) at the granularity of geometry classes: whether bodies of
+ * class_a and class_b (DMX_GEOM_SPHERE / BOX / CONVEX; symmetric) collide with one another.  Default: every class with every
+ * class, as the reference's bits have it (CMASK_OBJ bodies collide with CMASK_OBJ | CMASK_MAP).  Pairs switched off are not kept
+ * apart by the safe zones, not enumerated by the pair search and never reach a collider -- what ODE does with geoms whose bits do
+ * not match.  (Static boxes and the ground plane collide with every body.) */
+int dmxBatchSetClassPairs(dmxBatchID b, int class_a, int class_b, int enable);
 /* DMX_STATIC_FUSED (default; DMX_STATIC_FAST=0 in the environment picks the other): as described above.  DMX_STATIC_EXACT:
  * every body whose bounding sphere reaches a static box goes through the exact path every tick (how round 2 did it; kept
  * for A/B runs and for the tests that hold the two against each other). */
@@ -117,16 +123,20 @@ int dmxBatchUploadGeomType(dmxBatchID b, const uint8_t *types, int64_t first, in
  * origin = centre of mass, e.g. from dmxHullBuild in dmx_hull.h).  *radius_out (may be NULL) = the hull's bounding
  * radius: upload it as sides[0] of every convex body (the broadphase reads it there, as it does a sphere's radius).
  * Contacts: convex against the ground plane as ODE's dCollideConvexPlane makes them (the hull's points in array order,
- * the first max_contacts <= 8 on or below the plane); a convex body has no collider against other bodies (ODE's
- * dCollideConvexBox is an empty stub; convex-convex / convex-sphere are not built). */
+ * the first max_contacts <= 8 on or below the plane); against boxes, spheres and other convex bodies: this library's own
+ * colliders, which need the hull's faces (dmxBatchSetConvexHullFaces below). */
 int dmxBatchSetConvexHull(dmxBatchID b, int32_t n_points, const double *points_xyz, double *radius_out);
 /* dCreateConvex's plane set for the same hull: n_faces x 4 doubles (unit outward normal, offset; body frame), e.g. from
  * dmxHullPlanes.  Contacts of a convex body with BOXES -- static boxes (dmxBatchSetStaticBoxes: the floor of BASELINE
  * configs[4]) and box bodies -- are this library's own collider (ODE's dCollideConvexBox is an empty stub): hull vertices
  * inside the box in array order, each along the box face it is nearest to, then -- with the faces given here -- box
  * corners inside the hull, each along the hull face it is nearest to; the first max_contacts <= 8 are kept (edge-edge
- * penetrations are not detected).  Convex against sphere / convex: no collider; such AABB pairs are counted
- * (dmxBatchCollisionStats [6]) and named once on stderr. */
+ * penetrations are not detected).  Convex against CONVEX (both bodies carry the batch's one hull): the same two primitives --
+ * the second body's vertices inside the first, in array order, each along the first's face it is nearest to, then the first
+ * body's vertices inside the second; the first max_contacts are kept.  SPHERE against convex: the hull's face planes' largest
+ * signed distance to the sphere's centre (first face on ties); within the radius, one contact along that face -- exact over a
+ * face's interior, met early by up to (1 - cos) of the radius over an edge or a vertex.  Without the faces a convex body
+ * collides with the ground plane only. */
 int dmxBatchSetConvexHullFaces(dmxBatchID b, int32_t n_faces, const double *planes);
 /* device address of component c of a field for body 0.  The slab is tiled: bodies are stored in tiles of
  * DMX_SLAB_TILE; inside a tile each of the DMX_SLAB_COMPONENTS components holds DMX_SLAB_TILE consecutive
@@ -186,7 +196,7 @@ int dmxBatchSetExactPipeline(dmxBatchID b, int mode);
  * per launch instead of per tick.  Default 1 (one launch per tick); 1..64. */
 int dmxBatchSetTicksPerLaunch(dmxBatchID b, int ticks);
 int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6]);
-/* the same six numbers and [6] AABB pairs met so far that have no collider (convex-convex, convex-sphere), [7] reserved */
+/* the same six numbers and [6] AABB pairs met so far that had no collider (always 0 since every class pair has one), [7] reserved */
 int dmxBatchCollisionStatsEx(dmxBatchID b, int64_t out[8]);
 
 /* ---- the collision-checked tick loop in pieces.  dmxBatchStep(b, h, n) with body collisions enabled runs, inside

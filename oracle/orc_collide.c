@@ -242,6 +242,88 @@ static int collide_box_convex(const orc_world *w, const real *pb, const real *Rb
     return n;
 }
 
+/* ---- sphere against convex hull, and convex hull against convex hull (bodies sharing the world's one hull shape).  ODE has
+ * colliders of these names; they are NOT restated here (no call site in the reference creates a convex geom at all, SURVEY F9,
+ * and ODE's own convex-convex is an elaborate SAT + clipping): these two are this repository's own, defined here and mirrored by
+ * the device kernels (csrc/dmx_collide_wave.hpp), built from the same two primitives as collide_box_convex above -- "a point
+ * inside a hull, along the face it is nearest to" -- and sharing its blind spot (edge-edge penetrations are not detected).
+ *
+ *   sphere (o1) - hull (o2): c = the sphere's centre in the hull's frame; s_f = n_f . c - d_f over the hull's faces in order;
+ *      s_max (first face on ties) > radius: no contact; else ONE contact along that face: normal = the face's outward normal
+ *      (into the sphere), depth = radius - s_max, position = the sphere's surface point against the face.  Exact when the
+ *      centre is over a face's interior; over an edge or a vertex the planes' maximum is less than the true distance, so the
+ *      sphere is met up to (1 - cos) of its radius early -- fine facets (the teapot: 2 526) make that small.
+ *   hull A (o1) - hull B (o2): (1) B's vertices inside A, in array order: contact at the vertex, along A's face it is nearest
+ *      to (first on ties), normal = MINUS that face's outward normal (into A); (2) if room is left, A's vertices inside B:
+ *      contact at the vertex, normal = B's nearest face's outward normal (into A).  The first maxc are kept. */
+static void to_hull_frame(real r[3], const real *Rh, const real *ph, const real v[3])
+{
+    const real d[3] = { v[0] - ph[0], v[1] - ph[1], v[2] - ph[2] };
+    for (int a = 0; a < 3; a++) r[a] = FMA(Rh[8 + a], d[2], FMA(Rh[4 + a], d[1], Rh[a] * d[0]));
+}
+
+/* is hull-frame point r inside the hull?  *dep = distance to the nearest face, *fbest = that face (first on ties) */
+static int point_in_hull(const orc_world *w, const real r[3], real *dep, int *fbest)
+{
+    *dep = ORC_INF; *fbest = -1;
+    for (int f = 0; f < w->hull_nf; f++) {
+        const real *pl = w->hull_planes + 4 * f;
+        const real e = pl[3] - orc_dot3(pl, r);
+        if (e < 0) return 0;
+        if (e < *dep) { *dep = e; *fbest = f; }
+    }
+    return *fbest >= 0;
+}
+
+static int collide_sphere_convex(const orc_world *w, const real *cs, real radius, const real *ph, const real *Rh,
+                                 orc_contactgeom *c)
+{
+    if (w->hull_nf <= 0) return 0;
+    real r[3];
+    to_hull_frame(r, Rh, ph, cs);
+    real smax = -ORC_INF;
+    int fbest = -1;
+    for (int f = 0; f < w->hull_nf; f++) {
+        const real *pl = w->hull_planes + 4 * f;
+        const real sdist = orc_dot3(pl, r) - pl[3];
+        if (sdist > smax) { smax = sdist; fbest = f; }
+    }
+    if (fbest < 0 || smax > radius) return 0;
+    real nw[3];
+    orc_mul0_331(nw, Rh, w->hull_planes + 4 * fbest);
+    c->normal[0] = nw[0]; c->normal[1] = nw[1]; c->normal[2] = nw[2];
+    c->depth = radius - smax;
+    c->pos[0] = cs[0] - nw[0] * radius; c->pos[1] = cs[1] - nw[1] * radius; c->pos[2] = cs[2] - nw[2] * radius;
+    return 1;
+}
+
+static int collide_convex_convex(const orc_world *w, const real *pa, const real *Ra, const real *pb, const real *Rb,
+                                 int maxc, orc_contactgeom *c)
+{
+    int n = 0;
+    if (w->hull_nf <= 0) return 0;
+    for (int pass = 0; pass < 2; pass++) {
+        /* pass 0: B's vertices against A; pass 1: A's vertices against B */
+        const real *pv = pass == 0 ? pb : pa, *Rv = pass == 0 ? Rb : Ra;      /* the hull whose vertices are walked */
+        const real *ph = pass == 0 ? pa : pb, *Rh = pass == 0 ? Ra : Rb;      /* the hull they are tested against */
+        for (int i = 0; i < w->hull_n && n < maxc; i++) {
+            real v[3], r[3], dep;
+            int fbest;
+            orc_mul0_331(v, Rv, w->hull + 3 * i);
+            v[0] += pv[0]; v[1] += pv[1]; v[2] += pv[2];
+            to_hull_frame(r, Rh, ph, v);
+            if (!point_in_hull(w, r, &dep, &fbest)) continue;
+            real nw[3];
+            orc_mul0_331(nw, Rh, w->hull_planes + 4 * fbest);
+            orc_contactgeom *t = &c[n++];
+            t->pos[0] = v[0]; t->pos[1] = v[1]; t->pos[2] = v[2];
+            for (int k = 0; k < 3; k++) t->normal[k] = pass == 0 ? -nw[k] : nw[k];      /* into A either way */
+            t->depth = dep;
+        }
+    }
+    return n;
+}
+
 static int collide_convex_plane(const orc_world *w, const real *pos, const real *Rm, const real *pl, int maxc,
                                 orc_contactgeom *c)
 {
@@ -290,12 +372,11 @@ static int collide_ordered(orc_world *w, const orc_geom *a, const orc_geom *b, i
         return collide_convex_plane(w, pa, Ra, b->plane, maxc, out);
     if (a->type == ORC_GEOM_BOX && b->type == ORC_GEOM_CONVEX)
         return collide_box_convex(w, pa, Ra, a->side, pb, Rb, maxc, out);
-    /* convex against sphere / convex: no contacts (ODE's convex-sphere and convex-convex colliders are not restated;
-       the product counts such pairs as unsupported).  (convex, box) has no collider in this order: dCollide swaps. */
-    if (a->type == ORC_GEOM_CONVEX && (b->type == ORC_GEOM_SPHERE || b->type == ORC_GEOM_CONVEX))
-        return 0;
     if (a->type == ORC_GEOM_SPHERE && b->type == ORC_GEOM_CONVEX)
-        return 0;
+        return collide_sphere_convex(w, pa, a->side[0], pb, Rb, out);
+    if (a->type == ORC_GEOM_CONVEX && b->type == ORC_GEOM_CONVEX)
+        return collide_convex_convex(w, pa, Ra, pb, Rb, maxc, out);
+    /* (convex, box) and (convex, sphere) have no collider in this order: dCollide swaps and flips the normals */
     *handled = 0;
     return 0;
 }

@@ -24,7 +24,7 @@ BATCH_SYMBOLS = [
     "dmxBatchChunkBegin", "dmxBatchChunkTick", "dmxBatchCheckZonesOnStream", "dmxBatchChunkEnd",
     "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream", "dmxBatchSetConvexHull", "dmxBatchChunkTicks", "dmxBatchSetTicksPerLaunch",
     "dmxBatchSetSnapshotMode", "dmxBatchSetStaticBoxes", "dmxBatchSetStepper", "dmxBatchSetConvexHullFaces",
-    "dmxBatchCollisionStatsEx", "dmxBatchFindPairs", "dmxBatchCrossPairs", "dmxBatchSetRowOrder", "dmxBatchSetExactPipeline", "dmxBatchSetStaticPath",
+    "dmxBatchCollisionStatsEx", "dmxBatchFindPairs", "dmxBatchCrossPairs", "dmxBatchSetRowOrder", "dmxBatchSetExactPipeline", "dmxBatchSetStaticPath", "dmxBatchSetClassPairs",
 ]
 SHARD_SYMBOLS = ["dmxShardRcclUniqueId", "dmxShardCreateRccl", "dmxShardCreate", "dmxShardRun", "dmxShardSettle", "dmxShardStats", "dmxShardDestroy"]
 
@@ -106,6 +106,7 @@ def load():
     sig("dmxBatchSetSnapshotMode", I, P, I)
     sig("dmxBatchSetExactPipeline", I, P, I)
     sig("dmxBatchSetStaticPath", I, P, I)
+    sig("dmxBatchSetClassPairs", I, P, I, I, I)
     # include/dmx_shard.h
     sig("dmxShardRcclUniqueId", I, P)
     sig("dmxShardCreateRccl", I, C.POINTER(P), P, L, L, L, I, I, P)

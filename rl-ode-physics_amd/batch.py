@@ -206,6 +206,10 @@ class BatchWorld:
         """EXACT_AUTO (default) / EXACT_STAGED / EXACT_ONE_WORKGROUP: how an exact tick runs its bookkeeping (include/dmx_batch.h)"""
         _check(self.lib.dmxBatchSetExactPipeline(self.h, mode), "dmxBatchSetExactPipeline")
 
+    def set_class_pairs(self, class_a, class_b, enable):
+        """whether bodies of two geometry classes collide with one another (the batch's form of ODE's category / collide bits)"""
+        _check(self.lib.dmxBatchSetClassPairs(self.h, int(class_a), int(class_b), 1 if enable else 0), "dmxBatchSetClassPairs")
+
     def set_static_path(self, fused=True):
         """bodies at static boxes: the fused path (default) or the exact tick for every one of them (include/dmx_batch.h)"""
         _check(self.lib.dmxBatchSetStaticPath(self.h, 1 if fused else 0), "dmxBatchSetStaticPath")

@@ -402,6 +402,16 @@ extern "C" int dmxBatchSetExactPipeline(dmxBatchID b, int mode)
     return DMX_OK;
 }
 
+extern "C" int dmxBatchSetClassPairs(dmxBatchID b, int class_a, int class_b, int enable)
+{
+    if (!b || class_a < DMX_GEOM_SPHERE || class_a > DMX_GEOM_CONVEX || class_b < DMX_GEOM_SPHERE || class_b > DMX_GEOM_CONVEX) return DMX_EINVAL;
+    SETTLE(b);
+    const uint32_t bits = (1u << (4 * class_a + class_b)) | (1u << (4 * class_b + class_a));
+    b->class_pairs = enable ? (b->class_pairs | bits) : (b->class_pairs & ~bits);
+    b->bp_valid = false;            // zones only keep apart what can collide
+    return DMX_OK;
+}
+
 extern "C" int dmxBatchSetStaticPath(dmxBatchID b, int mode)
 {
     if (!b || (mode != DMX_STATIC_EXACT && mode != DMX_STATIC_FUSED)) return DMX_EINVAL;

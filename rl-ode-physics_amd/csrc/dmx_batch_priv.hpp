@@ -116,7 +116,7 @@ struct dmxBatch {
     bool bp_valid = false;                     // safe zones match the current constant data
     int bp_chunk = 0;                          // current fast-chunk length in ticks (adaptive, dmx_general.cpp)
     uint32_t bp_crowded = 0;                   // bodies whose safe radius is <= 0 at the last build
-    double bp_rmax = 0, bp_rmax_box = 0, bp_rmax_solid = 0;
+    double bp_rmax = 0, bp_rcls[4] = { 0, 0, 0, 0 };
     uint32_t bp_mask = 0; int bp_cap = 8; int bp_xbits = -1;      // -1: not chosen yet
     DevBuf bp_count, bp_items, bp_flags, bp_inpair, bp_snapshot;
     // device-resident bookkeeping of the exact tick (dmx_exact.hip): capacity estimates carried from tick to tick, one arena
@@ -136,6 +136,7 @@ struct dmxBatch {
     DevBuf sbox; int n_static = 0;             // static box geoms (dmxBatchSetStaticBoxes), SBOX_REALS reals each
     // the fused path of bodies at static geometry (np_static -> step_contacts): per-body contact buffer and counts
     DevBuf sbuf, scount;
+    uint32_t class_pairs = CLASS_PAIRS_ALL;     // dmxBatchSetClassPairs: which geometry classes collide with which
     bool has_simple = true;                    // some slot is a box or a sphere (kept by dmxBatchUploadGeomType)
     bool static_fast = true;                   // DMX_STATIC_FAST=0: every body at a static box goes through the exact tick (round 2's way)
     bool static_need8 = false;                 // a body with 5..8 static contacts has been met: the second step_contacts launch rides along

@@ -16,6 +16,7 @@
 #include "dmx_internal.hpp"
 #include "dmx_math.hpp"
 #include "dmx_grid.hpp"
+#include "dmx_collide_wave.hpp"
 
 namespace dmx {
 
@@ -26,6 +27,26 @@ __global__ __launch_bounds__(256) void bp_insert(T *__restrict__ S, const uint8_
 {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n) grid_insert<T>(S, gtype, i, G);
+}
+
+// Convex bodies: the exact world AABB -- the bounds of the hull's transformed points, what ODE's dxConvex::computeAABB keeps
+// [ODE-recall] and what the oracle's pair search tests -- over the bounding sphere's box bp_insert wrote: one wavefront per hull.
+// The sphere's box is up to twice as wide as a teapot; with it, neighbours on a 3 m grid that have rocked half a metre towards one
+// another are "pairs", each costing two walks over 1 265 vertices x 2 526 faces to find nothing.
+template <class T>
+__global__ __launch_bounds__(256) void bp_convex_aabb(const T *__restrict__ S, const uint8_t *__restrict__ gtype, int64_t n, GridParams<T> G)
+{
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n || gtype[i] != GEOM_CONVEX) return;             // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const V3<T> x = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
+    const M3<T> R = quat_to_R(Q4<T>{ S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)], S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] });
+    T lo[3], hi[3];
+    wave_hull_aabb<T>(x, R, G.hull, G.hull_n, lane, lo, hi);
+    if (lane < 3) {        // (selects, not lo[lane]: a runtime index would send the arrays to scratch memory)
+        G.rec[i].lo[lane] = lane == 0 ? lo[0] : (lane == 1 ? lo[1] : lo[2]);
+        G.rec[i].hi[lane] = lane == 0 ? hi[0] : (lane == 1 ? hi[1] : hi[2]);
+    }
 }
 
 // per active body: build position (x,z) and safe radius = half the horizontal gap to the nearest bounding sphere
@@ -42,7 +63,9 @@ __global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uin
         const T ri = bound_radius<T>(gt, S, i);
         const int ix = (int)floor((double)(x * G.inv_cell)), iz = (int)floor((double)(z * G.inv_cell));
         // nothing outside the 3x3 block is closer than one cell: gap >= cell - r_i - (largest radius of a class i collides with)
-        const T rm = gt == GEOM_CONVEX ? G.r_max_box : gt == GEOM_SPHERE ? G.r_max_solid : G.r_max;
+        T rm = T(0);                 // the largest radius among the classes this body's class collides with (0: none of them here)
+#pragma unroll
+        for (int c = 1; c < 4; c++) if (classes_collide(gt, c, G.class_pairs) && G.r_cls[c] > rm) rm = G.r_cls[c];
         T gap = rm > T(0) ? G.cell - ri - rm : Limits<T>::inf();
         for (int dz = -1; dz <= 1; dz++)
             for (int dx = -1; dx <= 1; dx++) {
@@ -51,7 +74,7 @@ __global__ __launch_bounds__(256) void bp_safe_zone(T *__restrict__ S, const uin
                 if (cnt > (uint32_t)G.cap) cnt = (uint32_t)G.cap;
                 for (uint32_t s = 0; s < cnt; s++) {
                     const int64_t j = G.items[(size_t)h * G.cap + s];
-                    if (j == i || !classes_collide(gt, gtype[j])) continue;
+                    if (j == i || !classes_collide(gt, gtype[j], G.class_pairs)) continue;
                     const T ddx = S[slab_ix(C_POS + 0, j)] - x, ddz = S[slab_ix(C_POS + 2, j)] - z;
                     const T g = tsqrt<T>(ddx * ddx + ddz * ddz) - ri - S[slab_ix(C_BPR, j)];
                     if (g < gap) gap = g;
@@ -105,6 +128,13 @@ hipError_t launch_bp_insert(T *S, const uint8_t *gtype, int64_t stride, int64_t 
     return hipGetLastError();
 }
 template <class T>
+hipError_t launch_bp_convex_aabb(const T *S, const uint8_t *gtype, int64_t n, const GridParams<T> &G, hipStream_t st)
+{
+    if (n <= 0 || G.hull_n <= 0 || G.rec == nullptr) return hipSuccess;
+    hipLaunchKernelGGL((bp_convex_aabb<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, S, gtype, n, G);
+    return hipGetLastError();
+}
+template <class T>
 hipError_t launch_bp_safe_zone(T *S, const uint8_t *gtype, int64_t stride, int64_t n_active, const GridParams<T> &G, hipStream_t st)
 {
     if (n_active <= 0) return hipSuccess;
@@ -112,6 +142,7 @@ hipError_t launch_bp_safe_zone(T *S, const uint8_t *gtype, int64_t stride, int64
     return hipGetLastError();
 }
 #define DMX_BP_INST(T)                                                                                              \
+    template hipError_t launch_bp_convex_aabb<T>(const T *, const uint8_t *, int64_t, const GridParams<T> &, hipStream_t); \
     template hipError_t launch_bp_insert<T>(T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, hipStream_t); \
     template hipError_t launch_bp_safe_zone<T>(T *, const uint8_t *, int64_t, int64_t, const GridParams<T> &, hipStream_t);
 DMX_BP_INST(float)

@@ -130,4 +130,159 @@ __device__ __forceinline__ int wave_box_convex(const V3<T> &xb, const M3<T> &Rb,
     return contacts;
 }
 
+// ---- a point of the world in a hull's frame: R^T (v - x), the oracle's to_hull_frame ------------------------------------------
+template <class T> __device__ __forceinline__ V3<T> to_hull_frame(const M3<T> &Rh, const V3<T> &xh, const V3<T> &v)
+{
+    const V3<T> d = { v.x - xh.x, v.y - xh.y, v.z - xh.z };
+    return { fma_(Rh.m[2][0], d.z, fma_(Rh.m[1][0], d.y, Rh.m[0][0] * d.x)),
+             fma_(Rh.m[2][1], d.z, fma_(Rh.m[1][1], d.y, Rh.m[0][1] * d.x)),
+             fma_(Rh.m[2][2], d.z, fma_(Rh.m[1][2], d.y, Rh.m[0][2] * d.x)) };
+}
+
+// ---- the hull's exact world AABB (dxConvex::computeAABB [ODE-recall]: the bounds of its transformed points), by the wave ----
+// The exact tick's pair search uses it for every hull (bp_convex_aabb, dmx_broadphase.hip: one wavefront per hull per exact tick);
+// the fused paths keep the bounding sphere's box (conservative, and free), which changes nothing for colliders that are exact
+// geometry (vertex in box / in hull: no contact unless the true AABBs overlap).  The sphere collider below is not -- beside an
+// edge it answers before the sphere arrives -- so ITS call site applies dSpaceCollide's own test on the exact AABB itself.
+template <class T>
+__device__ __forceinline__ void wave_hull_aabb(const V3<T> &x, const M3<T> &R, const T *hull, int hull_n, int lane, T lo[3], T hi[3])
+{
+    T l[3] = { Limits<T>::inf(), Limits<T>::inf(), Limits<T>::inf() }, h[3] = { -Limits<T>::inf(), -Limits<T>::inf(), -Limits<T>::inf() };
+    for (int k = lane; k < hull_n; k += 64) {
+        V3<T> v = mulv(R, V3<T>{ hull[3 * k], hull[3 * k + 1], hull[3 * k + 2] });
+        v.x += x.x; v.y += x.y; v.z += x.z;
+        l[0] = v.x < l[0] ? v.x : l[0]; h[0] = v.x > h[0] ? v.x : h[0];
+        l[1] = v.y < l[1] ? v.y : l[1]; h[1] = v.y > h[1] ? v.y : h[1];
+        l[2] = v.z < l[2] ? v.z : l[2]; h[2] = v.z > h[2] ? v.z : h[2];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const T ol = __shfl_xor(l[a], o, 64), oh = __shfl_xor(h[a], o, 64);
+            l[a] = ol < l[a] ? ol : l[a]; h[a] = oh > h[a] ? oh : h[a];
+        }
+        lo[a] = l[a]; hi[a] = h[a];
+    }
+}
+
+// ---- sphere (geom 1) against convex hull (geom 2): this library's collider (include/dmx_batch.h): the hull's face planes'
+// largest signed distance to the sphere's centre, first face on ties; one contact along that face, normal into the sphere.
+// Lane l walks faces l, l + 64, ...; a lexicographic (largest distance, lowest face) wave reduction picks the face.
+template <class T, class Emit>
+__device__ __forceinline__ int wave_sphere_convex(const V3<T> &cs, T radius, const V3<T> &xh, const M3<T> &Rh, const StepParams<T> &P,
+                                                  bool negate, int lane, Emit emit)
+{
+    if (P.hull_nf <= 0) return 0;
+    {   // dSpaceCollide's AABB test on the hull's exact box (see wave_hull_aabb)
+        T lo[3], hi[3];
+        wave_hull_aabb<T>(xh, Rh, P.hull, P.hull_n, lane, lo, hi);
+        if (cs.x - radius > hi[0] || lo[0] > cs.x + radius || cs.y - radius > hi[1] || lo[1] > cs.y + radius ||
+            cs.z - radius > hi[2] || lo[2] > cs.z + radius) return 0;
+    }
+    const V3<T> r = to_hull_frame(Rh, xh, cs);
+    T smax = -Limits<T>::inf();
+    int fbest = 0x7fffffff;
+    for (int f = lane; f < P.hull_nf; f += 64) {
+        const T *pl = P.hull_planes + 4 * f;
+        const T sd = dot(V3<T>{ pl[0], pl[1], pl[2] }, r) - pl[3];
+        if (sd > smax) { smax = sd; fbest = f; }              // (f ascends within a lane: the first maximum is kept)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T os = __shfl_xor(smax, o, 64);
+        const int of = __shfl_xor(fbest, o, 64);
+        if (os > smax || (os == smax && of < fbest)) { smax = os; fbest = of; }
+    }
+    if (fbest == 0x7fffffff || smax > radius) return 0;
+    if (lane == 0) {
+        const T *pl = P.hull_planes + 4 * fbest;
+        const V3<T> nw = mulv(Rh, V3<T>{ pl[0], pl[1], pl[2] });
+        const V3<T> pos = { cs.x - nw.x * radius, cs.y - nw.y * radius, cs.z - nw.z * radius };
+        emit(0, pos, negate ? V3<T>{ -nw.x, -nw.y, -nw.z } : nw, radius - smax);
+    }
+    return 1;
+}
+
+// ---- convex hull A (geom 1) against convex hull B (geom 2), both the batch's one hull shape: (1) B's vertices inside A, in
+// array order, each along A's face it is nearest to, normal into A; (2) A's vertices inside B, along B's nearest face.  Lane l
+// transforms vertex 64 j + l; the few that survive the culls are then tested one after the other, each by the whole wave.
+// Culling (it decides nothing, it only spares walks): a vertex inside a hull is inside that hull's bounding sphere and inside its
+// world AABB (boxA / boxB: lo3 hi3, the exact AABBs the pair search already holds), both taken with slack far above rounding.  Two
+// teapots that touch overlap in a sliver; nearly every chunk of 64 vertices then has no candidate and costs a dozen instructions.
+template <class T, class Emit>
+__device__ __forceinline__ int wave_convex_convex(const V3<T> &xa, const M3<T> &Ra, const V3<T> &xb, const M3<T> &Rb, T hull_radius,
+                                                  const T *boxA, const T *boxB, const StepParams<T> &P, int maxc, bool negate, int lane,
+                                                  Emit emit)
+{
+    if (P.hull_nf <= 0) return 0;
+    int contacts = 0;
+    const T slack = hull_radius * T(1e-4);
+    for (int pass = 0; pass < 2; pass++) {
+        const V3<T> &xv = pass == 0 ? xb : xa; const M3<T> &Rv = pass == 0 ? Rb : Ra;      // the hull whose vertices are walked
+        const V3<T> &xh = pass == 0 ? xa : xb; const M3<T> &Rh = pass == 0 ? Ra : Rb;      // the hull they are tested against
+        const T *box = pass == 0 ? boxA : boxB;
+        int fhint = -1;                    // the face that sent the last candidate away (wave-uniform)
+        for (int base = 0; base < P.hull_n && contacts < maxc; base += 64) {
+            const int k = base + lane;
+            V3<T> v = { T(0), T(0), T(0) }, r = { T(0), T(0), T(0) };
+            bool alive = false;
+            if (k < P.hull_n) {
+                v = mulv(Rv, V3<T>{ P.hull[3 * k], P.hull[3 * k + 1], P.hull[3 * k + 2] });
+                v.x += xv.x; v.y += xv.y; v.z += xv.z;
+                r = to_hull_frame(Rh, xh, v);
+                // inside the hull means inside its bounding sphere (slack for rounding): most vertices skip the walk
+                alive = !(r.x * r.x + r.y * r.y + r.z * r.z > hull_radius * hull_radius * T(1.0001)) &&
+                        !(v.x < box[0] - slack || v.x > box[3] + slack || v.y < box[1] - slack || v.y > box[4] + slack ||
+                          v.z < box[2] - slack || v.z > box[5] + slack);
+            }
+            // the candidates of this chunk, in array order; each one's walk over the faces is the WAVE's: lane l tests faces l, l + 64,
+            // ... (a vertex outside the hull leaves at the first group of 64 faces that holds a face it is outside of; before that,
+            // at the face that sent the last candidate away: neighbouring vertices tend to fail the same face)
+            unsigned long long cand = __ballot(alive);
+            while (cand != 0ull && contacts < maxc) {
+                const int l = __builtin_ctzll(cand);
+                cand &= cand - 1ull;
+                const V3<T> rr = { __shfl(r.x, l, 64), __shfl(r.y, l, 64), __shfl(r.z, l, 64) };
+                if (fhint >= 0) {
+                    const T *ph = P.hull_planes + 4 * fhint;
+                    if (ph[3] - dot(V3<T>{ ph[0], ph[1], ph[2] }, rr) < T(0)) continue;
+                }
+                T dep = Limits<T>::inf();
+                int fbest = 0x7fffffff;
+                bool outside = false;
+                for (int f0 = 0; f0 < P.hull_nf; f0 += 64) {
+                    const int f = f0 + lane;
+                    bool neg = false;
+                    if (f < P.hull_nf) {
+                        const T *pl = P.hull_planes + 4 * f;
+                        const T e = pl[3] - dot(V3<T>{ pl[0], pl[1], pl[2] }, rr);
+                        if (e < T(0)) neg = true;
+                        else if (e < dep) { dep = e; fbest = f; }          // (f ascends within a lane: the first minimum is kept)
+                    }
+                    const unsigned long long nb = __ballot(neg);
+                    if (nb != 0ull) { outside = true; fhint = f0 + __builtin_ctzll(nb); break; }
+                }
+                if (outside) continue;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {                         // lexicographic (depth, face) minimum over the wave
+                    const T od = __shfl_xor(dep, o, 64);
+                    const int of = __shfl_xor(fbest, o, 64);
+                    if (od < dep || (od == dep && of < fbest)) { dep = od; fbest = of; }
+                }
+                if (fbest == 0x7fffffff) continue;
+                if (lane == l) {
+                    const T *pl = P.hull_planes + 4 * fbest;
+                    const V3<T> nw = mulv(Rh, V3<T>{ pl[0], pl[1], pl[2] });
+                    const bool flip = (pass == 0) != negate;           // pass 0: against A's outward normal (into A); `negate` flips all
+                    emit(contacts, v, flip ? V3<T>{ -nw.x, -nw.y, -nw.z } : nw, dep);
+                }
+                contacts++;
+            }
+        }
+        if (contacts > maxc) contacts = maxc;
+    }
+    return contacts;
+}
+
 }  // namespace dmx

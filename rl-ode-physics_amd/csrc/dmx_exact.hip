@@ -71,17 +71,7 @@ __device__ __forceinline__ void for_each_partner(const T *S, const uint8_t *gtyp
             const int64_t j = js[q];
             // hashed buckets can mix columns: keep only true 3x3 neighbours so (i,j) is met in one cell only
             if (o[q].ix != cx || o[q].iz != cz) continue;
-            if (!classes_collide(gti, gtj[q])) {
-                // no collider for this pair of classes (convex-convex, convex-sphere): not a pair; said once per pair when
-                // the bounding spheres reach one another
-                if (j > i && unsupported != nullptr) {
-                    const T dx = S[slab_ix(C_POS + 0, i)] - S[slab_ix(C_POS + 0, j)], dy = S[slab_ix(C_POS + 1, i)] - S[slab_ix(C_POS + 1, j)],
-                            dz = S[slab_ix(C_POS + 2, i)] - S[slab_ix(C_POS + 2, j)];
-                    const T rr = S[slab_ix(C_BPR, i)] + S[slab_ix(C_BPR, j)];
-                    if (dx * dx + dy * dy + dz * dz < rr * rr) atomicAdd(unsupported, 1u);
-                }
-                continue;
-            }
+            if (!classes_collide(gti, gtj[q], G.class_pairs)) continue;      // switched off by the caller (dmxBatchSetClassPairs): not a pair
             if (o[q].lo[0] > me.hi[0] || me.lo[0] > o[q].hi[0] || o[q].lo[1] > me.hi[1] || me.lo[1] > o[q].hi[1] ||
                 o[q].lo[2] > me.hi[2] || me.lo[2] > o[q].hi[2])
                 continue;
@@ -426,7 +416,22 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
                 if (P.hull_n > 0)
                     nc = wave_box_convex<T>(Bx.x, Bx.R, Bx.side, H.x, H.R, H.side[0], P, maxc, gi != GEOM_BOX, lane,
                                             [&](int rank, const V3<T> &pp, const V3<T> &nn, T dep) { put_c(gpos, gnormal, gdepth, slot0 + rank, pp, nn, dep); });
-            }       // (pairs of classes without a collider never reach the pair list: for_each_partner)
+            } else if (gi == GEOM_CONVEX && gj == GEOM_CONVEX) {
+                // hull i (geom 1, created first) against hull j: vertices of each inside the other, normals into i
+                const BodyGeomX<T> A = geom_of<T>(S, gtype, i), Bh = geom_of<T>(S, gtype, j);
+                const size_t slot0 = cap.pair_slot0() + (size_t)8 * p;
+                const T boxA[6] = { rec[i].lo[0], rec[i].lo[1], rec[i].lo[2], rec[i].hi[0], rec[i].hi[1], rec[i].hi[2] };
+                const T boxB[6] = { rec[j].lo[0], rec[j].lo[1], rec[j].lo[2], rec[j].hi[0], rec[j].hi[1], rec[j].hi[2] };
+                nc = wave_convex_convex<T>(A.x, A.R, Bh.x, Bh.R, A.side[0], boxA, boxB, P, maxc, false, lane,
+                                           [&](int rank, const V3<T> &pp, const V3<T> &nn, T dep) { put_c(gpos, gnormal, gdepth, slot0 + rank, pp, nn, dep); });
+            } else if (gi == GEOM_SPHERE || gj == GEOM_SPHERE) {
+                // (sphere i, hull j): the collider's own order, normal into the sphere.  (hull i, sphere j): dCollide swaps and flips.
+                const BodyGeomX<T> Sp = geom_of<T>(S, gtype, gi == GEOM_SPHERE ? i : j);
+                const BodyGeomX<T> H = geom_of<T>(S, gtype, gi == GEOM_SPHERE ? j : i);
+                const size_t slot0 = cap.pair_slot0() + (size_t)8 * p;
+                nc = wave_sphere_convex<T>(Sp.x, Sp.side[0], H.x, H.R, P, gi != GEOM_SPHERE, lane,
+                                           [&](int rank, const V3<T> &pp, const V3<T> &nn, T dep) { put_c(gpos, gnormal, gdepth, slot0 + rank, pp, nn, dep); });
+            }
         }
         if (lane == 0) cc[e] = (uint32_t)nc;
     }
@@ -677,6 +682,20 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gt
     if (tid < sizeof(ExactCounts) / 4) ((uint32_t *)C)[tid] = 0u;
     __syncthreads(); EXS_STAMP();
     for (int64_t i = tid; i < n; i += EXS_WG) grid_insert<T>(S, gtype, i, G);      // ghosts included
+    if (G.hull_n > 0) {
+        // convex bodies: the exact AABB over the bounding sphere's box (bp_convex_aabb's job in the stage-per-launch form), a
+        // wavefront per hull, behind a barrier: another wave's thread wrote the record just now
+        __syncthreads();
+        for (int64_t i = tid >> 6; i < n; i += EXS_WG / 64) {
+            if (gtype[i] != GEOM_CONVEX) continue;
+            const V3<T> x = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
+            const M3<T> R = quat_to_R(Q4<T>{ S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)], S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] });
+            T lo[3], hi[3];
+            wave_hull_aabb<T>(x, R, G.hull, G.hull_n, (int)(tid & 63), lo, hi);
+            const int l = (int)(tid & 63);
+            if (l < 3) { G.rec[i].lo[l] = l == 0 ? lo[0] : (l == 1 ? lo[1] : lo[2]); G.rec[i].hi[l] = l == 0 ? hi[0] : (l == 1 ? hi[1] : hi[2]); }
+        }
+    }
     __syncthreads(); EXS_STAMP();
     st_pair_count<T>(S, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
@@ -836,8 +855,26 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
 
 bool exact_small_fits(int64_t n, uint32_t grid_mask, const ExactCaps &cap)
 {
-    return n <= 8192 && grid_mask < 32768u && cap.entries() <= (uint32_t)(EXS_WG * 8) && cap.inv <= 8192u;
+    return n <= 8192 && grid_mask < 32768u && exact_back_fits(cap);
 }
+bool exact_back_fits(const ExactCaps &cap)
+{
+    return cap.entries() <= (uint32_t)(EXS_WG * 8) && cap.inv <= 8192u;
+}
+
+// islands' roots of the pairs launch_exact_pairs left (stages 3: union-find, flatten, root numbering) -- the part of
+// launch_exact_group that ex_small_front also ends with, for a caller that goes on with launch_exact_small_group
+template <class T>
+hipError_t launch_exact_roots(const ExactBuffers<T> &B, const ExactCaps &cap, hipStream_t st)
+{
+    size_t tb = B.temp_bytes;
+    hipLaunchKernelGGL(ex_unite, dim3(grid_for(cap.pairs)), dim3(256), 0, st, B.pairs, B.pc, B.inc, B.parent, B.counts);
+    hipLaunchKernelGGL(ex_flatten, dim3(grid_for(cap.inv)), dim3(256), 0, st, B.parent, B.root, B.rf, cap, B.counts);
+    EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.rf, B.rinc, (size_t)cap.inv, rocprim::plus<uint32_t>(), st));
+    return hipGetLastError();
+}
+template hipError_t launch_exact_roots<float>(const ExactBuffers<float> &, const ExactCaps &, hipStream_t);
+template hipError_t launch_exact_roots<double>(const ExactBuffers<double> &, const ExactCaps &, hipStream_t);
 
 template <class T>
 hipError_t launch_exact_small_front(T *S, const uint8_t *gtype, int64_t n, int64_t n_active, const GridParams<T> &G, const ExactBuffers<T> &B,

@@ -76,6 +76,12 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
 // fills the grid (what fill_grid does); group: narrowphase + the rest, zeroes *diag.  A non-null host_counts / host_flags
 // (device-visible pinned memory) receives ExactCounts and the BPF_* flags at the end of that kernel.
 bool exact_small_fits(int64_t n, uint32_t grid_mask, const ExactCaps &cap);
+// Many bodies, few of them involved: the body-sized stages as launches over the chip (fill_grid, launch_exact_pairs,
+// launch_exact_roots), the entry-sized ones -- sort, joints by island, level schedules: a dozen launches of a few microseconds of work
+// each -- as launch_exact_small_group's one-workgroup kernel, when the entry arrays fit it (exact_back_fits)
+bool exact_back_fits(const ExactCaps &cap);
+template <class T>
+hipError_t launch_exact_roots(const ExactBuffers<T> &B, const ExactCaps &cap, hipStream_t st);
 template <class T>
 hipError_t launch_exact_small_front(T *S, const uint8_t *gtype, int64_t n, int64_t n_active, const GridParams<T> &G, const ExactBuffers<T> &B,
                                     const ExactCaps &cap, ExactCounts *host_counts, uint32_t *host_flags, uint32_t seq, hipStream_t st);

@@ -34,7 +34,7 @@ template <class T> GridParams<T> grid_of(dmxBatch *b)
 {
     GridParams<T> G;
     G.r_max = (T)b->bp_rmax;
-    G.r_max_box = (T)b->bp_rmax_box; G.r_max_solid = (T)b->bp_rmax_solid;
+    for (int c = 0; c < 4; c++) G.r_cls[c] = (T)b->bp_rcls[c];
     G.cell = (T)(2.0 * kSkin * b->bp_rmax);
     G.inv_cell = T(1) / G.cell;
     G.mask = b->bp_mask;
@@ -46,6 +46,8 @@ template <class T> GridParams<T> grid_of(dmxBatch *b)
     G.rec = (GridRec<T> *)b->ex_aabb.p;     // null until an exact tick has asked for it
     G.sbox = (const T *)b->sbox.p; G.n_static = b->n_static;
     G.static_fast = b->static_fast ? 1 : 0; G.plane_on = b->plane_on;
+    G.hull = (const T *)b->hull.p; G.hull_n = b->hull_n;
+    G.class_pairs = b->class_pairs;
     return G;
 }
 
@@ -77,17 +79,16 @@ int read_flags(dmxBatch *b)
 int ensure_buffers(dmxBatch *b)
 {
     if (b->bp_rmax <= 0) {
-        double r = 0, rbox = 0, rsolid = 0;
+        double r = 0, rcls[4] = { 0, 0, 0, 0 };
         for (int64_t i = 0; i < b->n; i++) {
             const double *s = &b->h_sides[(size_t)3 * i];
             const double ri = (b->h_gtype[(size_t)i] == GEOM_SPHERE || b->h_gtype[(size_t)i] == GEOM_CONVEX) ? s[0]     // convex: the hull's bounding radius
                             : b->h_gtype[(size_t)i] == GEOM_BOX ? 0.5 * std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]) : 0.0;
             r = std::max(r, ri);
-            if (b->h_gtype[(size_t)i] == GEOM_BOX) rbox = std::max(rbox, ri);
-            if (b->h_gtype[(size_t)i] == GEOM_BOX || b->h_gtype[(size_t)i] == GEOM_SPHERE) rsolid = std::max(rsolid, ri);
+            if (b->h_gtype[(size_t)i] < 4) rcls[b->h_gtype[(size_t)i]] = std::max(rcls[b->h_gtype[(size_t)i]], ri);
         }
         b->bp_rmax = r > 0 ? r : 1.0;
-        b->bp_rmax_box = rbox; b->bp_rmax_solid = rsolid;
+        for (int c = 0; c < 4; c++) b->bp_rcls[c] = rcls[c];
     }
     if (!b->bp_mask) {
         uint32_t h = 1024;
@@ -130,6 +131,8 @@ template <class T> int fill_grid(dmxBatch *b, void *rec_a = nullptr, size_t byte
     HIP_TRY(launch_bp_clear((uint32_t *)b->bp_count.p, (size_t)b->bp_mask + 1, (uint32_t *)b->bp_flags.p, rec_a, bytes_a, rec_b, bytes_b,
                             b->stream));
     HIP_TRY(launch_bp_insert<T>((T *)b->slab, b->gtype, b->stride, b->n, G, b->stream));   // ghosts included
+    if (G.rec != nullptr && b->hull_n > 0)      // the pair search is coming: hulls get their exact AABBs (the zones keep bounding spheres)
+        HIP_TRY(launch_bp_convex_aabb<T>((const T *)b->slab, b->gtype, b->n, G, b->stream));
     return DMX_OK;
 }
 
@@ -286,6 +289,14 @@ bool use_small_exact(const dmxBatch *b, const ExactCaps &cap, bool pairs_matter)
     return b->n <= kSmallExactBodies && (!pairs_matter || b->last_pairs <= (unsigned long long)kSmallExactPairs);
 }
 
+// (DMX_EXACT_STAGED forces the stage-per-launch form throughout; DMX_HYBRID_EXACT=0 switches this form off for A/B runs)
+bool use_hybrid_exact(const dmxBatch *b, const ExactCaps &cap)
+{
+    static const bool on = [] { const char *e = getenv("DMX_HYBRID_EXACT"); return !(e && atoi(e) == 0); }();
+    const int mode = b->exact_pipeline != DMX_EXACT_AUTO ? b->exact_pipeline : default_exact_pipeline();
+    return on && mode != DMX_EXACT_STAGED && exact_back_fits(cap) && b->last_pairs <= (unsigned long long)kSmallExactPairs;
+}
+
 bool exs_timing_enabled()
 {
     static const bool v = [] { const char *e = getenv("DMX_EXS_TIMING"); return e && atoi(e) != 0; }();
@@ -428,6 +439,19 @@ template <class T> int careful_tick(dmxBatch *b, double h)
                 for (int k = 1; k < 9; k++) { b->exs_acc[k] += (double)(st[k] - st[k - 1]); b->exs_acc[32 + k] += (double)(st[32 + k] - st[32 + k - 1]); }
                 b->exs_ticks++;
             }
+        } else if (use_hybrid_exact(b, cap)) {
+            // many bodies, few involved (a handful of teapots leaning on one another among thousands at rest): the body-sized stages
+            // over the chip, the entry-sized ones in the one-workgroup kernel; one wait, on the record that kernel writes
+            ExactCounts *hc; uint32_t *hf;
+            if ((rc = host_record_pointers(b, &hc, &hf)) != DMX_OK) return rc;
+            const uint32_t seq = next_record_seq();
+            if ((rc = fill_grid<T>(b, B.counts, sizeof(ExactCounts), b->diag_isl, sizeof(StepDiag))) != DMX_OK) return rc;
+            const GridParams<T> G = grid_of<T>(b);
+            HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, G, B, cap, b->stream));
+            HIP_TRY(launch_exact_roots<T>(B, cap, b->stream));
+            HIP_TRY(launch_exact_small_group<T>((const T *)b->slab, b->gtype, G, P, B, cap, rpc, big_island_rows_general(), b->diag_isl,
+                                                hc, hf, seq, b->stream));
+            if ((rc = await_host_record(b, seq)) != DMX_OK) return rc;
         } else {
         // (the count record and the island solve's diagnostics are zeroed with the grid: one launch)
         if ((rc = fill_grid<T>(b, B.counts, sizeof(ExactCounts), b->diag_isl, sizeof(StepDiag))) != DMX_OK) return rc;

@@ -42,15 +42,14 @@ __host__ __device__ __forceinline__ int64_t slab_ix(int c, int64_t i)
 
 // GEOM_CONVEX: the batch's one convex hull (StepParams::hull); its bounding radius sits in sides[0] like a sphere's
 enum : int { GEOM_NONE = 0, GEOM_SPHERE = 1, GEOM_BOX = 2, GEOM_CONVEX = 3 };
-// can a geom of class a ever produce a contact with one of class b?  A convex hull has colliders against boxes (and the
-// ground plane / static boxes) only; convex-convex and convex-sphere pairs pass through one another, so the broadphase
-// need not keep them apart nor hand them to the narrowphase
-__host__ __device__ __forceinline__ bool classes_collide(int a, int b)
+// can a geom of class a ever produce a contact with one of class b?  Every pair of classes has a collider since round 3 (box /
+// sphere / convex hull against one another: dmx_collide.hpp, dmx_collide_wave.hpp); empty slots collide with nobody, and the
+// caller may switch class pairs off -- the batch's form of dGeomSetCategoryBits / dGeomSetCollideBits (main.c:724-725), which the
+// reference sets per geom: bit (4 a + b) of `mask` says that classes a and b collide (dmxBatchSetClassPairs; symmetric).
+constexpr uint32_t CLASS_PAIRS_ALL = 0xffffu;
+__host__ __device__ __forceinline__ bool classes_collide(int a, int b, uint32_t mask)
 {
-    if (a == GEOM_NONE || b == GEOM_NONE) return false;
-    if (a == GEOM_CONVEX) return b == GEOM_BOX;
-    if (b == GEOM_CONVEX) return a == GEOM_BOX;
-    return true;
+    return a != GEOM_NONE && b != GEOM_NONE && ((mask >> (4 * a + b)) & 1u) != 0u;
 }
 constexpr int CONVEX_MAXC = 8;      // contact slots per convex body per tick (the reference's MAX_CONTACTS, main.c:675)
 enum : int { SURF_BOUNCE = 0x004, SURF_SOFT_ERP = 0x008, SURF_SOFT_CFM = 0x010 };
@@ -151,8 +150,8 @@ constexpr int BPF_CHUNK_FLAGS = 4;      // VIOLATION, WARN, NOFAST, NEED8
 template <class T> struct alignas(16) GridRec { T lo[3], hi[3]; int32_t ix, iz; };
 template <class T> struct GridParams {
     T cell, inv_cell, r_max;
-    T r_max_box, r_max_solid;   // largest bounding radius among the boxes / among boxes and spheres (0: none): what a convex hull /
-                                // a sphere can collide with at all (classes_collide)
+    T r_cls[4];            // largest bounding radius per geometry class (0: the batch has none of it): what a body of a class can
+                           // meet outside its 3x3 block of columns is bounded by the classes it collides with (classes_collide)
     uint32_t mask;         // table size - 1 (power of two)
     int xbits;             // > 0: the table is a 2-D torus of 2^xbits columns per row (neighbouring cells are neighbouring
                            // entries: coalesced lookups); 0: scrambled hash (scenes too elongated for the torus)
@@ -166,6 +165,8 @@ template <class T> struct GridParams {
     // over two or more static boxes, or over one with a ground plane present: only those are "involved" in an exact tick,
     // and being near a static box does not make a body crowded.  0 (DMX_STATIC_FAST=0): every body at a static box is.
     int static_fast, plane_on;
+    const T *hull; int hull_n;     // the batch's hull shape (convex bodies' exact AABBs for the pair search: bp_convex_aabb)
+    uint32_t class_pairs;          // which geometry classes collide with which (classes_collide)
 };
 
 struct StepDiag {
@@ -192,6 +193,10 @@ hipError_t launch_bp_clear(uint32_t *count, size_t n_count, uint32_t *flags, voi
                            hipStream_t st);
 template <class T>
 hipError_t launch_bp_insert(T *S, const uint8_t *gtype, int64_t stride, int64_t n, const GridParams<T> &G, hipStream_t st);
+// the exact world AABB of every convex body among [0, n) into G.rec (one wavefront per hull), over the bounding sphere's box
+// bp_insert left there
+template <class T>
+hipError_t launch_bp_convex_aabb(const T *S, const uint8_t *gtype, int64_t n, const GridParams<T> &G, hipStream_t st);
 template <class T>
 hipError_t launch_bp_safe_zone(T *S, const uint8_t *gtype, int64_t stride, int64_t n_active, const GridParams<T> &G, hipStream_t st);
 // ground-plane contacts of the convex bodies among [0, n): one wavefront per body walks the hull (dCollideConvexPlane)

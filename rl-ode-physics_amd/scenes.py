@@ -105,12 +105,14 @@ def config3(n_side=512):
 HULL_PITCH = 3.0      # grid pitch of the hull scenes: the 0.01-scale teapot hull is 2.13 m across its bounding sphere
 
 
-def hull_grid(hull, nx, nz, *, seed=1, y_range=(1.5, 3.5), spin=False, density=1.0, plane=True, tilt=0.0, floor_box=False):
+def hull_grid(hull, nx, nz, *, seed=1, y_range=(1.5, 3.5), spin=False, density=1.0, plane=True, tilt=0.0, floor_box=False, pitch=None):
     """nx x nz copies of one convex hull (a hull.Hull) over the ground plane, or -- floor_box -- over one static box whose
     top is at y = 0 (BASELINE configs[4]: "dropping on a static box floor, box-convex contacts").
 
     Every body starts upright (the hull's input-frame orientation) unless tilt > 0, which turns body i about a
-    drawn horizontal axis by a drawn angle in [0, tilt]; heights and spin are drawn like box_grid's."""
+    drawn horizontal axis by a drawn angle in [0, tilt]; heights and spin are drawn like box_grid's.  pitch: the grid's pitch
+    (default HULL_PITCH = 3 m: tipped teapots rock and roll into their neighbours -- hull-hull contacts; BASELINE configs[4]
+    names box-trimesh contacts only, every island one body as in SURVEY 8(d)'s other grids: bench.py spreads them to 4.5 m)."""
     n = nx * nz
     r = Rand(seed)
     d = r.next(n * DRAWS_PER_BODY).astype(np.float64).reshape(n, DRAWS_PER_BODY) / float(0xFFFFFFFF)
@@ -118,7 +120,8 @@ def hull_grid(hull, nx, nz, *, seed=1, y_range=(1.5, 3.5), spin=False, density=1
     omega = (-1.0 + d[:, 4:7] * 2.0) if spin else np.zeros((n, 3))
     col = np.tile(np.arange(nx, dtype=np.float64), nz)
     row = np.repeat(np.arange(nz, dtype=np.float64), nx)
-    pos = np.stack([(col - (nx - 1) / 2.0) * HULL_PITCH, y, (row - (nz - 1) / 2.0) * HULL_PITCH], axis=1)
+    pitch = HULL_PITCH if pitch is None else float(pitch)
+    pos = np.stack([(col - (nx - 1) / 2.0) * pitch, y, (row - (nz - 1) / 2.0) * pitch], axis=1)
     q0 = hull.upright_quaternion()
     quat = np.tile(q0, (n, 1))
     if tilt > 0:
@@ -137,7 +140,7 @@ def hull_grid(hull, nx, nz, *, seed=1, y_range=(1.5, 3.5), spin=False, density=1
     from . import hull as hull_mod
     statics = None
     if floor_box:
-        span = max(nx, nz) * HULL_PITCH + 20.0
+        span = max(nx, nz) * pitch + 20.0
         statics = [((span, 1.0, span), (0.0, -0.5, 0.0), _rot_z(0.0))]
         plane = False
     return Scene(pos, quat, np.zeros((n, 3)), omega, mass, inertia, sides, np.full(n, GEOM_CONVEX, np.uint8),

@@ -717,3 +717,96 @@ def test_kat5_convex_plane_needs_points_on_both_sides():
         for i in range(n):
             assert abs(out[i].depth - (0.5 - y)) < 1e-15 and list(out[i].normal) == [0.0, 1.0, 0.0]
             assert out[i].pos[1] == y - 0.5
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# sphere against hull, hull against hull (round 3): the repository's own colliders -- closed-form cases
+def _hull_world(orc, half, hull_poses, spheres=()):
+    """convex bodies sharing one cube hull of half-extent `half` (8 points, 6 face planes), plus spheres (pos, radius);
+    geoms are numbered in creation order: hulls first, then spheres"""
+    import itertools
+    pts = np.array(list(itertools.product((-half, half), repeat=3)), float)
+    planes = []
+    for a in range(3):
+        for sg in (-1.0, 1.0):
+            n = [0.0, 0.0, 0.0]; n[a] = sg
+            planes.append(n + [half])
+    ow = orc.world()
+    ow.set_hull(pts); ow.set_hull_faces(np.array(planes))
+    k = len(hull_poses)
+    ow.add_convex(np.array([p for p, _ in hull_poses], float), np.array([q for _, q in hull_poses], float), np.zeros((k, 3)), np.zeros((k, 3)),
+                  np.ones(k), np.ones((k, 3)))
+    if spheres:
+        m = len(spheres)
+        ow.add_spheres(np.array([p for p, _ in spheres], float), None, None, None, np.ones(m), np.ones((m, 3)), np.array([r for _, r in spheres], float))
+    return ow
+
+
+IDQ = (1.0, 0.0, 0.0, 0.0)
+
+
+def test_sphere_on_a_hull_face_and_beside_an_edge():
+    from oracle.orc_ctypes import Oracle
+    orc = Oracle("float64")
+    # sphere r = 0.3, centre 0.28 above the top face of a unit-cube hull: one contact, 0.02 deep, along +y (into the sphere, o1)
+    ow = _hull_world(orc, 0.5, [((0.0, 0.0, 0.0), IDQ)], spheres=[((0.1, 0.78, -0.05), 0.3)])
+    (pos, nrm, dep), = _collide(orc, ow, 1, 0)                    # dCollide(sphere, hull)
+    assert np.allclose(nrm, [0, 1, 0]) and abs(dep - 0.02) < 1e-12 and np.allclose(pos, [0.1, 0.48, -0.05])
+    (pos2, nrm2, dep2), = _collide(orc, ow, 0, 1)                 # (hull, sphere): swapped and flipped
+    assert np.allclose(nrm2, [0, -1, 0]) and abs(dep2 - 0.02) < 1e-12 and np.allclose(pos2, pos)
+    # out of reach of every face plane: nothing
+    ow = _hull_world(orc, 0.5, [((0.0, 0.0, 0.0), IDQ)], spheres=[((0.1, 0.81, -0.05), 0.3)])
+    assert _collide(orc, ow, 1, 0) == []
+    # the stated over-estimate: diagonally off an edge the true distance is 0.2 sqrt(2) = 0.283 > r = 0.25, but the face planes'
+    # maximum is 0.2: met early, 0.05 deep, along the FIRST of the two faces at that distance (+x comes before +y)
+    ow = _hull_world(orc, 0.5, [((0.0, 0.0, 0.0), IDQ)], spheres=[((0.7, 0.7, 0.0), 0.25)])
+    (pos, nrm, dep), = _collide(orc, ow, 1, 0)
+    assert np.allclose(nrm, [1, 0, 0]) and abs(dep - 0.05) < 1e-12
+    # a rotated, displaced hull: the same contact in the hull's frame
+    a = 0.4
+    q = (np.cos(a / 2), 0.0, 0.0, np.sin(a / 2))                  # about z
+    up = np.array([-np.sin(a), np.cos(a), 0.0])                   # the hull's +y face normal in the world
+    c = np.array([2.0, 1.0, -3.0]) + 0.78 * up
+    ow = _hull_world(orc, 0.5, [((2.0, 1.0, -3.0), q)], spheres=[(tuple(c), 0.3)])
+    (pos, nrm, dep), = _collide(orc, ow, 1, 0)
+    assert np.allclose(nrm, up, atol=1e-12) and abs(dep - 0.02) < 1e-12 and np.allclose(pos, c - 0.3 * up, atol=1e-12)
+
+
+def test_hull_against_hull_vertices_in_the_other():
+    from oracle.orc_ctypes import Oracle
+    orc = Oracle("float64")
+    # B shifted 0.9 along x (and a little in y, z): ONE vertex of B is inside A and ONE of A inside B (the other two corners of
+    # the common face region are edge-edge crossings, which this collider does not see)
+    ow = _hull_world(orc, 0.5, [((0.0, 0.0, 0.0), IDQ), ((0.9, 0.2, -0.15), IDQ)])
+    cs = _collide(orc, ow, 0, 1)
+    assert len(cs) == 2
+    (p0, n0, d0), (p1, n1, d1) = cs
+    assert np.allclose(p0, [0.4, -0.3, 0.35]) and np.allclose(n0, [-1, 0, 0]) and abs(d0 - 0.1) < 1e-12      # B's vertex in A: against A's +x face, into A
+    assert np.allclose(p1, [0.5, 0.5, -0.5]) and np.allclose(n1, [-1, 0, 0]) and abs(d1 - 0.1) < 1e-12       # A's vertex in B: B's -x face normal
+    flipped = _collide(orc, ow, 1, 0)
+    assert len(flipped) == 2 and np.allclose(flipped[0][1], [1, 0, 0]) and np.allclose(flipped[0][0], p1)    # B is o1 now: A's vertex in B comes first
+    assert len(_collide(orc, ow, 0, 1, maxc=1)) == 1
+    # apart by a hair: nothing
+    ow = _hull_world(orc, 0.5, [((0.0, 0.0, 0.0), IDQ), ((1.0001, 0.2, -0.15), IDQ)])
+    assert _collide(orc, ow, 0, 1) == []
+
+
+def test_a_hull_balanced_on_another_shares_its_weight_by_the_lever_rule():
+    """an upper cube hull shifted by (0.1, 0.1) on a lower one that rests on the ground plane: the collider sees the two diagonal
+    corners of the common square -- one vertex of each hull in the other -- and the line between them passes under the upper
+    hull's centre, so one exact step leaves it at rest with the two contacts sharing m g as a lever does: the corner 0.4 sqrt(2)
+    from the centre (the lower hull's, at (0.5, 0.5)) carries 5/9, the one 0.5 sqrt(2) away (the upper hull's own) 4/9"""
+    from oracle.orc_ctypes import Oracle
+    orc = Oracle("float64")
+    ow = _hull_world(orc, 0.5, [((0.0, 0.4999, 0.0), IDQ), ((0.1, 1.4997, 0.1), IDQ)])
+    ow.add_plane(0.0, 1.0, 0.0, 0.0)
+    orc.lib.orc_world_set_erp(ow.w, 0.0)
+    ow.set_stepper(True)
+    ow.tick(1.0 / 60.0)
+    between = [j for j in ow.joints() if j[0] >= 0 and j[1] >= 0]
+    assert len(between) == 2
+    lam = {tuple(np.round(j[2], 6)[[0, 2]]): j[5] for j in between}
+    assert abs(sum(lam.values()) - 9.8) < 1e-6
+    near, far = lam[(-0.4, -0.4)], lam[(0.5, 0.5)]                  # the upper hull's own corner; the lower hull's corner
+    assert abs(near - 9.8 * 4 / 9) < 1e-6 and abs(far - 9.8 * 5 / 9) < 1e-6
+    assert np.max(np.abs(ow.state()[2][1])) < 1e-8                  # the upper hull stays put
