@@ -1250,11 +1250,10 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
             // per CU; f64: 144 KB of the CU's 160 KB)
             const int lanes = 64;
             const size_t lds = (size_t)lanes * 3 * SINGLE_MAXC_LDS * RS_FIELDS * sizeof(T);
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_singles_lds<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr_set = true;
-            }
+            // (set per launch: the attribute belongs to the function ON THE CURRENT DEVICE, and the call is a table write -- a
+            //  process-wide "done once" flag would leave a second device, or a second thread racing the first, without it)
+            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_singles_lds<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) return ea;
             hipLaunchKernelGGL((solve_singles_lds<T>), dim3((unsigned)((I.n_islands + lanes - 1) / lanes)), dim3(lanes), lds, st, S, bflags,
                                stride, I, P, diag);
         }

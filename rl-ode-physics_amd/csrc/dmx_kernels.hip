@@ -1008,11 +1008,8 @@ hipError_t launch_step(T *S, T *So, const uint8_t *gtype, int64_t stride, int64_
             const int64_t ntiles = (n + SLAB_TILE - 1) / SLAB_TILE;
             const int per_cu = (-P.vec) / 32 > 0 ? ((-P.vec) % 32 == 0 ? 4 : (-P.vec) % 32) : 4;
             const size_t lds = (size_t)4 * 2 * C_SIDES * SLAB_TILE * sizeof(T);
-            static bool attr_done[2] = { false, false };
-            if (!attr_done[sizeof(T) == 8]) {
-                (void)hipFuncSetAttribute((const void *)integrate_free_dma<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr_done[sizeof(T) == 8] = true;
-            }
+            const hipError_t ea = hipFuncSetAttribute((const void *)integrate_free_dma<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) return ea;
             int64_t blocks = (ntiles + 3) / 4;
             if (blocks > (int64_t)256 * per_cu) blocks = (int64_t)256 * per_cu;
             hipLaunchKernelGGL((integrate_free_dma<T>), dim3((unsigned)blocks), dim3(256), lds, st, S, So, ntiles, P);
