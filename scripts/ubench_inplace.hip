@@ -110,6 +110,15 @@ __global__ __launch_bounds__(256) void k_dense17(const float *X, float *Y, int n
     for (int c = 0; c < 13; c++) o[c * 64] = x[c] * (1.0f + s);
 }
 
+// slab contents other than zeros: the memory system moves zeros measurably faster (see main)
+__global__ void k_fill(float *a, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    a[i] = 0.5f + (float)(h & 0xffffff) * (1.0f / 16777216.0f);
+}
+
 template <class F> static double time_us(F launch, int reps)
 {
     hipEvent_t e0, e1;
@@ -140,6 +149,13 @@ int main(int argc, char **argv)
     CHECK(hipMalloc(&B, n * 30 * sizeof(float)));
     CHECK(hipMemset(A, 0, n * 30 * sizeof(float)));
     CHECK(hipMemset(B, 0, n * 30 * sizeof(float)));
+    const bool rnd = argc > 2 && atoi(argv[2]) != 0;       // 0: both slabs hold zeros; 1: pseudo-random values in [0.5, 1.5)
+    if (rnd) {
+        k_fill<<<(unsigned)((n * 30 + 255) / 256), 256>>>(A, n * 30);
+        k_fill<<<(unsigned)((n * 30 + 255) / 256), 256>>>(B, n * 30);
+        CHECK(hipDeviceSynchronize());
+    }
+    printf("slab contents: %s\n", rnd ? "pseudo-random" : "zeros");
     const int reps = 40;
     printf("n = %zu bodies, %.0f MB algorithmic per pass (120 B per body)\n", n, n * 120.0 / 1e6);
     const size_t n4 = n * 60 / 16;
