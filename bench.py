@@ -347,7 +347,11 @@ def roofline_of(m, kind, rsize, evidence=None, hull_points=0):
          "stream_us_per_launch": stream_s * 1e6, "ticks_per_launch": tpl, "traffic": None}
     if bound == "hbm":
         r.update({"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                  "algorithmic_bytes_per_body_step": BYTES_PER_BODY_STEP[kind] * rsize})
+                  "algorithmic_bytes_per_body_step": BYTES_PER_BODY_STEP[kind] * rsize,
+                  # measured ceiling for this access pattern (a compute-free kernel, same reads and writes, non-zero slab contents;
+                  # f32, 1 Mi bodies -- a static reference from profiles/, NOT measured by this run)
+                  "bare_pattern_frac_reference": {"frac": 0.82, "plain_copy_frac": 0.84,
+                                                  "evidence": "profiles/r03_ubench_fill_effect.txt"}})
     elif bound == "valu":
         rows = 3 * m["contacts"]
         flops = 20 * rows * SOR_FLOP_PER_ROW_SWEEP + m["bodies"] * hull_points * HULL_FLOP_PER_POINT
