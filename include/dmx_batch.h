@@ -196,7 +196,9 @@ int dmxBatchSetExactPipeline(dmxBatchID b, int mode);
  * per launch instead of per tick.  Default 1 (one launch per tick); 1..64. */
 int dmxBatchSetTicksPerLaunch(dmxBatchID b, int ticks);
 int dmxBatchCollisionStats(dmxBatchID b, int64_t out[6]);
-/* the same six numbers and [6] AABB pairs met so far that had no collider (always 0 since every class pair has one), [7] reserved */
+/* the same six numbers and [6] AABB pairs met so far that had no collider (always 0 since every class pair has one), [7] exact ticks
+ * of the one-workgroup pipeline whose island solve and fused step were enqueued before the host had the tick's counts, and stood
+ * (the device's record gates them; DMX_SPECULATE=0 in the environment makes every tick wait for its counts first) */
 int dmxBatchCollisionStatsEx(dmxBatchID b, int64_t out[8]);
 
 /* ---- the collision-checked tick loop in pieces.  dmxBatchStep(b, h, n) with body collisions enabled runs, inside

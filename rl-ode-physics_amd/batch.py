@@ -183,6 +183,7 @@ class BatchWorld:
         ex = (C.c_int64 * 8)()
         _check(self.lib.dmxBatchCollisionStatsEx(self.h, ex), "dmxBatchCollisionStatsEx")
         d["unsupported_pairs"] = ex[6]
+        d["speculated_ticks"] = ex[7]
         return d
 
     # -- the collision-checked loop in pieces (include/dmx_batch.h), for callers with per-tick work of their own --

@@ -132,7 +132,7 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
     (void)dmx_settle(b);
     if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
     if (b->prof_on) {
-        static const char *names[12] = { "pair search + flag read", "pair list D2H + sort", "narrowphase + counts D2H", "joint list",
+        static const char *names[12] = { "exact tick up to the record", "  of it: waiting for the record", "safe-zone rebuilds", "fast chunks (sync loop)",
                                          "joints: canonical + union-find", "joints: level schedules", "joints: staging fill",
                                          "joints: upload + launch", "fused kernel for the rest", "", "", "" };
         fprintf(stderr, "libode_mi355 host profile (exact ticks: %lld):\n", (long long)b->stat_careful_ticks);
@@ -631,7 +631,7 @@ extern "C" int dmxBatchCollisionStatsEx(dmxBatchID b, int64_t out[8])
     if (!b || !out) return DMX_EINVAL;
     int rc = dmxBatchCollisionStats(b, out);
     if (rc != DMX_OK) return rc;
-    out[6] = b->stat_unsupported; out[7] = 0;
+    out[6] = b->stat_unsupported; out[7] = b->stat_spec_ticks;
     return DMX_OK;
 }
 

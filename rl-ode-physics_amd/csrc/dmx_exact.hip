@@ -16,6 +16,7 @@
 // touched the state by then.
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <cstdlib>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
@@ -48,8 +49,7 @@ template <class T> __device__ __forceinline__ bool rec_meets_static(const GridRe
 // their way while this column's candidates are tested.  The column loop stays rolled: straight-line code that runs once per
 // launch is paid for in instruction fetches.
 template <class T, class F>
-__device__ __forceinline__ void for_each_partner(const T *S, const uint8_t *gtype, int64_t i, const GridParams<T> &G, F f,
-                                                 uint32_t *unsupported = nullptr)
+__device__ __forceinline__ void for_each_partner(const T *S, const uint8_t *gtype, int64_t i, const GridParams<T> &G, F f)
 {
     const GridRec<T> me = G.rec[i];
     const int gti = gtype[i];
@@ -98,17 +98,53 @@ __device__ __forceinline__ void for_each_partner(const T *S, const uint8_t *gtyp
     }
 }
 
+// the walk above as a callable, for the stage functions below
+template <class T> struct GridWalk {
+    const T *S; const uint8_t *gtype; const GridParams<T> &G;
+    template <class F> __device__ __forceinline__ void operator()(int64_t i, F f) const { for_each_partner<T>(S, gtype, i, G, f); }
+};
+// ... and the same walk over a grid that lives in LDS (ex_small_front: the scene of a one-workgroup launch fits there).  Cells as
+// runs of one index array (start[h] .. start[h + 1]), every body's record and class beside it: a candidate costs LDS round trips,
+// not L2 ones -- the walk is a chain of dependent reads, and that chain was the kernel's longest stage.  The order in which a
+// body's partners come up differs from the bucket walk's; both callers are indifferent to it (a count; a run that is sorted).
+template <class T> struct LdsGridWalk {
+    const GridRec<T> *rec; const uint32_t *start; const uint16_t *sorted; const uint8_t *gt;
+    uint32_t mask; int xbits; uint32_t class_pairs;
+    template <class F> __device__ __forceinline__ void operator()(int64_t i, F f) const
+    {
+        const GridRec<T> me = rec[i];
+        const int gti = gt[i];
+#pragma unroll 1
+        for (int c = 0; c < 9; c++) {
+            const int cx = me.ix + (c % 3) - 1, cz = me.iz + (c / 3) - 1;
+            const uint32_t h = cell_hash(cx, cz, mask, xbits);
+            const uint32_t a = start[h], e = start[h + 1];
+            for (uint32_t k = a; k < e; k++) {
+                const int64_t j = sorted[k];
+                if (j == i) continue;
+                const GridRec<T> o = rec[j];
+                if (o.ix != cx || o.iz != cz) continue;          // buckets can mix columns: (i, j) is met in one cell only
+                if (!classes_collide(gti, gt[j], class_pairs)) continue;
+                if (o.lo[0] > me.hi[0] || me.lo[0] > o.hi[0] || o.lo[1] > me.hi[1] || me.lo[1] > o.hi[1] ||
+                    o.lo[2] > me.hi[2] || me.lo[2] > o.hi[2])
+                    continue;
+                f(j);
+            }
+        }
+    }
+};
+
 // ---- 1. per active body: partners above it (the pairs it owns) and whether it is in any pair at all ---------------
 // pc[i] = (owned pairs << 32) | in-any-pair; inpair[i] = in-any-pair (the fused kernel's skip mask).  A partner in a ghost
 // slot means an island spanning two ranks.
-template <class T>
-__device__ __forceinline__ void st_pair_count(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G, uint64_t *pc,
+template <class T, class W>
+__device__ __forceinline__ void st_pair_count(const W &walk, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G, uint64_t *pc,
                                               uint8_t *inpair, ExactCounts *C, int32_t *cross_list, int64_t first, int64_t step)
 {
     for (int64_t i = first; i < n_active; i += step) {
         uint32_t owned = 0, any = 0;
         if (gtype[i] != GEOM_NONE) {
-            for_each_partner<T>(S, gtype, i, G, [&](int64_t j) {
+            walk(i, [&](int64_t j) {
                 any = 1;
                 if (j >= n_active) {
                     if (atomicOr(&C->cross, 1u) == 0u) { C->cross_a = (uint32_t)i; C->cross_b = (uint32_t)j; }
@@ -116,7 +152,7 @@ __device__ __forceinline__ void st_pair_count(const T *S, const uint8_t *gtype, 
                     if (at < EX_CROSS_CAP) { cross_list[2 * at] = (int32_t)i; cross_list[2 * at + 1] = (int32_t)j; }
                 }
                 else if (j > i) owned++;
-            }, &C->unsupported);
+            });
             // static box geoms are "big geoms against everyone".  A body whose AABB overlaps static boxes but no other body's
             // is a one-body island: the fused path (np_static -> step_contacts) steps it -- unless its contacts might not fit
             // that path's buffer of SC_MAXC: AABB over two or more static boxes, or over one with a ground plane present
@@ -138,14 +174,14 @@ __global__ __launch_bounds__(256) void ex_pair_count(const T *__restrict__ S, co
                                                      GridParams<T> G, uint64_t *__restrict__ pc, uint8_t *__restrict__ inpair,
                                                      ExactCounts *__restrict__ C, int32_t *__restrict__ cross_list)
 {
-    st_pair_count<T>(S, gtype, n_active, G, pc, inpair, C, cross_list, blockIdx.x * (int64_t)blockDim.x + threadIdx.x,
+    st_pair_count<T>(GridWalk<T>{ S, gtype, G }, gtype, n_active, G, pc, inpair, C, cross_list, blockIdx.x * (int64_t)blockDim.x + threadIdx.x,
                      (int64_t)gridDim.x * blockDim.x);
 }
 
 // ---- 2. pairs in canonical order, the involved bodies ascending, union-find initialised ----------------------------
 // inc = inclusive scan of pc.  Body i owns pairs [hi(exc), hi(exc) + owned) and, if involved, is entry lo(exc) of `inv`.
-template <class T>
-__device__ __forceinline__ void st_pair_write(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G, const uint64_t *pc,
+template <class T, class W>
+__device__ __forceinline__ void st_pair_write(const W &walk, int64_t n_active, const GridParams<T> &G, const uint64_t *pc,
                                               const uint64_t *inc, int32_t *pairs, int32_t *inv, int32_t *parent, const ExactCaps &cap,
                                               ExactCounts *C, int64_t first, int64_t step)
 {
@@ -167,7 +203,7 @@ __device__ __forceinline__ void st_pair_write(const T *S, const uint8_t *gtype, 
         if (owned == 0) continue;
         int32_t *out = pairs + 2 * (size_t)hi32(exc);
         uint32_t w = 0;
-        for_each_partner<T>(S, gtype, i, G, [&](int64_t j) {
+        walk(i, [&](int64_t j) {
             if (j > i && j < n_active && w < owned) { out[2 * w] = (int32_t)i; out[2 * w + 1] = (int32_t)j; w++; }
         });
         // this thread's own run of partners, ascending (runs are short: insertion sort in place)
@@ -185,7 +221,7 @@ __global__ __launch_bounds__(256) void ex_pair_write(const T *__restrict__ S, co
                                                      int32_t *__restrict__ pairs, int32_t *__restrict__ inv, int32_t *__restrict__ parent,
                                                      ExactCaps cap, ExactCounts *__restrict__ C)
 {
-    st_pair_write<T>(S, gtype, n_active, G, pc, inc, pairs, inv, parent, cap, C, blockIdx.x * (int64_t)blockDim.x + threadIdx.x,
+    st_pair_write<T>(GridWalk<T>{ S, gtype, G }, n_active, G, pc, inc, pairs, inv, parent, cap, C, blockIdx.x * (int64_t)blockDim.x + threadIdx.x,
                      (int64_t)gridDim.x * blockDim.x);
 }
 
@@ -666,22 +702,48 @@ __device__ __forceinline__ void publish_counts(const ExactCounts *C, const uint3
 // stage averages when the batch is destroyed
 #define EXS_STAMP() do { if (threadIdx.x == 0) stamps[sk] = wall_clock64(); sk++; } while (0)
 
-// grid fill (fill_grid's memsets + bp_insert) and stages 1-3: pairs, involved bodies, islands' roots
-template <class T>
+// grid fill (fill_grid's memsets + bp_insert) and stages 1-3: pairs, involved bodies, islands' roots.
+// LG: the grid is built in LDS as cell runs (LdsGridWalk) instead of in the batch's bucket table -- every record, class, cell
+// start and the sorted index array fit (exact_small_lds_bytes); the table in device memory is then not touched at all (nothing
+// after this kernel reads it: the zones' rebuild fills it itself), the records still go to G.rec for the narrowphase.
+template <class T, bool LG>
 __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gtype, int64_t n, int64_t n_active, GridParams<T> G,
                                                          ExactBuffers<T> B, ExactCaps cap, ExactCounts *host_counts, uint32_t *host_flags,
                                                          uint32_t seq)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char exs_lds[];
     __shared__ uint64_t wt[EXS_WG / 64];
     const uint32_t tid = threadIdx.x;
     ExactCounts *C = B.counts;
     uint64_t *stamps = B.stamps; int sk = 0;
+    const uint32_t cells = G.mask + 1u;
+    GridRec<T> *rec_l = reinterpret_cast<GridRec<T> *>(exs_lds);                          // [n]
+    uint32_t *start = reinterpret_cast<uint32_t *>(rec_l + (LG ? n : 0));                  // [cells + 1]
+    uint16_t *sorted = reinterpret_cast<uint16_t *>(start + (LG ? cells + 1u : 0u));       // [n]
+    uint8_t *gt_l = reinterpret_cast<uint8_t *>(sorted + (LG ? n : 0));                    // [n]
     EXS_STAMP();
-    for (uint32_t k = tid; k <= G.mask; k += EXS_WG) G.count[k] = 0u;
+    if (LG) { for (uint32_t k = tid; k <= cells; k += EXS_WG) start[k] = 0u; }
+    else { for (uint32_t k = tid; k <= G.mask; k += EXS_WG) G.count[k] = 0u; }
     if (tid < (uint32_t)BPF_COUNT) G.flags[tid] = 0u;
     if (tid < sizeof(ExactCounts) / 4) ((uint32_t *)C)[tid] = 0u;
     __syncthreads(); EXS_STAMP();
-    for (int64_t i = tid; i < n; i += EXS_WG) grid_insert<T>(S, gtype, i, G);      // ghosts included
+    if (LG) {
+        // grid_insert's work with the bucket replaced by a count: the cell's run is laid out below
+        for (int64_t i = tid; i < n; i += EXS_WG) {
+            const uint8_t gt = gtype[i];
+            gt_l[i] = gt;
+            if (gt == GEOM_NONE) continue;
+            S[slab_ix(C_BPR, i)] = bound_radius<T>(gt, S, i);
+            GridRec<T> r;
+            body_aabb<T>(S, gtype, i, r.lo, r.hi);
+            r.ix = (int)floor((double)(S[slab_ix(C_POS + 0, i)] * G.inv_cell));
+            r.iz = (int)floor((double)(S[slab_ix(C_POS + 2, i)] * G.inv_cell));
+            G.rec[i] = r; rec_l[i] = r;
+            atomicAdd(&start[cell_hash(r.ix, r.iz, G.mask, G.xbits)], 1u);
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += EXS_WG) grid_insert<T>(S, gtype, i, G);      // ghosts included
+    }
     if (G.hull_n > 0) {
         // convex bodies: the exact AABB over the bounding sphere's box (bp_convex_aabb's job in the stage-per-launch form), a
         // wavefront per hull, behind a barrier: another wave's thread wrote the record just now
@@ -693,14 +755,36 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gt
             T lo[3], hi[3];
             wave_hull_aabb<T>(x, R, G.hull, G.hull_n, (int)(tid & 63), lo, hi);
             const int l = (int)(tid & 63);
-            if (l < 3) { G.rec[i].lo[l] = l == 0 ? lo[0] : (l == 1 ? lo[1] : lo[2]); G.rec[i].hi[l] = l == 0 ? hi[0] : (l == 1 ? hi[1] : hi[2]); }
+            if (l < 3) {
+                const T lv = l == 0 ? lo[0] : (l == 1 ? lo[1] : lo[2]), hv = l == 0 ? hi[0] : (l == 1 ? hi[1] : hi[2]);
+                G.rec[i].lo[l] = lv; G.rec[i].hi[l] = hv;
+                if (LG) { rec_l[i].lo[l] = lv; rec_l[i].hi[l] = hv; }
+            }
         }
     }
-    __syncthreads(); EXS_STAMP();
-    st_pair_count<T>(S, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG);
+    __syncthreads();
+    if (LG) {
+        // counts -> run ends (inclusive scan in place) -> every body takes the slot below its cell's end: start[h] is the run's
+        // first slot when all have, and start[h + 1] -- the next run's first -- its end
+        block_scan_inclusive<uint32_t>(start, start, cells, reinterpret_cast<uint32_t *>(wt));
+        if (tid == 0) start[cells] = start[cells - 1];
+        __syncthreads();
+        for (int64_t i = tid; i < n; i += EXS_WG) {
+            if (gt_l[i] == GEOM_NONE) continue;
+            const uint32_t at = atomicSub(&start[cell_hash(rec_l[i].ix, rec_l[i].iz, G.mask, G.xbits)], 1u) - 1u;
+            sorted[at] = (uint16_t)i;
+        }
+        __syncthreads();
+    }
+    EXS_STAMP();
+    const LdsGridWalk<T> lw{ rec_l, start, sorted, gt_l, G.mask, G.xbits, G.class_pairs };
+    const GridWalk<T> gw{ S, gtype, G };
+    if (LG) st_pair_count<T>(lw, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG);
+    else    st_pair_count<T>(gw, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
     block_scan_inclusive<uint64_t>(B.pc, B.inc, (uint32_t)n_active, wt); EXS_STAMP();
-    st_pair_write<T>(S, gtype, n_active, G, B.pc, B.inc, B.pairs, B.inv, B.parent, cap, C, tid, EXS_WG);
+    if (LG) st_pair_write<T>(lw, n_active, G, B.pc, B.inc, B.pairs, B.inv, B.parent, cap, C, tid, EXS_WG);
+    else    st_pair_write<T>(gw, n_active, G, B.pc, B.inc, B.pairs, B.inv, B.parent, cap, C, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
     st_unite(B.pairs, B.pc, B.inc, B.parent, C, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
@@ -767,7 +851,13 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_back(ExactBuffers<T> B, Exact
     st_levels(B.con_off, B.body_off, B.cb1, B.cb2, B.bg, B.binc, cap, rpc, B.big, B.big_list, B.lev_count, B.lev_off, B.lev_rows,
               B.row_level, B.last, C, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
-    if (tid == 0) { diag->contacts = 0ull; diag->residual = 0.0; }       // the island kernels add to it next
+    if (tid == 0) {
+        diag->contacts = 0ull; diag->residual = 0.0;       // the island kernels add to it next
+        // careful_tick's speculative launches (solve_island_wg<64> over the capacity, the fused step behind it) read this
+        C->spec_ok = (C->overflow == 0u && C->bp_overflow == 0u && flags[BPF_OVERFLOW] == 0u && C->cross == 0u && C->nbig == C->ni &&
+                      C->big_max_width <= 64u) ? 1u : 0u;
+    }
+    __syncthreads();
     publish_counts(C, flags, host_counts, host_flags, seq);
 }
 
@@ -853,6 +943,18 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
     return hipGetLastError();
 }
 
+// LDS the one-workgroup front kernel needs to keep the whole grid there (LdsGridWalk): records, cell starts, the sorted index
+// array (16-bit), classes.  0: does not fit (or DMX_SMALL_LDS_GRID=0) -- the kernel walks the bucket table in device memory.
+size_t exact_small_lds_bytes(int64_t n, uint32_t grid_mask, size_t real_bytes)
+{
+    static const bool on = [] { const char *e = getenv("DMX_SMALL_LDS_GRID"); return !(e && atoi(e) == 0); }();
+    if (!on || n > 65535) return 0;
+    const size_t rec = real_bytes == 4 ? sizeof(GridRec<float>) : sizeof(GridRec<double>);
+    size_t b = (size_t)n * rec + ((size_t)grid_mask + 2) * 4 + (size_t)n * 2 + (size_t)n;
+    b = (b + 15) & ~(size_t)15;
+    return b <= 150 * 1024 ? b : 0;        // of the CU's 160 KiB; the kernel's static LDS is a few hundred bytes
+}
+
 bool exact_small_fits(int64_t n, uint32_t grid_mask, const ExactCaps &cap)
 {
     return n <= 8192 && grid_mask < 32768u && exact_back_fits(cap);
@@ -880,7 +982,16 @@ template <class T>
 hipError_t launch_exact_small_front(T *S, const uint8_t *gtype, int64_t n, int64_t n_active, const GridParams<T> &G, const ExactBuffers<T> &B,
                                     const ExactCaps &cap, ExactCounts *host_counts, uint32_t *host_flags, uint32_t seq, hipStream_t st)
 {
-    hipLaunchKernelGGL((ex_small_front<T>), dim3(1), dim3(EXS_WG), 0, st, S, gtype, n, n_active, G, B, cap, host_counts, host_flags, seq);
+    const size_t lds = exact_small_lds_bytes(n, G.mask, sizeof(T));
+    if (lds != 0) {
+        if (lds > 48 * 1024) {       // (the default limit on dynamic LDS; a table write, and scenes this size are the rarer ones)
+            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&ex_small_front<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) return ea;
+        }
+        hipLaunchKernelGGL((ex_small_front<T, true>), dim3(1), dim3(EXS_WG), lds, st, S, gtype, n, n_active, G, B, cap, host_counts, host_flags, seq);
+    } else {
+        hipLaunchKernelGGL((ex_small_front<T, false>), dim3(1), dim3(EXS_WG), 0, st, S, gtype, n, n_active, G, B, cap, host_counts, host_flags, seq);
+    }
     return hipGetLastError();
 }
 

@@ -27,7 +27,9 @@ struct ExactCounts {
     uint32_t overflow;      // bit 0: pairs / involved bodies above capacity; bit 1: level-schedule rows above capacity
     uint32_t cross;         // a pair reaches into a ghost slot (an island spanning two ranks); the pair:
     uint32_t cross_a, cross_b;
-    uint32_t unsupported;   // AABB pairs of this tick that have no collider (convex-convex, convex-sphere)
+    uint32_t spec_ok;       // small-scene kernels: 1 = the island solve and the fused step enqueued BEHIND the bookkeeping may go ahead
+                            // without the host (no overflow, no island across ranks, every island a one-wavefront job of
+                            // solve_island_wg<64>); 0 = they return at once and the host launches what the counts call for
     uint32_t ncross;        // pairs (own body, ghost slot) met; the first EX_CROSS_CAP of them are in ExactBuffers::cross_list
     uint32_t bp_overflow;   // the grid's BPF_OVERFLOW flag as of the pair search (a bucket overflowed: the host widens them and searches
                             // again), carried here so that one read-back brings everything
@@ -89,5 +91,11 @@ template <class T>
 hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const GridParams<T> &G, const StepParams<T> &P, const ExactBuffers<T> &B,
                                     const ExactCaps &cap, int rpc, int big_rows, StepDiag *diag, ExactCounts *host_counts,
                                     uint32_t *host_flags, uint32_t seq, hipStream_t st);
+
+// solve_island_wg<64> over `max_big` islands, enqueued behind launch_exact_small_group before the host has its counts: the
+// workgroups ask the record on the device (counts_dev) whether they exist and whether the launch may act (ExactCounts::spec_ok)
+template <class T>
+hipError_t launch_islands_speculative(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
+                                      StepDiag *diag, const ExactCounts *counts_dev, unsigned max_big, hipStream_t st);
 
 }  // namespace dmx

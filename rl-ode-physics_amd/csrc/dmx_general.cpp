@@ -139,6 +139,7 @@ template <class T> int fill_grid(dmxBatch *b, void *rec_a = nullptr, size_t byte
 // (re)build every body's safe zone from the current poses
 template <class T> int build_safe_zones(dmxBatch *b)
 {
+    DmxPhase pz(b, 2);
     int rc = ensure_buffers(b);
     if (rc != DMX_OK) return rc;
     if ((rc = fill_grid<T>(b)) != DMX_OK) return rc;
@@ -224,12 +225,13 @@ template <class T> int launch_fast(dmxBatch *b, const StepParams<T> &P, bool ext
     return DMX_OK;
 }
 
-template <class T> int fused_tick(dmxBatch *b, double h, bool check, const uint8_t *skip)
+template <class T> int fused_tick(dmxBatch *b, double h, bool check, const uint8_t *skip, const uint32_t *gate = nullptr)
 {
     StepParams<T> P = dmx_make_params<T>(b, h);
     P.bp_check = check ? BPC_ALL : 0;
     P.bp_flags = (uint32_t *)b->bp_flags.p;
     P.skip = skip;
+    P.gate = gate;
     // static fused path: the launch for bodies with 5..8 contacts rides along once such a body has been met; a checked tick
     // that meets one without it says so (BPF_NEED8) and its chunk is run again, an unchecked tick cannot be
     P.have8 = (b->static_need8 || !check) ? 1 : 0;
@@ -400,6 +402,34 @@ template <class T> int ensure_exact_buffers(dmxBatch *b, const ExactCaps &cap, E
     return DMX_OK;
 }
 
+// the device pipeline's output as the island kernels' input; C: the tick's counts (null: not known yet -- a speculative launch,
+// whose workgroups read them from the device's record)
+template <class T> IslandSet<T> island_set_of(dmxBatch *b, const ExactBuffers<T> &B, const ExactCounts *C)
+{
+    IslandSet<T> I;
+    memset(&I, 0, sizeof(I));
+    I.body_off = B.body_off; I.bodies = B.bodies; I.con_off = B.con_off; I.row_off = B.row_off;
+    I.cb1 = B.cb1; I.cb2 = B.cb2; I.csrc = B.csrc; I.crow = B.crow;
+    I.gpos = B.gpos; I.gnormal = B.gnormal; I.gdepth = B.gdepth;
+    I.big = B.big; I.big_list = B.big_list; I.lev_count = B.lev_count;
+    I.lev_off = B.lev_off; I.lev_rows = B.lev_rows; I.row_level = B.row_level;
+    if (C != nullptr) {
+        I.n_islands = (int)C->ni; I.n_big = (int)C->nbig;
+        I.big_max_bodies = (int)C->big_max_bodies; I.big_max_width = (int)C->big_max_width;
+    }
+    I.rows = (T *)b->jd_rows.p; I.rowjb = (int *)b->jd_rowjb.p; I.bscr = (T *)b->jd_bscr.p; I.local = (int *)b->jd_local.p;
+    I.singles = 1;
+    // (cmode / cmu / cbounce ... stay null: every contact carries the batch's surface, NearCallback's policy, main.c:684-687)
+    return I;
+}
+
+// DMX_SPECULATE=0: the small-scene exact tick waits for its record before it launches the solve (A/B runs)
+bool speculate_small_exact()
+{
+    static const bool on = [] { const char *e = getenv("DMX_SPECULATE"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 template <class T> int careful_tick(dmxBatch *b, double h)
 {
     int rc;
@@ -412,7 +442,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     ExactCounts &C = *(ExactCounts *)b->ex_counts_host;
     if (b->ex_cap_pairs == 0) { b->ex_cap_pairs = 1024; b->ex_cap_rows = 16384; }
     if (!b->bp_flags_host && (rc = alloc_host_record((void **)&b->bp_flags_host, 64)) != DMX_OK) return rc;
-    bool small = false;
+    bool small = false, speculated = false;
     for (int attempt = 0;; attempt++) {
         if (attempt > 40) return DMX_ECAPACITY;
         ExactCaps cap;
@@ -422,6 +452,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
         cap.nstatic = (uint32_t)b->n_static;
         if ((rc = ensure_exact_buffers<T>(b, cap, B)) != DMX_OK) return rc;
         small = use_small_exact(b, cap, true);
+        speculated = false;
         if (small) {
             // everything between here and the island solve in three launches; the last one leaves the counts and the
             // flags in host memory: the tick's one wait is all the host does
@@ -432,7 +463,25 @@ template <class T> int careful_tick(dmxBatch *b, double h)
             HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, G, B, cap, nullptr, nullptr, 0u, b->stream));
             HIP_TRY(launch_exact_small_group<T>((const T *)b->slab, b->gtype, G, P, B, cap, rpc, big_island_rows_general(), b->diag_isl,
                                                 hc, hf, seq, b->stream));
-            if ((rc = await_host_record(b, seq)) != DMX_OK) return rc;
+            if (speculate_small_exact() && !b->ext_pending && (size_t)3 * cap.slots() * 29 * sizeof(T) <= ((size_t)64 << 20)) {
+                // The rest of the tick goes out BEHIND those, before the host has seen a count: the island solve over the capacity
+                // (workgroups ask the device's record whether they exist) and the fused step for everyone else, both gated on
+                // the record's spec_ok -- the last kernel above clears it when anything overflowed, an island spans two ranks,
+                // or an island is not solve_island_wg<64>'s kind; then neither does anything and the host, which still reads
+                // the record below, launches what the counts call for as it always did.  In the common case the device goes
+                // from the bookkeeping straight into the solve (10 us of host round trip per tick gone), and the host is back
+                // enqueueing the next tick while it runs.  Scratch sized for the capacity, not the counts.
+                const size_t max_rows = (size_t)3 * cap.slots();
+                if ((rc = dmx_ensure_dev(b->jd_rows, (max_rows + 1) * 29 * sizeof(T))) != DMX_OK) return rc;
+                if ((rc = dmx_ensure_dev(b->jd_rowjb, (max_rows + 1) * 2 * sizeof(int))) != DMX_OK) return rc;
+                if ((rc = dmx_ensure_dev(b->jd_bscr, ((size_t)cap.inv + 1) * 28 * sizeof(T))) != DMX_OK) return rc;
+                if ((rc = dmx_ensure_dev(b->jd_local, (size_t)b->stride * sizeof(int))) != DMX_OK) return rc;
+                const IslandSet<T> I = island_set_of<T>(b, B, nullptr);
+                HIP_TRY(launch_islands_speculative<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, B.counts, cap.inv, b->stream));
+                if ((rc = fused_tick<T>(b, h, false, (const uint8_t *)b->bp_inpair.p, &B.counts->spec_ok)) != DMX_OK) return rc;
+                speculated = true;
+            }
+            { DmxPhase pw(b, 1); if ((rc = await_host_record(b, seq)) != DMX_OK) return rc; }
             if (exs_timing_enabled()) {
                 uint64_t st[64];
                 HIP_TRY(hipMemcpy(st, B.stamps, sizeof(st), hipMemcpyDeviceToHost));
@@ -493,25 +542,28 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     }
     b->last_pairs = C.npairs;
     b->ex_prev_inv = C.ninv;
-    if (C.unsupported) {
-        if (b->stat_unsupported == 0)
-            fprintf(stderr, "libode_mi355: %u pair(s) of convex bodies with spheres / other convex bodies whose bounding spheres overlap this "
-                            "tick: no collider exists for them, they pass through one another (counted in dmxBatchCollisionStatsEx)\n", C.unsupported);
-        b->stat_unsupported += C.unsupported;
-    }
     b->stat_careful_ticks++;
     if (C.cross) {
         fprintf(stderr, "libode_mi355: bodies %u and %u touch across two ranks' slabs; an island spanning ranks has to be "
                         "migrated to one owner first\n", C.cross_a, C.cross_b);
         return DMX_ECROSS;
     }
+    // the speculative launches went ahead (the record says so): the tick is on the device in full, nothing is left to launch
+    const bool done = speculated && C.spec_ok != 0u;
+    if (done) b->stat_spec_ticks++;
     if (C.ninv == 0) {                      // nobody in a body pair, nobody at a static box
         b->last_mixed = false;
-        return fused_tick<T>(b, h, false, nullptr);
+        return done ? DMX_OK : fused_tick<T>(b, h, false, nullptr);
     }
     if (C.npairs > 0) b->stat_pair_ticks++;
     // a quiet scene that has turned busy: leave head room so the next ticks do not run the pipeline twice
     if (2ull * C.npairs > b->ex_cap_pairs) b->ex_cap_pairs = (uint32_t)std::min<uint64_t>(2ull * b->ex_cap_pairs, 1ull << 28);
+    if (done) {
+        b->last_islands = false;
+        b->last_mixed = true;
+        b->stepped_with_plane = true;
+        return DMX_OK;
+    }
 
     // ---- islands of the bodies in pairs; everyone else through the fused kernel ------------------------------------
     ph.reset(new DmxPhase(b, 7));
@@ -520,18 +572,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     if ((rc = dmx_ensure_dev(b->jd_rowjb, (nrows + 1) * 2 * sizeof(int))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->jd_bscr, ((size_t)C.ninv + 1) * 28 * sizeof(T))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->jd_local, (size_t)b->stride * sizeof(int))) != DMX_OK) return rc;
-    IslandSet<T> I;
-    memset(&I, 0, sizeof(I));
-    I.n_islands = (int)C.ni;
-    I.body_off = B.body_off; I.bodies = B.bodies; I.con_off = B.con_off; I.row_off = B.row_off;
-    I.cb1 = B.cb1; I.cb2 = B.cb2; I.csrc = B.csrc; I.crow = B.crow;
-    I.gpos = B.gpos; I.gnormal = B.gnormal; I.gdepth = B.gdepth;
-    I.big = B.big; I.n_big = (int)C.nbig; I.big_list = B.big_list; I.lev_count = B.lev_count;
-    I.lev_off = B.lev_off; I.lev_rows = B.lev_rows; I.row_level = B.row_level;
-    I.big_max_bodies = (int)C.big_max_bodies; I.big_max_width = (int)C.big_max_width;
-    I.rows = (T *)b->jd_rows.p; I.rowjb = (int *)b->jd_rowjb.p; I.bscr = (T *)b->jd_bscr.p; I.local = (int *)b->jd_local.p;
-    I.singles = 1;
-    // (cmode / cmu / cbounce ... stay null: every contact carries the batch's surface, NearCallback's policy, main.c:684-687)
+    const IslandSet<T> I = island_set_of<T>(b, B, &C);
     // (diag_isl was zeroed with the grid / by the small-scene kernel)
     HIP_TRY(launch_islands<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, b->stream));
     ph.reset(new DmxPhase(b, 8));
@@ -589,6 +630,7 @@ template <class T> int step_sync_t(dmxBatch *b, double h, int nsteps)
         // left its zone the chunk is rolled back; the first retry only refreshes the zones (a body that has
         // drifted since the last build usually fits again), the second replays the chunk exactly.
         for (int attempt = 0; !careful; attempt++) {
+            DmxPhase pf(b, 3);
             if ((rc = snapshot_begin<T>(b)) != DMX_OK) return rc;
             HIP_TRY(hipMemsetAsync((uint32_t *)b->bp_flags.p + BPF_VIOLATION, 0, BPF_CHUNK_FLAGS * sizeof(uint32_t), b->stream));
             // Without a ground plane and with gravity along y nothing acts horizontally: every body's (x,z) moves on a

@@ -122,6 +122,9 @@ template <class T> struct StepParams {
     // for bodies with 5..8 contacts follows the one for 0..4 (otherwise the latter reports BPF_NEED8 when it meets one)
     T *sbuf; int *scount; int have8;
     int has_simple;     // the batch has box / sphere bodies (0: np_static, which serves those, need not be launched)
+    // a launch enqueued before the host knows whether it should run (careful_tick's speculative tick): the fused kernels
+    // return at once unless *gate != 0 (ExactCounts::spec_ok on the device).  Null: no question asked.
+    const uint32_t *gate = nullptr;
 };
 // contact buffer of the static fused path: SC_MAXC contacts of SC_REALS reals per body, field f of contact k of body i at
 // sbuf[sc_ix(k, f, i)] -- tiles of 64 bodies, so a wavefront's access to one field of one contact is one contiguous run

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include "dmx_internal.hpp"
+#include "dmx_exact.hpp"
 #include "dmx_math.hpp"
 
 namespace dmx {
@@ -896,8 +897,11 @@ constexpr int FC_LDS_BYTES = 48 * 1024;     // islands of up to 2048 (f32) / 102
 template <class T, int WG>
 __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const uint8_t *__restrict__ bflags,
                                                       int64_t stride, IslandSet<T> I, StepParams<T> P,
-                                                      StepDiag *__restrict__ diag, int lds_bodies)
+                                                      StepDiag *__restrict__ diag, int lds_bodies, const ExactCounts *__restrict__ dc)
 {
+    // dc: a launch enqueued before the host has seen the tick's counts (careful_tick, small scenes) -- the grid covers the
+    // capacity, the record on the device says how many islands there are and whether this launch may act at all
+    if (dc != nullptr && (dc->spec_ok == 0u || blockIdx.x >= dc->nbig)) return;
     const int isl = I.big_list[blockIdx.x];
     const int tid = threadIdx.x;
     const T h = P.h, hinv = T(1) / h;
@@ -955,7 +959,7 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
             for (int j = 0; j < 6; j++) fc_lds[6 * k + j] = bs[(size_t)k * BW_COUNT + BW_FC + j];
         const int *row_level = I.row_level + lev_off[0];
         // (rows per lane as a template parameter: an island of up to 64 rows pays for one row's tests per level, not four)
-        const bool eager = gridDim.x < 2048u;           // few islands: every one waits on its own chain of rows
+        const bool eager = (dc != nullptr ? dc->nbig : gridDim.x) < 2048u;           // few islands: every one waits on its own chain of rows
         auto build = [&](int v, ContactRegs<T> &c) { contact_build(S, stride, I, P, bs, c0 + v, hinv, c); };
         if (by_contact && nc <= 64) resid = wave_island_contact_sweeps<T, 1>(rows, row_level, I.crow + c0, nc, nlev, P.iters, tid, fc_lds, eager, false, build);
         else if (by_contact) resid = wave_island_contact_sweeps<T, sizeof(T) == 4 ? 2 : 1>(rows, row_level, I.crow + c0, nc, nlev, P.iters, tid, fc_lds, eager, false, build);
@@ -1264,12 +1268,31 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
         const int lds_bodies = std::min<int>(std::max(I.big_max_bodies, 1), lds_cap);
         const size_t lds = (size_t)lds_bodies * 6 * sizeof(T);
         if (I.big_max_width <= 64)      // no level has more than 64 rows: one wavefront per island, barriers cost nothing
-            hipLaunchKernelGGL((solve_island_wg<T, 64>), dim3((unsigned)I.n_big), dim3(64), lds, st, S, bflags, stride, I, P, diag, lds_bodies);
+            hipLaunchKernelGGL((solve_island_wg<T, 64>), dim3((unsigned)I.n_big), dim3(64), lds, st, S, bflags, stride, I, P, diag, lds_bodies, (const ExactCounts *)nullptr);
         else
-            hipLaunchKernelGGL((solve_island_wg<T, 256>), dim3((unsigned)I.n_big), dim3(256), lds, st, S, bflags, stride, I, P, diag, lds_bodies);
+            hipLaunchKernelGGL((solve_island_wg<T, 256>), dim3((unsigned)I.n_big), dim3(256), lds, st, S, bflags, stride, I, P, diag, lds_bodies, (const ExactCounts *)nullptr);
     }
     return hipGetLastError();
 }
+
+// The island solve of a small-scene exact tick, enqueued BEHIND the bookkeeping kernels and before the host has seen their
+// counts: one-wavefront workgroups over `max_big` islands (the capacity), every one asking the device's count record whether it
+// exists and whether the launch may act (ExactCounts::spec_ok: all islands are solve_island_wg<64>'s kind, nothing overflowed).
+// LDS for the largest island the kernel takes at all; I's counts are not read.
+template <class T>
+hipError_t launch_islands_speculative(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
+                                      StepDiag *diag, const ExactCounts *counts_dev, unsigned max_big, hipStream_t st)
+{
+    if (max_big == 0) return hipSuccess;
+    const int lds_bodies = FC_LDS_BYTES / (int)(6 * sizeof(T));
+    const size_t lds = (size_t)lds_bodies * 6 * sizeof(T);
+    hipLaunchKernelGGL((solve_island_wg<T, 64>), dim3(max_big), dim3(64), lds, st, S, bflags, stride, I, P, diag, lds_bodies, counts_dev);
+    return hipGetLastError();
+}
+template hipError_t launch_islands_speculative<float>(float *, const uint8_t *, int64_t, const IslandSet<float> &, const StepParams<float> &,
+                                                      StepDiag *, const ExactCounts *, unsigned, hipStream_t);
+template hipError_t launch_islands_speculative<double>(double *, const uint8_t *, int64_t, const IslandSet<double> &, const StepParams<double> &,
+                                                       StepDiag *, const ExactCounts *, unsigned, hipStream_t);
 
 template hipError_t launch_islands_exact<float>(float *, const uint8_t *, int64_t, const IslandSet<float> &, const StepParams<float> &,
                                                 StepDiag *, float *, const long long *, int *, int, hipStream_t);

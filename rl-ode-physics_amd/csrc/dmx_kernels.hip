@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256, MINW) void integrate_free(T *S, T *So, int64_t
 {
     // So = where the new state goes: S itself (in place) or the batch's other slab (the first launch of a
     // collision-proof chunk, which thereby leaves the chunk's start state behind as the rollback snapshot)
+    if (P.gate != nullptr && *P.gate == 0u) return;
     const int nticks = MULTI ? P.ticks : 1;         // MULTI = false: the one-tick kernel, no loop
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nvec;
          t += (int64_t)gridDim.x * blockDim.x) {
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(256, MINW) void step_plane(T *S, T *So, const uint8
     double my_resid = 0.0;
     // a chunk in which a body has left its zone is rolled back whole: once the flag is up, its remaining ticks need no work
     if (P.bp_check && P.bp_flags[BPF_VIOLATION] != 0u) return;
+    if (P.gate != nullptr && *P.gate == 0u) return;
     if (i < n && !(P.skip != nullptr && P.skip[i])) {
         V3<T> x = { S[slab_ix(C_POS + 0, i)], S[slab_ix(C_POS + 1, i)], S[slab_ix(C_POS + 2, i)] };
         if (P.bp_check) {
@@ -630,6 +632,7 @@ __global__ __launch_bounds__(256, MINW) void step_contacts(T *S, T *So, int64_t 
     int my_contacts = 0;
     double my_resid = 0.0;
     if (P.bp_check && P.bp_flags[BPF_VIOLATION] != 0u) return;      // the chunk will be rolled back whole
+    if (P.gate != nullptr && *P.gate == 0u) return;
     const int cnt = (i < n && !(P.skip != nullptr && P.skip[i])) ? P.scount[i] : -1;
     // (a body with more contacts than the buffer holds is flagged, and stepped with the first SC_MAXC of them: what a caller
     //  who has switched the collision proof off -- nobody reads the flag then -- gets, and says so in include/dmx_batch.h)

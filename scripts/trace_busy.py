@@ -16,3 +16,13 @@ for s, e, n in ev:
     k = n.replace("(anonymous namespace)::", "").split("(")[0][-60:]; by[k][0] += 1; by[k][1] += e - s
 for k, (c, t) in sorted(by.items(), key=lambda kv: -kv[1][1])[:25]:
     print(f"  {k:60s} {c:7d} calls {t/1e6:9.3f} ms  avg {t/c/1e3:8.2f} us" + (f"  {c/ticks:5.2f}/tick" if ticks else ""))
+# idle time on the device by transition (which kernel the device waited for, after which): where the host is in the loop
+def short(n):
+    return n.replace("(anonymous namespace)::", "").replace("void ", "").replace("dmx::", "").split("<")[0].split("(")[0][-28:]
+tr = collections.defaultdict(list)
+for i in range(1, len(ev)):
+    tr[(short(ev[i - 1][2]), short(ev[i][2]))].append(max(0, ev[i][0] - ev[i - 1][1]))
+print("idle before a kernel, by (previous -> next), largest totals first:")
+for k, v in sorted(tr.items(), key=lambda kv: -sum(kv[1]))[:14]:
+    v2 = sorted(v)
+    print(f"  {k[0]:>28s} -> {k[1]:28s} n={len(v):5d}  median {v2[len(v2) // 2] / 1e3:7.2f} us  total {sum(v) / 1e6:7.2f} ms" + (f"  {sum(v) / ticks / 1e3:6.2f} us/tick" if ticks else ""))
