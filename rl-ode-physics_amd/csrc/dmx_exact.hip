@@ -103,43 +103,57 @@ template <class T> struct GridWalk {
     const T *S; const uint8_t *gtype; const GridParams<T> &G;
     template <class F> __device__ __forceinline__ void operator()(int64_t i, F f) const { for_each_partner<T>(S, gtype, i, G, f); }
 };
-// ... and the same walk over a grid that lives in LDS (ex_small_front: the scene of a one-workgroup launch fits there).  Cells as
-// runs of one index array (start[h] .. start[h + 1]), every body's record and class beside it: a candidate costs LDS round trips,
-// not L2 ones -- the walk is a chain of dependent reads, and that chain was the kernel's longest stage.  The order in which a
-// body's partners come up differs from the bucket walk's; both callers are indifferent to it (a count; a run that is sorted).
+// ... and the same walk over a grid that lives in LDS (ex_small_front: the scene of a one-workgroup launch fits there).  Cells
+// are runs of ONE array of records sorted by cell (start[h] .. start[h + 1]); a record carries the body's AABB, its slot and class
+// and the low halves of its column -- everything a candidate is tested on -- so the walk's reads do not depend on one another:
+// the nine cells' bounds are fetched together, then the candidates two at a time.  (The bucket walk in device memory is a chain of
+// dependent L2 round trips -- count, items, record -- and was the kernel's longest stage.)  The order in which a body's partners
+// come up differs from the bucket walk's; both callers are indifferent to it (a count; a run that is sorted).
+template <class T> struct alignas(16) CellRec { T lo[3], hi[3]; uint32_t id, key; };      // id = slot | class << 16; key = (ix & 0xffff) | iz << 16
 template <class T> struct LdsGridWalk {
-    const GridRec<T> *rec; const uint32_t *start; const uint16_t *sorted; const uint8_t *gt;
+    const GridRec<T> *rec_g;         // the body's own record comes from device memory (one read, before the walk)
+    const CellRec<T> *cr; const uint32_t *start; const uint8_t *gtype;
     uint32_t mask; int xbits; uint32_t class_pairs;
     template <class F> __device__ __forceinline__ void operator()(int64_t i, F f) const
     {
-        const GridRec<T> me = rec[i];
-        const int gti = gt[i];
-#pragma unroll 1
+        const GridRec<T> me = rec_g[i];
+        const int gti = gtype[i];
+        uint32_t a[9], e[9];
+#pragma unroll
         for (int c = 0; c < 9; c++) {
-            const int cx = me.ix + (c % 3) - 1, cz = me.iz + (c / 3) - 1;
-            const uint32_t h = cell_hash(cx, cz, mask, xbits);
-            const uint32_t a = start[h], e = start[h + 1];
-            for (uint32_t k = a; k < e; k++) {
-                const int64_t j = sorted[k];
-                if (j == i) continue;
-                const GridRec<T> o = rec[j];
-                if (o.ix != cx || o.iz != cz) continue;          // buckets can mix columns: (i, j) is met in one cell only
-                if (!classes_collide(gti, gt[j], class_pairs)) continue;
-                if (o.lo[0] > me.hi[0] || me.lo[0] > o.hi[0] || o.lo[1] > me.hi[1] || me.lo[1] > o.hi[1] ||
-                    o.lo[2] > me.hi[2] || me.lo[2] > o.hi[2])
-                    continue;
-                f(j);
+            const uint32_t h = cell_hash(me.ix + (c % 3) - 1, me.iz + (c / 3) - 1, mask, xbits);
+            a[c] = start[h]; e[c] = start[h + 1];
+        }
+        auto test = [&](const CellRec<T> &o, uint32_t key) {
+            const int64_t j = (int64_t)(o.id & 0xffffu);
+            if (j == i || o.key != key) return;                  // buckets can mix columns: (i, j) is met in one cell only
+            if (!classes_collide(gti, (int)(o.id >> 16), class_pairs)) return;
+            if (o.lo[0] > me.hi[0] || me.lo[0] > o.hi[0] || o.lo[1] > me.hi[1] || me.lo[1] > o.hi[1] ||
+                o.lo[2] > me.hi[2] || me.lo[2] > o.hi[2])
+                return;
+            f(j);
+        };
+#pragma unroll
+        for (int c = 0; c < 9; c++) {
+            const uint32_t key = ((uint32_t)(me.ix + (c % 3) - 1) & 0xffffu) | ((uint32_t)(me.iz + (c / 3) - 1) << 16);
+            for (uint32_t k = a[c]; k < e[c]; k += 2) {
+                const bool two = k + 1 < e[c];
+                const CellRec<T> o0 = cr[k], o1 = cr[two ? k + 1 : k];
+                test(o0, key);
+                if (two) test(o1, key);
             }
         }
     }
 };
+constexpr int EXS_PARTNERS = 8;        // partners above it that a body's count pass leaves in LDS for the write pass (more: that body walks again)
 
 // ---- 1. per active body: partners above it (the pairs it owns) and whether it is in any pair at all ---------------
 // pc[i] = (owned pairs << 32) | in-any-pair; inpair[i] = in-any-pair (the fused kernel's skip mask).  A partner in a ghost
 // slot means an island spanning two ranks.
 template <class T, class W>
 __device__ __forceinline__ void st_pair_count(const W &walk, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G, uint64_t *pc,
-                                              uint8_t *inpair, ExactCounts *C, int32_t *cross_list, int64_t first, int64_t step)
+                                              uint8_t *inpair, ExactCounts *C, int32_t *cross_list, int64_t first, int64_t step,
+                                              uint16_t *staged = nullptr)
 {
     for (int64_t i = first; i < n_active; i += step) {
         uint32_t owned = 0, any = 0;
@@ -151,7 +165,11 @@ __device__ __forceinline__ void st_pair_count(const W &walk, const uint8_t *gtyp
                     const uint32_t at = atomicAdd(&C->ncross, 1u);
                     if (at < EX_CROSS_CAP) { cross_list[2 * at] = (int32_t)i; cross_list[2 * at + 1] = (int32_t)j; }
                 }
-                else if (j > i) owned++;
+                else if (j > i) {
+                    // (staged: the first EXS_PARTNERS of them stay in LDS, so the write pass need not walk again)
+                    if (staged != nullptr && owned < (uint32_t)EXS_PARTNERS) staged[(size_t)i * EXS_PARTNERS + owned] = (uint16_t)j;
+                    owned++;
+                }
             });
             // static box geoms are "big geoms against everyone".  A body whose AABB overlaps static boxes but no other body's
             // is a one-body island: the fused path (np_static -> step_contacts) steps it -- unless its contacts might not fit
@@ -183,7 +201,7 @@ __global__ __launch_bounds__(256) void ex_pair_count(const T *__restrict__ S, co
 template <class T, class W>
 __device__ __forceinline__ void st_pair_write(const W &walk, int64_t n_active, const GridParams<T> &G, const uint64_t *pc,
                                               const uint64_t *inc, int32_t *pairs, int32_t *inv, int32_t *parent, const ExactCaps &cap,
-                                              ExactCounts *C, int64_t first, int64_t step)
+                                              ExactCounts *C, int64_t first, int64_t step, const uint16_t *staged = nullptr)
 {
     const uint64_t tot = inc[n_active - 1];
     if (first == 0) {
@@ -203,9 +221,13 @@ __device__ __forceinline__ void st_pair_write(const W &walk, int64_t n_active, c
         if (owned == 0) continue;
         int32_t *out = pairs + 2 * (size_t)hi32(exc);
         uint32_t w = 0;
-        walk(i, [&](int64_t j) {
-            if (j > i && j < n_active && w < owned) { out[2 * w] = (int32_t)i; out[2 * w + 1] = (int32_t)j; w++; }
-        });
+        if (staged != nullptr && owned <= (uint32_t)EXS_PARTNERS) {
+            for (; w < owned; w++) { out[2 * w] = (int32_t)i; out[2 * w + 1] = (int32_t)staged[(size_t)i * EXS_PARTNERS + w]; }
+        } else {
+            walk(i, [&](int64_t j) {
+                if (j > i && j < n_active && w < owned) { out[2 * w] = (int32_t)i; out[2 * w + 1] = (int32_t)j; w++; }
+            });
+        }
         // this thread's own run of partners, ascending (runs are short: insertion sort in place)
         for (uint32_t a = 1; a < w; a++) {
             const int32_t v = out[2 * a + 1];
@@ -703,8 +725,8 @@ __device__ __forceinline__ void publish_counts(const ExactCounts *C, const uint3
 #define EXS_STAMP() do { if (threadIdx.x == 0) stamps[sk] = wall_clock64(); sk++; } while (0)
 
 // grid fill (fill_grid's memsets + bp_insert) and stages 1-3: pairs, involved bodies, islands' roots.
-// LG: the grid is built in LDS as cell runs (LdsGridWalk) instead of in the batch's bucket table -- every record, class, cell
-// start and the sorted index array fit (exact_small_lds_bytes); the table in device memory is then not touched at all (nothing
+// LG: the grid is built in LDS as cell runs (LdsGridWalk) instead of in the batch's bucket table -- the records sorted by cell, the
+// cells' starts and the staged partners fit (exact_small_lds_bytes); the table in device memory is then not touched at all (nothing
 // after this kernel reads it: the zones' rebuild fills it itself), the records still go to G.rec for the narrowphase.
 template <class T, bool LG>
 __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gtype, int64_t n, int64_t n_active, GridParams<T> G,
@@ -717,10 +739,9 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gt
     ExactCounts *C = B.counts;
     uint64_t *stamps = B.stamps; int sk = 0;
     const uint32_t cells = G.mask + 1u;
-    GridRec<T> *rec_l = reinterpret_cast<GridRec<T> *>(exs_lds);                          // [n]
-    uint32_t *start = reinterpret_cast<uint32_t *>(rec_l + (LG ? n : 0));                  // [cells + 1]
-    uint16_t *sorted = reinterpret_cast<uint16_t *>(start + (LG ? cells + 1u : 0u));       // [n]
-    uint8_t *gt_l = reinterpret_cast<uint8_t *>(sorted + (LG ? n : 0));                    // [n]
+    CellRec<T> *cr = reinterpret_cast<CellRec<T> *>(exs_lds);                              // [n] records sorted by cell
+    uint32_t *start = reinterpret_cast<uint32_t *>(cr + (LG ? n : 0));                     // [cells + 1]
+    uint16_t *staged = reinterpret_cast<uint16_t *>(start + (LG ? cells + 1u : 0u));       // [n EXS_PARTNERS] partners above a body
     EXS_STAMP();
     if (LG) { for (uint32_t k = tid; k <= cells; k += EXS_WG) start[k] = 0u; }
     else { for (uint32_t k = tid; k <= G.mask; k += EXS_WG) G.count[k] = 0u; }
@@ -731,14 +752,13 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gt
         // grid_insert's work with the bucket replaced by a count: the cell's run is laid out below
         for (int64_t i = tid; i < n; i += EXS_WG) {
             const uint8_t gt = gtype[i];
-            gt_l[i] = gt;
             if (gt == GEOM_NONE) continue;
             S[slab_ix(C_BPR, i)] = bound_radius<T>(gt, S, i);
             GridRec<T> r;
             body_aabb<T>(S, gtype, i, r.lo, r.hi);
             r.ix = (int)floor((double)(S[slab_ix(C_POS + 0, i)] * G.inv_cell));
             r.iz = (int)floor((double)(S[slab_ix(C_POS + 2, i)] * G.inv_cell));
-            G.rec[i] = r; rec_l[i] = r;
+            G.rec[i] = r;
             atomicAdd(&start[cell_hash(r.ix, r.iz, G.mask, G.xbits)], 1u);
         }
     } else {
@@ -758,7 +778,6 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gt
             if (l < 3) {
                 const T lv = l == 0 ? lo[0] : (l == 1 ? lo[1] : lo[2]), hv = l == 0 ? hi[0] : (l == 1 ? hi[1] : hi[2]);
                 G.rec[i].lo[l] = lv; G.rec[i].hi[l] = hv;
-                if (LG) { rec_l[i].lo[l] = lv; rec_l[i].hi[l] = hv; }
             }
         }
     }
@@ -770,20 +789,27 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gt
         if (tid == 0) start[cells] = start[cells - 1];
         __syncthreads();
         for (int64_t i = tid; i < n; i += EXS_WG) {
-            if (gt_l[i] == GEOM_NONE) continue;
-            const uint32_t at = atomicSub(&start[cell_hash(rec_l[i].ix, rec_l[i].iz, G.mask, G.xbits)], 1u) - 1u;
-            sorted[at] = (uint16_t)i;
+            const uint8_t gt = gtype[i];
+            if (gt == GEOM_NONE) continue;
+            const GridRec<T> r = G.rec[i];       // (this thread's own write, or -- a hull's exact box -- another wave's before the barrier)
+            const uint32_t at = atomicSub(&start[cell_hash(r.ix, r.iz, G.mask, G.xbits)], 1u) - 1u;
+            CellRec<T> o;
+#pragma unroll
+            for (int a = 0; a < 3; a++) { o.lo[a] = r.lo[a]; o.hi[a] = r.hi[a]; }
+            o.id = (uint32_t)i | ((uint32_t)gt << 16);
+            o.key = ((uint32_t)r.ix & 0xffffu) | ((uint32_t)r.iz << 16);
+            cr[at] = o;
         }
         __syncthreads();
     }
     EXS_STAMP();
-    const LdsGridWalk<T> lw{ rec_l, start, sorted, gt_l, G.mask, G.xbits, G.class_pairs };
+    const LdsGridWalk<T> lw{ G.rec, cr, start, gtype, G.mask, G.xbits, G.class_pairs };
     const GridWalk<T> gw{ S, gtype, G };
-    if (LG) st_pair_count<T>(lw, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG);
+    if (LG) st_pair_count<T>(lw, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG, staged);
     else    st_pair_count<T>(gw, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
     block_scan_inclusive<uint64_t>(B.pc, B.inc, (uint32_t)n_active, wt); EXS_STAMP();
-    if (LG) st_pair_write<T>(lw, n_active, G, B.pc, B.inc, B.pairs, B.inv, B.parent, cap, C, tid, EXS_WG);
+    if (LG) st_pair_write<T>(lw, n_active, G, B.pc, B.inc, B.pairs, B.inv, B.parent, cap, C, tid, EXS_WG, staged);
     else    st_pair_write<T>(gw, n_active, G, B.pc, B.inc, B.pairs, B.inv, B.parent, cap, C, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
     st_unite(B.pairs, B.pc, B.inc, B.parent, C, tid, EXS_WG);
@@ -798,8 +824,13 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gt
 // ITEMS entries per thread (2, 4 or 8: up to 8192 entries).
 template <class T, int ITEMS>
 __global__ __launch_bounds__(EXS_WG) void ex_small_back(ExactBuffers<T> B, ExactCaps cap, int rpc, int big_rows, const uint32_t *flags,
-                                                        StepDiag *diag, ExactCounts *host_counts, uint32_t *host_flags, uint32_t seq)
+                                                        StepDiag *diag, ExactCounts *host_counts, uint32_t *host_flags, uint32_t seq,
+                                                        int lds_slots)
 {
+    // lds_slots > 0: the level schedules' per-slot `last` array lives in LDS for this launch (that many slots, all idle) -- the
+    // stage is one lane per island walking a chain of read-modify-writes of it, a round trip to L2 each otherwise
+    extern __shared__ int32_t last_l[];
+    for (int k = threadIdx.x; k < lds_slots; k += EXS_WG) last_l[k] = -1;        // (barriers follow before its first use)
     using sort_t = rocprim::block_radix_sort<uint32_t, EXS_WG, ITEMS>;
     __shared__ typename sort_t::storage_type sort_storage;
     __shared__ uint64_t wt[EXS_WG / 64];
@@ -849,13 +880,13 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_back(ExactBuffers<T> B, Exact
     __syncthreads(); EXS_STAMP();
     block_scan_inclusive<uint64_t>(B.bg, B.binc, cap.inv, wt); EXS_STAMP();
     st_levels(B.con_off, B.body_off, B.cb1, B.cb2, B.bg, B.binc, cap, rpc, B.big, B.big_list, B.lev_count, B.lev_off, B.lev_rows,
-              B.row_level, B.last, C, tid, EXS_WG);
+              B.row_level, lds_slots > 0 ? last_l : B.last, C, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
     if (tid == 0) {
         diag->contacts = 0ull; diag->residual = 0.0;       // the island kernels add to it next
         // careful_tick's speculative launches (solve_island_wg<64> over the capacity, the fused step behind it) read this
         C->spec_ok = (C->overflow == 0u && C->bp_overflow == 0u && flags[BPF_OVERFLOW] == 0u && C->cross == 0u && C->nbig == C->ni &&
-                      C->big_max_width <= 64u) ? 1u : 0u;
+                      C->big_max_width <= 64u && C->big_max_bodies <= EX_SPEC_ISLAND_BODIES) ? 1u : 0u;
     }
     __syncthreads();
     publish_counts(C, flags, host_counts, host_flags, seq);
@@ -943,14 +974,14 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
     return hipGetLastError();
 }
 
-// LDS the one-workgroup front kernel needs to keep the whole grid there (LdsGridWalk): records, cell starts, the sorted index
-// array (16-bit), classes.  0: does not fit (or DMX_SMALL_LDS_GRID=0) -- the kernel walks the bucket table in device memory.
+// LDS the one-workgroup front kernel needs to keep the whole grid there (LdsGridWalk): records sorted by cell, cell starts,
+// staged partners.  0: does not fit (or DMX_SMALL_LDS_GRID=0) -- the kernel walks the bucket table in device memory.
 size_t exact_small_lds_bytes(int64_t n, uint32_t grid_mask, size_t real_bytes)
 {
     static const bool on = [] { const char *e = getenv("DMX_SMALL_LDS_GRID"); return !(e && atoi(e) == 0); }();
     if (!on || n > 65535) return 0;
-    const size_t rec = real_bytes == 4 ? sizeof(GridRec<float>) : sizeof(GridRec<double>);
-    size_t b = (size_t)n * rec + ((size_t)grid_mask + 2) * 4 + (size_t)n * 2 + (size_t)n;
+    const size_t rec = real_bytes == 4 ? sizeof(CellRec<float>) : sizeof(CellRec<double>);
+    size_t b = (size_t)n * rec + ((size_t)grid_mask + 2) * 4 + (size_t)n * EXS_PARTNERS * 2;
     b = (b + 15) & ~(size_t)15;
     return b <= 150 * 1024 ? b : 0;        // of the CU's 160 KiB; the kernel's static LDS is a few hundred bytes
 }
@@ -984,7 +1015,7 @@ hipError_t launch_exact_small_front(T *S, const uint8_t *gtype, int64_t n, int64
 {
     const size_t lds = exact_small_lds_bytes(n, G.mask, sizeof(T));
     if (lds != 0) {
-        if (lds > 48 * 1024) {       // (the default limit on dynamic LDS; a table write, and scenes this size are the rarer ones)
+        if (lds > 64 * 1024) {       // (the default limit on dynamic LDS; a table write, and scenes this size are the rarer ones)
             const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&ex_small_front<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (ea != hipSuccess) return ea;
         }
@@ -998,9 +1029,12 @@ hipError_t launch_exact_small_front(T *S, const uint8_t *gtype, int64_t n, int64
 template <class T>
 hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const GridParams<T> &G, const StepParams<T> &P, const ExactBuffers<T> &B,
                                     const ExactCaps &cap, int rpc, int big_rows, StepDiag *diag, ExactCounts *host_counts,
-                                    uint32_t *host_flags, uint32_t seq, hipStream_t st)
+                                    uint32_t *host_flags, uint32_t seq, int64_t n_slots, hipStream_t st)
 {
     const size_t ne = (size_t)cap.entries();
+    // (beside the block sort's storage within the default 64 KiB: up to 4096 slots with 2 or 4 entries per thread)
+    const int ls = (n_slots > 0 && n_slots <= 4096 && ne <= 4 * (size_t)EXS_WG) ? (int)n_slots : 0;
+    const size_t lds = (size_t)ls * sizeof(int32_t);
     hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.rec, P, cap,
                        B.gpos, B.gnormal, B.gdepth, B.cc, B.counts, SortKeyArgs{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr });
     if (P.hull_n > 0)
@@ -1008,11 +1042,11 @@ hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const Grid
                            B.pairs, G.rec, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
     const uint32_t *flags = G.flags;
     if (ne <= 2 * EXS_WG)
-        hipLaunchKernelGGL((ex_small_back<T, 2>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq);
+        hipLaunchKernelGGL((ex_small_back<T, 2>), dim3(1), dim3(EXS_WG), lds, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq, ls);
     else if (ne <= 4 * EXS_WG)
-        hipLaunchKernelGGL((ex_small_back<T, 4>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq);
+        hipLaunchKernelGGL((ex_small_back<T, 4>), dim3(1), dim3(EXS_WG), lds, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq, ls);
     else
-        hipLaunchKernelGGL((ex_small_back<T, 8>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq);
+        hipLaunchKernelGGL((ex_small_back<T, 8>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq, 0);
     return hipGetLastError();
 }
 
@@ -1021,7 +1055,7 @@ hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const Grid
                                                     const ExactCaps &, ExactCounts *, uint32_t *, uint32_t, hipStream_t);                \
     template hipError_t launch_exact_small_group<T>(const T *, const uint8_t *, const GridParams<T> &, const StepParams<T> &,            \
                                                     const ExactBuffers<T> &, const ExactCaps &, int, int, StepDiag *, ExactCounts *,     \
-                                                    uint32_t *, uint32_t, hipStream_t);
+                                                    uint32_t *, uint32_t, int64_t, hipStream_t);
 DMX_EXS_INST(float)
 DMX_EXS_INST(double)
 

@@ -38,6 +38,9 @@ struct ExactCounts {
 };
 
 constexpr uint32_t EX_CROSS_CAP = 256;
+// the speculative island launch reserves LDS for islands of up to this many bodies (a workgroup's accumulators: 6 reals each);
+// a tick with a larger island clears spec_ok and is launched by the host with the island's true size
+constexpr uint32_t EX_SPEC_ISLAND_BODIES = 512;
 
 template <class T> struct ExactBuffers {
     ExactCounts *counts;
@@ -90,7 +93,7 @@ hipError_t launch_exact_small_front(T *S, const uint8_t *gtype, int64_t n, int64
 template <class T>
 hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const GridParams<T> &G, const StepParams<T> &P, const ExactBuffers<T> &B,
                                     const ExactCaps &cap, int rpc, int big_rows, StepDiag *diag, ExactCounts *host_counts,
-                                    uint32_t *host_flags, uint32_t seq, hipStream_t st);
+                                    uint32_t *host_flags, uint32_t seq, int64_t n_slots, hipStream_t st);
 
 // solve_island_wg<64> over `max_big` islands, enqueued behind launch_exact_small_group before the host has its counts: the
 // workgroups ask the record on the device (counts_dev) whether they exist and whether the launch may act (ExactCounts::spec_ok)

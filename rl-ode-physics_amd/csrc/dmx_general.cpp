@@ -462,7 +462,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
             const uint32_t seq = next_record_seq();
             HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, G, B, cap, nullptr, nullptr, 0u, b->stream));
             HIP_TRY(launch_exact_small_group<T>((const T *)b->slab, b->gtype, G, P, B, cap, rpc, big_island_rows_general(), b->diag_isl,
-                                                hc, hf, seq, b->stream));
+                                                hc, hf, seq, b->n, b->stream));
             if (speculate_small_exact() && !b->ext_pending && (size_t)3 * cap.slots() * 29 * sizeof(T) <= ((size_t)64 << 20)) {
                 // The rest of the tick goes out BEHIND those, before the host has seen a count: the island solve over the capacity
                 // (workgroups ask the device's record whether they exist) and the fused step for everyone else, both gated on
@@ -499,7 +499,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
             HIP_TRY(launch_exact_pairs<T>((const T *)b->slab, b->gtype, b->n_active, G, B, cap, b->stream));
             HIP_TRY(launch_exact_roots<T>(B, cap, b->stream));
             HIP_TRY(launch_exact_small_group<T>((const T *)b->slab, b->gtype, G, P, B, cap, rpc, big_island_rows_general(), b->diag_isl,
-                                                hc, hf, seq, b->stream));
+                                                hc, hf, seq, b->n, b->stream));
             if ((rc = await_host_record(b, seq)) != DMX_OK) return rc;
         } else {
         // (the count record and the island solve's diagnostics are zeroed with the grid: one launch)

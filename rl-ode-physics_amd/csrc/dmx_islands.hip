@@ -1278,13 +1278,13 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
 // The island solve of a small-scene exact tick, enqueued BEHIND the bookkeeping kernels and before the host has seen their
 // counts: one-wavefront workgroups over `max_big` islands (the capacity), every one asking the device's count record whether it
 // exists and whether the launch may act (ExactCounts::spec_ok: all islands are solve_island_wg<64>'s kind, nothing overflowed).
-// LDS for the largest island the kernel takes at all; I's counts are not read.
+// I's counts are not read.
 template <class T>
 hipError_t launch_islands_speculative(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
                                       StepDiag *diag, const ExactCounts *counts_dev, unsigned max_big, hipStream_t st)
 {
     if (max_big == 0) return hipSuccess;
-    const int lds_bodies = FC_LDS_BYTES / (int)(6 * sizeof(T));
+    const int lds_bodies = (int)EX_SPEC_ISLAND_BODIES;        // (<= FC_LDS_BYTES' worth: every island of a tick that passes takes the LDS path, as in launch_islands)
     const size_t lds = (size_t)lds_bodies * 6 * sizeof(T);
     hipLaunchKernelGGL((solve_island_wg<T, 64>), dim3(max_big), dim3(64), lds, st, S, bflags, stride, I, P, diag, lds_bodies, counts_dev);
     return hipGetLastError();
