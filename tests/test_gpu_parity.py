@@ -144,6 +144,8 @@ def test_config1_boxes_on_plane_matches_oracle(dtype):
     _compare(w.state(), ow.state())
     st = w.collision_stats()
     assert st["fast_ticks"] >= 96 and st["pair_ticks"] > 0 and st["careful_ticks"] >= st["pair_ticks"]
+    # the exact ticks of a scene this size enqueue their solve before the host has the counts; nearly all of them stand
+    assert st["careful_ticks"] >= st["speculated_ticks"] > st["careful_ticks"] // 2
     assert w.last_contact_count() == ow.n_contacts() > 0
     assert abs(w.last_residual() - ow.sor_residual()) <= 1e-6 * max(1.0, ow.sor_residual())
 
