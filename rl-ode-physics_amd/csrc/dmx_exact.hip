@@ -599,8 +599,10 @@ __device__ __forceinline__ void st_bigflags(const int *con_off, const int *body_
 __device__ __forceinline__ void st_levels(const int *con_off, const int *body_off, const int *cb1, const int *cb2, const uint64_t *bg,
                                           const uint64_t *binc, const ExactCaps &cap, int rpc, int *big, int *big_list, int *lev_count,
                                           int *lev_off, int *lev_rows, int *row_level, int *last, ExactCounts *C, uint32_t first,
-                                          uint32_t step)
+                                          uint32_t step, int coop_rows = 0)
 {
+    // coop_rows > 0: islands of more rows than that are only entered in the big list here; their schedules are built by a whole
+    // workgroup (levels_coop below) -- one lane walking thousands of contacts through device memory is a millisecond
     const uint32_t ni = C->overflow ? 0u : C->ni;
     for (uint32_t i = first; i < ni; i += step) {
         if (i == 0) {
@@ -616,6 +618,7 @@ __device__ __forceinline__ void st_levels(const int *con_off, const int *body_of
         big_list[k] = (int)i;
         atomicMax(&C->big_max_bodies, (uint32_t)(body_off[i + 1] - body_off[i]));
         if ((uint32_t)(base + m) > cap.rows) continue;          // flagged above; the host grows the capacity
+        if (coop_rows > 0 && m > coop_rows) continue;
         int *lv_out = row_level + base, *off = lev_off + base + k, *rows_out = lev_rows + base;
         // consecutive contacts between the same bodies (a box's four contacts with the plane, a pair's) form one group: its
         // rows take consecutive levels, and `last` is touched once per group, not once per row
@@ -660,10 +663,10 @@ __global__ __launch_bounds__(64) void ex_levels(const int *__restrict__ con_off,
                                                 const uint64_t *__restrict__ bg, const uint64_t *__restrict__ binc, ExactCaps cap, int rpc,
                                                 int *__restrict__ big, int *__restrict__ big_list, int *__restrict__ lev_count,
                                                 int *__restrict__ lev_off, int *__restrict__ lev_rows, int *__restrict__ row_level,
-                                                int *__restrict__ last, ExactCounts *C)
+                                                int *__restrict__ last, ExactCounts *C, int coop_rows)
 {
     st_levels(con_off, body_off, cb1, cb2, bg, binc, cap, rpc, big, big_list, lev_count, lev_off, lev_rows, row_level, last, C,
-              blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+              blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, coop_rows);
 }
 
 // ================================================================================================ small scenes
@@ -718,6 +721,166 @@ __device__ __forceinline__ void publish_counts(const ExactCounts *C, const uint3
     if (t < NW + (uint32_t)BPF_COUNT) __threadfence_system();
     __syncthreads();
     if (t == 0) { ((volatile uint32_t *)host_counts)[NW - 1] = seq; __threadfence_system(); }
+}
+
+// ---- 10b. the level schedule of ONE large island, by a whole workgroup of EXS_WG threads.  Same schedule as st_levels' (a row's
+// level is one more than the latest level of any earlier row on either of its bodies; a group's rows -- consecutive contacts
+// between the same two bodies -- take consecutive levels), built differently: groups found by a scan, the bodies' slots mapped to
+// island-local numbers through `last` (all -1 on entry and on return), the one sequential part -- the walk over the GROUPS, two
+// LDS reads and two writes each -- done by one lane in LDS, then every row's level, the per-level counts, offsets and row lists
+// in parallel.  Rows of one level touch disjoint bodies, so their order inside a level list is free (atomic cursors).
+// lds: at least levels_coop_bytes(nb, groups) bytes; returns false (nothing written) when the island does not fit -- the caller
+// falls back on the one-lane walk.
+constexpr int LEVELS_COOP_ROWS = 768;          // islands above this many rows get the workgroup form
+__host__ __device__ inline size_t levels_coop_bytes(size_t nb, size_t groups) { return 4 * nb + 12 * groups + 16; }
+
+__device__ __forceinline__ bool levels_coop(int isl, int k, const int *con_off, const int *body_off, const int *bodies, const int *cb1,
+                                            const int *cb2, int rpc, const int *big, int *lev_count, int *lev_off, int *lev_rows,
+                                            int *row_level, int *last, ExactCounts *C, unsigned char *lds, size_t lds_bytes, uint32_t *wt)
+{
+    const int tid = threadIdx.x;
+    const int c0 = con_off[isl], nc = con_off[isl + 1] - c0, b0 = body_off[isl], nb = body_off[isl + 1] - b0;
+    const int m = nc * rpc, base = big[isl] - k;
+    int *lv_out = row_level + base, *off = lev_off + base + k, *rows_out = lev_rows + base;
+    uint32_t *gidx = reinterpret_cast<uint32_t *>(rows_out);       // scratch until the lists are filled: contact -> its group + 1
+    for (int d = tid; d < nc; d += EXS_WG)
+        gidx[d] = (d == 0 || cb1[c0 + d] != cb1[c0 + d - 1] || cb2[c0 + d] != cb2[c0 + d - 1]) ? 1u : 0u;
+    __syncthreads();
+    block_scan_inclusive<uint32_t>(gidx, gidx, (uint32_t)nc, wt);
+    const int G = (int)gidx[nc - 1];
+    if (levels_coop_bytes((size_t)nb, (size_t)G) > lds_bytes || nb > 65535) { __syncthreads(); return false; }
+    int32_t *lastL = reinterpret_cast<int32_t *>(lds);             // [nb] latest level per island-local body
+    int32_t *ghead = lastL + nb;                                    // [G + 1] a group's first contact (island-relative)
+    int32_t *glev = ghead + G + 1;                                  // [G] the level below the group's first row
+    uint16_t *gl1 = reinterpret_cast<uint16_t *>(glev + G), *gl2 = gl1 + G;     // [G] its bodies, island-local (0xffff: none)
+    __shared__ int nlev_s;
+    for (int t = tid; t < nb; t += EXS_WG) { last[bodies[b0 + t]] = t; lastL[t] = -1; }
+    if (tid == 0) ghead[G] = nc;
+    __syncthreads();
+    for (int d = tid; d < nc; d += EXS_WG) {
+        const int g = (int)gidx[d] - 1;
+        if (d == 0 || (int)gidx[d - 1] - 1 != g) {
+            ghead[g] = d;
+            gl1[g] = (uint16_t)last[cb1[c0 + d]];
+            gl2[g] = cb2[c0 + d] >= 0 ? (uint16_t)last[cb2[c0 + d]] : (uint16_t)0xffffu;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int nlev = 0;
+        for (int g = 0; g < G; g++) {
+            const int l1 = gl1[g], l2 = gl2[g], rows = (ghead[g + 1] - ghead[g]) * rpc;
+            int lv = lastL[l1];
+            if (l2 != 0xffff && lastL[l2] > lv) lv = lastL[l2];
+            glev[g] = lv;
+            const int nl = lv + rows;
+            lastL[l1] = nl;
+            if (l2 != 0xffff) lastL[l2] = nl;
+            if (nl + 1 > nlev) nlev = nl + 1;
+        }
+        nlev_s = nlev;
+        lev_count[k] = nlev;
+    }
+    for (int t = tid; t < nb; t += EXS_WG) last[bodies[b0 + t]] = -1;      // back to the idle state
+    __syncthreads();
+    const int nlev = nlev_s;
+    for (int d = tid; d < nc; d += EXS_WG) {
+        const int g = (int)gidx[d] - 1, l0 = glev[g] + 1 + (d - ghead[g]) * rpc;
+        for (int q = 0; q < rpc; q++) lv_out[d * rpc + q] = l0 + q;
+    }
+    for (int q = tid; q <= nlev; q += EXS_WG) off[q] = 0;
+    __syncthreads();                                                         // (gidx is dead from here on: rows_out becomes the lists)
+    if (m <= WAVE_ISLAND_ROWS) {
+        if (tid == 0) { off[0] = base; off[nlev] = base + m; }
+        __syncthreads();
+        return true;
+    }
+    for (int r = tid; r < m; r += EXS_WG) atomicAdd(&off[lv_out[r] + 1], 1);
+    __syncthreads();
+    int w = 0;
+    for (int q = 1 + tid; q <= nlev; q += EXS_WG) w = off[q] > w ? off[q] : w;
+    if (w > 0) atomicMax(&C->big_max_width, (uint32_t)w);
+    if (tid == 0) off[0] = base;
+    __syncthreads();
+    block_scan_inclusive<uint32_t>(reinterpret_cast<uint32_t *>(off), reinterpret_cast<uint32_t *>(off), (uint32_t)nlev + 1u, wt);
+    for (int r = tid; r < m; r += EXS_WG) rows_out[atomicAdd(&off[lv_out[r]], 1) - base] = r;       // off[lv]: the fill cursor
+    __syncthreads();
+    for (int hi = nlev; hi > 0; hi -= EXS_WG) {                               // cursors (= the next level's start) back to starts
+        const int q = hi - tid;
+        const int v = q >= 1 ? off[q - 1] : 0;
+        __syncthreads();
+        if (q >= 1) off[q] = v;
+        __syncthreads();
+    }
+    if (tid == 0) off[0] = base;
+    __syncthreads();
+    return true;
+}
+// the one-lane walk of st_levels for one island (the fallback of levels_coop: an island too large for its LDS)
+__device__ __forceinline__ void levels_one_lane(int isl, int k, const int *con_off, const int *cb1, const int *cb2, int rpc, const int *big,
+                                                int *lev_count, int *lev_off, int *lev_rows, int *row_level, int *last, ExactCounts *C)
+{
+    const int base = big[isl] - k, m = (con_off[isl + 1] - con_off[isl]) * rpc;
+    int *lv_out = row_level + base, *off = lev_off + base + k, *rows_out = lev_rows + base;
+    int nlev = 0, r = 0, gb1 = -2, gb2 = -2, glast = -1;
+    for (int d = con_off[isl]; d < con_off[isl + 1]; d++) {
+        const int b1 = cb1[d], b2 = cb2[d];
+        if (b1 != gb1 || b2 != gb2) {
+            if (gb1 >= 0) { last[gb1] = glast; if (gb2 >= 0) last[gb2] = glast; }
+            int lv = last[b1];
+            if (b2 >= 0 && last[b2] > lv) lv = last[b2];
+            glast = lv; gb1 = b1; gb2 = b2;
+        }
+        for (int q = 0; q < rpc; q++, r++) lv_out[r] = ++glast;
+        if (glast + 1 > nlev) nlev = glast + 1;
+    }
+    for (int d = con_off[isl]; d < con_off[isl + 1]; d++) {
+        last[cb1[d]] = -1;
+        if (cb2[d] >= 0) last[cb2[d]] = -1;
+    }
+    lev_count[k] = nlev;
+    if (m <= WAVE_ISLAND_ROWS) { off[0] = base; off[nlev] = base + m; return; }
+    for (int q = 0; q <= nlev; q++) off[q] = 0;
+    for (int q = 0; q < m; q++) off[lv_out[q] + 1]++;
+    int w = 0;
+    for (int q = 1; q <= nlev; q++) w = off[q] > w ? off[q] : w;
+    atomicMax(&C->big_max_width, (uint32_t)w);
+    off[0] = base;
+    for (int q = 0; q < nlev; q++) off[q + 1] += off[q];
+    for (int q = 0; q < m; q++) rows_out[off[lv_out[q]]++ - base] = q;
+    for (int q = nlev; q > 0; q--) off[q] = off[q - 1];
+    off[0] = base;
+}
+// every island of the big list that st_levels left out (more than LEVELS_COOP_ROWS rows), by the calling workgroup(s)
+__device__ __forceinline__ void st_levels_coop(const int *con_off, const int *body_off, const int *bodies, const int *cb1, const int *cb2,
+                                               const ExactCaps &cap, int rpc, const int *big, const int *big_list, int *lev_count,
+                                               int *lev_off, int *lev_rows, int *row_level, int *last, ExactCounts *C,
+                                               unsigned char *lds, size_t lds_bytes, uint32_t *wt, uint32_t first, uint32_t step)
+{
+    if (C->overflow) return;               // (capacities are being grown: the tick runs again)
+    const uint32_t nbig = C->nbig;
+    for (uint32_t k = first; k < nbig; k += step) {
+        const int isl = big_list[k];
+        const int m = (con_off[isl + 1] - con_off[isl]) * rpc;
+        if (m <= LEVELS_COOP_ROWS) continue;
+        if (!levels_coop(isl, (int)k, con_off, body_off, bodies, cb1, cb2, rpc, big, lev_count, lev_off, lev_rows, row_level, last, C, lds,
+                         lds_bytes, wt)) {
+            if (threadIdx.x == 0) levels_one_lane(isl, (int)k, con_off, cb1, cb2, rpc, big, lev_count, lev_off, lev_rows, row_level, last, C);
+            __syncthreads();
+        }
+    }
+}
+__global__ __launch_bounds__(EXS_WG) void ex_levels_coop(const int *__restrict__ con_off, const int *__restrict__ body_off,
+                                                         const int *__restrict__ bodies, const int *__restrict__ cb1,
+                                                         const int *__restrict__ cb2, ExactCaps cap, int rpc, const int *__restrict__ big,
+                                                         const int *__restrict__ big_list, int *__restrict__ lev_count,
+                                                         int *__restrict__ lev_off, int *__restrict__ lev_rows, int *__restrict__ row_level,
+                                                         int *__restrict__ last, ExactCounts *C, uint32_t lds_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char coop_lds[];
+    __shared__ uint32_t wt[EXS_WG / 64];
+    st_levels_coop(con_off, body_off, bodies, cb1, cb2, cap, rpc, big, big_list, lev_count, lev_off, lev_rows, row_level, last, C, coop_lds,
+                   lds_bytes, wt, blockIdx.x, gridDim.x);
 }
 
 // B.stamps: wall_clock64() (100 MHz) after every stage, front kernel from [0], back kernel from [32]; DMX_EXS_TIMING=1 prints the
@@ -825,11 +988,12 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gt
 template <class T, int ITEMS>
 __global__ __launch_bounds__(EXS_WG) void ex_small_back(ExactBuffers<T> B, ExactCaps cap, int rpc, int big_rows, const uint32_t *flags,
                                                         StepDiag *diag, ExactCounts *host_counts, uint32_t *host_flags, uint32_t seq,
-                                                        int lds_slots)
+                                                        int lds_slots, uint32_t lds_bytes)
 {
     // lds_slots > 0: the level schedules' per-slot `last` array lives in LDS for this launch (that many slots, all idle) -- the
-    // stage is one lane per island walking a chain of read-modify-writes of it, a round trip to L2 each otherwise
-    extern __shared__ int32_t last_l[];
+    // stage is one lane per island walking a chain of read-modify-writes of it, a round trip to L2 each otherwise.  The same
+    // lds_bytes of dynamic LDS then serve the large islands' schedules (levels_coop), which use B.last in device memory.
+    extern __shared__ __attribute__((aligned(16))) int32_t last_l[];
     for (int k = threadIdx.x; k < lds_slots; k += EXS_WG) last_l[k] = -1;        // (barriers follow before its first use)
     using sort_t = rocprim::block_radix_sort<uint32_t, EXS_WG, ITEMS>;
     __shared__ typename sort_t::storage_type sort_storage;
@@ -880,7 +1044,10 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_back(ExactBuffers<T> B, Exact
     __syncthreads(); EXS_STAMP();
     block_scan_inclusive<uint64_t>(B.bg, B.binc, cap.inv, wt); EXS_STAMP();
     st_levels(B.con_off, B.body_off, B.cb1, B.cb2, B.bg, B.binc, cap, rpc, B.big, B.big_list, B.lev_count, B.lev_off, B.lev_rows,
-              B.row_level, lds_slots > 0 ? last_l : B.last, C, tid, EXS_WG);
+              B.row_level, lds_slots > 0 ? last_l : B.last, C, tid, EXS_WG, LEVELS_COOP_ROWS);
+    __syncthreads();
+    st_levels_coop(B.con_off, B.body_off, B.bodies, B.cb1, B.cb2, cap, rpc, B.big, B.big_list, B.lev_count, B.lev_off, B.lev_rows,
+                   B.row_level, B.last, C, reinterpret_cast<unsigned char *>(last_l), lds_bytes, reinterpret_cast<uint32_t *>(wt), 0u, 1u);
     __syncthreads(); EXS_STAMP();
     if (tid == 0) {
         diag->contacts = 0ull; diag->residual = 0.0;       // the island kernels add to it next
@@ -970,7 +1137,14 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
     tb = B.temp_bytes;
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.bg, B.binc, (size_t)cap.inv, rocprim::plus<uint64_t>(), st));
     hipLaunchKernelGGL(ex_levels, dim3((unsigned)(((size_t)cap.inv + 63) / 64)), dim3(64), 0, st, B.con_off, B.body_off, B.cb1, B.cb2, B.bg, B.binc,
-                       cap, rpc, B.big, B.big_list, B.lev_count, B.lev_off, B.lev_rows, B.row_level, B.last, B.counts);
+                       cap, rpc, B.big, B.big_list, B.lev_count, B.lev_off, B.lev_rows, B.row_level, B.last, B.counts, LEVELS_COOP_ROWS);
+    {
+        // the islands that left out (a pile in the reference's pen: thousands of contacts in one island), a workgroup each
+        const size_t lds = 128 * 1024;
+        EX_TRY(hipFuncSetAttribute((const void *)&ex_levels_coop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ex_levels_coop, dim3(32), dim3(EXS_WG), lds, st, B.con_off, B.body_off, B.bodies, B.cb1, B.cb2, cap, rpc, B.big, B.big_list,
+                           B.lev_count, B.lev_off, B.lev_rows, B.row_level, B.last, B.counts, (uint32_t)lds);
+    }
     return hipGetLastError();
 }
 
@@ -1032,9 +1206,15 @@ hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const Grid
                                     uint32_t *host_flags, uint32_t seq, int64_t n_slots, hipStream_t st)
 {
     const size_t ne = (size_t)cap.entries();
-    // (beside the block sort's storage within the default 64 KiB: up to 4096 slots with 2 or 4 entries per thread)
-    const int ls = (n_slots > 0 && n_slots <= 4096 && ne <= 4 * (size_t)EXS_WG) ? (int)n_slots : 0;
-    const size_t lds = (size_t)ls * sizeof(int32_t);
+    // dynamic LDS beside the block sort's storage: the per-slot `last` array of the one-lane schedules (up to 8192 slots), then the
+    // large islands' group arrays (levels_coop)
+    const int ls = (n_slots > 0 && n_slots <= 8192) ? (int)n_slots : 0;
+    const size_t lds = 64 * 1024;
+    {
+        const void *fn = ne <= 2 * EXS_WG ? (const void *)&ex_small_back<T, 2> : ne <= 4 * EXS_WG ? (const void *)&ex_small_back<T, 4> : (const void *)&ex_small_back<T, 8>;
+        const hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return ea;
+    }
     hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.rec, P, cap,
                        B.gpos, B.gnormal, B.gdepth, B.cc, B.counts, SortKeyArgs{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr });
     if (P.hull_n > 0)
@@ -1042,11 +1222,11 @@ hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const Grid
                            B.pairs, G.rec, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
     const uint32_t *flags = G.flags;
     if (ne <= 2 * EXS_WG)
-        hipLaunchKernelGGL((ex_small_back<T, 2>), dim3(1), dim3(EXS_WG), lds, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq, ls);
+        hipLaunchKernelGGL((ex_small_back<T, 2>), dim3(1), dim3(EXS_WG), lds, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq, ls, (uint32_t)lds);
     else if (ne <= 4 * EXS_WG)
-        hipLaunchKernelGGL((ex_small_back<T, 4>), dim3(1), dim3(EXS_WG), lds, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq, ls);
+        hipLaunchKernelGGL((ex_small_back<T, 4>), dim3(1), dim3(EXS_WG), lds, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq, ls, (uint32_t)lds);
     else
-        hipLaunchKernelGGL((ex_small_back<T, 8>), dim3(1), dim3(EXS_WG), 0, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq, 0);
+        hipLaunchKernelGGL((ex_small_back<T, 8>), dim3(1), dim3(EXS_WG), lds, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq, ls, (uint32_t)lds);
     return hipGetLastError();
 }
 
