@@ -132,6 +132,7 @@ struct dmxBatch {
     // convex bodies: the shared hull's body-frame points, and the per-tick plane contacts of every convex body
     DevBuf hull, cbuf, ccount;
     DevBuf hull_planes; int hull_nf = 0;       // the hull's faces (dmxBatchSetConvexHullFaces): 4 reals each
+    bool spec_refused = false;                 // the last exact tick's record refused (or would have refused) the speculative launches
     int64_t stat_spec_ticks = 0;               // exact ticks whose solve + fused step went out before the host had the counts, and stood
     int64_t stat_unsupported = 0;              // AABB pairs met that have no collider (convex-convex, convex-sphere)
     DevBuf sbox; int n_static = 0;             // static box geoms (dmxBatchSetStaticBoxes), SBOX_REALS reals each

@@ -593,6 +593,14 @@ __device__ __forceinline__ void st_bigflags(const int *con_off, const int *body_
     }
 }
 
+// which form builds an island's schedule: the workgroup's (levels_coop) for islands that need row lists at all, when few islands
+// have a workgroup (nbig) -- see st_levels
+constexpr int LEVELS_COOP_ROWS = WAVE_ISLAND_ROWS, LEVELS_COOP_MAX_ISLANDS = 64;
+__device__ __forceinline__ bool levels_by_workgroup(int m, int nbig, int coop_rows)
+{
+    return coop_rows > 0 && m > coop_rows && nbig <= LEVELS_COOP_MAX_ISLANDS;
+}
+
 // ---- 10. level schedules.  One lane per island; islands own disjoint bodies, so `last` (per slot, -1 when idle) is
 //          private to the lane while it works.  lev_off of island k (big index) lives at row_base + k, nlev + 1 <= rows + 1
 //          entries; lev_rows / row_level at row_base. -----------------------------------------------------------------------
@@ -601,8 +609,9 @@ __device__ __forceinline__ void st_levels(const int *con_off, const int *body_of
                                           int *lev_off, int *lev_rows, int *row_level, int *last, ExactCounts *C, uint32_t first,
                                           uint32_t step, int coop_rows = 0)
 {
-    // coop_rows > 0: islands of more rows than that are only entered in the big list here; their schedules are built by a whole
-    // workgroup (levels_coop below) -- one lane walking thousands of contacts through device memory is a millisecond
+    // coop_rows > 0: islands of more rows than that are only entered in the big list here when the list is short; their schedules
+    // are built by a whole workgroup (levels_coop below) -- one lane walking thousands of contacts through device memory is a
+    // millisecond.  (Thousands of such islands are the other case: a lane each, all at once, is the faster form then.)
     const uint32_t ni = C->overflow ? 0u : C->ni;
     for (uint32_t i = first; i < ni; i += step) {
         if (i == 0) {
@@ -618,7 +627,7 @@ __device__ __forceinline__ void st_levels(const int *con_off, const int *body_of
         big_list[k] = (int)i;
         atomicMax(&C->big_max_bodies, (uint32_t)(body_off[i + 1] - body_off[i]));
         if ((uint32_t)(base + m) > cap.rows) continue;          // flagged above; the host grows the capacity
-        if (coop_rows > 0 && m > coop_rows) continue;
+        if (levels_by_workgroup(m, (int)lo32(binc[cap.inv - 1]), coop_rows)) continue;
         int *lv_out = row_level + base, *off = lev_off + base + k, *rows_out = lev_rows + base;
         // consecutive contacts between the same bodies (a box's four contacts with the plane, a pair's) form one group: its
         // rows take consecutive levels, and `last` is touched once per group, not once per row
@@ -731,7 +740,6 @@ __device__ __forceinline__ void publish_counts(const ExactCounts *C, const uint3
 // in parallel.  Rows of one level touch disjoint bodies, so their order inside a level list is free (atomic cursors).
 // lds: at least levels_coop_bytes(nb, groups) bytes; returns false (nothing written) when the island does not fit -- the caller
 // falls back on the one-lane walk.
-constexpr int LEVELS_COOP_ROWS = 768;          // islands above this many rows get the workgroup form
 __host__ __device__ inline size_t levels_coop_bytes(size_t nb, size_t groups) { return 4 * nb + 12 * groups + 16; }
 
 __device__ __forceinline__ bool levels_coop(int isl, int k, const int *con_off, const int *body_off, const int *bodies, const int *cb1,
@@ -859,10 +867,11 @@ __device__ __forceinline__ void st_levels_coop(const int *con_off, const int *bo
 {
     if (C->overflow) return;               // (capacities are being grown: the tick runs again)
     const uint32_t nbig = C->nbig;
+    if (nbig > (uint32_t)LEVELS_COOP_MAX_ISLANDS) return;       // (st_levels has built them all, a lane each)
     for (uint32_t k = first; k < nbig; k += step) {
         const int isl = big_list[k];
         const int m = (con_off[isl + 1] - con_off[isl]) * rpc;
-        if (m <= LEVELS_COOP_ROWS) continue;
+        if (!levels_by_workgroup(m, (int)nbig, LEVELS_COOP_ROWS)) continue;
         if (!levels_coop(isl, (int)k, con_off, body_off, bodies, cb1, cb2, rpc, big, lev_count, lev_off, lev_rows, row_level, last, C, lds,
                          lds_bytes, wt)) {
             if (threadIdx.x == 0) levels_one_lane(isl, (int)k, con_off, cb1, cb2, rpc, big, lev_count, lev_off, lev_rows, row_level, last, C);

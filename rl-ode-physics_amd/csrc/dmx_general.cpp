@@ -463,7 +463,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
             HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, G, B, cap, nullptr, nullptr, 0u, b->stream));
             HIP_TRY(launch_exact_small_group<T>((const T *)b->slab, b->gtype, G, P, B, cap, rpc, big_island_rows_general(), b->diag_isl,
                                                 hc, hf, seq, b->n, b->stream));
-            if (speculate_small_exact() && !b->ext_pending && (size_t)3 * cap.slots() * 29 * sizeof(T) <= ((size_t)64 << 20)) {
+            if (speculate_small_exact() && !b->spec_refused && !b->ext_pending && (size_t)3 * cap.slots() * 29 * sizeof(T) <= ((size_t)64 << 20)) {
                 // The rest of the tick goes out BEHIND those, before the host has seen a count: the island solve over the capacity
                 // (workgroups ask the device's record whether they exist) and the fused step for everyone else, both gated on
                 // the record's spec_ok -- the last kernel above clears it when anything overflowed, an island spans two ranks,
@@ -551,6 +551,9 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     // the speculative launches went ahead (the record says so): the tick is on the device in full, nothing is left to launch
     const bool done = speculated && C.spec_ok != 0u;
     if (done) b->stat_spec_ticks++;
+    // the device's verdict on THIS tick is the forecast for the next one (a pile at the pen's walls stays the kind of island it is):
+    // launches that would be refused are not enqueued (they cost the narrowphase of the fused path and three dispatches)
+    b->spec_refused = C.spec_ok == 0u;
     if (C.ninv == 0) {                      // nobody in a body pair, nobody at a static box
         b->last_mixed = false;
         return done ? DMX_OK : fused_tick<T>(b, h, false, nullptr);
