@@ -626,6 +626,7 @@ __device__ __forceinline__ void st_levels(const int *con_off, const int *body_of
         big[i] = base + k;
         big_list[k] = (int)i;
         atomicMax(&C->big_max_bodies, (uint32_t)(body_off[i + 1] - body_off[i]));
+        atomicMax(&C->big_max_rows, (uint32_t)m);
         if ((uint32_t)(base + m) > cap.rows) continue;          // flagged above; the host grows the capacity
         if (levels_by_workgroup(m, (int)lo32(binc[cap.inv - 1]), coop_rows)) continue;
         int *lv_out = row_level + base, *off = lev_off + base + k, *rows_out = lev_rows + base;
@@ -714,8 +715,8 @@ template <class V> __device__ __forceinline__ void block_scan_inclusive(const V 
     __syncthreads();
 }
 
-// the count record and the broadphase flags into pinned host memory: one lane per word, so the record crosses the bus as one
-// 64-byte write and one of 20 bytes, not as 21 writes one after the other.  Called by the whole workgroup after a barrier.
+// the count record and the broadphase flags into pinned host memory: one lane per word, so the record crosses the bus as a
+// couple of wide writes, not as two dozen one after the other.  Called by the whole workgroup after a barrier.
 // The record's last word is the caller's sequence number and goes out after everything else has been fenced to the system:
 // the host may watch for it instead of waiting for the stream (a stream synchronisation costs it 10-20 us to wake up).
 __device__ __forceinline__ void publish_counts(const ExactCounts *C, const uint32_t *flags, ExactCounts *host_counts, uint32_t *host_flags,

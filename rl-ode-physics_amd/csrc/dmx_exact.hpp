@@ -21,7 +21,7 @@ struct ExactCaps {
     __host__ __device__ size_t slots() const { return pair_slot0() + (size_t)8 * pairs; }
 };
 
-// what the pipeline found, read back by the host once per tick (device struct, 64 B)
+// what the pipeline found, read back by the host once per tick (device struct, 80 B)
 struct ExactCounts {
     uint32_t npairs, ninv, ni, njoints, nbig, big_rows, big_max_bodies, big_max_width;
     uint32_t overflow;      // bit 0: pairs / involved bodies above capacity; bit 1: level-schedule rows above capacity
@@ -33,6 +33,8 @@ struct ExactCounts {
     uint32_t ncross;        // pairs (own body, ghost slot) met; the first EX_CROSS_CAP of them are in ExactBuffers::cross_list
     uint32_t bp_overflow;   // the grid's BPF_OVERFLOW flag as of the pair search (a bucket overflowed: the host widens them and searches
                             // again), carried here so that one read-back brings everything
+    uint32_t big_max_rows;  // rows of the largest island that gets a workgroup (the launch shape of its solve: rows in registers or streamed)
+    uint32_t pad_[3];
     uint32_t seq;           // small-scene kernels: the caller's sequence number, written to the host copy LAST: a host that watches
                             // for it has the whole record (and the flags) without waiting for the stream
 };

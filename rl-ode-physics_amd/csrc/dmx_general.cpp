@@ -416,6 +416,7 @@ template <class T> IslandSet<T> island_set_of(dmxBatch *b, const ExactBuffers<T>
     if (C != nullptr) {
         I.n_islands = (int)C->ni; I.n_big = (int)C->nbig;
         I.big_max_bodies = (int)C->big_max_bodies; I.big_max_width = (int)C->big_max_width;
+        I.big_rows_total = (int)C->big_rows; I.big_max_rows = (int)C->big_max_rows;
     }
     I.rows = (T *)b->jd_rows.p; I.rowjb = (int *)b->jd_rowjb.p; I.bscr = (T *)b->jd_bscr.p; I.local = (int *)b->jd_local.p;
     I.singles = 1;
@@ -463,7 +464,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
             HIP_TRY(launch_exact_small_front<T>((T *)b->slab, b->gtype, b->n, b->n_active, G, B, cap, nullptr, nullptr, 0u, b->stream));
             HIP_TRY(launch_exact_small_group<T>((const T *)b->slab, b->gtype, G, P, B, cap, rpc, big_island_rows_general(), b->diag_isl,
                                                 hc, hf, seq, b->n, b->stream));
-            if (speculate_small_exact() && !b->spec_refused && !b->ext_pending && (size_t)3 * cap.slots() * 29 * sizeof(T) <= ((size_t)64 << 20)) {
+            if (speculate_small_exact() && !b->spec_refused && !b->ext_pending && (size_t)3 * cap.slots() * ISLAND_ROW_REALS * sizeof(T) <= ((size_t)64 << 20)) {
                 // The rest of the tick goes out BEHIND those, before the host has seen a count: the island solve over the capacity
                 // (workgroups ask the device's record whether they exist) and the fused step for everyone else, both gated on
                 // the record's spec_ok -- the last kernel above clears it when anything overflowed, an island spans two ranks,
@@ -472,7 +473,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
                 // from the bookkeeping straight into the solve (10 us of host round trip per tick gone), and the host is back
                 // enqueueing the next tick while it runs.  Scratch sized for the capacity, not the counts.
                 const size_t max_rows = (size_t)3 * cap.slots();
-                if ((rc = dmx_ensure_dev(b->jd_rows, (max_rows + 1) * 29 * sizeof(T))) != DMX_OK) return rc;
+                if ((rc = dmx_ensure_dev(b->jd_rows, (max_rows + 1) * ISLAND_ROW_REALS * sizeof(T))) != DMX_OK) return rc;
                 if ((rc = dmx_ensure_dev(b->jd_rowjb, (max_rows + 1) * 2 * sizeof(int))) != DMX_OK) return rc;
                 if ((rc = dmx_ensure_dev(b->jd_bscr, ((size_t)cap.inv + 1) * 28 * sizeof(T))) != DMX_OK) return rc;
                 if ((rc = dmx_ensure_dev(b->jd_local, (size_t)b->stride * sizeof(int))) != DMX_OK) return rc;
@@ -571,7 +572,7 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     // ---- islands of the bodies in pairs; everyone else through the fused kernel ------------------------------------
     ph.reset(new DmxPhase(b, 7));
     const size_t nrows = (size_t)3 * C.njoints;
-    if ((rc = dmx_ensure_dev(b->jd_rows, (nrows + 1) * 29 * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->jd_rows, (nrows + 1) * ISLAND_ROW_REALS * sizeof(T))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->jd_rowjb, (nrows + 1) * 2 * sizeof(int))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->jd_bscr, ((size_t)C.ninv + 1) * 28 * sizeof(T))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->jd_local, (size_t)b->stride * sizeof(int))) != DMX_OK) return rc;

@@ -70,7 +70,7 @@ template <class T> struct IslandSet {
     const T *gpos, *gnormal, *gdepth;
     const int *cb1, *cb2, *cmode;
     const T *cmu, *cbounce, *cbounce_vel, *csoft_erp, *csoft_cfm;      // all null: every contact carries the batch's surface (StepParams)
-    T *rows;               // scratch: 29 reals per row
+    T *rows;               // scratch: ISLAND_ROW_REALS reals per row (29 fields), the base aligned to 256 bytes
     int *rowjb;            // scratch: 2 ints per row
     T *bscr;               // scratch: 28 reals per island body
     int *local;            // scratch: per slot, index of the body inside its island
@@ -81,6 +81,8 @@ template <class T> struct IslandSet {
     // launch shape of solve_island_wg: bodies of the largest such island (its accumulators go to LDS when they fit) and
     // the widest level of any schedule (64 lanes per island are enough when no level is wider)
     int big_max_bodies, big_max_width;
+    int big_rows_total;    // rows of all large islands together (0: not known): bounds the schedule one of them may bring into LDS
+    int big_max_rows;      // rows of the largest of them (0: not known): up to 256 x 8 (f32) a workgroup keeps them all in registers
     const int *row_level;  // level of every scheduled row, laid out like lev_rows (an island's rows start at its lev_off[0])
     const int *order;      // optional (dmxBatchSetRowOrder, DMX_ORDER_ODE): sweep `it` visits row order[(it / 8) * order_stride +
     int order_stride;      //   row_off[island] + i] at its i-th step; null: rows in creation order (solve_islands only)
@@ -134,6 +136,8 @@ __host__ __device__ __forceinline__ int64_t sc_ix(int k, int f, int64_t i)
 {
     return ((i >> SLAB_TILE_LOG2) * (int64_t)(SC_MAXC * SC_REALS) + (int64_t)(k * SC_REALS + f)) * SLAB_TILE + (i & (SLAB_TILE - 1));
 }
+// reals per constraint row in the island kernels' row scratch (IslandSet::rows): 29 fields, padded to one aligned line
+constexpr int ISLAND_ROW_REALS = 32;
 // islands of up to this many rows: one wavefront of solve_island_wg, rows in registers, only row_level of the schedule read
 constexpr int WAVE_ISLAND_ROWS = 256;
 // layout of one static box in StepParams::sbox / GridParams::sbox

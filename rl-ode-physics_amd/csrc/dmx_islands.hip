@@ -21,7 +21,11 @@
 namespace dmx {
 
 // per-row scratch layout (reals)
-enum : int { RW_J = 0, RW_IMJ = 12, RW_RHS = 24, RW_AD = 25, RW_LO = 26, RW_HI = 27, RW_LAM = 28, RW_COUNT = 29 };
+// (29 fields in ISLAND_ROW_REALS = 32 reals: a row is one aligned 128-byte line in f32 (two in f64) and solve_island_wg fetches it as
+//  16-byte pieces -- eight requests that touch one line instead of 29 that touch two: a large island's sweeps are bound by how many
+//  cache-line look-ups its lanes' scattered rows cost the compute unit's one L1, see row_load)
+enum : int { RW_J = 0, RW_IMJ = 12, RW_RHS = 24, RW_AD = 25, RW_LO = 26, RW_HI = 27, RW_LAM = 28, RW_COUNT = ISLAND_ROW_REALS };
+static_assert(RW_COUNT >= 29 && RW_COUNT % 4 == 0, "a row is read in 16-byte pieces");
 // per island-body scratch layout (reals)
 enum : int { BW_INVI = 0, BW_FACC = 9, BW_TACC = 12, BW_INVM = 15, BW_FC = 16, BW_TMP = 22, BW_COUNT = 28 };
 
@@ -227,16 +231,30 @@ __device__ __forceinline__ T row_sor(T *rows, const int *jb, T *bs, int i)
 
 // ---- the same row update with the row in registers and the bodies' constraint-force accumulators in LDS
 //      (solve_island_wg): identical arithmetic, identical bits ---------------------------------------------------
+// workgroup barrier that orders LDS traffic only (see solve_island_wg's level loop)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <class T> struct RowRegs { T J[12], iMJ[12], rhs, ad, lo, hi, lam; int l1, l2, row; };
 
 template <class T>
 __device__ __forceinline__ void row_load(const T *rows, const int *jb, int i, RowRegs<T> &r)
 {
-    const T *row = rows + (size_t)i * RW_COUNT;
+    // the whole row as 16-byte pieces (rows are aligned to their own size: ISLAND_ROW_REALS reals from an aligned base)
+    constexpr int PER = 16 / (int)sizeof(T), NP = RW_COUNT / PER;
+    struct alignas(16) Piece { T v[PER]; };
+    const Piece *row = reinterpret_cast<const Piece *>(rows + (size_t)i * RW_COUNT);
+    T f[RW_COUNT];
 #pragma unroll
-    for (int j = 0; j < 12; j++) { r.J[j] = row[RW_J + j]; r.iMJ[j] = row[RW_IMJ + j]; }
-    r.rhs = row[RW_RHS]; r.ad = row[RW_AD]; r.lo = row[RW_LO]; r.hi = row[RW_HI]; r.lam = row[RW_LAM];
-    r.l1 = jb[2 * i]; r.l2 = jb[2 * i + 1];
+    for (int p = 0; p < NP; p++) {
+        const Piece q = row[p];
+#pragma unroll
+        for (int e = 0; e < PER; e++) f[p * PER + e] = q.v[e];
+    }
+#pragma unroll
+    for (int j = 0; j < 12; j++) { r.J[j] = f[RW_J + j]; r.iMJ[j] = f[RW_IMJ + j]; }
+    r.rhs = f[RW_RHS]; r.ad = f[RW_AD]; r.lo = f[RW_LO]; r.hi = f[RW_HI]; r.lam = f[RW_LAM];
+    const int2 b = *reinterpret_cast<const int2 *>(jb + 2 * (size_t)i);
+    r.l1 = b.x; r.l2 = b.y;
     r.row = i;
 }
 
@@ -889,15 +907,56 @@ __device__ __forceinline__ double wave_island_contact_sweeps(T *rows, const int 
     return resid;
 }
 
+// The sweeps of a large island by a whole workgroup with every row in REGISTERS: the row at position t of the island's level
+// lists (rows grouped by level, lev_rows) belongs to thread t mod WG, RPL rows per thread, for all twenty sweeps; a level step is
+// "threads holding a row of this level update it" and an LDS hand-over of the accumulators.  Nothing is fetched from device
+// memory between the first sweep and the last.  (Streaming a lane's row of each level from L2 instead -- solve_island_wg's
+// general form -- makes every level step one L2 round trip long: 0.9 us in the reference's pen, 45 levels x 20 sweeps.)  A level's
+// rows are consecutive positions, so they sit in at most two of a thread's slots (one, if the level is no wider than what is
+// left of the slot): a wavefront runs one or two row updates per level, not RPL.  Returns the thread's share of the last sweep's residual.
+template <class T, int RPL, int WG>
+__device__ __forceinline__ double wg_island_sweeps(T *rows, const int *jb, const int *row_level, const int *lev_rows, int m, int nlev, int iters,
+                                                   int tid, T *fc_lds)
+{
+    RowRegs<T> mine[RPL];
+    int my_level[RPL];
+#pragma unroll
+    for (int j = 0; j < RPL; j++) {
+        const int t = tid + WG * j;
+        my_level[j] = -1;
+        if (t < m) { const int r = lev_rows[t]; row_load(rows, jb, r, mine[j]); my_level[j] = row_level[r]; }
+    }
+    double resid = 0.0;
+    for (int it = 0; it < iters; it++) {
+        const bool last = it + 1 == iters;
+        for (int lv = 0; lv < nlev; lv++) {
+#pragma unroll
+            for (int j = 0; j < RPL; j++)
+                if (my_level[j] == lv) {
+                    const T d = row_sor_lds<T, false>(nullptr, mine[j], fc_lds, true);
+                    if (last) resid += (double)d;
+                }
+            lds_barrier();
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RPL; j++)
+        if (my_level[j] >= 0) rows[(size_t)mine[j].row * RW_COUNT + RW_LAM] = mine[j].lam;
+    return resid;
+}
+
 // ================================================================================ one workgroup per large island
 constexpr int FC_LDS_BYTES = 48 * 1024;     // islands of up to 2048 (f32) / 1024 (f64) bodies keep their accumulators in LDS
 // (WAVE_ISLAND_ROWS, dmx_internal.hpp: islands of up to that many rows are solved by one wavefront with the rows in registers;
 //  such an island has at most 2 x 256 bodies, which always fit the LDS above)
 
-template <class T, int WG>
+// REGS: islands of up to WG x 8 (f32) / WG x 4 (f64) rows keep them in registers for the sweeps (wg_island_sweeps); a separate
+// instantiation, so that the streaming forms keep their register budget
+template <class T, int WG, bool REGS = false>
 __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const uint8_t *__restrict__ bflags,
                                                       int64_t stride, IslandSet<T> I, StepParams<T> P,
-                                                      StepDiag *__restrict__ diag, int lds_bodies, const ExactCounts *__restrict__ dc)
+                                                      StepDiag *__restrict__ diag, int lds_bodies, const ExactCounts *__restrict__ dc,
+                                                      int sched_ints)
 {
     // dc: a launch enqueued before the host has seen the tick's counts (careful_tick, small scenes) -- the grid covers the
     // capacity, the record on the device says how many islands there are and whether this launch may act at all
@@ -968,35 +1027,70 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
         else resid = wave_island_sweeps<T, WAVE_ISLAND_ROWS / 64>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds, eager);
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) bs[(size_t)k * BW_COUNT + BW_FC + j] = fc_lds[6 * k + j];
-    } else if (use_lds) {
+    } else if (REGS && use_lds && m <= WG * (sizeof(T) == 4 ? 8 : 4)) {
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) fc_lds[6 * k + j] = bs[(size_t)k * BW_COUNT + BW_FC + j];
         __syncthreads();
+        const int *row_level = I.row_level + lev_off[0], *lev_rows = I.lev_rows + lev_off[0];
+        if (m <= 2 * WG) resid = wg_island_sweeps<T, 2, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
+        else if (m <= 4 * WG || sizeof(T) == 8) resid = wg_island_sweeps<T, 4, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
+        else resid = wg_island_sweeps<T, sizeof(T) == 4 ? 8 : 4, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
+        __syncthreads();
+        for (int k = tid; k < nb; k += WG)
+            for (int j = 0; j < 6; j++) bs[(size_t)k * BW_COUNT + BW_FC + j] = fc_lds[6 * k + j];
+    } else if (use_lds) {
+        for (int k = tid; k < nb; k += WG)
+            for (int j = 0; j < 6; j++) fc_lds[6 * k + j] = bs[(size_t)k * BW_COUNT + BW_FC + j];
+        // The schedule itself in LDS when the launch made room for it (sched_ints): a level step's row is found by two dependent
+        // look-ups (the level's offset, then the row list) before the row can be fetched -- three L2 round trips in a chain, the
+        // whole length of a level step, when they go to device memory; here they are LDS reads and the fetch is issued two
+        // steps ahead of its use.
+        int *loff = reinterpret_cast<int *>(fc_lds + (size_t)6 * lds_bodies), *lrows = loff + nlev + 1;
+        const bool sched = sched_ints >= nlev + 1 + m;
+        if (sched) {
+            for (int q = tid; q <= nlev; q += WG) loff[q] = lev_off[q] - lev_off[0];
+            for (int t = tid; t < m; t += WG) lrows[t] = I.lev_rows[lev_off[0] + t];
+        }
+        __syncthreads();
         const int total = nlev * P.iters;
-        auto first_row = [&](int lv) { const int t = lev_off[lv] + tid; return t < lev_off[lv + 1] ? I.lev_rows[t] : -1; };
-        RowRegs<T> cur, nxt;
-        int rn = total > 0 ? first_row(0) : -1;
-        if (rn >= 0) row_load(rows, jb, rn, nxt);
-        for (int g = 0, lv = 0; g < total; g++, lv = (lv + 1 == nlev ? 0 : lv + 1)) {
+        auto first_row = [&](int lv) {
+            if (sched) { const int t = loff[lv] + tid; return t < loff[lv + 1] ? lrows[t] : -1; }
+            const int t = lev_off[lv] + tid;
+            return t < lev_off[lv + 1] ? I.lev_rows[t] : -1;
+        };
+        auto next_level = [&](int lv) { return lv + 1 == nlev ? 0 : lv + 1; };
+        // rows of steps g, g + 1, g + 2 (a lane's row of each level: position tid of the level's list)
+        RowRegs<T> cur, n1, n2;
+        int lv0 = 0, lv1 = next_level(0), lv2 = next_level(lv1);
+        int rc = total > 0 ? first_row(lv0) : -1, r1 = total > 1 ? first_row(lv1) : -1, r2 = -1;
+        if (rc >= 0) row_load(rows, jb, rc, cur);
+        if (r1 >= 0) row_load(rows, jb, r1, n1);
+        for (int g = 0; g < total; g++) {
             const bool last = g >= total - nlev;
-            const int rc = rn;
-            cur = nxt;
-            if (g + 1 < total) {
-                rn = first_row(lv + 1 == nlev ? 0 : lv + 1);
-                if (rn >= 0) row_load(rows, jb, rn, nxt);
-            }
+            r2 = g + 2 < total ? first_row(lv2) : -1;
+            if (r2 >= 0) row_load(rows, jb, r2, n2);
             if (rc >= 0) {
                 const T d = row_sor_lds(rows, cur, fc_lds);
                 if (last) resid += (double)d;
-                if (rn == rc) nxt.lam = cur.lam;              // one-level schedule: the prefetch predates this update
+                // schedules of one or two levels: a fetch issued before this update holds the old multiplier
+                if (r1 == rc) n1.lam = cur.lam;
+                if (r2 == rc) n2.lam = cur.lam;
             }
-            for (int t = lev_off[lv] + tid + WG; t < lev_off[lv + 1]; t += WG) {       // levels wider than the workgroup
-                RowRegs<T> x;
-                row_load(rows, jb, I.lev_rows[t], x);
-                const T d = row_sor_lds(rows, x, fc_lds);
-                if (last) resid += (double)d;
+            {                                                                       // levels wider than the workgroup
+                const int a = sched ? loff[lv0] + lev_off[0] : lev_off[lv0], e = sched ? loff[lv0 + 1] + lev_off[0] : lev_off[lv0 + 1];
+                for (int t = a + tid + WG; t < e; t += WG) {
+                    RowRegs<T> x;
+                    row_load(rows, jb, I.lev_rows[t], x);
+                    const T d = row_sor_lds(rows, x, fc_lds);
+                    if (last) resid += (double)d;
+                }
             }
-            __syncthreads();                                  // the next level reads the fc this one wrote
+            // the next level reads the accumulators this one wrote: an LDS hand-over.  NOT __syncthreads(): that also waits for
+            // every outstanding global access (vmcnt(0)) -- the rows fetched for the levels ahead, which are in flight precisely
+            // so that nobody waits for them; with it every level step was one L2 round trip long (800 ns in the pen's pile).
+            lds_barrier();
+            cur = n1; rc = r1; n1 = n2; r1 = r2;
+            lv0 = lv1; lv1 = lv2; lv2 = next_level(lv2);
         }
         for (int k = tid; k < nb; k += WG)                     // back for finish_body (same lane, same bodies)
             for (int j = 0; j < 6; j++) bs[(size_t)k * BW_COUNT + BW_FC + j] = fc_lds[6 * k + j];
@@ -1266,11 +1360,29 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
         // islands of up to lds_bodies bodies keep their accumulators in LDS (larger ones: HBM/L2)
         const int lds_cap = FC_LDS_BYTES / (int)(6 * sizeof(T));
         const int lds_bodies = std::min<int>(std::max(I.big_max_bodies, 1), lds_cap);
-        const size_t lds = (size_t)lds_bodies * 6 * sizeof(T);
-        if (I.big_max_width <= 64)      // no level has more than 64 rows: one wavefront per island, barriers cost nothing
-            hipLaunchKernelGGL((solve_island_wg<T, 64>), dim3((unsigned)I.n_big), dim3(64), lds, st, S, bflags, stride, I, P, diag, lds_bodies, (const ExactCounts *)nullptr);
-        else
-            hipLaunchKernelGGL((solve_island_wg<T, 256>), dim3((unsigned)I.n_big), dim3(256), lds, st, S, bflags, stride, I, P, diag, lds_bodies, (const ExactCounts *)nullptr);
+        size_t lds = (size_t)lds_bodies * 6 * sizeof(T);
+        // a launch whose largest island has more rows than one wavefront holds but few enough for a workgroup's registers (and not
+        // thousands of islands: the form runs one workgroup per compute unit) keeps every island's rows in registers for the sweeps
+        const int regs_rows = 256 * (sizeof(T) == 4 ? 8 : 4);
+        if (I.big_max_rows > WAVE_ISLAND_ROWS && I.big_max_rows <= regs_rows && I.n_big <= 1024) {
+            hipLaunchKernelGGL((solve_island_wg<T, 256, true>), dim3((unsigned)I.n_big), dim3(256), lds, st, S, bflags, stride, I, P, diag, lds_bodies,
+                               (const ExactCounts *)nullptr, 0);
+        } else {
+            // room for an island's level schedule behind the accumulators (offsets + row lists; big_rows_total bounds any one island's):
+            // taken when it is modest -- a few large islands (a pile in the pen) -- not when thousands of small ones share the launch
+            const size_t sched = I.big_rows_total > 0 ? (size_t)2 * I.big_rows_total + 2 : 0;
+            int sched_ints = 0;
+            if (sched > 0 && lds + sched * sizeof(int) <= (size_t)96 * 1024 && I.n_big <= 64) { sched_ints = (int)sched; lds += sched * sizeof(int); }
+            if (lds > (size_t)64 * 1024) {
+                const void *fn = I.big_max_width <= 64 ? (const void *)&solve_island_wg<T, 64, false> : (const void *)&solve_island_wg<T, 256, false>;
+                const hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (ea != hipSuccess) return ea;
+            }
+            if (I.big_max_width <= 64)      // no level has more than 64 rows: one wavefront per island, barriers cost nothing
+                hipLaunchKernelGGL((solve_island_wg<T, 64>), dim3((unsigned)I.n_big), dim3(64), lds, st, S, bflags, stride, I, P, diag, lds_bodies, (const ExactCounts *)nullptr, sched_ints);
+            else
+                hipLaunchKernelGGL((solve_island_wg<T, 256>), dim3((unsigned)I.n_big), dim3(256), lds, st, S, bflags, stride, I, P, diag, lds_bodies, (const ExactCounts *)nullptr, sched_ints);
+        }
     }
     return hipGetLastError();
 }
@@ -1286,7 +1398,7 @@ hipError_t launch_islands_speculative(T *S, const uint8_t *bflags, int64_t strid
     if (max_big == 0) return hipSuccess;
     const int lds_bodies = (int)EX_SPEC_ISLAND_BODIES;        // (<= FC_LDS_BYTES' worth: every island of a tick that passes takes the LDS path, as in launch_islands)
     const size_t lds = (size_t)lds_bodies * 6 * sizeof(T);
-    hipLaunchKernelGGL((solve_island_wg<T, 64>), dim3(max_big), dim3(64), lds, st, S, bflags, stride, I, P, diag, lds_bodies, counts_dev);
+    hipLaunchKernelGGL((solve_island_wg<T, 64>), dim3(max_big), dim3(64), lds, st, S, bflags, stride, I, P, diag, lds_bodies, counts_dev, 0);
     return hipGetLastError();
 }
 template hipError_t launch_islands_speculative<float>(float *, const uint8_t *, int64_t, const IslandSet<float> &, const StepParams<float> &,

@@ -164,7 +164,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     std::vector<int> &big_h = b->sc_iv[3], &big_list_h = b->sc_iv[4], &lev_count_h = b->sc_iv[5], &lev_off_h = b->sc_iv[6],
                      &lev_rows_h = b->sc_iv[7], &lvl_all = b->sc_iv[8];
     big_h.assign((size_t)ni, -1); big_list_h.clear(); lev_count_h.clear(); lev_off_h.clear(); lev_rows_h.clear(); lvl_all.clear();
-    int big_max_bodies = 0, big_max_width = 0;
+    int big_max_bodies = 0, big_max_width = 0, big_rows_total = 0, big_max_rows = 0;
     std::vector<int> &island_bodies = b->sc_iv[9];
     island_bodies.assign((size_t)ni, 0);
     for (int s : slots) island_bodies[(size_t)island_of[(size_t)s]]++;
@@ -206,6 +206,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
             row_base.push_back(rows_total);
             rows_total += m_of[(size_t)i];
             big_max_bodies = std::max(big_max_bodies, island_bodies[(size_t)i]);
+            big_max_rows = std::max(big_max_rows, m_of[(size_t)i]);
         }
         const int nbig = (int)big_list_h.size();
         if (exact) {
@@ -226,6 +227,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
         // (3) row r's level = 1 + the latest level of an earlier row sharing a body with it (creation order)
         std::vector<int> &lvl = lvl_all;                // row -> level, laid out like lev_rows (island k's rows from row_base[k])
         lvl.assign((size_t)rows_total, 0);
+        big_rows_total = rows_total;
         lev_count_h.assign((size_t)nbig, 0);
         std::vector<int> &last = b->sc_last;          // per slot: level of the latest row touching the body; islands own disjoint slots
         dmx_parallel_for(nbig_sched, 64, [&](int64_t lo, int64_t hi, int) {
@@ -348,7 +350,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     const size_t nrows = (size_t)3 * nc;
     if ((rc = dmx_ensure_dev(b->jd_int, n_int * sizeof(int) + 64)) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->jd_real, n_real * sizeof(T) + 64)) != DMX_OK) return rc;
-    if ((rc = dmx_ensure_dev(b->jd_rows, (nrows + 1) * 29 * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(b->jd_rows, (nrows + 1) * ISLAND_ROW_REALS * sizeof(T))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->jd_rowjb, (nrows + 1) * 2 * sizeof(int))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->jd_bscr, ((size_t)nlive + 1) * 28 * sizeof(T))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(b->jd_local, (size_t)b->stride * sizeof(int))) != DMX_OK) return rc;
@@ -366,6 +368,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     I.big = I.crow + nc; I.n_big = n_big; I.big_list = I.big + ni; I.lev_count = I.big_list + n_big;
     I.lev_off = I.lev_count + n_big; I.lev_rows = I.lev_off + lev_off_h.size();
     I.big_max_bodies = big_max_bodies; I.big_max_width = big_max_width;
+    I.big_rows_total = big_rows_total; I.big_max_rows = exact ? 0 : big_max_rows;
     I.row_level = I.lev_rows + lev_rows_h.size();
     I.gpos = geo ? (const T *)geo->pos : nullptr; I.gnormal = geo ? (const T *)geo->normal : nullptr;
     I.gdepth = geo ? (const T *)geo->depth : nullptr;
