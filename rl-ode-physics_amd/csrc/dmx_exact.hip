@@ -150,10 +150,10 @@ constexpr int EXS_PARTNERS = 8;        // partners above it that a body's count 
 // ---- 1. per active body: partners above it (the pairs it owns) and whether it is in any pair at all ---------------
 // pc[i] = (owned pairs << 32) | in-any-pair; inpair[i] = in-any-pair (the fused kernel's skip mask).  A partner in a ghost
 // slot means an island spanning two ranks.
-template <class T, class W>
+template <class T, class W, class ST = uint16_t, int NST = EXS_PARTNERS>
 __device__ __forceinline__ void st_pair_count(const W &walk, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G, uint64_t *pc,
                                               uint8_t *inpair, ExactCounts *C, int32_t *cross_list, int64_t first, int64_t step,
-                                              uint16_t *staged = nullptr)
+                                              ST *staged = nullptr)
 {
     for (int64_t i = first; i < n_active; i += step) {
         uint32_t owned = 0, any = 0;
@@ -167,7 +167,7 @@ __device__ __forceinline__ void st_pair_count(const W &walk, const uint8_t *gtyp
                 }
                 else if (j > i) {
                     // (staged: the first EXS_PARTNERS of them stay in LDS, so the write pass need not walk again)
-                    if (staged != nullptr && owned < (uint32_t)EXS_PARTNERS) staged[(size_t)i * EXS_PARTNERS + owned] = (uint16_t)j;
+                    if (staged != nullptr && owned < (uint32_t)NST) staged[(size_t)i * NST + owned] = (ST)j;
                     owned++;
                 }
             });
@@ -190,18 +190,18 @@ __device__ __forceinline__ void st_pair_count(const W &walk, const uint8_t *gtyp
 template <class T>
 __global__ __launch_bounds__(256) void ex_pair_count(const T *__restrict__ S, const uint8_t *__restrict__ gtype, int64_t n_active,
                                                      GridParams<T> G, uint64_t *__restrict__ pc, uint8_t *__restrict__ inpair,
-                                                     ExactCounts *__restrict__ C, int32_t *__restrict__ cross_list)
+                                                     ExactCounts *__restrict__ C, int32_t *__restrict__ cross_list, int32_t *__restrict__ stage)
 {
-    st_pair_count<T>(GridWalk<T>{ S, gtype, G }, gtype, n_active, G, pc, inpair, C, cross_list, blockIdx.x * (int64_t)blockDim.x + threadIdx.x,
-                     (int64_t)gridDim.x * blockDim.x);
+    st_pair_count<T, GridWalk<T>, int32_t, EX_STAGE_PARTNERS>(GridWalk<T>{ S, gtype, G }, gtype, n_active, G, pc, inpair, C, cross_list,
+                                                               blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, stage);
 }
 
 // ---- 2. pairs in canonical order, the involved bodies ascending, union-find initialised ----------------------------
 // inc = inclusive scan of pc.  Body i owns pairs [hi(exc), hi(exc) + owned) and, if involved, is entry lo(exc) of `inv`.
-template <class T, class W>
+template <class T, class W, class ST = uint16_t, int NST = EXS_PARTNERS>
 __device__ __forceinline__ void st_pair_write(const W &walk, int64_t n_active, const GridParams<T> &G, const uint64_t *pc,
                                               const uint64_t *inc, int32_t *pairs, int32_t *inv, int32_t *parent, const ExactCaps &cap,
-                                              ExactCounts *C, int64_t first, int64_t step, const uint16_t *staged = nullptr)
+                                              ExactCounts *C, int64_t first, int64_t step, const ST *staged = nullptr)
 {
     const uint64_t tot = inc[n_active - 1];
     if (first == 0) {
@@ -221,8 +221,8 @@ __device__ __forceinline__ void st_pair_write(const W &walk, int64_t n_active, c
         if (owned == 0) continue;
         int32_t *out = pairs + 2 * (size_t)hi32(exc);
         uint32_t w = 0;
-        if (staged != nullptr && owned <= (uint32_t)EXS_PARTNERS) {
-            for (; w < owned; w++) { out[2 * w] = (int32_t)i; out[2 * w + 1] = (int32_t)staged[(size_t)i * EXS_PARTNERS + w]; }
+        if (staged != nullptr && owned <= (uint32_t)NST) {
+            for (; w < owned; w++) { out[2 * w] = (int32_t)i; out[2 * w + 1] = (int32_t)staged[(size_t)i * NST + w]; }
         } else {
             walk(i, [&](int64_t j) {
                 if (j > i && j < n_active && w < owned) { out[2 * w] = (int32_t)i; out[2 * w + 1] = (int32_t)j; w++; }
@@ -241,10 +241,10 @@ template <class T>
 __global__ __launch_bounds__(256) void ex_pair_write(const T *__restrict__ S, const uint8_t *__restrict__ gtype, int64_t n_active,
                                                      GridParams<T> G, const uint64_t *__restrict__ pc, const uint64_t *__restrict__ inc,
                                                      int32_t *__restrict__ pairs, int32_t *__restrict__ inv, int32_t *__restrict__ parent,
-                                                     ExactCaps cap, ExactCounts *__restrict__ C)
+                                                     ExactCaps cap, ExactCounts *__restrict__ C, const int32_t *__restrict__ stage)
 {
-    st_pair_write<T>(GridWalk<T>{ S, gtype, G }, n_active, G, pc, inc, pairs, inv, parent, cap, C, blockIdx.x * (int64_t)blockDim.x + threadIdx.x,
-                     (int64_t)gridDim.x * blockDim.x);
+    st_pair_write<T, GridWalk<T>, int32_t, EX_STAGE_PARTNERS>(GridWalk<T>{ S, gtype, G }, n_active, G, pc, inc, pairs, inv, parent, cap, C,
+                                                               blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, stage);
 }
 
 // ---- 3. connected components: lock-free union-find over the involved bodies' indices k (ascending slot order) -------
@@ -979,11 +979,11 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gt
     const LdsGridWalk<T> lw{ G.rec, cr, start, gtype, G.mask, G.xbits, G.class_pairs };
     const GridWalk<T> gw{ S, gtype, G };
     if (LG) st_pair_count<T>(lw, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG, staged);
-    else    st_pair_count<T>(gw, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG);
+    else    st_pair_count<T, GridWalk<T>, int32_t, EX_STAGE_PARTNERS>(gw, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG, B.stage);
     __syncthreads(); EXS_STAMP();
     block_scan_inclusive<uint64_t>(B.pc, B.inc, (uint32_t)n_active, wt); EXS_STAMP();
     if (LG) st_pair_write<T>(lw, n_active, G, B.pc, B.inc, B.pairs, B.inv, B.parent, cap, C, tid, EXS_WG, staged);
-    else    st_pair_write<T>(gw, n_active, G, B.pc, B.inc, B.pairs, B.inv, B.parent, cap, C, tid, EXS_WG);
+    else    st_pair_write<T, GridWalk<T>, int32_t, EX_STAGE_PARTNERS>(gw, n_active, G, B.pc, B.inc, B.pairs, B.inv, B.parent, cap, C, tid, EXS_WG, B.stage);
     __syncthreads(); EXS_STAMP();
     st_unite(B.pairs, B.pc, B.inc, B.parent, C, tid, EXS_WG);
     __syncthreads(); EXS_STAMP();
@@ -1109,10 +1109,10 @@ hipError_t launch_exact_pairs(const T *S, const uint8_t *gtype, int64_t n_active
                               const ExactBuffers<T> &B, const ExactCaps &cap, hipStream_t st)
 {
     size_t tb = B.temp_bytes;          // (B.counts was zeroed by the caller, with the grid)
-    hipLaunchKernelGGL((ex_pair_count<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inpair, B.counts, B.cross_list);
+    hipLaunchKernelGGL((ex_pair_count<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inpair, B.counts, B.cross_list, B.stage);
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.pc, B.inc, (size_t)n_active, rocprim::plus<uint64_t>(), st));
     hipLaunchKernelGGL((ex_pair_write<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inc,
-                       B.pairs, B.inv, B.parent, cap, B.counts);
+                       B.pairs, B.inv, B.parent, cap, B.counts, B.stage);
     return hipGetLastError();
 }
 

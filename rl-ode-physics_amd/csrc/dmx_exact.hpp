@@ -40,6 +40,7 @@ struct ExactCounts {
 };
 
 constexpr uint32_t EX_CROSS_CAP = 256;
+constexpr int EX_STAGE_PARTNERS = 16;
 // the speculative island launch reserves LDS for islands of up to this many bodies (a workgroup's accumulators: 6 reals each);
 // a tick with a larger island clears spec_ok and is launched by the host with the island's true size
 constexpr uint32_t EX_SPEC_ISLAND_BODIES = 512;
@@ -66,6 +67,7 @@ template <class T> struct ExactBuffers {
     int *lev_rows, *row_level;                  // [rows]
     int32_t *last;                              // [stride] per slot, -1 when idle
     uint64_t *stamps;                           // [64] stage time stamps of the small-scene kernels (100 MHz ticks)
+    int32_t *stage;                             // optional [n_active EX_STAGE_PARTNERS]: the partners above a body, left by the count pass for the write pass
 };
 
 size_t exact_temp_bytes(const ExactCaps &cap, int64_t n_active);

@@ -372,6 +372,10 @@ template <class T> int ensure_exact_buffers(dmxBatch *b, const ExactCaps &cap, E
                  o_bg = take((size_t)cap.inv * 8), o_binc = take((size_t)cap.inv * 8),
                  o_big = take((size_t)cap.inv * 4), o_big_list = take((size_t)cap.inv * 4), o_lev_count = take((size_t)cap.inv * 4),
                  o_lev_off = take(((size_t)cap.rows + cap.inv + 1) * 4), o_lev_rows = take((size_t)cap.rows * 4), o_row_level = take((size_t)cap.rows * 4);
+    // partners found by the pair search's count pass, EX_STAGE_PARTNERS per body, so that the write pass need not walk the
+    // grid again (scenes of up to 65 536 slots: where the walk is the tick -- a crowded pen -- not memory for a million bodies)
+    const bool stage = n <= 65536;
+    const size_t o_stage = stage ? take(n * EX_STAGE_PARTNERS * sizeof(int32_t)) : 0;
     if (off > ((size_t)128 << 30)) {         // (involved bodies x (1 + static boxes) entries, 8 contact slots each: say so rather than fail in hipMalloc)
         fprintf(stderr, "libode_mi355: the exact tick would need %.1f GB of work arrays (%u involved bodies x %u static boxes)\n",
                 (double)off / 1e9, cap.inv, cap.nstatic);
@@ -398,6 +402,7 @@ template <class T> int ensure_exact_buffers(dmxBatch *b, const ExactCaps &cap, E
     B.bg = (uint64_t *)(A + o_bg); B.binc = (uint64_t *)(A + o_binc);
     B.big = (int *)(A + o_big); B.big_list = (int *)(A + o_big_list); B.lev_count = (int *)(A + o_lev_count);
     B.lev_off = (int *)(A + o_lev_off); B.lev_rows = (int *)(A + o_lev_rows); B.row_level = (int *)(A + o_row_level);
+    B.stage = stage ? (int32_t *)(A + o_stage) : nullptr;
     B.last = (int32_t *)b->ex_last.p;
     return DMX_OK;
 }
