@@ -259,8 +259,27 @@ def measure(cx, a, scene, layout, kind, dtype, *, exchanging, every_tick=False, 
         if c_loop:
             # collectives: the library's own RCCL binding (ncclAllGather on its side stream), or -- ranks sharing one GPU, which
             # RCCL does not allow -- callbacks that stage through host memory over the gloo group (REHEARSAL, flagged in `data`)
-            st = pkg.shard.CShardedStepper(w, layout, cx.rank, cx.world, collectives="staged" if cx.rehearse else "rccl")
-        else:
+            # Should the library's communicator fail to come up on ANY rank (this path has never run on more than one GPU before the
+            # driver's own run), every rank falls back on the torch.distributed exchange below -- same kernels, same loop in
+            # Python -- and the line says so (`c_loop_error`): a scaling run without a number helps nobody.
+            err = None
+            try:
+                st = pkg.shard.CShardedStepper(w, layout, cx.rank, cx.world, collectives="staged" if cx.rehearse else "rccl")
+            except Exception as e:      # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+            if cx.world > 1:
+                flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=cx.device if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                failed = int(flag.item()) != 0
+            else:
+                failed = err is not None
+            if failed:
+                if st is not None:
+                    st.close()
+                    st = None
+                c_loop = False
+                cx.c_loop_error = err or "another rank's communicator did not come up"
+        if not c_loop:
             ops = None
             if exchanging and cx.rehearse:
                 ops = pkg.shard.StagedDeviceOps(w, cx.device, cx.stream)
@@ -323,7 +342,7 @@ def measure(cx, a, scene, layout, kind, dtype, *, exchanging, every_tick=False, 
                 "dev_s": statistics.median(dev), "blocks": nblocks, "wall_min": min(wall), "wall_max": max(wall),
                 "steps": steps, "n_exchanges": n_ex, "ticks_timed": nblocks * steps, "graphed": graphed, "stats": stats,
                 "exchanging": c_loop or st.exchange is not None, "tpl": ticks_per_launch if kind == "free" else 1,
-                "bodies": scene.n, "c_loop": c_loop}
+                "bodies": scene.n, "c_loop": c_loop, "c_loop_error": getattr(cx, "c_loop_error", None)}
     finally:
         if st is not None and getattr(st, "exchange", None) is not None and st.exchange.fused:
             st.exchange.ops.disarm_pack()       # the send buffers die with the stepper: the batch must not keep aiming at them
@@ -561,6 +580,9 @@ def rank_main(a):
                                  + ("; box-plane and box-box contacts, 20 SOR sweeps" if kind == "small" else "")},
         "roofline": roofline_of(head, kind, rsize, profile_evidence(kind, a.dtype, scene.n), hull_points),
     }
+    if head.get("c_loop_error"):
+        out["config"]["c_loop_error"] = ("the rank loop behind the C ABI could not bring up its own RCCL communicator; this run used the same loop "
+                                         "in Python over torch.distributed instead: " + str(head["c_loop_error"]))
     out["timing"]["ms_per_step_mean"] = head["mean_dt"] * 1e3 / head["steps"]
     out["timing"]["note"] += ("; ms_per_step_mean = (all blocks + the close of the last open chunk) / all timed ticks: every chunk close "
                               "(zone test, flag read) is in it, which a median of short blocks leaves out")
