@@ -111,6 +111,10 @@ __global__ __launch_bounds__(256) void np_static(const T *__restrict__ S, const 
 template <class T>
 __global__ __launch_bounds__(256) void np_convex_static(const T *__restrict__ S, const uint8_t *__restrict__ gtype, int64_t n, StepParams<T> P)
 {
+    // (Tried on 16 384 teapots on a floor box, 0.071 ms/tick as it is: the hull's points staged in LDS once per workgroup, 0.081 --
+    //  the walk is bound by instruction issue, the points come from L1 anyway; a cull in the hull's frame first -- a point's box
+    //  coordinates by nine multiply-adds, a pass of 64 points skipped when none is near -- 0.083: a pass of 64 consecutive points
+    //  spans the whole teapot, so nearly every pass holds a point near the floor.)
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n || gtype[i] != GEOM_CONVEX || (P.skip != nullptr && P.skip[i])) return;      // wave-uniform
     const int lane = threadIdx.x & 63;
