@@ -81,6 +81,10 @@ template <class T>
 hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active, const GridParams<T> &G, const StepParams<T> &P,
                               const ExactBuffers<T> &B, const ExactCaps &cap, int rpc, int big_rows, hipStream_t st);
 
+// the record B.counts and the grid's flags into pinned host memory behind everything enqueued so far; the record's last word is `seq`
+hipError_t launch_exact_publish(const ExactCounts *counts, const uint32_t *flags, ExactCounts *host_counts, uint32_t *host_flags, uint32_t seq,
+                                hipStream_t st);
+
 // Small scenes (exact_small_fits): the same pipeline as two one-workgroup kernels around the narrowphase.  front: also
 // fills the grid (what fill_grid does); group: narrowphase + the rest, zeroes *diag.  A non-null host_counts / host_flags
 // (device-visible pinned memory) receives ExactCounts and the BPF_* flags at the end of that kernel.

@@ -527,7 +527,12 @@ template <class T> int careful_tick(dmxBatch *b, double h)
         if (!looked || (!b->bp_flags_host[BPF_OVERFLOW] && !(C.overflow & 1u) && C.ninv > 0 && !C.cross)) {
             HIP_TRY(launch_exact_group<T>((const T *)b->slab, b->gtype, b->n_active, grid_of<T>(b), P, B, cap, rpc,
                                           big_island_rows_general(), b->stream));
-            if ((rc = read_back()) != DMX_OK) return rc;
+            // the record travels by itself (one small launch writes it to pinned memory) and the host watches for it
+            ExactCounts *hc; uint32_t *hf;
+            if ((rc = host_record_pointers(b, &hc, &hf)) != DMX_OK) return rc;
+            const uint32_t seq = next_record_seq();
+            HIP_TRY(launch_exact_publish(B.counts, (const uint32_t *)b->bp_flags.p, hc, hf, seq, b->stream));
+            { DmxPhase pw(b, 1); if ((rc = await_host_record(b, seq)) != DMX_OK) return rc; }
         }
         }
         if (b->bp_flags_host[BPF_OVERFLOW]) {                  // a column holds more bodies than a bucket: widen and search again
