@@ -296,7 +296,8 @@ bool use_hybrid_exact(const dmxBatch *b, const ExactCaps &cap)
 {
     static const bool on = [] { const char *e = getenv("DMX_HYBRID_EXACT"); return !(e && atoi(e) == 0); }();
     const int mode = b->exact_pipeline != DMX_EXACT_AUTO ? b->exact_pipeline : default_exact_pipeline();
-    return on && mode != DMX_EXACT_STAGED && exact_back_fits(cap) && b->last_pairs <= (unsigned long long)kSmallExactPairs;
+    static const long long maxp = [] { const char *e = getenv("DMX_HYBRID_PAIRS"); return e ? atoll(e) : (long long)kSmallExactPairs; }();
+    return on && mode != DMX_EXACT_STAGED && exact_back_fits(cap) && (long long)b->last_pairs <= maxp;
 }
 
 bool exs_timing_enabled()
