@@ -210,6 +210,40 @@ __device__ __forceinline__ int wave_sphere_convex(const V3<T> &cs, T radius, con
 // Culling (it decides nothing, it only spares walks): a vertex inside a hull is inside that hull's bounding sphere and inside its
 // world AABB (boxA / boxB: lo3 hi3, the exact AABBs the pair search already holds), both taken with slack far above rounding.  Two
 // teapots that touch overlap in a sliver; nearly every chunk of 64 vertices then has no candidate and costs a dozen instructions.
+// Is the point rr (hull frame) inside the hull?  The WAVE's walk over the faces: lane l tests faces l, l + 64, ... -- a point outside
+// leaves at the first group of 64 faces that holds a face it is outside of; before that, at `fhint`, the face that sent the last
+// candidate away (wave-uniform, updated here: neighbouring vertices tend to fail the same face).  Inside: (dep, fbest) = the
+// nearest face, lowest index on ties, on every lane.
+template <class T>
+__device__ __forceinline__ bool wave_point_in_hull(const V3<T> &rr, const StepParams<T> &P, int lane, int &fhint, T &dep, int &fbest)
+{
+    if (fhint >= 0) {
+        const T *ph = P.hull_planes + 4 * fhint;
+        if (ph[3] - dot(V3<T>{ ph[0], ph[1], ph[2] }, rr) < T(0)) return false;
+    }
+    dep = Limits<T>::inf();
+    fbest = 0x7fffffff;
+    for (int f0 = 0; f0 < P.hull_nf; f0 += 64) {
+        const int f = f0 + lane;
+        bool neg = false;
+        if (f < P.hull_nf) {
+            const T *pl = P.hull_planes + 4 * f;
+            const T e = pl[3] - dot(V3<T>{ pl[0], pl[1], pl[2] }, rr);
+            if (e < T(0)) neg = true;
+            else if (e < dep) { dep = e; fbest = f; }          // (f ascends within a lane: the first minimum is kept)
+        }
+        const unsigned long long nb = __ballot(neg);
+        if (nb != 0ull) { fhint = f0 + __builtin_ctzll(nb); return false; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {                         // lexicographic (depth, face) minimum over the wave
+        const T od = __shfl_xor(dep, o, 64);
+        const int of = __shfl_xor(fbest, o, 64);
+        if (od < dep || (od == dep && of < fbest)) { dep = od; fbest = of; }
+    }
+    return fbest != 0x7fffffff;
+}
+
 template <class T, class Emit>
 __device__ __forceinline__ int wave_convex_convex(const V3<T> &xa, const M3<T> &Ra, const V3<T> &xb, const M3<T> &Rb, T hull_radius,
                                                   const T *boxA, const T *boxB, const StepParams<T> &P, int maxc, bool negate, int lane,
@@ -244,33 +278,9 @@ __device__ __forceinline__ int wave_convex_convex(const V3<T> &xa, const M3<T> &
                 const int l = __builtin_ctzll(cand);
                 cand &= cand - 1ull;
                 const V3<T> rr = { __shfl(r.x, l, 64), __shfl(r.y, l, 64), __shfl(r.z, l, 64) };
-                if (fhint >= 0) {
-                    const T *ph = P.hull_planes + 4 * fhint;
-                    if (ph[3] - dot(V3<T>{ ph[0], ph[1], ph[2] }, rr) < T(0)) continue;
-                }
-                T dep = Limits<T>::inf();
-                int fbest = 0x7fffffff;
-                bool outside = false;
-                for (int f0 = 0; f0 < P.hull_nf; f0 += 64) {
-                    const int f = f0 + lane;
-                    bool neg = false;
-                    if (f < P.hull_nf) {
-                        const T *pl = P.hull_planes + 4 * f;
-                        const T e = pl[3] - dot(V3<T>{ pl[0], pl[1], pl[2] }, rr);
-                        if (e < T(0)) neg = true;
-                        else if (e < dep) { dep = e; fbest = f; }          // (f ascends within a lane: the first minimum is kept)
-                    }
-                    const unsigned long long nb = __ballot(neg);
-                    if (nb != 0ull) { outside = true; fhint = f0 + __builtin_ctzll(nb); break; }
-                }
-                if (outside) continue;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {                         // lexicographic (depth, face) minimum over the wave
-                    const T od = __shfl_xor(dep, o, 64);
-                    const int of = __shfl_xor(fbest, o, 64);
-                    if (od < dep || (od == dep && of < fbest)) { dep = od; fbest = of; }
-                }
-                if (fbest == 0x7fffffff) continue;
+                T dep;
+                int fbest;
+                if (!wave_point_in_hull<T>(rr, P, lane, fhint, dep, fbest)) continue;
                 if (lane == l) {
                     const T *pl = P.hull_planes + 4 * fbest;
                     const V3<T> nw = mulv(Rh, V3<T>{ pl[0], pl[1], pl[2] });
@@ -281,6 +291,88 @@ __device__ __forceinline__ int wave_convex_convex(const V3<T> &xa, const M3<T> &
             }
         }
         if (contacts > maxc) contacts = maxc;
+    }
+    return contacts;
+}
+
+// ---- the same collider by a WORKGROUP of NW wavefronts: one deep pair of hulls is a hundred candidate vertices, each a walk over
+// 2 500 faces by a whole wavefront -- 150-180 us for one wavefront, and the duration of the narrowphase launch whatever the
+// number of pairs.  Here the vertices are taken 64 NW at a time: every thread tests one against the other hull's bounding
+// sphere and box, the survivors are listed in array order (ballots + a prefix over the waves), the waves take them in turn
+// (wave w: candidates w, w + NW, ...), and the first maxc that are inside -- in array order, as the one-wavefront walk keeps
+// them -- become contacts.  Same arithmetic per vertex, same contacts, same bits.  Called by every thread of the workgroup;
+// returns the number of contacts on every thread; emit(rank, ...) runs on one thread per contact.
+template <class T, int NW, class Emit>
+__device__ __forceinline__ int wg_convex_convex(const V3<T> &xa, const M3<T> &Ra, const V3<T> &xb, const M3<T> &Rb, T hull_radius,
+                                                const T *boxA, const T *boxB, const StepParams<T> &P, int maxc, bool negate, Emit emit)
+{
+    constexpr int CH = 64 * NW;
+    __shared__ int s_k[CH], s_face[CH], s_rank[CH], s_wcount[NW], s_contacts;
+    __shared__ T s_r[3 * CH], s_dep[CH];
+    if (P.hull_nf <= 0) return 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T slack = hull_radius * T(1e-4);
+    if (tid == 0) s_contacts = 0;
+    __syncthreads();
+    int contacts = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const V3<T> &xv = pass == 0 ? xb : xa; const M3<T> &Rv = pass == 0 ? Rb : Ra;      // the hull whose vertices are walked
+        const V3<T> &xh = pass == 0 ? xa : xb; const M3<T> &Rh = pass == 0 ? Ra : Rb;      // the hull they are tested against
+        const T *box = pass == 0 ? boxA : boxB;
+        int fhint = -1;
+        for (int base = 0; base < P.hull_n && contacts < maxc; base += CH) {
+            const int k = base + tid;
+            V3<T> r = { T(0), T(0), T(0) };
+            bool alive = false;
+            if (k < P.hull_n) {
+                V3<T> v = mulv(Rv, V3<T>{ P.hull[3 * k], P.hull[3 * k + 1], P.hull[3 * k + 2] });
+                v.x += xv.x; v.y += xv.y; v.z += xv.z;
+                r = to_hull_frame(Rh, xh, v);
+                alive = !(r.x * r.x + r.y * r.y + r.z * r.z > hull_radius * hull_radius * T(1.0001)) &&
+                        !(v.x < box[0] - slack || v.x > box[3] + slack || v.y < box[1] - slack || v.y > box[4] + slack ||
+                          v.z < box[2] - slack || v.z > box[5] + slack);
+            }
+            const unsigned long long mb = __ballot(alive);
+            if (lane == 0) s_wcount[wave] = __popcll(mb);
+            __syncthreads();
+            int before = 0, ncand = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) { const int c = s_wcount[w]; if (w < wave) before += c; ncand += c; }
+            if (alive) {
+                const int c = before + __popcll(mb & ((1ull << lane) - 1ull));
+                s_k[c] = k; s_r[3 * c] = r.x; s_r[3 * c + 1] = r.y; s_r[3 * c + 2] = r.z;
+            }
+            __syncthreads();
+            for (int c = wave; c < ncand; c += NW) {                      // wave-uniform
+                const V3<T> rr = { s_r[3 * c], s_r[3 * c + 1], s_r[3 * c + 2] };
+                T dep;
+                int fbest;
+                const bool in = wave_point_in_hull<T>(rr, P, lane, fhint, dep, fbest);
+                if (lane == 0) { s_face[c] = in ? fbest : -1; s_dep[c] = dep; }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int n = s_contacts;                                       // (the one-wavefront walk stops at maxc: so does the count)
+                for (int c = 0; c < ncand; c++) {
+                    const bool take = s_face[c] >= 0 && n < maxc;
+                    s_rank[c] = take ? n : -1;
+                    if (take) n++;
+                }
+                s_contacts = n;
+            }
+            __syncthreads();
+            if (tid < ncand && s_rank[tid] >= 0) {
+                const int kk = s_k[tid];
+                V3<T> v = mulv(Rv, V3<T>{ P.hull[3 * kk], P.hull[3 * kk + 1], P.hull[3 * kk + 2] });
+                v.x += xv.x; v.y += xv.y; v.z += xv.z;
+                const T *pl = P.hull_planes + 4 * s_face[tid];
+                const V3<T> nw = mulv(Rh, V3<T>{ pl[0], pl[1], pl[2] });
+                const bool flip = (pass == 0) != negate;
+                emit(s_rank[tid], v, flip ? V3<T>{ -nw.x, -nw.y, -nw.z } : nw, s_dep[tid]);
+            }
+            contacts = s_contacts;
+            __syncthreads();
+        }
     }
     return contacts;
 }

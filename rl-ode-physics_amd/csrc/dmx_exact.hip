@@ -427,8 +427,9 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
                                                         const int32_t *__restrict__ inv, const int32_t *__restrict__ pairs,
                                                         const GridRec<T> *__restrict__ rec, StepParams<T> P, ExactCaps cap,
                                                         T *__restrict__ gpos, T *__restrict__ gnormal, T *__restrict__ gdepth,
-                                                        uint32_t *__restrict__ cc, ExactCounts *__restrict__ C)
+                                                        uint32_t *__restrict__ cc, ExactCounts *__restrict__ C, int hull_pairs_elsewhere)
 {
+    // hull_pairs_elsewhere: pairs of two hulls are ex_narrow_hull_pairs' (a workgroup each), not this kernel's
     const uint32_t ninv = C->overflow ? 0u : C->ninv, np = C->overflow ? 0u : C->npairs;
     const uint32_t ne = cap.entries(), e_pairs = cap.pair_entry0();
     const int lane = threadIdx.x & 63;
@@ -475,6 +476,7 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
                     nc = wave_box_convex<T>(Bx.x, Bx.R, Bx.side, H.x, H.R, H.side[0], P, maxc, gi != GEOM_BOX, lane,
                                             [&](int rank, const V3<T> &pp, const V3<T> &nn, T dep) { put_c(gpos, gnormal, gdepth, slot0 + rank, pp, nn, dep); });
             } else if (gi == GEOM_CONVEX && gj == GEOM_CONVEX) {
+                if (hull_pairs_elsewhere) continue;
                 // hull i (geom 1, created first) against hull j: vertices of each inside the other, normals into i
                 const BodyGeomX<T> A = geom_of<T>(S, gtype, i), Bh = geom_of<T>(S, gtype, j);
                 const size_t slot0 = cap.pair_slot0() + (size_t)8 * p;
@@ -492,6 +494,30 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
             }
         }
         if (lane == 0) cc[e] = (uint32_t)nc;
+    }
+}
+
+// ---- 4c. pairs of two hulls: one WORKGROUP per pair (wg_convex_convex, dmx_collide_wave.hpp) ---------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void ex_narrow_hull_pairs(const T *__restrict__ S, const uint8_t *__restrict__ gtype,
+                                                            const int32_t *__restrict__ pairs, const GridRec<T> *__restrict__ rec,
+                                                            StepParams<T> P, ExactCaps cap, T *__restrict__ gpos, T *__restrict__ gnormal,
+                                                            T *__restrict__ gdepth, uint32_t *__restrict__ cc, ExactCounts *__restrict__ C)
+{
+    const uint32_t np = C->overflow ? 0u : C->npairs;
+    const uint32_t e_pairs = cap.pair_entry0();
+    const int maxc = P.max_contacts < CONVEX_MAXC ? P.max_contacts : CONVEX_MAXC;
+    for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {                     // workgroup-uniform
+        const int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
+        if (gtype[i] != GEOM_CONVEX || gtype[j] != GEOM_CONVEX) continue;
+        const BodyGeomX<T> A = geom_of<T>(S, gtype, i), Bh = geom_of<T>(S, gtype, j);
+        const size_t slot0 = cap.pair_slot0() + (size_t)8 * p;
+        const T boxA[6] = { rec[i].lo[0], rec[i].lo[1], rec[i].lo[2], rec[i].hi[0], rec[i].hi[1], rec[i].hi[2] };
+        const T boxB[6] = { rec[j].lo[0], rec[j].lo[1], rec[j].lo[2], rec[j].hi[0], rec[j].hi[1], rec[j].hi[2] };
+        const int nc = wg_convex_convex<T, 4>(A.x, A.R, Bh.x, Bh.R, A.side[0], boxA, boxB, P, maxc, false,
+                                              [&](int rank, const V3<T> &pp, const V3<T> &nn, T dep) { put_c(gpos, gnormal, gdepth, slot0 + rank, pp, nn, dep); });
+        if (threadIdx.x == 0) cc[e_pairs + p] = (uint32_t)nc;
+        __syncthreads();
     }
 }
 
@@ -1142,9 +1168,12 @@ hipError_t launch_exact_group(const T *S, const uint8_t *gtype, int64_t n_active
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.rf, B.rinc, (size_t)cap.inv, rocprim::plus<uint32_t>(), st));
     hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.rec, P, cap,
                        B.gpos, B.gnormal, B.gdepth, B.cc, B.counts, SortKeyArgs{ B.pc, B.inc, B.root, B.rinc, B.keys, B.vals });
-    if (P.hull_n > 0)
+    if (P.hull_n > 0) {
         hipLaunchKernelGGL((ex_narrow_convex<T>), dim3((unsigned)std::min<size_t>((ne + 3) / 4, 65535)), dim3(256), 0, st, S, gtype, B.inv,
+                           B.pairs, G.rec, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts, 1);
+        hipLaunchKernelGGL((ex_narrow_hull_pairs<T>), dim3((unsigned)std::min<size_t>(std::max<size_t>(cap.pairs, 1), 4096)), dim3(256), 0, st, S, gtype,
                            B.pairs, G.rec, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
+    }
     int bits = 1;
     while ((1u << bits) <= cap.inv && bits < 32) bits++;        // keys are island numbers < cap.inv and the padding key cap.inv
     tb = B.temp_bytes;
@@ -1241,9 +1270,12 @@ hipError_t launch_exact_small_group(const T *S, const uint8_t *gtype, const Grid
     }
     hipLaunchKernelGGL((ex_narrow<T>), dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, st, S, gtype, B.inv, B.pairs, G.rec, P, cap,
                        B.gpos, B.gnormal, B.gdepth, B.cc, B.counts, SortKeyArgs{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr });
-    if (P.hull_n > 0)
+    if (P.hull_n > 0) {
         hipLaunchKernelGGL((ex_narrow_convex<T>), dim3((unsigned)std::min<size_t>((ne + 3) / 4, 65535)), dim3(256), 0, st, S, gtype, B.inv,
+                           B.pairs, G.rec, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts, 1);
+        hipLaunchKernelGGL((ex_narrow_hull_pairs<T>), dim3((unsigned)std::min<size_t>(std::max<size_t>(cap.pairs, 1), 4096)), dim3(256), 0, st, S, gtype,
                            B.pairs, G.rec, P, cap, B.gpos, B.gnormal, B.gdepth, B.cc, B.counts);
+    }
     const uint32_t *flags = G.flags;
     if (ne <= 2 * EXS_WG)
         hipLaunchKernelGGL((ex_small_back<T, 2>), dim3(1), dim3(EXS_WG), lds, st, B, cap, rpc, big_rows, flags, diag, host_counts, host_flags, seq, ls, (uint32_t)lds);

@@ -16,6 +16,9 @@ template <class T>
 __global__ __launch_bounds__(256) void np_convex_plane(const T *__restrict__ S, const uint8_t *__restrict__ gtype, int64_t n,
                                                        StepParams<T> P)
 {
+    // a chunk in which a body has left its zone is rolled back whole, and a speculative launch the device's record refuses does
+    // nothing: the step kernel behind this one returns at once in both cases (step_plane / step_contacts), so its contacts need not be made
+    if ((P.bp_check && P.bp_flags[BPF_VIOLATION] != 0u) || (P.gate != nullptr && *P.gate == 0u)) return;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // 4 wavefronts per workgroup
     if (i >= n || gtype[i] != GEOM_CONVEX) return;                         // wave-uniform
     const int lane = threadIdx.x & 63;
@@ -55,6 +58,9 @@ template <class T> __device__ __forceinline__ bool aabb_meets_static(const T lo[
 template <class T>
 __global__ __launch_bounds__(256) void np_static(const T *__restrict__ S, const uint8_t *__restrict__ gtype, int64_t n, StepParams<T> P)
 {
+    // a chunk in which a body has left its zone is rolled back whole, and a speculative launch the device's record refuses does
+    // nothing: the step kernel behind this one returns at once in both cases (step_plane / step_contacts), so its contacts need not be made
+    if ((P.bp_check && P.bp_flags[BPF_VIOLATION] != 0u) || (P.gate != nullptr && *P.gate == 0u)) return;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n || (P.skip != nullptr && P.skip[i])) return;
     const int gt = gtype[i];
@@ -115,6 +121,9 @@ __global__ __launch_bounds__(256) void np_convex_static(const T *__restrict__ S,
     //  the walk is bound by instruction issue, the points come from L1 anyway; a cull in the hull's frame first -- a point's box
     //  coordinates by nine multiply-adds, a pass of 64 points skipped when none is near -- 0.083: a pass of 64 consecutive points
     //  spans the whole teapot, so nearly every pass holds a point near the floor.)
+    // a chunk in which a body has left its zone is rolled back whole, and a speculative launch the device's record refuses does
+    // nothing: the step kernel behind this one returns at once in both cases (step_plane / step_contacts), so its contacts need not be made
+    if ((P.bp_check && P.bp_flags[BPF_VIOLATION] != 0u) || (P.gate != nullptr && *P.gate == 0u)) return;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n || gtype[i] != GEOM_CONVEX || (P.skip != nullptr && P.skip[i])) return;      // wave-uniform
     const int lane = threadIdx.x & 63;
