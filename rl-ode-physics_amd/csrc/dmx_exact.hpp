@@ -109,4 +109,10 @@ template <class T>
 hipError_t launch_islands_speculative(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
                                       StepDiag *diag, const ExactCounts *counts_dev, unsigned max_big, hipStream_t st);
 
+// the same launch carrying the fused ground-plane step for everyone else too (Pf: skip mask, gate): see solve_islands_and_step
+template <class T>
+hipError_t launch_islands_and_step_speculative(T *S, const uint8_t *bflags, const uint8_t *gtype, int64_t stride, int64_t n, const IslandSet<T> &I,
+                                               const StepParams<T> &P, const StepParams<T> &Pf, StepDiag *diag_isl, StepDiag *diag_fused,
+                                               const ExactCounts *counts_dev, unsigned max_big, hipStream_t st);
+
 }  // namespace dmx

@@ -437,6 +437,13 @@ bool speculate_small_exact()
     return on;
 }
 
+// DMX_SPEC_FUSE=0: the speculative tick's fused step is a launch of its own behind the solve (A/B runs)
+bool fuse_spec_tail()
+{
+    static const bool on = [] { const char *e = getenv("DMX_SPEC_FUSE"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 template <class T> int careful_tick(dmxBatch *b, double h)
 {
     int rc;
@@ -484,8 +491,21 @@ template <class T> int careful_tick(dmxBatch *b, double h)
                 if ((rc = dmx_ensure_dev(b->jd_bscr, ((size_t)cap.inv + 1) * 28 * sizeof(T))) != DMX_OK) return rc;
                 if ((rc = dmx_ensure_dev(b->jd_local, (size_t)b->stride * sizeof(int))) != DMX_OK) return rc;
                 const IslandSet<T> I = island_set_of<T>(b, B, nullptr);
-                HIP_TRY(launch_islands_speculative<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, B.counts, cap.inv, b->stream));
-                if ((rc = fused_tick<T>(b, h, false, (const uint8_t *)b->bp_inpair.p, &B.counts->spec_ok)) != DMX_OK) return rc;
+                if (b->plane_on && b->n_static == 0 && b->hull_n == 0 && fuse_spec_tail()) {
+                    // boxes and spheres on the ground plane: the fused step for everyone else rides in the solve's launch (the two
+                    // touch disjoint bodies): what fused_tick would set up, with the skip mask and the gate
+                    StepParams<T> Pf = dmx_make_params<T>(b, h);
+                    Pf.bp_check = 0;
+                    Pf.bp_flags = (uint32_t *)b->bp_flags.p;
+                    Pf.skip = (const uint8_t *)b->bp_inpair.p;
+                    Pf.gate = &B.counts->spec_ok;
+                    HIP_TRY(launch_islands_and_step_speculative<T>((T *)b->slab, b->bflags, b->gtype, b->stride, b->n_active, I, P, Pf, b->diag_isl,
+                                                                   b->diag, B.counts, cap.inv, b->stream));
+                    b->bp_fresh = false;
+                } else {
+                    HIP_TRY(launch_islands_speculative<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, B.counts, cap.inv, b->stream));
+                    if ((rc = fused_tick<T>(b, h, false, (const uint8_t *)b->bp_inpair.p, &B.counts->spec_ok)) != DMX_OK) return rc;
+                }
                 speculated = true;
             }
             { DmxPhase pw(b, 1); if ((rc = await_host_record(b, seq)) != DMX_OK) return rc; }

@@ -17,6 +17,7 @@
 #include "dmx_internal.hpp"
 #include "dmx_exact.hpp"
 #include "dmx_math.hpp"
+#include "dmx_step_fused.hpp"
 
 namespace dmx {
 
@@ -952,11 +953,11 @@ constexpr int FC_LDS_BYTES = 48 * 1024;     // islands of up to 2048 (f32) / 102
 
 // REGS: islands of up to WG x 8 (f32) / WG x 4 (f64) rows keep them in registers for the sweeps (wg_island_sweeps); a separate
 // instantiation, so that the streaming forms keep their register budget
-template <class T, int WG, bool REGS = false>
-__global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const uint8_t *__restrict__ bflags,
-                                                      int64_t stride, IslandSet<T> I, StepParams<T> P,
-                                                      StepDiag *__restrict__ diag, int lds_bodies, const ExactCounts *__restrict__ dc,
-                                                      int sched_ints)
+template <class T, int WG, bool REGS>
+__device__ __forceinline__ void solve_island_wg_body(T *__restrict__ S, const uint8_t *__restrict__ bflags,
+                                                     int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
+                                                     StepDiag *__restrict__ diag, int lds_bodies, const ExactCounts *__restrict__ dc,
+                                                     int sched_ints)
 {
     // dc: a launch enqueued before the host has seen the tick's counts (careful_tick, small scenes) -- the grid covers the
     // capacity, the record on the device says how many islands there are and whether this launch may act at all
@@ -1114,6 +1115,28 @@ __global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const u
     for (int o = 32; o > 0; o >>= 1) resid += __shfl_xor(resid, o, 64);
     if ((tid & 63) == 0) atomicAdd(&diag->residual, resid);
     if (tid == 0) atomicAdd(&diag->contacts, (unsigned long long)nc);
+}
+template <class T, int WG, bool REGS = false>
+__global__ __launch_bounds__(WG) void solve_island_wg(T *__restrict__ S, const uint8_t *__restrict__ bflags,
+                                                      int64_t stride, IslandSet<T> I, StepParams<T> P,
+                                                      StepDiag *__restrict__ diag, int lds_bodies, const ExactCounts *__restrict__ dc,
+                                                      int sched_ints)
+{
+    solve_island_wg_body<T, WG, REGS>(S, bflags, stride, I, P, diag, lds_bodies, dc, sched_ints);
+}
+// The tail of a small-scene exact tick in ONE launch: workgroups [0, max_big) are solve_island_wg<64>'s (speculative form: they ask
+// the device's record whether their island exists), the workgroups behind them step 64 bodies each of everyone else with the fused
+// ground-plane kernel's own code (step_plane_body, dmx_step_fused.hpp; Pf carries the involved bodies' skip mask and the same
+// gate).  The two touch disjoint bodies; one after the other they cost 49 + 15 us on a 1 024-body scene, side by side 49.
+template <class T>
+__global__ __launch_bounds__(64) void solve_islands_and_step(T *__restrict__ S, const uint8_t *__restrict__ bflags,
+                                                             const uint8_t *__restrict__ gtype, int64_t stride, int64_t n, IslandSet<T> I,
+                                                             StepParams<T> P, StepParams<T> Pf, StepDiag *__restrict__ diag_isl,
+                                                             StepDiag *__restrict__ diag_fused, int lds_bodies,
+                                                             const ExactCounts *__restrict__ dc, unsigned max_big)
+{
+    if (blockIdx.x < max_big) solve_island_wg_body<T, 64, false>(S, bflags, stride, I, P, diag_isl, lds_bodies, dc, 0);
+    else step_plane_body<T, false, 4>(S, S, gtype, stride, n, Pf, diag_fused, (int64_t)(blockIdx.x - max_big) * 64 + threadIdx.x);
 }
 
 // ================================================================================ dWorldStep: the island's LCP solved exactly
@@ -1401,6 +1424,27 @@ hipError_t launch_islands_speculative(T *S, const uint8_t *bflags, int64_t strid
     hipLaunchKernelGGL((solve_island_wg<T, 64>), dim3(max_big), dim3(64), lds, st, S, bflags, stride, I, P, diag, lds_bodies, counts_dev, 0);
     return hipGetLastError();
 }
+// ... and the same with the fused ground-plane step for everyone else in the launch (solve_islands_and_step): scenes of boxes and
+// spheres on the plane, no static boxes, no hulls, no pending external forces
+template <class T>
+hipError_t launch_islands_and_step_speculative(T *S, const uint8_t *bflags, const uint8_t *gtype, int64_t stride, int64_t n, const IslandSet<T> &I,
+                                               const StepParams<T> &P, const StepParams<T> &Pf, StepDiag *diag_isl, StepDiag *diag_fused,
+                                               const ExactCounts *counts_dev, unsigned max_big, hipStream_t st)
+{
+    const int lds_bodies = (int)EX_SPEC_ISLAND_BODIES;
+    const size_t lds = (size_t)lds_bodies * 6 * sizeof(T);
+    const unsigned blocks = max_big + (unsigned)((n + 63) / 64);
+    hipLaunchKernelGGL((solve_islands_and_step<T>), dim3(blocks), dim3(64), lds, st, S, bflags, gtype, stride, n, I, P, Pf, diag_isl, diag_fused,
+                       lds_bodies, counts_dev, max_big);
+    return hipGetLastError();
+}
+template hipError_t launch_islands_and_step_speculative<float>(float *, const uint8_t *, const uint8_t *, int64_t, int64_t, const IslandSet<float> &,
+                                                               const StepParams<float> &, const StepParams<float> &, StepDiag *, StepDiag *,
+                                                               const ExactCounts *, unsigned, hipStream_t);
+template hipError_t launch_islands_and_step_speculative<double>(double *, const uint8_t *, const uint8_t *, int64_t, int64_t, const IslandSet<double> &,
+                                                                const StepParams<double> &, const StepParams<double> &, StepDiag *, StepDiag *,
+                                                                const ExactCounts *, unsigned, hipStream_t);
+
 template hipError_t launch_islands_speculative<float>(float *, const uint8_t *, int64_t, const IslandSet<float> &, const StepParams<float> &,
                                                       StepDiag *, const ExactCounts *, unsigned, hipStream_t);
 template hipError_t launch_islands_speculative<double>(double *, const uint8_t *, int64_t, const IslandSet<double> &, const StepParams<double> &,
