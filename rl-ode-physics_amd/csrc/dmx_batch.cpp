@@ -165,6 +165,9 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
     if (b->stage) (void)hipFree(b->stage);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
+    if (b->fork_ev) (void)hipEventDestroy(b->fork_ev);
+    if (b->join_ev) (void)hipEventDestroy(b->join_ev);
+    if (b->fork_stream) (void)hipStreamDestroy(b->fork_stream);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
     delete b;
     return DMX_OK;

@@ -64,6 +64,9 @@ struct dmxBatch {
     void *stage = nullptr;           // device staging between host-order rows and the tiled slab
     size_t stage_bytes = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // an exact tick's fused step for the bodies outside the islands runs beside the island solve (disjoint bodies): a second
+    // stream forked from `stream` after the tick's record and joined behind the solve (dmx_general.cpp: careful_tick)
+    hipStream_t fork_stream = nullptr; hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // world parameters (defaults: dWorldCreate [ODE], gravity unset = 0)
     double g[3] = { 0, 0, 0 };

@@ -437,6 +437,13 @@ bool speculate_small_exact()
     return on;
 }
 
+// DMX_FORK_FUSED=0: an exact tick's fused step runs behind the island solve on the batch's stream, not beside it on a second one
+bool fork_fused_enabled()
+{
+    static const bool on = [] { const char *e = getenv("DMX_FORK_FUSED"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 // DMX_SPEC_FUSE=0: the speculative tick's fused step is a launch of its own behind the solve (A/B runs)
 bool fuse_spec_tail()
 {
@@ -609,10 +616,31 @@ template <class T> int careful_tick(dmxBatch *b, double h)
     if ((rc = dmx_ensure_dev(b->jd_local, (size_t)b->stride * sizeof(int))) != DMX_OK) return rc;
     const IslandSet<T> I = island_set_of<T>(b, B, &C);
     // (diag_isl was zeroed with the grid / by the small-scene kernel)
+    // The fused step for everyone else touches none of the islands' bodies: it goes to a second stream, forked here (the record has
+    // been read: nothing can call the tick off any more) and joined behind the solve, so the two run side by side -- in the pen the
+    // solve is a few workgroups for 200 us, in a field of hulls the fused step is the longer of the two.  (DMX_FORK_FUSED=0: one
+    // after the other.)  The island step consumed the accumulators of ITS bodies only; everyone else's are still pending for the fused kernel.
+    bool forked = false;
+    if (fork_fused_enabled()) {
+        if (!b->fork_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&b->fork_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&b->join_ev, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(b->fork_ev, b->stream));
+        HIP_TRY(hipStreamWaitEvent(b->fork_stream, b->fork_ev, 0));
+        hipStream_t main_stream = b->stream;
+        b->stream = b->fork_stream;
+        rc = fused_tick<T>(b, h, false, (const uint8_t *)b->bp_inpair.p);
+        b->stream = main_stream;
+        if (rc != DMX_OK) return rc;
+        HIP_TRY(hipEventRecord(b->join_ev, b->fork_stream));
+        forked = true;
+    }
     HIP_TRY(launch_islands<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, b->stream));
     ph.reset(new DmxPhase(b, 8));
-    // the island step consumed the accumulators of ITS bodies only; everyone else's are still pending for the fused kernel
-    if ((rc = fused_tick<T>(b, h, false, (const uint8_t *)b->bp_inpair.p)) != DMX_OK) return rc;
+    if (forked) HIP_TRY(hipStreamWaitEvent(b->stream, b->join_ev, 0));
+    else if ((rc = fused_tick<T>(b, h, false, (const uint8_t *)b->bp_inpair.p)) != DMX_OK) return rc;
     ph.reset();
     b->last_islands = false;
     b->last_mixed = true;
