@@ -908,6 +908,10 @@ __device__ __forceinline__ double wave_island_contact_sweeps(T *rows, const int 
     return resid;
 }
 
+// rows a thread of the register-resident form holds at most: a workgroup of 256 owns up to 3 072 rows in f32, 1 536 in f64 (the
+// reference's pen holds at most 512 bodies, body.h:6 -- their pile is 2 000-2 600 rows)
+template <class T> constexpr int REGS_ROWS_PER_THREAD = sizeof(T) == 4 ? 12 : 6;
+
 // The sweeps of a large island by a whole workgroup with every row in REGISTERS: the row at position t of the island's level
 // lists (rows grouped by level, lev_rows) belongs to thread t mod WG, RPL rows per thread, for all twenty sweeps; a level step is
 // "threads holding a row of this level update it" and an LDS hand-over of the accumulators.  Nothing is fetched from device
@@ -951,7 +955,7 @@ constexpr int FC_LDS_BYTES = 48 * 1024;     // islands of up to 2048 (f32) / 102
 // (WAVE_ISLAND_ROWS, dmx_internal.hpp: islands of up to that many rows are solved by one wavefront with the rows in registers;
 //  such an island has at most 2 x 256 bodies, which always fit the LDS above)
 
-// REGS: islands of up to WG x 8 (f32) / WG x 4 (f64) rows keep them in registers for the sweeps (wg_island_sweeps); a separate
+// REGS: islands of up to WG x 12 (f32) / WG x 6 (f64) rows keep them in registers for the sweeps (wg_island_sweeps); a separate
 // instantiation, so that the streaming forms keep their register budget
 template <class T, int WG, bool REGS>
 __device__ __forceinline__ void solve_island_wg_body(T *__restrict__ S, const uint8_t *__restrict__ bflags,
@@ -1028,14 +1032,17 @@ __device__ __forceinline__ void solve_island_wg_body(T *__restrict__ S, const ui
         else resid = wave_island_sweeps<T, WAVE_ISLAND_ROWS / 64>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds, eager);
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) bs[(size_t)k * BW_COUNT + BW_FC + j] = fc_lds[6 * k + j];
-    } else if (REGS && use_lds && m <= WG * (sizeof(T) == 4 ? 8 : 4)) {
+    } else if (REGS && use_lds && m <= WG * REGS_ROWS_PER_THREAD<T>) {
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) fc_lds[6 * k + j] = bs[(size_t)k * BW_COUNT + BW_FC + j];
         __syncthreads();
         const int *row_level = I.row_level + lev_off[0], *lev_rows = I.lev_rows + lev_off[0];
+        // (rows per thread as a template parameter: 32 registers a row in f32, 64 in f64 -- of a lane's 512 at one wave per SIMD)
         if (m <= 2 * WG) resid = wg_island_sweeps<T, 2, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
-        else if (m <= 4 * WG || sizeof(T) == 8) resid = wg_island_sweeps<T, 4, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
-        else resid = wg_island_sweeps<T, sizeof(T) == 4 ? 8 : 4, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
+        else if (m <= 4 * WG) resid = wg_island_sweeps<T, 4, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
+        else if (m <= 6 * WG || sizeof(T) == 8) resid = wg_island_sweeps<T, 6, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
+        else if (m <= 8 * WG) resid = wg_island_sweeps<T, sizeof(T) == 4 ? 8 : 6, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
+        else resid = wg_island_sweeps<T, REGS_ROWS_PER_THREAD<T>, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
         __syncthreads();
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) bs[(size_t)k * BW_COUNT + BW_FC + j] = fc_lds[6 * k + j];
@@ -1386,7 +1393,7 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
         size_t lds = (size_t)lds_bodies * 6 * sizeof(T);
         // a launch whose largest island has more rows than one wavefront holds but few enough for a workgroup's registers (and not
         // thousands of islands: the form runs one workgroup per compute unit) keeps every island's rows in registers for the sweeps
-        const int regs_rows = 256 * (sizeof(T) == 4 ? 8 : 4);
+        const int regs_rows = 256 * REGS_ROWS_PER_THREAD<T>;
         if (I.big_max_rows > WAVE_ISLAND_ROWS && I.big_max_rows <= regs_rows && I.n_big <= 1024) {
             hipLaunchKernelGGL((solve_island_wg<T, 256, true>), dim3((unsigned)I.n_big), dim3(256), lds, st, S, bflags, stride, I, P, diag, lds_bodies,
                                (const ExactCounts *)nullptr, 0);

@@ -1,8 +1,8 @@
 """One large island: the reference's own scene shape (static floor + walls, a pile of boxes and spheres: main.c:115-121, 502-521)
 at sizes where the pile is ONE island of more rows than a wavefront holds.  Covers, bit for bit against the oracle:
   * level schedules built by a workgroup (dmx_exact.hip: levels_coop) in both pipelines;
-  * the island's rows kept in registers by a workgroup for the sweeps (dmx_islands.hip: wg_island_sweeps, 2 / 4 / 8 rows a thread);
-  * past 2 048 rows, the streamed form (schedule in LDS, rows fetched two level steps ahead)."""
+  * the island's rows kept in registers by a workgroup for the sweeps (dmx_islands.hip: wg_island_sweeps, 2 ... 12 rows a thread);
+  * past 3 072 rows, the streamed form (schedule in LDS, rows fetched two level steps ahead)."""
 import numpy as np
 import pytest
 
@@ -48,6 +48,12 @@ def test_pile_of_four_hundred_in_the_pen(dtype):
     1 024 rows) the later ticks stream"""
     most, st = _run_both(400, dtype, 260)
     assert most * 3 > 1024 and st["pair_ticks"] > 100
+
+
+def test_pile_of_the_reference_s_maximum():
+    """512 bodies -- MAX_BODIES in the reference (inc/body.h:6): 2 000-2 600 rows once they are down, 12 rows a thread in f32"""
+    most, st = _run_both(512, "float32", 280)
+    assert most * 3 > 1536
 
 
 def test_pile_of_a_thousand_streams_its_rows():
