@@ -196,6 +196,81 @@ __global__ __launch_bounds__(256) void ex_pair_count(const T *__restrict__ S, co
                                                                blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, stage);
 }
 
+// ---- 1b. the same count by a WAVEFRONT per body, for launches of a few thousand bodies: a lane per candidate instead of a lane
+// per body.  In a crowded pen every body's nine columns hold every other body -- a lane walking 400 candidates through the
+// buckets is a chain of a hundred dependent L2 round trips (94 us for 400 bodies) while the chip idles; here the nine columns'
+// counts are fetched together, the candidates are numbered across the columns and dealt to the lanes (two dependent loads each:
+// the item, its record), hits are ranked by ballots.  Same pc / inpair / stage as st_pair_count (the staged partners in another
+// order: the write pass sorts them).
+template <class T>
+__global__ __launch_bounds__(256) void ex_pair_count_wave(const T *__restrict__ S, const uint8_t *__restrict__ gtype, int64_t n_active,
+                                                          GridParams<T> G, uint64_t *__restrict__ pc, uint8_t *__restrict__ inpair,
+                                                          ExactCounts *__restrict__ C, int32_t *__restrict__ cross_list,
+                                                          int32_t *__restrict__ stage)
+{
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n_active; i += (int64_t)gridDim.x * 4) {      // wave-uniform
+        uint32_t owned = 0, any = 0;
+        const int gti = gtype[i];
+        if (gti != GEOM_NONE) {
+            const GridRec<T> me = G.rec[i];
+            // lanes 0..8: their column's bucket and its count; everyone: the running totals
+            uint32_t myh = 0, mycnt = 0;
+            if (lane < 9) {
+                myh = cell_hash(me.ix + (lane % 3) - 1, me.iz + (lane / 3) - 1, G.mask, G.xbits);
+                mycnt = G.count[myh];
+                if (mycnt > (uint32_t)G.cap) mycnt = (uint32_t)G.cap;
+            }
+            uint32_t start[10], hh[9];
+            start[0] = 0;
+#pragma unroll
+            for (int c = 0; c < 9; c++) { hh[c] = __shfl(myh, c, 64); start[c + 1] = start[c] + __shfl(mycnt, c, 64); }
+            const uint32_t total = start[9];
+            for (uint32_t u0 = 0; u0 < total; u0 += 64) {
+                const uint32_t u = u0 + lane;
+                bool hit = false;
+                int64_t j = -1;
+                if (u < total) {
+                    int c = 0;
+#pragma unroll
+                    for (int q = 1; q < 9; q++) c += u >= start[q] ? 1 : 0;
+                    uint32_t hb = hh[0], sb = start[0];
+#pragma unroll
+                    for (int q = 1; q < 9; q++) if (c == q) { hb = hh[q]; sb = start[q]; }
+                    j = G.items[(size_t)hb * G.cap + (u - sb)];
+                    if (j != i) {
+                        const GridRec<T> o = G.rec[j];
+                        const int cx = me.ix + (c % 3) - 1, cz = me.iz + (c / 3) - 1;
+                        hit = o.ix == cx && o.iz == cz && classes_collide(gti, gtype[j], G.class_pairs) &&
+                              !(o.lo[0] > me.hi[0] || me.lo[0] > o.hi[0] || o.lo[1] > me.hi[1] || me.lo[1] > o.hi[1] ||
+                                o.lo[2] > me.hi[2] || me.lo[2] > o.hi[2]);
+                    }
+                }
+                if (__ballot(hit) != 0ull) any = 1;
+                if (hit && j >= n_active) {
+                    if (atomicOr(&C->cross, 1u) == 0u) { C->cross_a = (uint32_t)i; C->cross_b = (uint32_t)j; }
+                    const uint32_t at = atomicAdd(&C->ncross, 1u);
+                    if (at < EX_CROSS_CAP) { cross_list[2 * at] = (int32_t)i; cross_list[2 * at + 1] = (int32_t)j; }
+                }
+                const bool mine = hit && j < n_active && j > i;
+                const unsigned long long mb = __ballot(mine);
+                if (mine && stage != nullptr) {
+                    const uint32_t r = owned + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+                    if (r < (uint32_t)EX_STAGE_PARTNERS) stage[(size_t)i * EX_STAGE_PARTNERS + r] = (int32_t)j;
+                }
+                owned += (uint32_t)__popcll(mb);
+            }
+            if (G.n_static > 0) {
+                bool meets = false;
+                for (int s0 = 0; s0 < G.n_static; s0 += 64) meets = meets || (s0 + lane < G.n_static && rec_meets_static(me, G.sbox + (s0 + lane) * SBOX_REALS));
+                const int ns = __popcll(__ballot(meets));          // (at most 64 static boxes: one pass)
+                if (G.static_fast ? (ns >= 2 || (ns >= 1 && G.plane_on)) : ns >= 1) any = 1;
+            }
+        }
+        if (lane == 0) { pc[i] = ((uint64_t)owned << 32) | any; inpair[i] = (uint8_t)any; }
+    }
+}
+
 // ---- 2. pairs in canonical order, the involved bodies ascending, union-find initialised ----------------------------
 // inc = inclusive scan of pc.  Body i owns pairs [hi(exc), hi(exc) + owned) and, if involved, is entry lo(exc) of `inv`.
 template <class T, class W, class ST = uint16_t, int NST = EXS_PARTNERS>
@@ -1135,7 +1210,13 @@ hipError_t launch_exact_pairs(const T *S, const uint8_t *gtype, int64_t n_active
                               const ExactBuffers<T> &B, const ExactCaps &cap, hipStream_t st)
 {
     size_t tb = B.temp_bytes;          // (B.counts was zeroed by the caller, with the grid)
-    hipLaunchKernelGGL((ex_pair_count<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inpair, B.counts, B.cross_list, B.stage);
+    // a few thousand bodies: a wavefront per body (a lane per candidate); more: a lane per body
+    static const bool wave_on = [] { const char *e = getenv("DMX_PAIR_COUNT_WAVE"); return !(e && atoi(e) == 0); }();
+    if (wave_on && n_active <= 8192 && G.n_static <= 64)
+        hipLaunchKernelGGL((ex_pair_count_wave<T>), dim3((unsigned)((n_active + 3) / 4)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inpair, B.counts,
+                           B.cross_list, B.stage);
+    else
+        hipLaunchKernelGGL((ex_pair_count<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inpair, B.counts, B.cross_list, B.stage);
     EX_TRY(rocprim::inclusive_scan(B.temp, tb, B.pc, B.inc, (size_t)n_active, rocprim::plus<uint64_t>(), st));
     hipLaunchKernelGGL((ex_pair_write<T>), dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, S, gtype, n_active, G, B.pc, B.inc,
                        B.pairs, B.inv, B.parent, cap, B.counts, B.stage);
