@@ -114,7 +114,8 @@ template <class T> struct LdsGridWalk {
     const GridRec<T> *rec_g;         // the body's own record comes from device memory (one read, before the walk)
     const CellRec<T> *cr; const uint32_t *start; const uint8_t *gtype;
     uint32_t mask; int xbits; uint32_t class_pairs;
-    template <class F> __device__ __forceinline__ void operator()(int64_t i, F f) const
+    // (sub, K): this caller is lane `sub` of K that share body i -- it takes every K-th pair of candidates of every run
+    template <class F> __device__ __forceinline__ void operator()(int64_t i, F f, uint32_t sub = 0, uint32_t K = 1) const
     {
         const GridRec<T> me = rec_g[i];
         const int gti = gtype[i];
@@ -136,7 +137,7 @@ template <class T> struct LdsGridWalk {
 #pragma unroll
         for (int c = 0; c < 9; c++) {
             const uint32_t key = ((uint32_t)(me.ix + (c % 3) - 1) & 0xffffu) | ((uint32_t)(me.iz + (c / 3) - 1) << 16);
-            for (uint32_t k = a[c]; k < e[c]; k += 2) {
+            for (uint32_t k = a[c] + 2 * sub; k < e[c]; k += 2 * K) {
                 const bool two = k + 1 < e[c];
                 const CellRec<T> o0 = cr[k], o1 = cr[two ? k + 1 : k];
                 test(o0, key);
@@ -1016,6 +1017,8 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gt
     CellRec<T> *cr = reinterpret_cast<CellRec<T> *>(exs_lds);                              // [n] records sorted by cell
     uint32_t *start = reinterpret_cast<uint32_t *>(cr + (LG ? n : 0));                     // [cells + 1]
     uint16_t *staged = reinterpret_cast<uint16_t *>(start + (LG ? cells + 1u : 0u));       // [n EXS_PARTNERS] partners above a body
+    uint32_t *own_l = reinterpret_cast<uint32_t *>(staged + (LG ? (size_t)n * EXS_PARTNERS : 0));    // [n] partners above it, counted by several lanes
+    uint8_t *any_l = reinterpret_cast<uint8_t *>(own_l + (LG ? n : 0));                     // [n] in any pair at all
     EXS_STAMP();
     if (LG) { for (uint32_t k = tid; k <= cells; k += EXS_WG) start[k] = 0u; }
     else { for (uint32_t k = tid; k <= G.mask; k += EXS_WG) G.count[k] = 0u; }
@@ -1079,7 +1082,43 @@ __global__ __launch_bounds__(EXS_WG) void ex_small_front(T *S, const uint8_t *gt
     EXS_STAMP();
     const LdsGridWalk<T> lw{ G.rec, cr, start, gtype, G.mask, G.xbits, G.class_pairs };
     const GridWalk<T> gw{ S, gtype, G };
-    if (LG) st_pair_count<T>(lw, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG, staged);
+    // a scene of far fewer bodies than the workgroup has lanes (a pile in the pen): K lanes share a body's walk -- in a crowded pen
+    // every body's nine runs hold every other body, and one lane's walk over them is the stage's duration
+    uint32_t K = 1;
+    while (LG && K < 32u && (uint64_t)n_active * 2u * K <= (uint64_t)EXS_WG) K *= 2u;
+    if (LG && K > 1u) {
+        for (int64_t i = tid; i < n_active; i += EXS_WG) { own_l[i] = 0u; any_l[i] = 0; }
+        __syncthreads();
+        for (uint64_t idx = tid; idx < (uint64_t)n_active * K; idx += EXS_WG) {
+            const int64_t i = (int64_t)(idx / K);
+            if (gtype[i] == GEOM_NONE) continue;
+            lw(i, [&](int64_t j) {
+                any_l[i] = 1;
+                if (j >= n_active) {
+                    if (atomicOr(&C->cross, 1u) == 0u) { C->cross_a = (uint32_t)i; C->cross_b = (uint32_t)j; }
+                    const uint32_t at = atomicAdd(&C->ncross, 1u);
+                    if (at < EX_CROSS_CAP) { B.cross_list[2 * at] = (int32_t)i; B.cross_list[2 * at + 1] = (int32_t)j; }
+                } else if (j > i) {
+                    const uint32_t r = atomicAdd(&own_l[i], 1u);
+                    if (r < (uint32_t)EXS_PARTNERS) staged[(size_t)i * EXS_PARTNERS + r] = (uint16_t)j;
+                }
+            }, (uint32_t)(idx % K), K);
+        }
+        __syncthreads();
+        for (int64_t i = tid; i < n_active; i += EXS_WG) {
+            uint32_t any = any_l[i];
+            if (gtype[i] != GEOM_NONE && G.n_static > 0) {         // (st_pair_count's rule for bodies at static boxes)
+                const GridRec<T> me = G.rec[i];
+                int ns = 0;
+                for (int s2 = 0; s2 < G.n_static; s2++)
+                    if (rec_meets_static(me, G.sbox + s2 * SBOX_REALS)) ns++;
+                if (G.static_fast ? (ns >= 2 || (ns >= 1 && G.plane_on)) : ns >= 1) any = 1;
+            }
+            B.pc[i] = ((uint64_t)own_l[i] << 32) | any;
+            B.inpair[i] = (uint8_t)any;
+        }
+    }
+    else if (LG) st_pair_count<T>(lw, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG, staged);
     else    st_pair_count<T, GridWalk<T>, int32_t, EX_STAGE_PARTNERS>(gw, gtype, n_active, G, B.pc, B.inpair, C, B.cross_list, tid, EXS_WG, B.stage);
     __syncthreads(); EXS_STAMP();
     block_scan_inclusive<uint64_t>(B.pc, B.inc, (uint32_t)n_active, wt); EXS_STAMP();
@@ -1289,7 +1328,7 @@ size_t exact_small_lds_bytes(int64_t n, uint32_t grid_mask, size_t real_bytes)
     static const bool on = [] { const char *e = getenv("DMX_SMALL_LDS_GRID"); return !(e && atoi(e) == 0); }();
     if (!on || n > 65535) return 0;
     const size_t rec = real_bytes == 4 ? sizeof(CellRec<float>) : sizeof(CellRec<double>);
-    size_t b = (size_t)n * rec + ((size_t)grid_mask + 2) * 4 + (size_t)n * EXS_PARTNERS * 2;
+    size_t b = (size_t)n * rec + ((size_t)grid_mask + 2) * 4 + (size_t)n * EXS_PARTNERS * 2 + (size_t)n * 5;
     b = (b + 15) & ~(size_t)15;
     return b <= 150 * 1024 ? b : 0;        // of the CU's 160 KiB; the kernel's static LDS is a few hundred bytes
 }
