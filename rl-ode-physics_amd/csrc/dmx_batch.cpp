@@ -92,6 +92,15 @@ extern "C" int dmxBatchCreate(dmxBatchID *out, int64_t n, int precision, int dev
     if (const char *v = getenv("DMX_NT")) b->nt = atoi(v);
     if (const char *v = getenv("DMX_OOP")) b->oop = atoi(v);
     b->prof_on = getenv("DMX_HOST_PROFILE") != nullptr;
+    {
+        // every translation unit's code object now, not at the first tick that launches one of its kernels (DMX_PRELOAD=0: lazily)
+        static const bool preload = [] { const char *e = getenv("DMX_PRELOAD"); return !(e && atoi(e) == 0); }();
+        if (preload) {
+            const int rb = b->precision == DMX_F32 ? 4 : 8;
+            (void)dmx::dmx_touch_kernels(rb); (void)dmx::dmx_touch_islands(rb); (void)dmx::dmx_touch_broadphase(rb);
+            (void)dmx::dmx_touch_narrow(rb); (void)dmx::dmx_touch_exact(rb);
+        }
+    }
     if (const char *v = getenv("DMX_LAZY_CHUNKS")) b->lazy_chunks = atoi(v) != 0;
     if (const char *v = getenv("DMX_STATIC_FAST")) b->static_fast = atoi(v) != 0;
     int rc = DMX_OK;

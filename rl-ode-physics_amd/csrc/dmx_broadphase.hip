@@ -148,4 +148,25 @@ hipError_t launch_bp_safe_zone(T *S, const uint8_t *gtype, int64_t stride, int64
 DMX_BP_INST(float)
 DMX_BP_INST(double)
 
+// HIP loads a translation unit's code object at the first launch of one of its kernels -- a couple of milliseconds each, which an
+// interactive caller would meet as a hitch at the first tick that needs the exact pipeline.  dmxBatchCreate asks for one
+// kernel's attributes per unit instead (dmx_preload_code, dmx_batch.cpp): the load happens there.
+hipError_t dmx_touch_broadphase(int real_bytes)
+{
+    // (the unit's code object, and -- what costs more -- each kernel's own first-use set-up: every kernel an exact tick or a fused
+    //  tick may launch, in the batch's precision)
+    hipFuncAttributes a;
+    hipError_t e = hipSuccess;
+    auto touch = [&](const void *k) { const hipError_t r = hipFuncGetAttributes(&a, k); if (r != hipSuccess) e = r; };
+    touch((const void *)&bp_clear);
+    if (real_bytes == 4) {
+        touch((const void *)&bp_insert<float>);
+        touch((const void *)&bp_safe_zone<float>);
+    } else {
+        touch((const void *)&bp_insert<double>);
+        touch((const void *)&bp_safe_zone<double>);
+    }
+    return e;
+}
+
 }  // namespace dmx

@@ -1424,4 +1424,46 @@ template hipError_t launch_exact_group<float>(const float *, const uint8_t *, in
 template hipError_t launch_exact_group<double>(const double *, const uint8_t *, int64_t, const GridParams<double> &, const StepParams<double> &,
                                                const ExactBuffers<double> &, const ExactCaps &, int, int, hipStream_t);
 
+// HIP loads a translation unit's code object at the first launch of one of its kernels -- a couple of milliseconds each, which an
+// interactive caller would meet as a hitch at the first tick that needs the exact pipeline.  dmxBatchCreate asks for one
+// kernel's attributes per unit instead (dmx_preload_code, dmx_batch.cpp): the load happens there.
+hipError_t dmx_touch_exact(int real_bytes)
+{
+    // (the unit's code object, and -- what costs more -- each kernel's own first-use set-up: every kernel an exact tick or a fused
+    //  tick may launch, in the batch's precision)
+    hipFuncAttributes a;
+    hipError_t e = hipSuccess;
+    auto touch = [&](const void *k) { const hipError_t r = hipFuncGetAttributes(&a, k); if (r != hipSuccess) e = r; };
+    touch((const void *)&ex_fill_i32);
+    touch((const void *)&ex_unite);
+    touch((const void *)&ex_flatten);
+    touch((const void *)&ex_levels);
+    touch((const void *)&ex_levels_coop);
+    touch((const void *)&ex_publish);
+    touch((const void *)&ex_bounds);
+    touch((const void *)&ex_fill);
+    if (real_bytes == 4) {
+        touch((const void *)&ex_small_front<float, true>);
+        touch((const void *)&ex_small_front<float, false>);
+        touch((const void *)&ex_small_back<float, 2>);
+        touch((const void *)&ex_small_back<float, 4>);
+        touch((const void *)&ex_small_back<float, 8>);
+        touch((const void *)&ex_narrow<float>);
+        touch((const void *)&ex_pair_count<float>);
+        touch((const void *)&ex_pair_count_wave<float>);
+        touch((const void *)&ex_pair_write<float>);
+    } else {
+        touch((const void *)&ex_small_front<double, true>);
+        touch((const void *)&ex_small_front<double, false>);
+        touch((const void *)&ex_small_back<double, 2>);
+        touch((const void *)&ex_small_back<double, 4>);
+        touch((const void *)&ex_small_back<double, 8>);
+        touch((const void *)&ex_narrow<double>);
+        touch((const void *)&ex_pair_count<double>);
+        touch((const void *)&ex_pair_count_wave<double>);
+        touch((const void *)&ex_pair_write<double>);
+    }
+    return e;
+}
+
 }  // namespace dmx

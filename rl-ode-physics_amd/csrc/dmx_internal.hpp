@@ -242,4 +242,8 @@ template <class T>
 hipError_t launch_soa_to_aos(const T *S, int64_t stride, int comp0, int k, int64_t first, int64_t count, T *aos,
                              hipStream_t st);
 
+// one per translation unit with device code: forces the unit's code object to load (see dmx_kernels.hip)
+hipError_t dmx_touch_kernels(int real_bytes); hipError_t dmx_touch_islands(int real_bytes); hipError_t dmx_touch_broadphase(int real_bytes);
+hipError_t dmx_touch_narrow(int real_bytes); hipError_t dmx_touch_exact(int real_bytes);
+
 }  // namespace dmx

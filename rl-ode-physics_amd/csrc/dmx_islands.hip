@@ -1466,4 +1466,34 @@ template hipError_t launch_islands<float>(float *, const uint8_t *, int64_t, con
 template hipError_t launch_islands<double>(double *, const uint8_t *, int64_t, const IslandSet<double> &,
                                            const StepParams<double> &, StepDiag *, hipStream_t);
 
+// HIP loads a translation unit's code object at the first launch of one of its kernels -- a couple of milliseconds each, which an
+// interactive caller would meet as a hitch at the first tick that needs the exact pipeline.  dmxBatchCreate asks for one
+// kernel's attributes per unit instead (dmx_preload_code, dmx_batch.cpp): the load happens there.
+hipError_t dmx_touch_islands(int real_bytes)
+{
+    // (the unit's code object, and -- what costs more -- each kernel's own first-use set-up: every kernel an exact tick or a fused
+    //  tick may launch, in the batch's precision)
+    hipFuncAttributes a;
+    hipError_t e = hipSuccess;
+    auto touch = [&](const void *k) { const hipError_t r = hipFuncGetAttributes(&a, k); if (r != hipSuccess) e = r; };
+    if (real_bytes == 4) {
+        touch((const void *)&solve_islands<float>);
+        touch((const void *)&solve_singles<float>);
+        touch((const void *)&solve_singles_lds<float>);
+        touch((const void *)&solve_island_wg<float, 64, false>);
+        touch((const void *)&solve_island_wg<float, 256, false>);
+        touch((const void *)&solve_island_wg<float, 256, true>);
+        touch((const void *)&solve_islands_and_step<float>);
+    } else {
+        touch((const void *)&solve_islands<double>);
+        touch((const void *)&solve_singles<double>);
+        touch((const void *)&solve_singles_lds<double>);
+        touch((const void *)&solve_island_wg<double, 64, false>);
+        touch((const void *)&solve_island_wg<double, 256, false>);
+        touch((const void *)&solve_island_wg<double, 256, true>);
+        touch((const void *)&solve_islands_and_step<double>);
+    }
+    return e;
+}
+
 }  // namespace dmx

@@ -853,4 +853,32 @@ hipError_t launch_soa_to_aos(const T *S, int64_t stride, int comp0, int k, int64
 DMX_INSTANTIATE(float)
 DMX_INSTANTIATE(double)
 
+// HIP loads a translation unit's code object at the first launch of one of its kernels -- a couple of milliseconds each, which an
+// interactive caller would meet as a hitch at the first tick that needs the exact pipeline.  dmxBatchCreate asks for one
+// kernel's attributes per unit instead (dmx_preload_code, dmx_batch.cpp): the load happens there.
+hipError_t dmx_touch_kernels(int real_bytes)
+{
+    // (the unit's code object, and -- what costs more -- each kernel's own first-use set-up: every kernel an exact tick or a fused
+    //  tick may launch, in the batch's precision)
+    hipFuncAttributes a;
+    hipError_t e = hipSuccess;
+    auto touch = [&](const void *k) { const hipError_t r = hipFuncGetAttributes(&a, k); if (r != hipSuccess) e = r; };
+    if (real_bytes == 4) {
+        touch((const void *)&integrate_free<float, 1, false, 1, false>);
+        touch((const void *)&step_plane<float, false, 1, 4>);
+        touch((const void *)&step_plane<float, false, 2, 4>);
+        touch((const void *)&step_contacts<float, false, 1, 8, true>);
+        touch((const void *)&check_zones<float>);
+        touch((const void *)&copy_components<float>);
+    } else {
+        touch((const void *)&integrate_free<double, 1, false, 1, false>);
+        touch((const void *)&step_plane<double, false, 1, 4>);
+        touch((const void *)&step_plane<double, false, 2, 4>);
+        touch((const void *)&step_contacts<double, false, 1, 8, true>);
+        touch((const void *)&check_zones<double>);
+        touch((const void *)&copy_components<double>);
+    }
+    return e;
+}
+
 }  // namespace dmx

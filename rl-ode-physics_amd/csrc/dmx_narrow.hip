@@ -177,4 +177,22 @@ hipError_t launch_np_static(const T *S, const uint8_t *gtype, int64_t n, const S
 DMX_NP_INST(float)
 DMX_NP_INST(double)
 
+// HIP loads a translation unit's code object at the first launch of one of its kernels -- a couple of milliseconds each, which an
+// interactive caller would meet as a hitch at the first tick that needs the exact pipeline.  dmxBatchCreate asks for one
+// kernel's attributes per unit instead (dmx_preload_code, dmx_batch.cpp): the load happens there.
+hipError_t dmx_touch_narrow(int real_bytes)
+{
+    // (the unit's code object, and -- what costs more -- each kernel's own first-use set-up: every kernel an exact tick or a fused
+    //  tick may launch, in the batch's precision)
+    hipFuncAttributes a;
+    hipError_t e = hipSuccess;
+    auto touch = [&](const void *k) { const hipError_t r = hipFuncGetAttributes(&a, k); if (r != hipSuccess) e = r; };
+    if (real_bytes == 4) {
+        touch((const void *)&np_static<float>);
+    } else {
+        touch((const void *)&np_static<double>);
+    }
+    return e;
+}
+
 }  // namespace dmx
