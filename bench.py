@@ -151,7 +151,9 @@ def profile_evidence(kind, dtype, n):
     have, want = o.get("kernels_blob"), kernel_source_id()
     if have != want:
         return None, None, f"stale: measured on dmx_kernels.hip {str(have)[:12]}, this build is {want[:12]}"
-    return o.get("traffic_bytes_per_launch"), o.get("rocprof_kernel_us"), f"profiles/{os.path.basename(path)}"
+    return (o.get("traffic_bytes_per_launch"), o.get("rocprof_kernel_us"),
+            f"profiles/{os.path.basename(path)} (rocprofv3 passes over this command on this kernel source, committed with the repository: another "
+            f"run, possibly another box -- `stream_us_per_launch` is this run's own figure, boxes differ by a few per cent)")
 
 
 # ------------------------------------------------------------------------------------------------------------
