@@ -70,6 +70,9 @@ enum { DMX_CONTACT_BOUNCE = 0x004 };
 
 /* ---- lifecycle: dInitODE/dWorldCreate/dHashSpaceCreate/dJointGroupCreate (main.c:94-98) */
 int dmxDeviceCount(void);                 /* >=1 or DMX_ENODEVICE; never touches a CPU path */
+/* (Creation also asks the HIP runtime for the attributes of every kernel a tick of this precision may launch: code objects and
+ * per-kernel set-up load here, ~15 ms once per process and precision, rather than as a hitch at the first tick that needs the
+ * exact pipeline -- DMX_PRELOAD=0 in the environment leaves that lazy.) */
 int dmxBatchCreate(dmxBatchID *out, int64_t n_bodies, int precision, int device);
 int dmxBatchDestroy(dmxBatchID b);        /* dWorldDestroy / dCloseODE  main.c:258-268 */
 int64_t dmxBatchBodyCount(dmxBatchID b);
