@@ -595,8 +595,8 @@ def rank_main(a):
     if world > 1 and config == 4:
         out["config"]["target_claim"] = (
             "north_star's >= 6x at 8 GPUs is judged on THIS line (value at N vs value at N = 1, both one launch per tick, ticks_per_launch 1). "
-            "A 131 072-body slab is launch-bound (~3.8-4.2 us per tick against 19.5 us for the whole scene on one GPU), so this line is "
-            "expected near 4.5-5x; `fused.ticks_per_launch_2` is the same loop with two ticks per launch -- what the reference's own loop "
+            "A 131 072-body slab is launch-bound (4.2 us per tick without, 4.7-4.8 us with the collision proof riding along, against "
+            "19.5-19.9 us for the whole scene on one GPU; scripts/time_small_slab.py), so this line is expected near 4-4.5x; `fused.ticks_per_launch_2` is the same loop with two ticks per launch -- what the reference's own loop "
             "observes, since it reads poses every other physics tick (main.c:208, 218) -- and is the variant expected past 6x. Both are "
             "reported; neither is substituted for the other.")
 
