@@ -14,6 +14,7 @@
 // the fused register-resident path (step_plane).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include "dmx_internal.hpp"
 #include "dmx_exact.hpp"
 #include "dmx_math.hpp"
@@ -910,7 +911,8 @@ __device__ __forceinline__ double wave_island_contact_sweeps(T *rows, const int 
 
 // rows a thread of the register-resident form holds at most: a workgroup of 256 owns up to 3 072 rows in f32, 1 536 in f64 (the
 // reference's pen holds at most 512 bodies, body.h:6 -- their pile is 2 000-2 600 rows)
-template <class T> constexpr int REGS_ROWS_PER_THREAD = sizeof(T) == 4 ? 12 : 6;
+template <class T> constexpr int REGS_ROWS = sizeof(T) == 4 ? 3072 : 1536;      // rows a workgroup of the register form holds at most
+template <class T, int WG> constexpr int REGS_ROWS_PER_THREAD = REGS_ROWS<T> / WG;
 
 // The sweeps of a large island by a whole workgroup with every row in REGISTERS: the row at position t of the island's level
 // lists (rows grouped by level, lev_rows) belongs to thread t mod WG, RPL rows per thread, for all twenty sweeps; a level step is
@@ -1032,17 +1034,19 @@ __device__ __forceinline__ void solve_island_wg_body(T *__restrict__ S, const ui
         else resid = wave_island_sweeps<T, WAVE_ISLAND_ROWS / 64>(rows, jb, row_level, m, nlev, P.iters, tid, fc_lds, eager);
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) bs[(size_t)k * BW_COUNT + BW_FC + j] = fc_lds[6 * k + j];
-    } else if (REGS && use_lds && m <= WG * REGS_ROWS_PER_THREAD<T>) {
+    } else if (REGS && use_lds && m <= REGS_ROWS<T>) {
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) fc_lds[6 * k + j] = bs[(size_t)k * BW_COUNT + BW_FC + j];
         __syncthreads();
         const int *row_level = I.row_level + lev_off[0], *lev_rows = I.lev_rows + lev_off[0];
         // (rows per thread as a template parameter: 32 registers a row in f32, 64 in f64 -- of a lane's 512 at one wave per SIMD)
+        constexpr int RMAX = REGS_ROWS_PER_THREAD<T, WG>;          // 6 (f32) / 3 (f64) at 512 threads, 12 / 6 at 256
         if (m <= 2 * WG) resid = wg_island_sweeps<T, 2, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
-        else if (m <= 4 * WG) resid = wg_island_sweeps<T, 4, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
-        else if (m <= 6 * WG || sizeof(T) == 8) resid = wg_island_sweeps<T, 6, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
-        else if (m <= 8 * WG) resid = wg_island_sweeps<T, sizeof(T) == 4 ? 8 : 6, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
-        else resid = wg_island_sweeps<T, REGS_ROWS_PER_THREAD<T>, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
+        else if (m <= 3 * WG || RMAX <= 3) resid = wg_island_sweeps<T, RMAX < 3 ? RMAX : 3, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
+        else if (m <= 4 * WG || RMAX <= 4) resid = wg_island_sweeps<T, RMAX < 4 ? RMAX : 4, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
+        else if (m <= 6 * WG || RMAX <= 6) resid = wg_island_sweeps<T, RMAX < 6 ? RMAX : 6, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
+        else if (m <= 8 * WG || RMAX <= 8) resid = wg_island_sweeps<T, RMAX < 8 ? RMAX : 8, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
+        else resid = wg_island_sweeps<T, RMAX, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
         __syncthreads();
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) bs[(size_t)k * BW_COUNT + BW_FC + j] = fc_lds[6 * k + j];
@@ -1393,10 +1397,20 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
         size_t lds = (size_t)lds_bodies * 6 * sizeof(T);
         // a launch whose largest island has more rows than one wavefront holds but few enough for a workgroup's registers (and not
         // thousands of islands: the form runs one workgroup per compute unit) keeps every island's rows in registers for the sweeps
-        const int regs_rows = 256 * REGS_ROWS_PER_THREAD<T>;
-        if (I.big_max_rows > WAVE_ISLAND_ROWS && I.big_max_rows <= regs_rows && I.n_big <= 1024) {
-            hipLaunchKernelGGL((solve_island_wg<T, 256, true>), dim3((unsigned)I.n_big), dim3(256), lds, st, S, bflags, stride, I, P, diag, lds_bodies,
-                               (const ExactCounts *)nullptr, 0);
+        // (512 threads, two waves per SIMD: six rows a thread all in the 256 architectural registers -- at 256 threads the same rows
+        //  are twelve a thread, half of them in accumulator registers that have to be copied out before every use, and twice the
+        //  slots to skip per level; DMX_REGS_WG=256 for that form)
+        static const int regs_wg = [] { const char *e = getenv("DMX_REGS_WG"); return e && atoi(e) == 256 ? 256 : 512; }();
+        if (I.big_max_rows > WAVE_ISLAND_ROWS && I.big_max_rows <= REGS_ROWS<T> && I.n_big <= 1024) {
+            // (f64 rows are 64 registers: three a thread at 512 threads spill; 256 threads, six a thread, do not.  Up to 1 024 rows
+            //  256 threads hold them in four slots a thread without the accumulator half, and a level step has four waves to
+            //  bring to the barrier, not eight: the pen 96 bodies 264 vs 270 us, 400 bodies 645 vs 583, 512 bodies 961 vs 793)
+            if (regs_wg == 512 && sizeof(T) == 4 && I.big_max_rows > 1024)
+                hipLaunchKernelGGL((solve_island_wg<T, 512, true>), dim3((unsigned)I.n_big), dim3(512), lds, st, S, bflags, stride, I, P, diag, lds_bodies,
+                                   (const ExactCounts *)nullptr, 0);
+            else
+                hipLaunchKernelGGL((solve_island_wg<T, 256, true>), dim3((unsigned)I.n_big), dim3(256), lds, st, S, bflags, stride, I, P, diag, lds_bodies,
+                                   (const ExactCounts *)nullptr, 0);
         } else {
             // room for an island's level schedule behind the accumulators (offsets + row lists; big_rows_total bounds any one island's):
             // taken when it is modest -- a few large islands (a pile in the pen) -- not when thousands of small ones share the launch
@@ -1483,6 +1497,7 @@ hipError_t dmx_touch_islands(int real_bytes)
         touch((const void *)&solve_island_wg<float, 64, false>);
         touch((const void *)&solve_island_wg<float, 256, false>);
         touch((const void *)&solve_island_wg<float, 256, true>);
+        touch((const void *)&solve_island_wg<float, 512, true>);
         touch((const void *)&solve_islands_and_step<float>);
     } else {
         touch((const void *)&solve_islands<double>);
@@ -1491,6 +1506,7 @@ hipError_t dmx_touch_islands(int real_bytes)
         touch((const void *)&solve_island_wg<double, 64, false>);
         touch((const void *)&solve_island_wg<double, 256, false>);
         touch((const void *)&solve_island_wg<double, 256, true>);
+        touch((const void *)&solve_island_wg<double, 512, true>);
         touch((const void *)&solve_islands_and_step<double>);
     }
     return e;
