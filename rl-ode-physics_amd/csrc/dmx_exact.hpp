@@ -40,7 +40,7 @@ struct ExactCounts {
 };
 
 constexpr uint32_t EX_CROSS_CAP = 256;
-constexpr int EX_STAGE_PARTNERS = 16;
+constexpr int EX_STAGE_PARTNERS = 32;      // (a body in a crowded pen has twenty AABB partners above it; past this a body walks again)
 // the speculative island launch reserves LDS for islands of up to this many bodies (a workgroup's accumulators: 6 reals each);
 // a tick with a larger island clears spec_ok and is launched by the host with the island's true size
 constexpr uint32_t EX_SPEC_ISLAND_BODIES = 512;
