@@ -639,6 +639,26 @@ def rank_main(a):
                 out["configs"][f"configs[{cfg - 1}]"] = config_leg(cfg)
             except Exception as e:      # noqa: BLE001 -- a companion leg must not take the headline down; the failure is reported
                 out["configs"][f"configs[{cfg - 1}]"] = {"error": f"{type(e).__name__}: {e}"}
+        # ... and the reference's OWN scene, which BASELINE's configs do not name: its floor and three walls as static boxes
+        # (main.c:115-121) and a pile of the key-M spawner's boxes and spheres (main.c:502-521) -- 400 bodies, and 512 = MAX_BODIES
+        # (inc/body.h:6).  Once down the pile is ONE island: the tick is the exact pipeline + one workgroup's level-scheduled sweeps.
+        out["reference_pen"] = {}
+        for nb_pen in (400, 512):
+            try:
+                psc, pboxes, _ = pkg.scenes.reference_pen(nb_pen)
+                psc = psc.astype(dtype)
+                w = pkg.BatchWorld(psc.n, dtype=dtype, device=cx.device_index)
+                try:
+                    w.load_scene(psc); w.set_static_boxes(pboxes); w.set_gyro_mode(a.gyro)
+                    w.step(H, 240); w.synchronize()             # the bodies are down (and the exact tick's kernels warm)
+                    t0 = time.perf_counter(); w.step(H, 240); w.synchronize(); dtp = time.perf_counter() - t0
+                    out["reference_pen"][f"{nb_pen}_bodies"] = {"ms_per_step": dtp * 1e3 / 240, "value": psc.n * 240 / dtp, "unit": "body-steps/s",
+                                                                "steps": 240, "contacts_last_tick": int(w.last_contact_count()),
+                                                                "collide": str(w.collision_stats())}
+                finally:
+                    w.close()
+            except Exception as e:      # noqa: BLE001
+                out["reference_pen"][f"{nb_pen}_bodies"] = {"error": f"{type(e).__name__}: {e}"}
     if extras and world > 1 and config == 4:
         # the weak-scaled companion: one whole configs[1] slab (1 048 576 bodies) per GPU
         wside = a.side or 1024

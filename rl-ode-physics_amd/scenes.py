@@ -174,6 +174,19 @@ def reference_map():
     ]
 
 
+def reference_pen(n, seed=7, y_range=(3.0, 12.0)):
+    """The reference's own scene as one Scene + its static boxes: reference_map()'s floor and walls, n bodies drawn by the key-M
+    spawner (reference_spawn), boxes first and spheres behind them (the order the batch's classes want).  Returns
+    (scene, static boxes, number of boxes).  m = 1, I = identity as AddBody leaves them (main.c:695-733)."""
+    spawn = reference_spawn(n, seed=seed, y_range=y_range)
+    spawn.sort(key=lambda s: -s[0])
+    k = len(spawn)
+    nb = sum(1 for s in spawn if s[0] == GEOM_BOX)
+    sc = Scene(np.array([s[2] for s in spawn], float), np.tile([1.0, 0, 0, 0], (k, 1)), np.zeros((k, 3)), np.zeros((k, 3)),
+               np.ones((k, 1)), np.ones((k, 3)), np.array([s[1] for s in spawn], float), np.array([s[0] for s in spawn], np.uint8), None)
+    return sc, reference_map(), nb
+
+
 def reference_spawn(n, seed=1, y_range=(20.0, 50.0)):
     """n bodies as the key-M spawner draws them (main.c:504-519): position x,z in [-4,4], y in y_range,
     then Rand_Int(0,2) == 0 -> box with three sides in [0.2,1.0], else sphere with radius in [0.1,0.4];

@@ -64,3 +64,16 @@ def test_box_mass_variant():
     assert np.allclose(s.mass[:, 0], m)
     assert np.allclose(s.inertia[:, 0], m / 12 * (s.sides[:, 1] ** 2 + s.sides[:, 2] ** 2))
     assert np.abs(s.avel).max() <= 1.0 and np.abs(s.avel).max() > 0.5
+
+
+def test_reference_pen_is_the_map_and_the_spawner():
+    """scenes.reference_pen: the reference's floor + walls (main.c:115-121) and n spawned bodies (main.c:502-521), boxes ahead of
+    the spheres, unit mass and identity inertia as AddBody leaves them (main.c:695-733), nobody above MAX_BODIES' pile height"""
+    scenes = pkg.scenes
+    sc, boxes, nb = scenes.reference_pen(64, seed=3)
+    assert sc.n == 64 and len(boxes) == len(scenes.reference_map()) == 4
+    assert (sc.gtype[:nb] == scenes.GEOM_BOX).all() and (sc.gtype[nb:] == scenes.GEOM_SPHERE).all()
+    assert np.all(sc.mass == 1.0) and np.all(sc.inertia == 1.0)
+    assert np.all(np.abs(sc.pos[:, [0, 2]]) <= 4.0) and sc.pos[:, 1].min() >= 3.0 and sc.pos[:, 1].max() <= 12.0
+    drawn = sorted(scenes.reference_spawn(64, seed=3, y_range=(3.0, 12.0)), key=lambda s: -s[0])
+    assert np.allclose(sc.pos, np.array([s[2] for s in drawn]))
