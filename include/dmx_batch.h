@@ -266,12 +266,19 @@ int dmxBatchStepJoints(dmxBatchID b, double h, int64_t n_joints, const dmxContac
 /* Which of ODE's two steppers dmxBatchStepJoints is.  DMX_STEPPER_QUICK (default): dWorldQuickStep, QuickStep's SOR sweeps.
  * DMX_STEPPER_EXACT: dWorldStep, the reference's own call (main.c:213): every island's system
  *   A lambda = b + w,  A = J M^-1 J^T + cfm / h,  lo <= lambda <= hi,  w complementary to lambda
- * -- the same contact rows -- is solved exactly, one workgroup per island (block principal pivoting over a Cholesky of the
- * free block; A is positive definite, so the solution is the one ODE's Dantzig solver reaches).  Cost grows with the cube
- * of an island's rows, as dWorldStep's does; a tick with an island above 4096 rows is stepped with the SOR instead (stderr
- * says so).  dmxBatchStep (the BASELINE configs, which name dWorldQuickStep) is not affected. */
+ * -- the same contact rows -- is solved exactly (block principal pivoting over a Cholesky of the free block; A is positive
+ * definite, so the solution is the one ODE's Dantzig solver reaches): small islands one workgroup each, islands of
+ * DMX_LCP_GRID_ROWS (192) rows or more -- the reference's pen holds up to 512 bodies in one island of 2 000 - 2 600 rows
+ * (main.c:208,213, inc/body.h:6) -- by a grid-wide blocked factorisation on the matrix cores with the rows that can never
+ * clamp eliminated once per tick and the active set carried from tick to tick (csrc/dmx_lcp.hip).  Cost grows with the cube
+ * of an island's rows, as dWorldStep's does; a tick with an island above DMX_MAX_EXACT_ROWS (16 384) rows is stepped with
+ * the SOR instead (stderr says so).  dmxBatchStep (the BASELINE configs, which name dWorldQuickStep) is not affected. */
 enum { DMX_STEPPER_QUICK = 0, DMX_STEPPER_EXACT = 1 };
 int dmxBatchSetStepper(dmxBatchID b, int stepper);
+/* Counters of the grid-wide exact solve since the batch was created: out[0] island solves, [1] pivoting rounds in all,
+ * [2] most rounds in one solve, [3..5] rows / never-clamping rows / bounded rows of the last island solved, [6] rounds that
+ * flipped a single row (Murty's rule), [7] ticks stepped with the SOR because an island exceeded DMX_MAX_EXACT_ROWS. */
+int dmxBatchLcpStats(dmxBatchID b, int64_t out[8]);
 /* The order QuickStep's SOR sweeps an island's rows in (dmxBatchStepJoints, DMX_STEPPER_QUICK).  DMX_ORDER_CREATION (default):
  * the order the contact joints were created in, every sweep -- deterministic, and what lets islands be solved by workgroups
  * under a level schedule.  DMX_ORDER_ODE: what stock ODE does [ODE-recall]: rows numbered in the order its island builder

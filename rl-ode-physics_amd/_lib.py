@@ -24,7 +24,7 @@ BATCH_SYMBOLS = [
     "dmxBatchChunkBegin", "dmxBatchChunkTick", "dmxBatchCheckZonesOnStream", "dmxBatchChunkEnd",
     "dmxBatchChunkCommit", "dmxBatchChunkRollback", "dmxBatchExactTick", "dmxBatchRefreshGhostsOnStream", "dmxBatchSetConvexHull", "dmxBatchChunkTicks", "dmxBatchSetTicksPerLaunch",
     "dmxBatchSetSnapshotMode", "dmxBatchSetStaticBoxes", "dmxBatchSetStepper", "dmxBatchSetConvexHullFaces",
-    "dmxBatchCollisionStatsEx", "dmxBatchFindPairs", "dmxBatchCrossPairs", "dmxBatchSetRowOrder", "dmxBatchSetExactPipeline", "dmxBatchSetStaticPath", "dmxBatchSetClassPairs",
+    "dmxBatchCollisionStatsEx", "dmxBatchFindPairs", "dmxBatchCrossPairs", "dmxBatchSetRowOrder", "dmxBatchLcpStats", "dmxBatchSetExactPipeline", "dmxBatchSetStaticPath", "dmxBatchSetClassPairs",
 ]
 SHARD_SYMBOLS = ["dmxShardRcclUniqueId", "dmxShardCreateRccl", "dmxShardCreate", "dmxShardRun", "dmxShardSettle", "dmxShardStats", "dmxShardDestroy"]
 
@@ -117,6 +117,7 @@ def load():
     sig("dmxShardDestroy", I, P)
     sig("dmxBatchSetStaticBoxes", I, P, C.c_int32, P, P, P)
     sig("dmxBatchSetStepper", I, P, I)
+    sig("dmxBatchLcpStats", I, P, P)
     sig("dmxBatchSetConvexHullFaces", I, P, C.c_int32, P)
     sig("dmxBatchCollisionStatsEx", I, P, C.POINTER(L))
     sig("dmxBatchFindPairs", I, P, C.POINTER(P), C.POINTER(L), C.POINTER(P), C.POINTER(L))

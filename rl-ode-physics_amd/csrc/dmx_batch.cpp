@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "dmx_batch_priv.hpp"
+#include "dmx_lcp.hpp"
 
 // a chunk dmxBatchStep left open is closed (flag read, rollback + replay if need be) before anything observes or changes the batch
 #define SETTLE(b)                                  \
@@ -154,6 +155,7 @@ extern "C" int dmxBatchDestroy(dmxBatchID b)
         for (int k = 1; k < 9; k++) fprintf(stderr, "  front %-18s %7.2f us\n", fn[k], b->exs_acc[k] / (double)b->exs_ticks / 100.0);
         for (int k = 1; k < 9; k++) fprintf(stderr, "  back  %-18s %7.2f us\n", bn[k], b->exs_acc[32 + k] / (double)b->exs_ticks / 100.0);
     }
+    dmx::lcp_grid_free(b);
     if (b->slab) (void)hipFree(b->slab);
     if (b->slab_alt) (void)hipFree(b->slab_alt);
     if (b->gtype) (void)hipFree(b->gtype);
@@ -384,6 +386,13 @@ extern "C" int dmxBatchSetStepper(dmxBatchID b, int stepper)
     if (!b || (stepper != DMX_STEPPER_QUICK && stepper != DMX_STEPPER_EXACT)) return DMX_EINVAL;
     SETTLE(b);
     b->stepper_exact = stepper == DMX_STEPPER_EXACT;
+    return DMX_OK;
+}
+
+extern "C" int dmxBatchLcpStats(dmxBatchID b, int64_t out[8])
+{
+    if (!b || !out) return DMX_EINVAL;
+    dmx::lcp_grid_stats(b, out);
     return DMX_OK;
 }
 

@@ -10,10 +10,10 @@
 #include <numeric>
 
 #include "dmx_batch_priv.hpp"
+#include "dmx_lcp.hpp"
 
 namespace {
 
-constexpr int kMaxExactRows = 4096;      // dWorldStep's exact solve keeps A (m x m) and its factor per island: 2 x 128 MB in f64 at this size
 
 // multi-body islands with at least this many rows get a workgroup and a level schedule (DMX_BIG_ISLAND_ROWS overrides, for
 // tests).  One lane walking an island pays a dependent L2 round trip per row and sweep, so every island with rows is better
@@ -165,6 +165,8 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
                      &lev_rows_h = b->sc_iv[7], &lvl_all = b->sc_iv[8];
     big_h.assign((size_t)ni, -1); big_list_h.clear(); lev_count_h.clear(); lev_off_h.clear(); lev_rows_h.clear(); lvl_all.clear();
     int big_max_bodies = 0, big_max_width = 0, big_rows_total = 0, big_max_rows = 0;
+    std::vector<int> &grid_list = b->sc_grid_list;      // dWorldStep: islands for the grid-wide exact solve
+    grid_list.clear();
     std::vector<int> &island_bodies = b->sc_iv[9];
     island_bodies.assign((size_t)ni, 0);
     for (int s : slots) island_bodies[(size_t)island_of[(size_t)s]]++;
@@ -189,12 +191,13 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
         int rows_total = 0;
         if (exact)
             for (int i = 0; i < ni; i++)
-                if (m_of[(size_t)i] > kMaxExactRows) {
+                if (m_of[(size_t)i] > lcp_max_exact_rows()) {
                     static bool warned = false;
                     if (!warned) fprintf(stderr, "libode_mi355: dWorldStep: an island of %d constraint rows exceeds the exact solver's limit (%d); "
-                                                 "such ticks are stepped with QuickStep's SOR instead\n", m_of[(size_t)i], kMaxExactRows);
+                                                 "such ticks are stepped with QuickStep's SOR instead\n", m_of[(size_t)i], lcp_max_exact_rows());
                     warned = true;
                     exact = false;
+                    lcp_grid_count_fallback(b);
                     break;
                 }
         for (int i = 0; i < ni; i++) {
@@ -202,6 +205,8 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
             if (m_of[(size_t)i] < (exact ? 1 : big_island_rows())) continue;
             // one body with 1..8 contacts: solve_singles' / solve_singles_lds' island (one lane), never a workgroup's
             if (!exact && island_bodies[(size_t)i] == 1 && con_start[(size_t)i + 1] - con_start[(size_t)i] <= 8) continue;
+            // dWorldStep, an island of hundreds of rows or more: the grid-wide solve (dmx_lcp.hip), not one workgroup
+            if (exact && m_of[(size_t)i] >= lcp_grid_threshold()) { grid_list.push_back(i); continue; }
             big_list_h.push_back(i);
             row_base.push_back(rows_total);
             rows_total += m_of[(size_t)i];
@@ -221,6 +226,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
             b->sc_lcp_off[(size_t)nbig] = at;
             lev_count_h.assign((size_t)nbig, 0);
             for (int k = 0; k < nbig; k++) big_h[(size_t)big_list_h[(size_t)k]] = 0;
+            for (int i : grid_list) big_h[(size_t)i] = 0;         // (not the lane-per-island kernel's either)
             rows_total = 0;
         }
         const int nbig_sched = exact ? 0 : nbig;
@@ -417,6 +423,39 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
         HIP_TRY(launch_islands_exact<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, (T *)b->jd_lcp.p,
                                         (const long long *)b->jd_lcp_off.p, (int *)b->jd_lcp_int.p, max_rows, b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));      // sc_lcp_off is pageable host memory: the copy must have read it before the next tick rewrites it
+        if (!grid_list.empty()) {
+            // the large islands, one after the other: per row whether it can ever clamp, and the key its active-set state is
+            // remembered under -- (body pair, ordinal of the contact within the pair this tick, row of the contact)
+            lcp_grid_begin_tick(b);
+            LcpIslandRows R;
+            std::vector<std::pair<uint64_t, int>> &ord = b->sc_pair_ord;
+            for (int isl : grid_list) {
+                R.isl = isl; R.m = b->sc_iv[10][(size_t)isl]; R.row_base = 3 * con_start[(size_t)isl];
+                R.unbounded.assign((size_t)R.m, 0); R.key.assign((size_t)R.m, 0);
+                const int d0 = con_start[(size_t)isl], d1 = con_start[(size_t)isl + 1];
+                ord.clear();
+                for (int d = d0; d < d1; d++) {
+                    const CJ &c = cj[(size_t)con_sorted[(size_t)d]];
+                    ord.push_back({ ((uint64_t)(uint32_t)(c.b1 + 1) << 32) | (uint32_t)(c.b2 + 1), d });
+                }
+                std::stable_sort(ord.begin(), ord.end(), [](const std::pair<uint64_t, int> &x, const std::pair<uint64_t, int> &y) { return x.first < y.first; });
+                for (size_t e = 0, run = 0; e < ord.size(); e++) {
+                    if (e > 0 && ord[e].first != ord[e - 1].first) run = e;
+                    const int d = ord[e].second;
+                    const CJ &c = cj[(size_t)con_sorted[(size_t)d]];
+                    const int r = crow_h[(size_t)d], rpc = c.j->mu > 0 ? 3 : 1;
+                    const uint64_t base = ((uint64_t)(uint32_t)(c.b1 + 1) << 38) | ((uint64_t)((uint32_t)(c.b2 + 1) & 0xffffffu) << 14) |
+                                          ((uint64_t)((e - run) & 0xfffu) << 2);
+                    for (int q = 0; q < rpc; q++) {
+                        R.key[(size_t)(r + q)] = base | (uint64_t)q;
+                        R.unbounded[(size_t)(r + q)] = (q > 0 && !(c.j->mu < __builtin_huge_val())) ? 1 : 0;
+                    }
+                }
+                if ((rc = lcp_grid_solve<T>(b, I, P, R)) != DMX_OK) return rc;
+            }
+            lcp_grid_end_tick(b);
+            HIP_TRY(hipStreamSynchronize(b->stream));
+        }
     } else {
         HIP_TRY(launch_islands<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, b->stream));
         if (ode_order) HIP_TRY(hipStreamSynchronize(b->stream));      // the order table came from pageable host memory

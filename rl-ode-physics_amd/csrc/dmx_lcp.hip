@@ -1,0 +1,772 @@
+// dmx_lcp.hip -- dWorldStep's exact solve of a LARGE island, spread over the whole chip.
+//
+// The reference's tick is dSpaceCollide -> dWorldStep(world, 1/120) -> dJointGroupEmpty (/root/reference/src/main.c:211-215)
+// with up to MAX_BODIES = 512 bodies (/root/reference/inc/body.h:6); piled into the pen they are ONE dynamics island of
+// 2 000 - 2 600 constraint rows, and dWorldStep [ODE-recall step.cpp dxStepIsland + lcp.cpp dSolveLCP] solves that island's
+//      A lambda = b + w,   A = J M^-1 J^T + diag(cfm / h),   lo <= lambda <= hi,   w complementary to lambda
+// to the end.  With cfm > 0 A is positive definite and the solution unique, so any exact pivoting method reaches ODE's lambda;
+// the CPU oracle's exact_lcp (oracle/, its step source) is the checker (north_star's 1e-5 on positions / quaternions; the order of operations is not
+// the oracle's here, and need not be).
+//
+// Method (what ODE's Dantzig solver does with its `nub` leading unbounded rows, restated for a GPU):
+//   1. the island's rows are built by the same phase functions as every other island kernel (dmx_island_rows.hpp);
+//   2. rows are permuted: U = rows that can never clamp (lo = -inf, hi = +inf: both friction rows of a contact with mu = inf,
+//      which is what the reference's NearCallback asks for, main.c:687) first, B = the rest (normal rows, bounded friction);
+//   3. A (permuted, tiles of 64, column-major lower triangle, the right-hand side riding along as one extra ROW so that the
+//      forward substitution comes for free) is assembled by a launch over tiles from the body-sharing structure;
+//   4. a blocked right-looking Cholesky runs over U's panels only: per panel one launch that factors the 64 x 64 diagonal
+//      block (every workgroup for itself, in LDS, one lane per row) and solves its own 64 rows of the panel against it, and one
+//      launch of rank-64 updates of the trailing tiles on the matrix cores (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32;
+//      one wavefront per 64 x 64 tile).  What is left in B's block is the Schur complement  S = A_BB - A_BU A_UU^-1 A_UB  and
+//      the reduced right-hand side  b' = b_B - A_BU A_UU^-1 b_U:  the LCP in B's rows alone, a third of the size;
+//   5. block principal pivoting (Judice & Pires; Murty's single flip once the violation count has stalled three times -- the
+//      oracle's rule) on  S lambda_B = b' + w_B:  per round the free rows' block of S is gathered and factored by the same two
+//      kernels, back-substituted, w_B = S lambda_B - b' and the violations are found by a launch, and the HOST flips (it reads
+//      one small array per round).  The active set a contact's rows ended a tick with is where they start the next tick
+//      (keyed by body pair and contact ordinal): a resting pile closes in one round;
+//   6. lambda_U by back-substitution through U's factor, constraint forces, integration (finish_body).
+// Cost per tick at m rows, |B| = m/3: one partial factorisation (m^3/3 less B's own block) + rounds x (|free B|^3/3).
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <unordered_map>
+
+#include "dmx_lcp.hpp"
+#include "dmx_island_rows.hpp"
+
+namespace dmx {
+
+int lcp_grid_threshold()
+{
+    static const int v = [] { const char *e = getenv("DMX_LCP_GRID_ROWS"); const int t = e ? atoi(e) : 192; return t < 1 ? 1 : t; }();
+    return v;
+}
+int lcp_max_exact_rows()
+{
+    static const int v = [] { const char *e = getenv("DMX_MAX_EXACT_ROWS"); const int t = e ? atoi(e) : 16384; return t < 1 ? 1 : t; }();
+    return v;
+}
+
+namespace {
+
+constexpr int NB = 64;                  // tile / panel width
+enum : int { ST_FREE = 0, ST_LO = 1, ST_HI = 2 };
+
+// ---- the matrix cores' 16 x 16 x 4 forms: D = A B + C, lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; D's column is
+//      l & 15, its row (l >> 4) * 4 + reg in f32 and (l >> 4) + 4 * reg in f64 (cdna_hip_programming.md section 3)
+template <class T> struct MF;
+template <> struct MF<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
+};
+template <> struct MF<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+
+// value of `v` in lane `lane` (uniform), to every lane
+__device__ __forceinline__ float bcast(float v, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ double bcast(double v, int lane)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// 1 / sqrt(x), x > 0: the hardware estimate and Newton steps to the format's precision (the pivots' square roots and
+// reciprocals sit on the factorisation's one serial chain: IEEE sqrt + division sequences would triple it)
+__device__ __forceinline__ float fast_rsqrt(float x)
+{
+    float y = __builtin_amdgcn_rsqf(x);
+    y = y * fma_(-0.5f * x * y, y, 1.5f);
+    return y;
+}
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma_(-0.5 * x * y, y, 1.5);
+    y = y * fma_(-0.5 * x * y, y, 1.5);
+    return y;
+}
+
+// =========================================================================================================== 1. the island's rows
+template <class T>
+__global__ __launch_bounds__(512) void lcp_prepare(T *__restrict__ S, const uint8_t *__restrict__ bflags, int64_t stride, IslandSet<T> I,
+                                                   StepParams<T> P, int isl, T *__restrict__ tol_out, T tol_rel)
+{
+    constexpr int WG = 512;
+    const int tid = threadIdx.x;
+    const T h = P.h, hinv = T(1) / h;
+    const int b0 = I.body_off[isl], nb = I.body_off[isl + 1] - b0;
+    const int c0 = I.con_off[isl], nc = I.con_off[isl + 1] - c0;
+    const int r0 = I.row_off[isl];
+    T *bs = I.bscr + (size_t)b0 * BW_COUNT;
+    T *rows = I.rows + (size_t)r0 * RW_COUNT;
+    int *jb = I.rowjb + 2 * (size_t)r0;
+    const int m = nc > 0 ? I.crow[c0 + nc - 1] + contact_rpc(I, P, c0 + nc - 1) : 0;
+    for (int k = tid; k < nb; k += WG) stage_body(S, bflags, stride, I, P, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], k);
+    __syncthreads();
+    for (int c = tid; c < nc; c += WG) contact_rows(S, stride, I, P, rows, jb, c0 + c, I.crow[c0 + c], hinv);
+    for (int k = tid; k < nb; k += WG) body_tmp(S, stride, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], hinv);
+    __syncthreads();
+    T bmax = T(0);
+    for (int i = tid; i < m; i += WG) {
+        row_setup<T, false>(rows, jb, bs, i, hinv, P.sor_w);
+        const T v = tabs(rows[(size_t)i * RW_COUNT + RW_RHS]);
+        if (v > bmax) bmax = v;
+    }
+    __shared__ T red[WG];
+    red[tid] = bmax;
+    __syncthreads();
+    for (int o = WG / 2; o > 0; o >>= 1) {
+        if (tid < o && red[tid + o] > red[tid]) red[tid] = red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) tol_out[0] = tol_rel * (T(1) + red[0]);      // the oracle's tolerance (its exact_lcp)
+}
+
+// =========================================================================================================== 3. A, permuted, in tiles
+// Element (r, c) of the matrix lives at A[c * ld + r]; tiles (tr, tc), tr >= tc, of 64 x 64; tile row nt holds ONE more row, the
+// right-hand side (row nt * 64; the rest of that tile row is zero).  perm[p] = island row at permuted position p, -1 = padding
+// (an identity row: its unknown is zero and touches nobody).  A(i, j) = J_i . (M^-1 J_j^T) over the bodies rows i and j share
+// + cfm / h on the diagonal, as the CPU oracle builds it.
+template <class T>
+__global__ __launch_bounds__(256) void lcp_assemble(const T *__restrict__ rows, const int *__restrict__ jb, const int *__restrict__ perm,
+                                                    int nt, T *__restrict__ A, int ld)
+{
+    const int tr = blockIdx.x, tc = blockIdx.y;
+    if (tc > tr) return;
+    __shared__ int pr[NB], pc[NB], r1[NB], r2[NB], c1[NB], c2[NB];
+    const int tid = threadIdx.x;
+    if (tid < NB) {
+        const int p = tr < nt ? perm[tr * NB + tid] : (tid == 0 ? -2 : -3);
+        pr[tid] = p;
+        r1[tid] = p >= 0 ? jb[2 * p] : -7; r2[tid] = p >= 0 ? jb[2 * p + 1] : -7;
+    } else if (tid < 2 * NB) {
+        const int t = tid - NB, p = perm[tc * NB + t];
+        pc[t] = p;
+        c1[t] = p >= 0 ? jb[2 * p] : -8; c2[t] = p >= 0 ? jb[2 * p + 1] : -8;
+    }
+    __syncthreads();
+    const int rl = tid & (NB - 1);
+    for (int cl = tid >> 6; cl < NB; cl += 4) {
+        const int i = pr[rl], j = pc[cl];
+        T a = T(0);
+        if (i == -2) a = j >= 0 ? rows[(size_t)j * RW_COUNT + RW_RHS] : T(0);
+        else if (i == -3) a = T(0);
+        else if (i < 0 || j < 0) a = (tr == tc && rl == cl) ? T(1) : T(0);
+        else {
+            const int i1 = r1[rl], i2 = r2[rl], j1 = c1[cl], j2 = c2[cl];
+            const T *ji = rows + (size_t)i * RW_COUNT + RW_J, *pj = rows + (size_t)j * RW_COUNT + RW_IMJ;
+            if (i1 == j1) { for (int q = 0; q < 6; q++) a = fma_(ji[q], pj[q], a); }
+            if (j2 >= 0 && i1 == j2) { for (int q = 0; q < 6; q++) a = fma_(ji[q], pj[6 + q], a); }
+            if (i2 >= 0 && i2 == j1) { for (int q = 0; q < 6; q++) a = fma_(ji[6 + q], pj[q], a); }
+            if (i2 >= 0 && j2 >= 0 && i2 == j2) { for (int q = 0; q < 6; q++) a = fma_(ji[6 + q], pj[6 + q], a); }
+            if (i == j) a += rows[(size_t)i * RW_COUNT + RW_AD];
+        }
+        A[(size_t)(tc * NB + cl) * ld + tr * NB + rl] = a;
+    }
+}
+
+// =========================================================================================================== 4a. panel: factor + solve
+constexpr int PANEL_WAVES = 16;          // one column of a 16-column sub-panel per wavefront in the left-looking updates
+
+// Column 16 b + w of a 64 x 64 block held in LDS (own[c * NB + r], lane r = row r), minus what the columns to its left
+// contribute:  own(r, 16 b + w) -= sum_{j < 16 b} own(r, j) * L(16 b + w, j),  L(., j) = Lb[j * NB + .] (one broadcast read)
+template <class T>
+__device__ __forceinline__ void subpanel_left(T *own, const T *Lb, int b, int w, int r)
+{
+    T p = own[(16 * b + w) * NB + r];
+    const int c = 16 * b + w;
+#pragma unroll 8
+    for (int j = 0; j < 16 * b; j++) p = fma_(-own[j * NB + r], Lb[j * NB + c], p);
+    own[c * NB + r] = p;
+}
+
+// One workgroup of 16 wavefronts per tile row below panel k.  Every workgroup factors the panel's 64 x 64 diagonal block for
+// itself, in LDS, lane r = row r: sixteen columns at a time -- first each wavefront brings ONE of the sixteen columns up to date
+// against the columns already factored (left-looking: a broadcast read and a multiply-add per earlier column), then wavefront 0
+// factors the sixteen in registers, pivots handed round by v_readlane -- and then solves ITS tile of the panel's rows (tile
+// k + 1 + blockIdx.x; lane r = a row of that tile) against the factor the same way:  X <- X L_kk^-T.  Workgroup 0 also leaves the
+// factored block in Ldiag[k] (the block of A itself stays as it was: late workgroups are still reading it).
+template <class T>
+__global__ __launch_bounds__(64 * PANEL_WAVES) void lcp_panel(T *__restrict__ A, int ld, int k, T *__restrict__ Ldiag, const T *__restrict__ tolp)
+{
+    extern __shared__ __align__(16) unsigned char lcp_panel_raw[];
+    T *Lb = reinterpret_cast<T *>(lcp_panel_raw), *Xb = Lb + NB * NB, *invd = Xb + NB * NB;
+    const int r = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const T tol = tolp[0];
+    const T *D = A + (size_t)k * NB * ld + (size_t)k * NB;
+    const int t = k + 1 + blockIdx.x;
+    T *Xg = A + (size_t)k * NB * ld + (size_t)t * NB;
+#pragma unroll
+    for (int c = w; c < NB; c += PANEL_WAVES) { Lb[c * NB + r] = D[(size_t)c * ld + r]; Xb[c * NB + r] = Xg[(size_t)c * ld + r]; }
+    __syncthreads();
+    for (int b = 0; b < 4; b++) {
+        if (b > 0) {
+            subpanel_left(Lb, Lb, b, w, r);
+            __syncthreads();
+        }
+        if (w == 0) {
+            T p[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) p[c] = Lb[(16 * b + c) * NB + r];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int gj = 16 * b + j;
+                T ajj = bcast(p[j], gj);
+                ajj = ajj > T(0) ? ajj : tol;               // (the oracle's guard: a pivot that rounding pushed below zero)
+                const T inv = fast_rsqrt(ajj);
+                p[j] = (r == gj) ? ajj * inv : p[j] * inv;
+                if (r == gj) invd[gj] = inv;
+#pragma unroll
+                for (int c = j + 1; c < 16; c++) p[c] = fma_(-p[j], bcast(p[j], 16 * b + c), p[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) Lb[(16 * b + c) * NB + r] = (r >= 16 * b + c) ? p[c] : T(0);
+        }
+        __syncthreads();
+    }
+    for (int b = 0; b < 4; b++) {
+        if (b > 0) {
+            subpanel_left(Xb, Lb, b, w, r);
+            __syncthreads();
+        }
+        if (w == 0) {
+            T p[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) p[c] = Xb[(16 * b + c) * NB + r];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int gj = 16 * b + j;
+                p[j] *= invd[gj];
+                const T *lr = Lb + gj * NB + 16 * b;
+#pragma unroll
+                for (int c = j + 1; c < 16; c++) p[c] = fma_(-p[j], lr[c], p[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) Xb[(16 * b + c) * NB + r] = p[c];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = w; c < NB; c += PANEL_WAVES) Xg[(size_t)c * ld + r] = Xb[c * NB + r];
+    if (blockIdx.x == 0) {
+        T *Lo = Ldiag + (size_t)k * NB * NB;
+#pragma unroll
+        for (int c = w; c < NB; c += PANEL_WAVES) Lo[c * NB + r] = Lb[c * NB + r];
+    }
+}
+
+// =========================================================================================================== 4b. trailing update
+// X(tr, tc) -= L(tr, k) L(tc, k)^T for every tile tr >= tc > k (tr up to the right-hand side's tile row nt): one workgroup of four
+// wavefronts per 64 x 64 tile, each wavefront a strip of 16 of the tile's columns: 1 x 4 blocks of 16 x 16 accumulators, 16 steps
+// of k = 4.  The matrix cores' "column" index (l & 15) runs along a tile's rows -- the contiguous direction of the storage -- so
+// every operand fetch is 16 consecutive reals per quarter-wave, straight from L2 (a panel is a few hundred KB and every tile of
+// a tile row reads the same slice).
+template <class T>
+__global__ __launch_bounds__(256) void lcp_syrk(T *__restrict__ A, int ld, int k)
+{
+    const int tr = k + 1 + blockIdx.x, tc = k + 1 + blockIdx.y;
+    if (tc > tr) return;
+    typedef typename MF<T>::acc_t acc_t;
+    const int l = threadIdx.x & 63, ic = threadIdx.x >> 6, lc = l & 15, lk = l >> 4;
+    T *X = A + (size_t)(tc * NB + ic * 16) * ld + (size_t)tr * NB;
+    acc_t acc[4];
+#pragma unroll
+    for (int ir = 0; ir < 4; ir++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc[ir][g] = X[(size_t)MF<T>::row(l, g) * ld + ir * 16 + lc];
+    const T *Lr = A + (size_t)k * NB * ld + (size_t)tr * NB, *Lc = A + (size_t)k * NB * ld + (size_t)tc * NB + ic * 16;
+#pragma unroll 4
+    for (int kk = 0; kk < NB / 4; kk++) {
+        const size_t o = (size_t)(kk * 4 + lk) * ld + lc;
+        const T fa = -Lc[o];
+        T fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) fb[i] = Lr[o + i * 16];
+#pragma unroll
+        for (int ir = 0; ir < 4; ir++) acc[ir] = MF<T>::mfma(fa, fb[ir], acc[ir]);
+    }
+#pragma unroll
+    for (int ir = 0; ir < 4; ir++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) X[(size_t)MF<T>::row(l, g) * ld + ir * 16 + lc] = acc[ir][g];
+}
+
+// =========================================================================================================== the reduced problem
+// S (B's block of A after U's panels, lower tiles) -> a dense symmetric array Sd[c * lds + r] of its own
+template <class T>
+__global__ __launch_bounds__(256) void lcp_extract(const T *__restrict__ A, int ld, int nuP, T *__restrict__ Sd, int lds)
+{
+    const int tr = blockIdx.x, tc = blockIdx.y, tid = threadIdx.x, rl = tid & (NB - 1);
+    const int r = tr * NB + rl;
+    for (int cl = tid >> 6; cl < NB; cl += 4) {
+        const int c = tc * NB + cl;
+        Sd[(size_t)c * lds + r] = r >= c ? A[(size_t)(nuP + c) * ld + nuP + r] : A[(size_t)(nuP + r) * ld + nuP + c];
+    }
+}
+// b' (the right-hand side's row after U's panels) and the bounds of B's rows
+template <class T>
+__global__ __launch_bounds__(256) void lcp_bvec(const T *__restrict__ A, int ld, int nuP, int mP, const int *__restrict__ perm,
+                                                const T *__restrict__ rows, int nbdP, T *__restrict__ bprime, T *__restrict__ lo, T *__restrict__ hi)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nbdP) return;
+    const int p = perm[nuP + i];
+    bprime[i] = A[(size_t)(nuP + i) * ld + mP];
+    lo[i] = p >= 0 ? rows[(size_t)p * RW_COUNT + RW_LO] : -Limits<T>::inf();
+    hi[i] = p >= 0 ? rows[(size_t)p * RW_COUNT + RW_HI] : Limits<T>::inf();
+}
+// lambda_B at the start of a round: clamped rows at their bounds, free rows zero
+template <class T>
+__global__ __launch_bounds__(256) void lcp_clamped(const int *__restrict__ state, const T *__restrict__ lo, const T *__restrict__ hi, int n,
+                                                   T *__restrict__ lam)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int s = state[i];
+    lam[i] = s == ST_LO ? lo[i] : s == ST_HI ? hi[i] : T(0);
+}
+// out = bvec - Sd v   (CLASSIFY = false: a round's right-hand side),   or
+// out = Sd v - bvec = w and every row's verdict (CLASSIFY = true): 0 fine, 1 free row below lo, 2 free row above hi, 3 clamped
+// row whose w has the wrong sign -- the oracle's tests and tolerance.  64 rows a workgroup, the columns in four fixed segments.
+template <class T, bool CLASSIFY>
+__global__ __launch_bounds__(256) void lcp_gemv(const T *__restrict__ Sd, int lds, int n, const T *__restrict__ v, const T *__restrict__ bvec,
+                                                T *__restrict__ out, const int *__restrict__ state, const T *__restrict__ lo,
+                                                const T *__restrict__ hi, const T *__restrict__ tolp, int *__restrict__ viol)
+{
+    __shared__ T part[4][NB];
+    const int tid = threadIdx.x, il = tid & (NB - 1), seg = tid >> 6;
+    const int i = blockIdx.x * NB + il;
+    const int per = (n + 3) / 4, j0 = seg * per, j1 = (j0 + per < n) ? j0 + per : n;
+    T s = T(0);
+    if (i < n)
+        for (int j = j0; j < j1; j++) s = fma_(Sd[(size_t)j * lds + i], v[j], s);
+    part[seg][il] = s;
+    __syncthreads();
+    if (seg != 0 || i >= n) return;
+    s = ((part[0][il] + part[1][il]) + part[2][il]) + part[3][il];
+    if (!CLASSIFY) { out[i] = bvec[i] - s; return; }
+    const T w = s - bvec[i], tol = tolp[0], lam = v[i];
+    out[i] = w;
+    const int st = state[i];
+    int vi = 0;
+    if (st == ST_FREE) vi = (lam < lo[i] - tol) ? 1 : (lam > hi[i] + tol) ? 2 : 0;
+    else if (st == ST_LO) vi = w < -tol ? 3 : 0;
+    else vi = w > tol ? 3 : 0;
+    viol[i] = vi;
+}
+// the free rows' block of S and their right-hand side, in the factorisation's layout (fidx: the free rows in order, -1 = padding)
+template <class T>
+__global__ __launch_bounds__(256) void lcp_gather(const T *__restrict__ Sd, int lds, const int *__restrict__ fidx, int nft,
+                                                  const T *__restrict__ rr, T *__restrict__ Mw, int ldw)
+{
+    const int tr = blockIdx.x, tc = blockIdx.y;
+    if (tc > tr) return;
+    __shared__ int fr[NB], fc[NB];
+    const int tid = threadIdx.x;
+    if (tid < NB) fr[tid] = tr < nft ? fidx[tr * NB + tid] : (tid == 0 ? -2 : -3);
+    else if (tid < 2 * NB) fc[tid - NB] = fidx[tc * NB + tid - NB];
+    __syncthreads();
+    const int rl = tid & (NB - 1);
+    for (int cl = tid >> 6; cl < NB; cl += 4) {
+        const int i = fr[rl], j = fc[cl];
+        T a;
+        if (i == -2) a = j >= 0 ? rr[j] : T(0);
+        else if (i == -3) a = T(0);
+        else if (i < 0 || j < 0) a = (tr == tc && rl == cl) ? T(1) : T(0);
+        else a = Sd[(size_t)j * lds + i];
+        Mw[(size_t)(tc * NB + cl) * ldw + tr * NB + rl] = a;
+    }
+}
+
+// =========================================================================================================== back-substitution
+// L^T x = y over nt panels of a factored matrix (the strictly lower tiles in A, the diagonal blocks in Ldiag), one workgroup:
+// per panel, last to first, the columns' dot products with the part of x already known (a wavefront per column, lanes along the
+// rows: contiguous), then the 64 x 64 triangle by one wavefront (lane = unknown).  y[c] = yv[c * ystride].
+// scatter != null: x goes to out[scatter[a]] for the entries with scatter[a] >= 0 (a round's free rows back into lambda_B);
+// otherwise out[a] = x[a].
+template <class T>
+__global__ __launch_bounds__(1024) void lcp_backsolve(const T *__restrict__ A, int ld, const T *__restrict__ Ldiag, int nt,
+                                                      const T *__restrict__ yv, size_t ystride, const int *__restrict__ scatter,
+                                                      T *__restrict__ out)
+{
+    extern __shared__ __align__(16) unsigned char lcp_bs_raw[];
+    constexpr int LP = NB + 1;
+    T *xs = reinterpret_cast<T *>(lcp_bs_raw);              // [nt * NB]
+    T *Lb = xs + (size_t)nt * NB;                           // [NB * LP]
+    T *v = Lb + NB * LP;                                    // [NB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = nt * NB;
+    for (int kp = nt - 1; kp >= 0; kp--) {
+        const T *Ld = Ldiag + (size_t)kp * NB * NB;
+        for (int e = tid; e < NB * NB; e += 1024) Lb[(e >> 6) * LP + (e & 63)] = Ld[e];     // L(r, c) at Lb[c * LP + r]
+        for (int cc = wave; cc < NB; cc += 16) {
+            const int c = kp * NB + cc;
+            const T *col = A + (size_t)c * ld;
+            T s = T(0);
+            for (int r = (kp + 1) * NB + lane; r < n; r += 64) s = fma_(col[r], xs[r], s);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) v[cc] = yv[(size_t)c * ystride] - s;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            T acc = v[lane];
+            const T invd = T(1) / Lb[lane * LP + lane];
+            T mine = T(0);
+            for (int rr = NB - 1; rr >= 0; rr--) {
+                const T xr = bcast(acc * invd, rr);
+                if (lane == rr) mine = xr;
+                if (lane < rr) acc = fma_(-Lb[lane * LP + rr], xr, acc);
+            }
+            xs[kp * NB + lane] = mine;
+        }
+        __syncthreads();
+    }
+    for (int a = tid; a < n; a += 1024) {
+        if (scatter) { const int d = scatter[a]; if (d >= 0) out[d] = xs[a]; }
+        else out[a] = xs[a];
+    }
+}
+
+// z = y_U - L_BU^T lambda_B, the right-hand side of U's back-substitution: a wavefront per column of U
+template <class T>
+__global__ __launch_bounds__(64) void lcp_zvec(const T *__restrict__ A, int ld, int nuP, int mP, int nbd, const T *__restrict__ lamB,
+                                               T *__restrict__ z)
+{
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const T *col = A + (size_t)c * ld;
+    T s = T(0);
+    for (int i = lane; i < nbd; i += 64) s = fma_(col[nuP + i], lamB[i], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) z[c] = col[mP] - s;
+}
+
+// =========================================================================================================== 6. forces, integration
+template <class T>
+__global__ __launch_bounds__(1024) void lcp_finish(T *__restrict__ S, const uint8_t *__restrict__ bflags, int64_t stride, IslandSet<T> I,
+                                                   StepParams<T> P, int isl, const int *__restrict__ perm, int nuP, int mP,
+                                                   const T *__restrict__ xU, const T *__restrict__ lamB, const T *__restrict__ wB,
+                                                   const int *__restrict__ state, StepDiag *__restrict__ diag)
+{
+    constexpr int WG = 1024;
+    const int tid = threadIdx.x;
+    const int b0 = I.body_off[isl], nb = I.body_off[isl + 1] - b0;
+    const int c0 = I.con_off[isl], nc = I.con_off[isl + 1] - c0;
+    const int r0 = I.row_off[isl];
+    T *bs = I.bscr + (size_t)b0 * BW_COUNT;
+    T *rows = I.rows + (size_t)r0 * RW_COUNT;
+    const int *jb = I.rowjb + 2 * (size_t)r0;
+    const int m = nc > 0 ? I.crow[c0 + nc - 1] + contact_rpc(I, P, c0 + nc - 1) : 0;
+    double resid = 0.0;
+    for (int p = tid; p < mP; p += WG) {
+        const int i = perm[p];
+        if (i < 0) continue;
+        T l;
+        if (p < nuP) l = xU[p];
+        else {
+            const int q = p - nuP;
+            l = lamB[q];
+            const int st = state[q];
+            const T w = wB[q];
+            if (st == ST_FREE) {      // clamp what the tolerance let through (the oracle does)
+                const T lo = rows[(size_t)i * RW_COUNT + RW_LO], hi = rows[(size_t)i * RW_COUNT + RW_HI];
+                if (l < lo) l = lo;
+                if (l > hi) l = hi;
+                resid += (double)tabs(w);
+            } else resid += (double)(st == ST_LO ? (w < T(0) ? -w : T(0)) : (w > T(0) ? w : T(0)));
+        }
+        rows[(size_t)i * RW_COUNT + RW_LAM] = l;
+    }
+    // the rows' body pairs go to LDS in chunks: every body's lane walks them all (broadcast reads), rows in order per body
+    extern __shared__ __align__(16) unsigned char lcp_fin_raw[];
+    int2 *jbs = reinterpret_cast<int2 *>(lcp_fin_raw);
+    for (int i = tid; i < m; i += WG) jbs[i] = *reinterpret_cast<const int2 *>(jb + 2 * (size_t)i);
+    __syncthreads();
+    // cforce = M^-1 J^T lambda
+    for (int k = tid; k < nb; k += WG) {
+        T f[6] = { T(0), T(0), T(0), T(0), T(0), T(0) };
+        for (int i = 0; i < m; i++) {
+            const int2 bb = jbs[i];
+            if (bb.x != k && bb.y != k) continue;
+            const T *ip = rows + (size_t)i * RW_COUNT + RW_IMJ;
+            const T lam = rows[(size_t)i * RW_COUNT + RW_LAM];
+            if (bb.x == k) { for (int q = 0; q < 6; q++) f[q] = fma_(lam, ip[q], f[q]); }
+            if (bb.y == k) { for (int q = 0; q < 6; q++) f[q] = fma_(lam, ip[6 + q], f[q]); }
+        }
+        T *b = bs + (size_t)k * BW_COUNT;
+        for (int q = 0; q < 6; q++) b[BW_FC + q] = f[q];
+        finish_body(S, bflags, stride, b, I.bodies[b0 + k], m > 0, P.h);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) resid += __shfl_xor(resid, o, 64);
+    if ((tid & 63) == 0 && resid != 0.0) atomicAdd(&diag->residual, resid);
+    if (tid == 0) atomicAdd(&diag->contacts, (unsigned long long)nc);
+}
+
+// =========================================================================================================== host side
+struct LcpGrid {
+    dmxBatch::DevBuf A, Ldiag, Sd, Mw, Mdiag, vec, ints;
+    void *pin = nullptr; size_t pin_bytes = 0;
+    std::unordered_map<uint64_t, uint8_t> warm_prev, warm_next;
+    std::vector<int> perm, state;
+    int64_t stats[8] = { 0 };
+    bool warm = true, murty_only = false;
+    double tol_rel = 0;          // DMX_LCP_TOL: the complementarity tolerance relative to 1 + max |rhs| (0: the oracle's, 1e-5 f32 / 1e-11 f64)
+};
+
+LcpGrid *grid_of(dmxBatch *b)
+{
+    if (!b->lcp_grid) {
+        LcpGrid *g = new LcpGrid;
+        const char *e = getenv("DMX_LCP_WARM");
+        g->warm = !(e && atoi(e) == 0);
+        e = getenv("DMX_LCP_MURTY");
+        g->murty_only = e && atoi(e) != 0;
+        e = getenv("DMX_LCP_TOL");
+        if (e) g->tol_rel = atof(e);
+        b->lcp_grid = g;
+    }
+    return (LcpGrid *)b->lcp_grid;
+}
+
+template <class T> size_t panel_lds() { return (size_t)(2 * NB * NB + NB) * sizeof(T); }
+
+// Cholesky of the first `np` panels of an augmented matrix of `nt` tiles (+ the right-hand side's tile row): per panel the
+// factor-and-solve launch over the tile rows below it and the matrix-core update of everything to its right
+template <class T>
+hipError_t factor_panels(T *A, int ld, int nt, int np, T *Ldiag, const T *tol, hipStream_t st)
+{
+    const size_t lds = panel_lds<T>();
+    for (int k = 0; k < np; k++) {
+        hipLaunchKernelGGL((lcp_panel<T>), dim3((unsigned)(nt - k)), dim3(64 * PANEL_WAVES), lds, st, A, ld, k, Ldiag, tol);
+        if (nt - k - 1 > 0)
+            hipLaunchKernelGGL((lcp_syrk<T>), dim3((unsigned)(nt - k), (unsigned)(nt - k - 1)), dim3(256), 0, st, A, ld, k);
+    }
+    return hipGetLastError();
+}
+
+template <class T> size_t backsolve_lds(int nt) { return ((size_t)nt * NB + NB * (NB + 1) + NB) * sizeof(T); }
+
+}  // namespace
+
+void lcp_grid_begin_tick(dmxBatch *b)
+{
+    if (!b->lcp_grid) return;
+    LcpGrid *g = (LcpGrid *)b->lcp_grid;
+    g->warm_next.clear();
+}
+void lcp_grid_end_tick(dmxBatch *b)
+{
+    if (!b->lcp_grid) return;
+    LcpGrid *g = (LcpGrid *)b->lcp_grid;
+    g->warm_prev.swap(g->warm_next);
+    g->warm_next.clear();
+}
+void lcp_grid_free(dmxBatch *b)
+{
+    if (!b->lcp_grid) return;
+    LcpGrid *g = (LcpGrid *)b->lcp_grid;
+    if (getenv("DMX_LCP_REPORT"))
+        fprintf(stderr, "libode_mi355 lcp grid: solves=%lld rounds=%lld max_rounds=%lld last_m=%lld last_nu=%lld last_nbd=%lld single=%lld fallback=%lld\n",
+                (long long)g->stats[0], (long long)g->stats[1], (long long)g->stats[2], (long long)g->stats[3], (long long)g->stats[4],
+                (long long)g->stats[5], (long long)g->stats[6], (long long)g->stats[7]);
+    for (dmxBatch::DevBuf *d : { &g->A, &g->Ldiag, &g->Sd, &g->Mw, &g->Mdiag, &g->vec, &g->ints })
+        if (d->p) (void)hipFree(d->p);
+    if (g->pin) (void)hipHostFree(g->pin);
+    delete g;
+    b->lcp_grid = nullptr;
+}
+
+template <class T>
+int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, const LcpIslandRows &R)
+{
+    LcpGrid *g = grid_of(b);
+    hipStream_t st = b->stream;
+    const int m = R.m, isl = R.isl;
+    // ---- the permutation: unbounded rows, padding, bounded rows, padding
+    int nu = 0;
+    for (int i = 0; i < m; i++) nu += R.unbounded[(size_t)i] ? 1 : 0;
+    const int nbd = m - nu;
+    const int nuT = (nu + NB - 1) / NB, nbT = (nbd + NB - 1) / NB;
+    const int nuP = nuT * NB, nbdP = nbT * NB, mP = nuP + nbdP, nt = nuT + nbT;
+    const int ld = mP + NB, lds = nbdP > 0 ? nbdP : NB, ldw = nbdP + NB;
+    std::vector<int> &perm = g->perm;
+    perm.assign((size_t)mP, -1);
+    {
+        int au = 0, ab = nuP;
+        for (int i = 0; i < m; i++) { if (R.unbounded[(size_t)i]) perm[(size_t)au++] = i; else perm[(size_t)ab++] = i; }
+    }
+    // ---- buffers
+    int rc;
+    if ((rc = dmx_ensure_dev(g->A, (size_t)mP * ld * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(g->Ldiag, (size_t)nt * NB * NB * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(g->Sd, (size_t)lds * lds * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(g->Mw, (size_t)(nbdP + NB) * ldw * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(g->Mdiag, (size_t)(nbT + 1) * NB * NB * sizeof(T))) != DMX_OK) return rc;
+    // vectors: tol[4] bprime lo hi lamB wB rr (nbdP each) z xU (nuP each)
+    const size_t nv = 4 + (size_t)6 * (nbdP + NB) + (size_t)2 * (nuP + NB);
+    if ((rc = dmx_ensure_dev(g->vec, nv * sizeof(T))) != DMX_OK) return rc;
+    // ints: perm[mP] state[nbdP] fidx[nbdP] viol[nbdP]
+    const size_t ni = (size_t)mP + (size_t)3 * (nbdP + NB);
+    if ((rc = dmx_ensure_dev(g->ints, ni * sizeof(int))) != DMX_OK) return rc;
+    if (g->pin_bytes < ni * sizeof(int)) {
+        if (g->pin) HIP_TRY(hipHostFree(g->pin));
+        g->pin = nullptr; g->pin_bytes = 0;
+        const size_t want = ni * sizeof(int) * 2 + 4096;
+        HIP_TRY(hipHostMalloc(&g->pin, want));
+        g->pin_bytes = want;
+    }
+    T *A = (T *)g->A.p, *Ldiag = (T *)g->Ldiag.p, *Sd = (T *)g->Sd.p, *Mw = (T *)g->Mw.p, *Mdiag = (T *)g->Mdiag.p;
+    T *tol = (T *)g->vec.p, *bprime = tol + 4, *lo = bprime + (nbdP + NB), *hi = lo + (nbdP + NB), *lamB = hi + (nbdP + NB),
+      *wB = lamB + (nbdP + NB), *rr = wB + (nbdP + NB), *z = rr + (nbdP + NB), *xU = z + (nuP + NB);
+    int *d_perm = (int *)g->ints.p, *d_state = d_perm + mP, *d_fidx = d_state + (nbdP + NB), *d_viol = d_fidx + (nbdP + NB);
+    int *h_perm = (int *)g->pin, *h_state = h_perm + mP, *h_fidx = h_state + (nbdP + NB), *h_viol = h_fidx + (nbdP + NB);
+
+    // (the pinned staging is reused by the next island / tick: every copy below is followed by a synchronisation before the
+    //  host writes it again -- the rounds' read-back)
+    memcpy(h_perm, perm.data(), (size_t)mP * sizeof(int));
+    HIP_TRY(hipMemcpyAsync(d_perm, h_perm, (size_t)mP * sizeof(int), hipMemcpyHostToDevice, st));
+
+    // rows of this island inside the flat arrays: row_off is a device array, but by construction row_off[isl] = 3 * con_off[isl],
+    // which the caller passes as R.row_base
+    T *rows = I.rows + (size_t)R.row_base * RW_COUNT;
+    const int *jb = I.rowjb + 2 * (size_t)R.row_base;
+
+    hipLaunchKernelGGL((lcp_prepare<T>), dim3(1), dim3(512), 0, st, (T *)b->slab, b->bflags, b->stride, I, P, isl, tol,
+                       (T)(g->tol_rel > 0 ? g->tol_rel : (sizeof(T) == 4 ? 1e-5 : 1e-11)));
+    hipLaunchKernelGGL((lcp_assemble<T>), dim3((unsigned)(nt + 1), (unsigned)nt), dim3(256), 0, st, rows, jb, d_perm, nt, A, ld);
+    {
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcp_panel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)panel_lds<T>());
+        if (ea != hipSuccess) HIP_TRY(ea);
+    }
+    HIP_TRY(factor_panels<T>(A, ld, nt, nuT, Ldiag, tol, st));
+
+    // ---- the reduced problem in B's rows
+    std::vector<int> &state = g->state;
+    state.assign((size_t)nbd, ST_FREE);
+    int rounds = 0, single_rounds = 0;
+    if (nbd > 0) {
+        hipLaunchKernelGGL((lcp_extract<T>), dim3((unsigned)nbT, (unsigned)nbT), dim3(256), 0, st, A, ld, nuP, Sd, lds);
+        hipLaunchKernelGGL((lcp_bvec<T>), dim3((unsigned)((nbdP + 255) / 256)), dim3(256), 0, st, A, ld, nuP, mP, d_perm, rows, nbdP, bprime, lo, hi);
+        // where the rows' active set starts: what the same contact's row ended the previous tick with
+        bool any_bounded_friction = false;
+        for (int q = 0; q < nbd; q++) {
+            const int i = perm[(size_t)(nuP + q)];
+            const uint64_t key = R.key[(size_t)i];
+            if ((key & 3u) != 0u) any_bounded_friction = true;
+            if (g->warm && key != 0) {
+                auto it = g->warm_prev.find(key);
+                if (it != g->warm_prev.end()) state[(size_t)q] = it->second;
+            }
+        }
+        int best = m + 1, patience = g->murty_only ? 0 : 3;
+        const int max_rounds = 20 * m + 100;
+        {
+            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcp_backsolve<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)backsolve_lds<T>(nuT > nbT ? nuT : nbT));
+            if (ea != hipSuccess) HIP_TRY(ea);
+        }
+        for (;; rounds++) {
+            // the free rows in order; a clamped row's value is non-zero only for bounded friction rows (a normal row clamps at 0)
+            int nf = 0;
+            bool clamped_nonzero = false;
+            for (int q = 0; q < nbd; q++) {
+                h_state[q] = state[(size_t)q];
+                if (state[(size_t)q] == ST_FREE) h_fidx[nf++] = q;
+                else if (any_bounded_friction && (R.key[(size_t)perm[(size_t)(nuP + q)]] & 3u) != 0u) clamped_nonzero = true;
+            }
+            const int nfT = (nf + NB - 1) / NB, nfP = nfT * NB;
+            for (int a = nf; a < nfP; a++) h_fidx[a] = -1;
+            HIP_TRY(hipMemcpyAsync(d_state, h_state, (size_t)nbd * sizeof(int), hipMemcpyHostToDevice, st));
+            if (nfP > 0) HIP_TRY(hipMemcpyAsync(d_fidx, h_fidx, (size_t)nfP * sizeof(int), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((lcp_clamped<T>), dim3((unsigned)((nbd + 255) / 256)), dim3(256), 0, st, d_state, lo, hi, nbd, lamB);
+            const T *rhs = bprime;
+            if (clamped_nonzero) {
+                hipLaunchKernelGGL((lcp_gemv<T, false>), dim3((unsigned)nbT), dim3(256), 0, st, Sd, lds, nbd, lamB, bprime, rr,
+                                   (const int *)nullptr, (const T *)nullptr, (const T *)nullptr, (const T *)nullptr, (int *)nullptr);
+                rhs = rr;
+            }
+            if (nf > 0) {
+                hipLaunchKernelGGL((lcp_gather<T>), dim3((unsigned)(nfT + 1), (unsigned)nfT), dim3(256), 0, st, Sd, lds, d_fidx, nfT, rhs, Mw, ldw);
+                HIP_TRY(factor_panels<T>(Mw, ldw, nfT, nfT, Mdiag, tol, st));
+                hipLaunchKernelGGL((lcp_backsolve<T>), dim3(1), dim3(1024), backsolve_lds<T>(nfT), st, Mw, ldw, Mdiag, nfT,
+                                   Mw + nfP, (size_t)ldw, d_fidx, lamB);
+            }
+            hipLaunchKernelGGL((lcp_gemv<T, true>), dim3((unsigned)nbT), dim3(256), 0, st, Sd, lds, nbd, lamB, bprime, wB, d_state, lo, hi, tol, d_viol);
+            HIP_TRY(hipMemcpyAsync(h_viol, d_viol, (size_t)nbd * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            int nviol = 0, top = -1;
+            for (int q = 0; q < nbd; q++) if (h_viol[q]) { nviol++; top = q; }
+            if (nviol == 0 || rounds >= max_rounds) break;
+            bool all = true;
+            if (nviol < best) { best = nviol; if (!g->murty_only) patience = 3; }
+            else if (patience > 0) patience--;
+            else all = false;
+            if (g->murty_only) all = false;
+            if (!all) single_rounds++;
+            for (int q = 0; q < nbd; q++) {
+                if (!h_viol[q] || (!all && q != top)) continue;
+                state[(size_t)q] = h_viol[q] == 1 ? ST_LO : h_viol[q] == 2 ? ST_HI : ST_FREE;
+            }
+        }
+        // remember the active set
+        for (int q = 0; q < nbd; q++) {
+            const uint64_t key = R.key[(size_t)perm[(size_t)(nuP + q)]];
+            if (key != 0) g->warm_next[key] = (uint8_t)state[(size_t)q];
+        }
+    } else {
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcp_backsolve<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)backsolve_lds<T>(nuT));
+        if (ea != hipSuccess) HIP_TRY(ea);
+    }
+    // ---- lambda_U, forces, integration
+    if (nuT > 0) {
+        hipLaunchKernelGGL((lcp_zvec<T>), dim3((unsigned)nuP), dim3(64), 0, st, A, ld, nuP, mP, nbd, lamB, z);
+        hipLaunchKernelGGL((lcp_backsolve<T>), dim3(1), dim3(1024), backsolve_lds<T>(nuT), st, A, ld, Ldiag, nuT, z, (size_t)1,
+                           (const int *)nullptr, xU);
+    }
+    if ((size_t)m * sizeof(int2) > (size_t)64 * 1024) {
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcp_finish<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)((size_t)m * sizeof(int2)));
+        if (ea != hipSuccess) HIP_TRY(ea);
+    }
+    hipLaunchKernelGGL((lcp_finish<T>), dim3(1), dim3(1024), (size_t)m * sizeof(int2), st, (T *)b->slab, b->bflags, b->stride, I, P, isl, d_perm, nuP, mP, xU, lamB, wB,
+                       d_state, b->diag_isl);
+    HIP_TRY(hipGetLastError());
+    g->stats[0] += 1; g->stats[1] += rounds + 1; if (rounds + 1 > g->stats[2]) g->stats[2] = rounds + 1;
+    g->stats[3] = m; g->stats[4] = nu; g->stats[5] = nbd; g->stats[6] += single_rounds;
+    return DMX_OK;
+}
+
+template int lcp_grid_solve<float>(dmxBatch *, const IslandSet<float> &, const StepParams<float> &, const LcpIslandRows &);
+template int lcp_grid_solve<double>(dmxBatch *, const IslandSet<double> &, const StepParams<double> &, const LcpIslandRows &);
+
+void lcp_grid_stats(dmxBatch *b, int64_t out[8])
+{
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    if (!b->lcp_grid) return;
+    const LcpGrid *g = (const LcpGrid *)b->lcp_grid;
+    for (int k = 0; k < 8; k++) out[k] = g->stats[k];
+}
+void lcp_grid_count_fallback(dmxBatch *b) { grid_of(b)->stats[7] += 1; }
+
+hipError_t dmx_touch_lcp(int real_bytes)
+{
+    hipFuncAttributes a;
+    hipError_t e = hipSuccess;
+    auto touch = [&](const void *k) { const hipError_t r = hipFuncGetAttributes(&a, k); if (r != hipSuccess) e = r; };
+    if (real_bytes == 4) { touch((const void *)&lcp_panel<float>); touch((const void *)&lcp_syrk<float>); }
+    else { touch((const void *)&lcp_panel<double>); touch((const void *)&lcp_syrk<double>); }
+    return e;
+}
+
+}  // namespace dmx

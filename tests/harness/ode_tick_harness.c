@@ -13,8 +13,10 @@
  *         n_body    then per body       : type(1 sphere, 2 box) sx sy sz  px py pz  R[12]
  * stdout: per body 16 numbers (column-major 4x4 transform), %.17g
  */
+#define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 #include <ode/ode.h>
 
 #define MAX_CONTACTS 8              /* main.c:675 */
@@ -50,6 +52,13 @@ static void pack_transform(dReal res[16], const dReal *pos, const dReal *rot)
     res[12] = pos[0]; res[13] = pos[1]; res[14] = pos[2]; res[15] = 1;
 }
 
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 static double rd(void)
 {
     double v;
@@ -59,8 +68,9 @@ static double rd(void)
 
 int main(void)
 {
-    int steps, use_plane, n_static, n_body, i, k, s, up_front, every, readback, created, quick;
-    double dt, sink = 0;
+    int steps, use_plane, n_static, n_body, i, k, s, up_front, every, readback, created, quick, exact_after;
+    double dt, sink = 0, t_collide = 0, t_step = 0, t0, t1, t2;
+    int time_from, timed = 0;
     struct spawn { int type; dReal size[3], pos[3]; dMatrix3 rm; } *spawn;
     dBodyID *bodies;
     dGeomID *geoms;
@@ -105,6 +115,10 @@ int main(void)
     if (getenv("HARNESS_SPAWN") && sscanf(getenv("HARNESS_SPAWN"), "%d %d", &up_front, &every) != 2) { up_front = n_body; every = 0; }
     if (getenv("HARNESS_READBACK")) readback = atoi(getenv("HARNESS_READBACK"));
     quick = getenv("HARNESS_STEPPER") && getenv("HARNESS_STEPPER")[0] == 'q';
+    /* HARNESS_EXACT_AFTER=n: dWorldQuickStep for the first n ticks (a pile settles cheaply), dWorldStep from then on */
+    exact_after = getenv("HARNESS_EXACT_AFTER") ? atoi(getenv("HARNESS_EXACT_AFTER")) : 0;
+    /* HARNESS_TIME_FROM=n: wall time of dSpaceCollide and of the step call, summed over ticks n.., reported on stderr */
+    time_from = getenv("HARNESS_TIME_FROM") ? atoi(getenv("HARNESS_TIME_FROM")) : -1;
     created = 0;
     for (s = 0; s <= steps; s++) {
         while (created < n_body && (created < up_front || s == steps || (every > 0 && s >= (created - up_front + 1) * every))) {
@@ -119,10 +133,18 @@ int main(void)
             dGeomSetBody(geoms[i], bodies[i]);
         }
         if (s == steps) break;
+        t0 = now_ms();
         dSpaceCollide(space, NULL, near_callback);
-        if (quick) dWorldQuickStep(world, (dReal)dt);          /* HARNESS_STEPPER=quick: BASELINE's configs name dWorldQuickStep */
+        t1 = now_ms();
+        if (quick || s < exact_after) dWorldQuickStep(world, (dReal)dt);          /* HARNESS_STEPPER=quick: BASELINE's configs name dWorldQuickStep */
         else dWorldStep(world, (dReal)dt);                     /* the reference's call, main.c:213 */
         dJointGroupEmpty(contactGroup);
+        if (time_from >= 0 && s >= time_from) {
+            /* the step is asynchronous until somebody reads a pose: read one, as the reference's broadcast loop does */
+            if (created > 0) sink += (double)dBodyGetPosition(bodies[0])[1];
+            t2 = now_ms();
+            t_collide += t1 - t0; t_step += t2 - t1; timed++;
+        }
         if (readback > 0 && (s + 1) % readback == 0)
             for (i = 0; i < created; i++) {
                 dReal t[16];
@@ -131,6 +153,9 @@ int main(void)
             }
     }
 
+    if (timed > 0)
+        fprintf(stderr, "harness: timed_ticks=%d ms_per_tick=%.4f collide_ms=%.4f step_ms=%.4f\n", timed, (t_collide + t_step) / timed,
+                t_collide / timed, t_step / timed);
     for (i = 0; i < n_body; i++) {
         dReal t[16];
         pack_transform(t, dBodyGetPosition(bodies[i]), dBodyGetRotation(bodies[i]));

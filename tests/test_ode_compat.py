@@ -36,7 +36,8 @@ def _scene_text(dt, steps, use_plane, statics, bodies):
     return "\n".join(lines) + "\n"
 
 
-def _oracle_poses(dtype, dt, steps, use_plane, statics, bodies, up_front=None, every=0, exact=False, ode_order_seed=None):
+def _oracle_poses(dtype, dt, steps, use_plane, statics, bodies, up_front=None, every=0, exact=False, ode_order_seed=None,
+                  exact_after=None):
     from oracle.orc_ctypes import Oracle
     import ctypes as C
     orc = Oracle(dtype)
@@ -75,6 +76,8 @@ def _oracle_poses(dtype, dt, steps, use_plane, statics, bodies, up_front=None, e
             create(*bodies[created])
             created += 1
         if s < steps:
+            if exact_after is not None:                 # HARNESS_EXACT_AFTER: QuickStep while the pile settles, dWorldStep from then on
+                ow.set_stepper(s >= exact_after)
             ow.run(dt, 1)
     out = np.zeros((len(bodies), 16), orc.dtype)
     RP = C.POINTER(orc.real)
