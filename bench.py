@@ -182,6 +182,40 @@ def cpu_baseline(scene, dtype, kind, budget_s):
             "system_libode": have_ode}
 
 
+def config_cpu_baseline(pkg, build_config, cfg, dtype, budget_s):
+    """cpu_baseline of one `configs` leg: the oracle on a BOUNDED sample of the same workload -- the same scene builder at a
+    smaller grid side where the full size would take minutes on one core (islands are independent: a block of the grid is
+    the same per-body work), settled by the same number of ticks, then timed."""
+    from oracle.orc_ctypes import Oracle
+    side = {1: 32, 3: 128, 5: 16}[cfg]
+    sc, _lay, kd, _wl, settle, stp, _hp = build_config(cfg, side)
+    ow = Oracle(dtype).world()
+    if sc.plane is not None:
+        ow.add_plane(*sc.plane)
+    if sc.hull_points is not None:
+        ow.set_hull(sc.hull_points)
+        if sc.hull_planes is not None:
+            ow.set_hull_faces(sc.hull_planes)
+    for sides, pos, R12 in (sc.static_boxes or []):
+        ow.add_static_box(sides, pos, R12)
+    if sc.hull_points is not None:
+        ow.add_convex(sc.pos, sc.quat, sc.lvel, sc.avel, sc.mass[:, 0], sc.inertia)
+    else:
+        ow.add_boxes(sc.pos, sc.quat, sc.lvel, sc.avel, sc.mass[:, 0], sc.inertia, sc.sides)
+    if settle:
+        ow.run(H, settle)
+    if stp:                                   # configs[0]: the workload IS these ticks from the start state
+        steps = stp
+    else:
+        t = ow.run(H, 2)
+        steps = int(max(2, min(400, budget_s / max(t / 2, 1e-9))))
+    t = ow.run(H, steps)
+    ow.close()
+    return {"value": sc.n * steps / t, "unit": "body-steps/s", "ms_per_step": t * 1e3 / steps, "cores": 1, "kind": "port",
+            "sample": f"{sc.n} bodies (grid side {side}) of the same scene builder, {settle} settling ticks, then {steps} timed ticks; oracle/ C "
+                      f"restatement -O2 single thread, {t:.1f} s; body-steps/s is per body, so the sample's rate is the full scene's on one core"}
+
+
 def cpu_baseline_all_cores(scene, dtype, kind, budget_s):
     """The same oracle, one independent slice of the scene per host core (islands are independent), one child
     process per core (oracle/cpu_worker.py); None if a child fails or overruns."""
@@ -214,6 +248,98 @@ def cpu_baseline_all_cores(scene, dtype, kind, budget_s):
     return {"value": rate, "unit": "body-steps/s", "cores": cores, "kind": "port",
             "sample": f"{cores} processes x {per} bodies of the same scene ({kind}), each the single-thread oracle for "
                       f"~{budget_s:.0f} s; rates summed"}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the reference's own tick through the ODE API: dSpaceCollide + dWorldStep(1/120) + dJointGroupEmpty (main.c:211-215)
+# ------------------------------------------------------------------------------------------------------------
+MATRIX_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}     # MI355X_MICROARCH.md: f32-input MFMA = the f32 vector rate; FP64 matrix (spec)
+
+
+def scene_text(dt, steps, statics, bodies):
+    """the stdin of tests/harness/ode_tick_harness.c: dt steps use_plane / static boxes / bodies"""
+    ident = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0]
+    lines = [f"{dt!r} {steps} 0", str(len(statics))]
+    for size, pos, R in statics:
+        lines.append(" ".join(repr(float(v)) for v in (*size, *pos, *R)))
+    lines.append(str(len(bodies)))
+    for kind, size, pos in bodies:
+        lines.append(f"{kind} " + " ".join(repr(float(v)) for v in (*size, *pos, *ident)))
+    return "\n".join(lines) + "\n"
+
+
+def reference_main_c(pkg, dtype, cpu_budget_s, with_cpu=True):
+    """The call the reference actually makes -- dWorldStep at h = 1/120 (main.c:208,213) -- through the ODE C API, from a C
+    program that makes main.c's own sequence of calls (tests/harness/ode_tick_harness.c: it is compiled here against
+    include/ode/ode.h and linked against the shipped library): the reference's floor and walls, 48 / 200 / 512 of the key-M
+    spawner's boxes and spheres (512 = MAX_BODIES, inc/body.h:6), QuickStep while they come down, then dWorldStep for the timed
+    ticks (wall time of dSpaceCollide + dWorldStep + dJointGroupEmpty + one pose read per tick, host included).  cpu_baseline:
+    the oracle's exact stepper on the same scene from the same settled state."""
+    import re
+    import tempfile
+    single = dtype == "float32"
+    tag = "f32" if single else "f64"
+    pkg_dir = os.path.join(ROOT, "rl-ode-physics_amd")
+    tmp = tempfile.mkdtemp()
+    exe = os.path.join(tmp, "ode_tick_harness")
+    cmd = ["gcc", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "harness", "ode_tick_harness.c"), "-o", exe,
+           "-L" + pkg_dir, "-lode_mi355_single" if single else "-lode_mi355", "-Wl,-rpath," + pkg_dir, "-lm"]
+    if single:
+        cmd.insert(1, "-DdSINGLE")
+    subprocess.run(cmd, check=True)
+    out = {"call_sequence": "dSpaceCollide(space, 0, NearCallback) -> dWorldStep(world, 1/120) -> dJointGroupEmpty (main.c:211-215), "
+                            "contact policy of main.c:674-693 (<= 8 contacts, bounce 0.2, mu = inf), through include/ode/ode.h from C",
+           "dtype": tag, "dt": "1/120"}
+    statics = pkg.scenes.reference_map()
+    settle, ticks = 900, 60
+    for n in (48, 200, 512):
+        bodies = pkg.scenes.reference_spawn(n, seed=7, y_range=(1.2, 12.0))
+        env = dict(os.environ, HARNESS_STEPPER="exact", HARNESS_EXACT_AFTER=str(settle), HARNESS_TIME_FROM=str(settle + 4), DMX_LCP_REPORT="1")
+        p = subprocess.run([exe], input=scene_text(1.0 / 120.0, settle + ticks, statics, bodies), capture_output=True, text=True, env=env, timeout=600)
+        leg = {"bodies": n}
+        t = re.search(r"harness: timed_ticks=(\d+) ms_per_tick=([0-9.]+) collide_ms=([0-9.]+) step_ms=([0-9.]+)", p.stderr)
+        if p.returncode != 0 or not t:
+            leg["error"] = p.stderr[-400:]
+            out[f"{n}_bodies"] = leg
+            continue
+        ms = float(t.group(2))
+        leg.update({"ms_per_step": ms, "value": n / (ms * 1e-3), "unit": "body-steps/s", "steps": int(t.group(1)),
+                    "collide_ms": float(t.group(3)), "step_ms": float(t.group(4)), "frame_budget_ms": 1e3 / 120.0})
+        g = re.search(r"lcp grid: solves=(\d+) rounds=(\d+) max_rounds=(\d+) last_m=(\d+) last_nu=(\d+) last_nbd=(\d+) single=(\d+) "
+                      r"fallback=(\d+) gflop=([0-9.]+)", p.stderr)
+        if g:
+            gf_tick = float(g.group(9)) / ticks
+            leg["grid_solve"] = {"island_solves": int(g.group(1)), "pivoting_rounds": int(g.group(2)), "most_rounds_in_one_solve": int(g.group(3)),
+                                 "last_island_rows": int(g.group(4)), "never_clamping_rows": int(g.group(5)), "bounded_rows": int(g.group(6)),
+                                 "single_flip_rounds": int(g.group(7)), "gflop_per_tick": gf_tick}
+            leg["roofline"] = {"bound": "mfma", "achieved": gf_tick / (float(t.group(4)) * 1e-3) * 1e-3, "peak": MATRIX_PEAK_TFLOPS[tag],
+                               "unit": "TFLOP/s", "frac": gf_tick / (float(t.group(4)) * 1e-3) * 1e-3 / MATRIX_PEAK_TFLOPS[tag], "traffic": None,
+                               "kernel": "lcp_panel + lcp_syrk (csrc/dmx_lcp.hip)",
+                               "note": "algorithmic flops of the tick's factorisations (nu^3/3 + nu^2 nb + nu nb^2 once, nf^3/3 per pivoting "
+                                       "round) over the wall time of the dWorldStep call: the solve is a chain of 64-wide panels, each one "
+                                       "launch of a serial 64-pivot factorisation and one of matrix-core updates -- latency of the chain, "
+                                       "not the matrix cores' rate, bounds it (profiles/r04_lcp_*)"}
+        else:
+            leg["grid_solve"] = None          # no island reached DMX_LCP_GRID_ROWS: every island was one workgroup's (lcp_island_wg)
+        if with_cpu:
+            try:
+                from oracle.orc_ctypes import Oracle
+                ow = Oracle(dtype).world()
+                ow.add_reference_scene(statics, bodies)
+                ow.set_stepper(False)
+                ow.run(1.0 / 120.0, settle)
+                ow.set_stepper(True)
+                t1 = ow.run(1.0 / 120.0, 1)
+                k = int(max(1, min(ticks - 1, cpu_budget_s / max(t1, 1e-6))))
+                tk = ow.run(1.0 / 120.0, k)
+                leg["cpu_baseline"] = {"value": n * k / tk, "unit": "body-steps/s", "ms_per_step": tk * 1e3 / k, "cores": 1, "kind": "port",
+                                       "sample": f"the same {n} bodies settled by {settle} QuickStep ticks, then {k} ticks of the oracle's exact "
+                                                 f"stepper (oracle/ C restatement, -O2, single thread), {tk:.2f} s"}
+                ow.close()
+            except Exception as e:      # noqa: BLE001
+                leg["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        out[f"{n}_bodies"] = leg
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -618,6 +744,11 @@ def rank_main(a):
                "ms_per_step": m["dt"] * 1e3 / m["steps"], "ms_per_step_mean": m["mean_dt"] * 1e3 / m["steps"], "steps": m["steps"],
                "blocks": m["blocks"], "contacts_last_tick": m["contacts"], "collide": collide_text(m, a, kd),
                "roofline": roofline_of(m, kd, rsize, profile_evidence(kd, a.dtype, sc.n), hp)}
+        if not a.no_cpu_baseline:
+            try:
+                leg["cpu_baseline"] = config_cpu_baseline(pkg, build_config, cfg, dtype, min(a.cpu_seconds, 3.0))
+            except Exception as e:      # noqa: BLE001
+                leg["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         if cold is not None:
             leg["first_pass_in_the_process"] = {"ms_per_step": cold["dt"] * 1e3 / cold["steps"],
                                                 "note": "the same 600 ticks the first time this process runs them: every kernel of the exact tick is "
@@ -659,6 +790,26 @@ def rank_main(a):
                     w.close()
             except Exception as e:      # noqa: BLE001
                 out["reference_pen"][f"{nb_pen}_bodies"] = {"error": f"{type(e).__name__}: {e}"}
+        if not a.no_cpu_baseline and "error" not in out["reference_pen"].get("400_bodies", {"error": 1}):
+            try:        # the oracle on the same 400-body pile, same 240 settling ticks: one core
+                from oracle.orc_ctypes import Oracle
+                ow = Oracle(dtype).world()
+                ow.add_reference_scene(pkg.scenes.reference_map(), sorted(pkg.scenes.reference_spawn(400, seed=7, y_range=(3.0, 12.0)), key=lambda s: -s[0]))
+                ow.run(H, 240)
+                tk = ow.run(H, 240)
+                out["reference_pen"]["400_bodies"]["cpu_baseline"] = {
+                    "value": 400 * 240 / tk, "unit": "body-steps/s", "ms_per_step": tk * 1e3 / 240, "cores": 1, "kind": "port",
+                    "sample": f"the same 400 bodies and static boxes, 240 settling ticks, then 240 timed QuickStep ticks; oracle/ C restatement, {tk:.2f} s"}
+                ow.close()
+            except Exception as e:      # noqa: BLE001
+                out["reference_pen"]["400_bodies"]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        # ... and the reference's own CALL: dWorldStep at 1/120 through the ODE API from C (main.c:211-215)
+        try:
+            out["reference_main_c"] = reference_main_c(pkg, dtype, min(a.cpu_seconds, 8.0), with_cpu=not a.no_cpu_baseline)
+            if dtype == "float32":
+                out["reference_main_c"]["f64"] = reference_main_c(pkg, "float64", 0, with_cpu=False)
+        except Exception as e:      # noqa: BLE001
+            out["reference_main_c"] = {"error": f"{type(e).__name__}: {e}"}
     if extras and world > 1 and config == 4:
         # the weak-scaled companion: one whole configs[1] slab (1 048 576 bodies) per GPU
         wside = a.side or 1024

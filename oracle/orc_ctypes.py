@@ -146,6 +146,28 @@ class World:
         self._keep.append(a)
         return a.ctypes.data
 
+    def add_reference_scene(self, statics, bodies):
+        """the reference's own scene through the oracle's ODE-shaped calls, in the order main.c makes them: static map boxes
+        (AddBodyMap, main.c:735-761, with its double dGeomSetCategoryBits) and the spawner's bodies (AddBody, main.c:695-733);
+        statics = [(size3, pos3, R12)], bodies = [(type 1 sphere / 2 box, size3, pos3)]"""
+        lib, o = self.lib, self.o
+        for size, pos, R in statics:
+            g = lib.orc_geom_create_box(self.w, *size)
+            lib.orc_geom_set_position(self.w, g, *pos)
+            _, rp = o.arr(R)
+            lib.orc_geom_set_rotation(self.w, g, rp)
+            lib.orc_geom_set_category_bits(self.w, g, 0xFFFFFFFE)
+        ident = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0]
+        for kind, size, pos in bodies:
+            b = lib.orc_body_create(self.w)
+            lib.orc_body_set_position(self.w, b, *pos)
+            _, rp = o.arr(ident)
+            lib.orc_body_set_rotation(self.w, b, rp)
+            g = lib.orc_geom_create_sphere(self.w, size[0]) if kind == 1 else lib.orc_geom_create_box(self.w, *size)
+            lib.orc_geom_set_category_bits(self.w, g, 2)
+            lib.orc_geom_set_collide_bits(self.w, g, 3)
+            lib.orc_geom_set_body(self.w, g, b)
+
     # bulk ------------------------------------------------------------------
     def add_boxes(self, pos, quat, lvel, avel, mass, idiag, sides):
         n = len(pos)

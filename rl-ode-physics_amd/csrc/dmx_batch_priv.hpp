@@ -101,7 +101,7 @@ struct dmxBatch {
     DevBuf jd_int, jd_real, jd_rows, jd_rowjb, jd_bscr, jd_local;   // device staging / scratch
     DevBuf jd_lcp, jd_lcp_off, jd_lcp_int;     // dWorldStep's exact island solve: A, factor, vectors per island; offsets; pivoting state
     std::vector<long long> sc_lcp_off;
-    std::vector<int> sc_grid_list; std::vector<std::pair<uint64_t, int>> sc_pair_ord;
+    std::vector<int> sc_nbd_of, sc_grid_list; std::vector<std::pair<uint64_t, int>> sc_pair_ord;
     void *lcp_grid = nullptr;                  // dWorldStep's grid-wide solve of large islands (dmx_lcp.hip): buffers, remembered active sets
     double exs_acc[64] = { 0 }; long exs_ticks = 0;      // DMX_EXS_TIMING: stage times of the small-scene exact tick, summed
     void *ex_counts_dev = nullptr, *bp_flags_dev = nullptr;    // device-visible addresses of ex_counts_host / bp_flags_host

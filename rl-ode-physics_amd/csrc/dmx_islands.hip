@@ -1048,12 +1048,13 @@ template <class T>
 hipError_t launch_islands_exact(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P,
                                 StepDiag *diag, T *scratch, const long long *scratch_off, int *iscratch, int max_rows, hipStream_t st)
 {
+    // (max_rows < 0: the caller solves the islands with rows itself -- lcp_island_lds, dmx_lcp.hip -- and wants the row-less ones only)
     if (I.n_islands <= 0) return hipSuccess;
     if (I.n_big < I.n_islands) {       // islands without rows: free bodies
         const unsigned grid = (unsigned)((I.n_islands + 63) / 64);
         hipLaunchKernelGGL((solve_islands<T>), dim3(grid), dim3(64), 0, st, S, bflags, stride, I, P, diag);
     }
-    if (I.n_big > 0) {
+    if (I.n_big > 0 && max_rows >= 0) {
         // LDS for the free block's factor + right-hand side, up to 60 KB
         int lds_rows = 0;
         while ((size_t)(lds_rows + 1) * (lds_rows + 2) * sizeof(T) <= (size_t)60 * 1024 && lds_rows < max_rows) lds_rows++;

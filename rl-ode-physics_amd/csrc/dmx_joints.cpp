@@ -20,6 +20,13 @@ namespace {
 // off with a wavefront: 500-body reference scene 5.2 / 3.3 / 2.4 / 1.7 / 1.3 / 1.1 / 0.8 ms per tick at 384 / 128 / 64 / 32 / 16 /
 // 8 / 4 rows (profiles/r01_big_island_threshold.txt), 0.90 -> 0.67 from 4 to 1 with the one-body islands on solve_singles
 // (profiles/r02_island_threshold.txt).
+// DMX_LCP_OLD=1: dWorldStep's islands below the grid threshold go to round 2's one-workgroup kernel (lcp_island_wg) -- for A/B runs
+bool lcp_old_kernel()
+{
+    static const bool v = [] { const char *e = getenv("DMX_LCP_OLD"); return e && atoi(e) != 0; }();
+    return v;
+}
+
 int big_island_rows()
 {
     static const int v = [] { const char *e = getenv("DMX_BIG_ISLAND_ROWS"); return e ? atoi(e) : 1; }();
@@ -167,6 +174,7 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
     int big_max_bodies = 0, big_max_width = 0, big_rows_total = 0, big_max_rows = 0;
     std::vector<int> &grid_list = b->sc_grid_list;      // dWorldStep: islands for the grid-wide exact solve
     grid_list.clear();
+    size_t lds_need = 0;                                // ... and what the largest of the others needs of a workgroup's LDS
     std::vector<int> &island_bodies = b->sc_iv[9];
     island_bodies.assign((size_t)ni, 0);
     for (int s : slots) island_bodies[(size_t)island_of[(size_t)s]]++;
@@ -174,15 +182,20 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
         // Islands are independent, so every per-island pass below is spread over the host's cores (dmx_parallel_for).
         // (1) rows per island and each contact's first row
         std::vector<int> &m_of = b->sc_iv[10];
+        std::vector<int> &nbd_of = b->sc_nbd_of;        // rows of the island that can clamp (normal rows, friction rows with finite mu)
         m_of.assign((size_t)ni, 0);
+        nbd_of.assign((size_t)ni, 0);
         dmx_parallel_for(ni, 512, [&](int64_t lo, int64_t hi, int) {
             for (int64_t i = lo; i < hi; i++) {
-                int m = 0;
+                int m = 0, nbd = 0;
                 for (int d = con_start[(size_t)i]; d < con_start[(size_t)i + 1]; d++) {
                     crow_h[(size_t)d] = m;
-                    m += cj[(size_t)con_sorted[(size_t)d]].j->mu > 0 ? 3 : 1;
+                    const double mu = cj[(size_t)con_sorted[(size_t)d]].j->mu;
+                    m += mu > 0 ? 3 : 1;
+                    nbd += (mu > 0 && mu < __builtin_huge_val()) ? 3 : 1;
                 }
                 m_of[(size_t)i] = m;
+                nbd_of[(size_t)i] = nbd;
             }
         });
         // (2) the islands that get a workgroup, and where their rows sit in the flat arrays
@@ -206,7 +219,10 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
             // one body with 1..8 contacts: solve_singles' / solve_singles_lds' island (one lane), never a workgroup's
             if (!exact && island_bodies[(size_t)i] == 1 && con_start[(size_t)i + 1] - con_start[(size_t)i] <= 8) continue;
             // dWorldStep, an island of hundreds of rows or more: the grid-wide solve (dmx_lcp.hip), not one workgroup
+            // (small and medium ones: one workgroup, the whole solve in LDS, while it fits)
+            if (exact && !lcp_old_kernel() && !lcp_lds_fits((int)sizeof(T), m_of[(size_t)i], nbd_of[(size_t)i])) { grid_list.push_back(i); continue; }
             if (exact && m_of[(size_t)i] >= lcp_grid_threshold()) { grid_list.push_back(i); continue; }
+            if (exact) lds_need = std::max(lds_need, lcp_lds_need((int)sizeof(T), m_of[(size_t)i], nbd_of[(size_t)i]));
             big_list_h.push_back(i);
             row_base.push_back(rows_total);
             rows_total += m_of[(size_t)i];
@@ -421,7 +437,8 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
         int max_rows = 0;
         for (int k = 0; k < n_big; k++) max_rows = std::max(max_rows, b->sc_iv[10][(size_t)big_list_h[(size_t)k]]);
         HIP_TRY(launch_islands_exact<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, (T *)b->jd_lcp.p,
-                                        (const long long *)b->jd_lcp_off.p, (int *)b->jd_lcp_int.p, max_rows, b->stream));
+                                        (const long long *)b->jd_lcp_off.p, (int *)b->jd_lcp_int.p, lcp_old_kernel() ? max_rows : -1, b->stream));
+        if (!lcp_old_kernel()) HIP_TRY(launch_lcp_lds<T>((T *)b->slab, b->bflags, b->stride, I, P, b->diag_isl, lds_need, b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));      // sc_lcp_off is pageable host memory: the copy must have read it before the next tick rewrites it
         if (!grid_list.empty()) {
             // the large islands, one after the other: per row whether it can ever clamp, and the key its active-set state is
@@ -451,6 +468,33 @@ template <class T> int step_joints_t(dmxBatch *b, double h, int64_t nj_in, const
                         R.unbounded[(size_t)(r + q)] = (q > 0 && !(c.j->mu < __builtin_huge_val())) ? 1 : 0;
                     }
                 }
+                // every body's rows (creation order): counting sort over the island's contacts; local index = position among the
+                // island's bodies, which are the ascending slots body_off lists
+                const int ib0 = body_off[isl], inb = body_off[isl + 1] - ib0;
+                std::vector<int> &loc = b->sc_last;         // (-1 outside this block)
+                for (int k = 0; k < inb; k++) loc[(size_t)bodies[ib0 + k]] = k;
+                R.boff.assign((size_t)inb + 1, 0);
+                for (int d = d0; d < d1; d++) {
+                    const CJ &c = cj[(size_t)con_sorted[(size_t)d]];
+                    const int rpc = c.j->mu > 0 ? 3 : 1;
+                    R.boff[(size_t)loc[(size_t)c.b1] + 1] += rpc;
+                    if (c.b2 >= 0) R.boff[(size_t)loc[(size_t)c.b2] + 1] += rpc;
+                }
+                for (int k = 0; k < inb; k++) R.boff[(size_t)k + 1] += R.boff[(size_t)k];
+                R.bodyrows.assign((size_t)R.boff[(size_t)inb], 0);
+                {
+                    std::vector<int> &fill = b->sc_iv[14];
+                    fill.assign(R.boff.begin(), R.boff.end() - 1);
+                    for (int d = d0; d < d1; d++) {
+                        const CJ &c = cj[(size_t)con_sorted[(size_t)d]];
+                        const int r = crow_h[(size_t)d], rpc = c.j->mu > 0 ? 3 : 1;
+                        for (int q = 0; q < rpc; q++) {
+                            R.bodyrows[(size_t)fill[(size_t)loc[(size_t)c.b1]]++] = 2 * (r + q);
+                            if (c.b2 >= 0) R.bodyrows[(size_t)fill[(size_t)loc[(size_t)c.b2]]++] = 2 * (r + q) + 1;
+                        }
+                    }
+                }
+                for (int k = 0; k < inb; k++) loc[(size_t)bodies[ib0 + k]] = -1;
                 if ((rc = lcp_grid_solve<T>(b, I, P, R)) != DMX_OK) return rc;
             }
             lcp_grid_end_tick(b);

@@ -282,15 +282,20 @@ __global__ __launch_bounds__(256) void lcp_syrk(T *__restrict__ A, int ld, int k
 #pragma unroll
         for (int g = 0; g < 4; g++) acc[ir][g] = X[(size_t)MF<T>::row(l, g) * ld + ir * 16 + lc];
     const T *Lr = A + (size_t)k * NB * ld + (size_t)tr * NB, *Lc = A + (size_t)k * NB * ld + (size_t)tc * NB + ic * 16;
-#pragma unroll 4
+    // every operand of the 16 steps is fetched before the first product: one round trip to L2, not one per step (the products
+    // themselves are a microsecond; a tile's time is its memory latency)
+    T fa[NB / 4], fb[NB / 4][4];
+#pragma unroll
     for (int kk = 0; kk < NB / 4; kk++) {
         const size_t o = (size_t)(kk * 4 + lk) * ld + lc;
-        const T fa = -Lc[o];
-        T fb[4];
+        fa[kk] = Lc[o];
 #pragma unroll
-        for (int i = 0; i < 4; i++) fb[i] = Lr[o + i * 16];
+        for (int i = 0; i < 4; i++) fb[kk][i] = Lr[o + i * 16];
+    }
 #pragma unroll
-        for (int ir = 0; ir < 4; ir++) acc[ir] = MF<T>::mfma(fa, fb[ir], acc[ir]);
+    for (int kk = 0; kk < NB / 4; kk++) {
+#pragma unroll
+        for (int ir = 0; ir < 4; ir++) acc[ir] = MF<T>::mfma(-fa[kk], fb[kk][ir], acc[ir]);
     }
 #pragma unroll
     for (int ir = 0; ir < 4; ir++)
@@ -398,22 +403,46 @@ __global__ __launch_bounds__(1024) void lcp_backsolve(const T *__restrict__ A, i
 {
     extern __shared__ __align__(16) unsigned char lcp_bs_raw[];
     constexpr int LP = NB + 1;
-    T *xs = reinterpret_cast<T *>(lcp_bs_raw);              // [nt * NB]
-    T *Lb = xs + (size_t)nt * NB;                           // [NB * LP]
-    T *v = Lb + NB * LP;                                    // [NB]
+    T *xs = reinterpret_cast<T *>(lcp_bs_raw);              // [nt * NB]: y, overwritten by x panel by panel
+    T *Lb0 = xs + (size_t)nt * NB;                          // two diagonal blocks [NB * LP]: the one in use, the next one arriving
+    T *v = Lb0 + 2 * NB * LP;                               // [NB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = nt * NB;
+    for (int a = tid; a < n; a += 1024) xs[a] = yv[(size_t)a * ystride];
+    {
+        const T *Ld = Ldiag + (size_t)(nt - 1) * NB * NB;
+        for (int e = tid; e < NB * NB; e += 1024) Lb0[(e >> 6) * LP + (e & 63)] = Ld[e];     // L(r, c) at Lb[c * LP + r]
+    }
+    __syncthreads();
+    int cur = 0;
     for (int kp = nt - 1; kp >= 0; kp--) {
-        const T *Ld = Ldiag + (size_t)kp * NB * NB;
-        for (int e = tid; e < NB * NB; e += 1024) Lb[(e >> 6) * LP + (e & 63)] = Ld[e];     // L(r, c) at Lb[c * LP + r]
-        for (int cc = wave; cc < NB; cc += 16) {
-            const int c = kp * NB + cc;
-            const T *col = A + (size_t)c * ld;
-            T s = T(0);
-            for (int r = (kp + 1) * NB + lane; r < n; r += 64) s = fma_(col[r], xs[r], s);
+        T *Lb = Lb0 + cur * NB * LP, *Ln = Lb0 + (cur ^ 1) * NB * LP;
+        T pre[4];
+        if (kp > 0) {
+            const T *Ld = Ldiag + (size_t)(kp - 1) * NB * NB;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if (lane == 0) v[cc] = yv[(size_t)c * ystride] - s;
+            for (int q = 0; q < 4; q++) pre[q] = Ld[tid + 1024 * q];
+        }
+        {   // four columns a wavefront, side by side (four independent chains of loads)
+            const T *c0 = A + (size_t)(kp * NB + wave) * ld, *c1 = c0 + (size_t)16 * ld, *c2 = c1 + (size_t)16 * ld, *c3 = c2 + (size_t)16 * ld;
+            T s0 = T(0), s1 = T(0), s2 = T(0), s3 = T(0);
+#pragma unroll 2
+            for (int r = (kp + 1) * NB + lane; r < n; r += 64) {
+                const T x = xs[r];
+                s0 = fma_(c0[r], x, s0); s1 = fma_(c1[r], x, s1); s2 = fma_(c2[r], x, s2); s3 = fma_(c3[r], x, s3);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); s3 += __shfl_xor(s3, o, 64);
+            }
+            if (lane == 0) {
+                v[wave] = xs[kp * NB + wave] - s0; v[wave + 16] = xs[kp * NB + wave + 16] - s1;
+                v[wave + 32] = xs[kp * NB + wave + 32] - s2; v[wave + 48] = xs[kp * NB + wave + 48] - s3;
+            }
+        }
+        if (kp > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int e = tid + 1024 * q; Ln[(e >> 6) * LP + (e & 63)] = pre[q]; }
         }
         __syncthreads();
         if (wave == 0) {
@@ -428,6 +457,7 @@ __global__ __launch_bounds__(1024) void lcp_backsolve(const T *__restrict__ A, i
             xs[kp * NB + lane] = mine;
         }
         __syncthreads();
+        cur ^= 1;
     }
     for (int a = tid; a < n; a += 1024) {
         if (scatter) { const int d = scatter[a]; if (d >= 0) out[d] = xs[a]; }
@@ -450,11 +480,17 @@ __global__ __launch_bounds__(64) void lcp_zvec(const T *__restrict__ A, int ld, 
 }
 
 // =========================================================================================================== 6. forces, integration
-template <class T>
-__global__ __launch_bounds__(1024) void lcp_finish(T *__restrict__ S, const uint8_t *__restrict__ bflags, int64_t stride, IslandSet<T> I,
-                                                   StepParams<T> P, int isl, const int *__restrict__ perm, int nuP, int mP,
-                                                   const T *__restrict__ xU, const T *__restrict__ lamB, const T *__restrict__ wB,
-                                                   const int *__restrict__ state, StepDiag *__restrict__ diag)
+// lambda (U's from the back-substitution, B's from the round) into the rows, then the constraint force of every body
+//   cforce = M^-1 J^T lambda   (rows in creation order per body: bodyrows lists them, entry = 2 row + side)
+// and then either (FINISH = false) every bounded row's  w = J cforce + (cfm / h) lambda - rhs  from the rows themselves -- the
+// quantity the complementarity conditions are about, free of the cancellation the Schur complement's entries carry when cfm is
+// tiny -- and its verdict (lcp_gemv's codes), or (FINISH = true) the integration of the island's bodies (finish_body).
+template <class T, bool FINISH>
+__global__ __launch_bounds__(1024) void lcp_forces(T *__restrict__ S, const uint8_t *__restrict__ bflags, int64_t stride, IslandSet<T> I,
+                                                   StepParams<T> P, int isl, const int *__restrict__ perm, int nuP, int mP, int nbd,
+                                                   const T *__restrict__ xU, const T *__restrict__ lamB, T *__restrict__ wB,
+                                                   const int *__restrict__ state, const int *__restrict__ boff, const int *__restrict__ bodyrows,
+                                                   const T *__restrict__ tolp, int *__restrict__ viol, StepDiag *__restrict__ diag)
 {
     constexpr int WG = 1024;
     const int tid = threadIdx.x;
@@ -464,7 +500,6 @@ __global__ __launch_bounds__(1024) void lcp_finish(T *__restrict__ S, const uint
     T *bs = I.bscr + (size_t)b0 * BW_COUNT;
     T *rows = I.rows + (size_t)r0 * RW_COUNT;
     const int *jb = I.rowjb + 2 * (size_t)r0;
-    const int m = nc > 0 ? I.crow[c0 + nc - 1] + contact_rpc(I, P, c0 + nc - 1) : 0;
     double resid = 0.0;
     for (int p = tid; p < mP; p += WG) {
         const int i = perm[p];
@@ -474,40 +509,351 @@ __global__ __launch_bounds__(1024) void lcp_finish(T *__restrict__ S, const uint
         else {
             const int q = p - nuP;
             l = lamB[q];
-            const int st = state[q];
-            const T w = wB[q];
-            if (st == ST_FREE) {      // clamp what the tolerance let through (the oracle does)
-                const T lo = rows[(size_t)i * RW_COUNT + RW_LO], hi = rows[(size_t)i * RW_COUNT + RW_HI];
-                if (l < lo) l = lo;
-                if (l > hi) l = hi;
-                resid += (double)tabs(w);
-            } else resid += (double)(st == ST_LO ? (w < T(0) ? -w : T(0)) : (w > T(0) ? w : T(0)));
+            if (FINISH) {
+                const int st = state[q];
+                const T w = wB[q];
+                if (st == ST_FREE) {      // clamp what the tolerance let through (the oracle does)
+                    const T lo = rows[(size_t)i * RW_COUNT + RW_LO], hi = rows[(size_t)i * RW_COUNT + RW_HI];
+                    if (l < lo) l = lo;
+                    if (l > hi) l = hi;
+                    resid += (double)tabs(w);
+                } else resid += (double)(st == ST_LO ? (w < T(0) ? -w : T(0)) : (w > T(0) ? w : T(0)));
+            }
         }
         rows[(size_t)i * RW_COUNT + RW_LAM] = l;
     }
-    // the rows' body pairs go to LDS in chunks: every body's lane walks them all (broadcast reads), rows in order per body
-    extern __shared__ __align__(16) unsigned char lcp_fin_raw[];
-    int2 *jbs = reinterpret_cast<int2 *>(lcp_fin_raw);
-    for (int i = tid; i < m; i += WG) jbs[i] = *reinterpret_cast<const int2 *>(jb + 2 * (size_t)i);
     __syncthreads();
-    // cforce = M^-1 J^T lambda
+    for (int k = tid; k < nb; k += WG) {
+        T f[6] = { T(0), T(0), T(0), T(0), T(0), T(0) };
+        for (int e = boff[k]; e < boff[k + 1]; e++) {
+            const int code = bodyrows[e], i = code >> 1, side = code & 1;
+            const T *ip = rows + (size_t)i * RW_COUNT + RW_IMJ + 6 * side;
+            const T lam = rows[(size_t)i * RW_COUNT + RW_LAM];
+#pragma unroll
+            for (int q = 0; q < 6; q++) f[q] = fma_(lam, ip[q], f[q]);
+        }
+        T *b = bs + (size_t)k * BW_COUNT;
+#pragma unroll
+        for (int q = 0; q < 6; q++) b[BW_FC + q] = f[q];
+        if (FINISH) finish_body(S, bflags, stride, b, I.bodies[b0 + k], true, P.h);
+    }
+    if (FINISH) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) resid += __shfl_xor(resid, o, 64);
+        if ((tid & 63) == 0 && resid != 0.0) atomicAdd(&diag->residual, resid);
+        if (tid == 0) atomicAdd(&diag->contacts, (unsigned long long)nc);
+        return;
+    }
+    __syncthreads();
+    const T tol = tolp[0];
+    for (int q = tid; q < nbd; q += WG) {
+        const int i = perm[nuP + q];
+        const T *row = rows + (size_t)i * RW_COUNT;
+        const int l1 = jb[2 * i], l2 = jb[2 * i + 1];
+        const T *f1 = bs + (size_t)l1 * BW_COUNT + BW_FC;
+        const T lam = row[RW_LAM];
+        T w = fma_(row[RW_AD], lam, -row[RW_RHS]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) w = fma_(row[RW_J + k], f1[k], w);
+        if (l2 >= 0) {
+            const T *f2 = bs + (size_t)l2 * BW_COUNT + BW_FC;
+#pragma unroll
+            for (int k = 0; k < 6; k++) w = fma_(row[RW_J + 6 + k], f2[k], w);
+        }
+        wB[q] = w;
+        const int st = state[q];
+        int vi = 0;
+        if (st == ST_FREE) vi = (lam < row[RW_LO] - tol) ? 1 : (lam > row[RW_HI] + tol) ? 2 : 0;
+        else if (st == ST_LO) vi = w < -tol ? 3 : 0;
+        else vi = w > tol ? 3 : 0;
+        viol[q] = vi;
+    }
+}
+
+// =========================================================================================================== small and medium islands
+// One workgroup per island, the whole solve in LDS: the same method as the grid solve above (never-clamping rows first, eliminated
+// once; block principal pivoting on the Schur complement in the bounded rows; lambda_U by back-substitution), as an LDL^T on a
+// packed lower triangle -- no square roots and ONE barrier per pivot: at step k every thread reads the pivot M(k,k) and the column
+// below it, which the previous step's barrier made final, and updates its share of the trailing triangle
+//   M(i,j) -= M(i,k) M(j,k) / M(k,k),   i > k, k < j <= i;
+// column k stays as it is (c_ik = l_ik d_k), the right-hand side rides along as the last row (it ends as y = L^-1 b).
+// Islands of up to a few hundred rows in the reference's pen while the pile is still loose (/root/reference/src/main.c:213).
+__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }      // j <= i
+
+// steps [k0, k1) of the LDL^T of the packed matrix M whose rows 0 .. last are stored (row `last` = the right-hand side; the
+// unknowns are rows / columns 0 .. last - 1); dinv[k] = 1 / pivot.  Ends with a barrier.
+template <class T, int WG>
+__device__ __forceinline__ void ldlt_steps(T *M, int last, int k0, int k1, T *dinv, T tol, int tid)
+{
+    const int ty = tid >> 4, tx = tid & 15;
+    for (int k = k0; k < k1; k++) {
+        T d = M[tri(k, k)];
+        d = d > T(0) ? d : tol;               // (the oracle's guard: a pivot that rounding pushed below zero)
+        const T inv = T(1) / d;
+        if (tid == 0) dinv[k] = inv;
+        for (int i = k + 1 + ty; i <= last; i += WG / 16) {
+            const T cik = M[tri(i, k)] * inv;
+            const int jmax = i < last ? i : last - 1;
+            for (int j = k + 1 + tx; j <= jmax; j += 16) M[tri(i, j)] = fma_(-cik, M[tri(j, k)], M[tri(i, j)]);
+        }
+        __syncthreads();
+    }
+}
+// L^T x = z in place over unknowns [0, n) of a packed LDL^T (L(i,k) = M(i,k) dinv[k]); z in LDS.  Ends with a barrier.
+template <class T, int WG>
+__device__ __forceinline__ void ldlt_backsub(const T *M, int n, const T *dinv, T *z, int tid)
+{
+    for (int i = n - 1; i >= 1; i--) {
+        const T xi = z[i];
+        for (int k = tid; k < i; k += WG) z[k] = fma_(-M[tri(i, k)] * dinv[k], xi, z[k]);
+        __syncthreads();
+    }
+}
+
+// LDS of lcp_island_lds: M (m + 1 packed rows), W (nbd + 1), lam / w / lo / hi [nbd], dinv [nu], z [max(nu, 2 nbd)]; then the ints
+__host__ __device__ inline size_t lcp_lds_reals(int m, int nbd)
+{
+    const int nu = m - nbd;
+    return (size_t)(m + 1) * (m + 2) / 2 + (size_t)(nbd + 1) * (nbd + 2) / 2 + (size_t)4 * nbd + (size_t)nu + (size_t)(nu > 2 * nbd ? nu : 2 * nbd) + 8;
+}
+template <class T> __host__ __device__ inline size_t lcp_lds_bytes(int m, int nbd)
+{
+    return ((lcp_lds_reals(m, nbd) * sizeof(T) + 15) / 16) * 16 + ((size_t)3 * m + (size_t)3 * nbd + 16) * sizeof(int);
+}
+
+template <class T, int WG>
+__global__ __launch_bounds__(WG) void lcp_island_lds(T *__restrict__ S, const uint8_t *__restrict__ bflags, int64_t stride, IslandSet<T> I,
+                                                     StepParams<T> P, StepDiag *__restrict__ diag, int murty_only, T tol_rel)
+{
+    const int isl = I.big_list[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T h = P.h, hinv = T(1) / h;
+    const int b0 = I.body_off[isl], nb = I.body_off[isl + 1] - b0;
+    const int c0 = I.con_off[isl], nc = I.con_off[isl + 1] - c0;
+    const int r0 = I.row_off[isl];
+    T *bs = I.bscr + (size_t)b0 * BW_COUNT;
+    T *rows = I.rows + (size_t)r0 * RW_COUNT;
+    int *jb = I.rowjb + 2 * (size_t)r0;
+    const int m = nc > 0 ? I.crow[c0 + nc - 1] + contact_rpc(I, P, c0 + nc - 1) : 0;
+
+    for (int k = tid; k < nb; k += WG) stage_body(S, bflags, stride, I, P, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], k);
+    __syncthreads();
+    for (int c = tid; c < nc; c += WG) contact_rows(S, stride, I, P, rows, jb, c0 + c, I.crow[c0 + c], hinv);
+    for (int k = tid; k < nb; k += WG) body_tmp(S, stride, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], hinv);
+    __syncthreads();
+    __shared__ int s_cnt[2][WG / 64 + 1];
+    __shared__ int s_nv, s_top;
+    __shared__ T s_red[WG / 64];
+    // rows: setup, the largest |rhs| (the tolerance's scale), and who can never clamp
+    T bmax = T(0);
+    for (int i = tid; i < m; i += WG) {
+        row_setup<T, false>(rows, jb, bs, i, hinv, P.sor_w);
+        const T v = tabs(rows[(size_t)i * RW_COUNT + RW_RHS]);
+        if (v > bmax) bmax = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const T v = __shfl_xor(bmax, o, 64); if (v > bmax) bmax = v; }
+    if (lane == 0) s_red[wave] = bmax;
+    __syncthreads();
+    bmax = s_red[0];
+    for (int q = 1; q < WG / 64; q++) if (s_red[q] > bmax) bmax = s_red[q];
+    const T tol = tol_rel * (T(1) + bmax);
+
+    extern __shared__ __align__(16) unsigned char lcp_lds_raw[];
+    // ---- the permutation: unbounded rows first (m <= a few hundred: passes of WG rows, ballot ranks)
+    int nu = 0;
+    {
+        // count first, then place: two passes over the rows, each with per-wave ballots
+        int mine_u = 0;
+        for (int base = 0; base < m; base += WG) {
+            const int i = base + tid;
+            const bool u = i < m && rows[(size_t)i * RW_COUNT + RW_LO] == -Limits<T>::inf() && rows[(size_t)i * RW_COUNT + RW_HI] == Limits<T>::inf();
+            const unsigned long long bal = __ballot(u);
+            if (lane == 0) mine_u += __popcll(bal);
+        }
+        if (lane == 0) s_cnt[0][wave] = mine_u;
+        __syncthreads();
+        for (int q = 0; q < WG / 64; q++) nu += s_cnt[0][q];
+        __syncthreads();
+    }
+    const int nbd = m - nu;
+    T *M = reinterpret_cast<T *>(lcp_lds_raw);
+    T *W = M + (size_t)(m + 1) * (m + 2) / 2;
+    T *lam = W + (size_t)(nbd + 1) * (nbd + 2) / 2, *wv = lam + nbd, *lo = wv + nbd, *hi = lo + nbd;
+    T *dinv = hi + nbd, *z = dinv + nu;
+    int *perm = reinterpret_cast<int *>(lcp_lds_raw + ((lcp_lds_reals(m, nbd) * sizeof(T) + 15) / 16) * 16);
+    int *pb1 = perm + m, *pb2 = pb1 + m, *state = pb2 + m, *fidx = state + nbd, *viol = fidx + nbd;
+    {
+        int ubase = 0, bbase = 0;
+        for (int base = 0; base < m; base += WG) {
+            const int i = base + tid;
+            const bool in = i < m;
+            const bool u = in && rows[(size_t)i * RW_COUNT + RW_LO] == -Limits<T>::inf() && rows[(size_t)i * RW_COUNT + RW_HI] == Limits<T>::inf();
+            const unsigned long long bu = __ballot(u), bb = __ballot(in && !u);
+            if (lane == 0) { s_cnt[0][wave] = __popcll(bu); s_cnt[1][wave] = __popcll(bb); }
+            __syncthreads();
+            int offu = ubase, offb = bbase;
+            for (int q = 0; q < wave; q++) { offu += s_cnt[0][q]; offb += s_cnt[1][q]; }
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            if (u) perm[offu + __popcll(bu & lt)] = i;
+            else if (in) perm[nu + offb + __popcll(bb & lt)] = i;
+            for (int q = 0; q < WG / 64; q++) { ubase += s_cnt[0][q]; bbase += s_cnt[1][q]; }
+            __syncthreads();
+        }
+    }
+    for (int p = tid; p < m; p += WG) {
+        const int i = perm[p];
+        pb1[p] = jb[2 * i]; pb2[p] = jb[2 * i + 1];
+        if (p >= nu) {
+            lo[p - nu] = rows[(size_t)i * RW_COUNT + RW_LO]; hi[p - nu] = rows[(size_t)i * RW_COUNT + RW_HI];
+            state[p - nu] = ST_FREE; lam[p - nu] = T(0);
+        }
+    }
+    __syncthreads();
+    // ---- A, permuted, packed lower, with the right-hand side as row m
+    for (int p = tid; p <= m; p += WG) {
+        T *Mp = M + tri(p, 0);
+        if (p == m) { for (int q = 0; q < m; q++) Mp[q] = rows[(size_t)perm[q] * RW_COUNT + RW_RHS]; Mp[m] = T(0); continue; }
+        const int i = perm[p], i1 = pb1[p], i2 = pb2[p];
+        const T *ji = rows + (size_t)i * RW_COUNT + RW_J;
+        for (int q = 0; q <= p; q++) {
+            const int j1 = pb1[q], j2 = pb2[q];
+            T a = T(0);
+            if (i1 == j1 || i1 == j2 || (i2 >= 0 && (i2 == j1 || i2 == j2))) {
+                const T *pj = rows + (size_t)perm[q] * RW_COUNT + RW_IMJ;
+                if (i1 == j1) { for (int e = 0; e < 6; e++) a = fma_(ji[e], pj[e], a); }
+                if (j2 >= 0 && i1 == j2) { for (int e = 0; e < 6; e++) a = fma_(ji[e], pj[6 + e], a); }
+                if (i2 >= 0 && i2 == j1) { for (int e = 0; e < 6; e++) a = fma_(ji[6 + e], pj[e], a); }
+                if (i2 >= 0 && j2 >= 0 && i2 == j2) { for (int e = 0; e < 6; e++) a = fma_(ji[6 + e], pj[6 + e], a); }
+            }
+            if (q == p) a += rows[(size_t)i * RW_COUNT + RW_AD];
+            Mp[q] = a;
+        }
+    }
+    __syncthreads();
+    // ---- U eliminated: what is left in rows / columns nu.. is the Schur complement and the reduced right-hand side
+    ldlt_steps<T, WG>(M, m, 0, nu, dinv, tol, tid);
+    // dinv[0 .. nu) belongs to U from here on; the rounds use their own (rd)
+    T *rd = z;            // (z is free until the end)
+    int best = m + 1, patience = murty_only ? 0 : 3;
+    const int max_rounds = 20 * m + 100;
+    if (nbd > 0)
+    for (int round = 0;; round++) {
+        // the free rows in order
+        int nf = 0;
+        {
+            int fbase = 0;
+            for (int base = 0; base < nbd; base += WG) {
+                const int q = base + tid;
+                const bool f = q < nbd && state[q] == ST_FREE;
+                const unsigned long long bf = __ballot(f);
+                if (lane == 0) s_cnt[0][wave] = __popcll(bf);
+                __syncthreads();
+                int off = fbase;
+                for (int e = 0; e < wave; e++) off += s_cnt[0][e];
+                if (f) fidx[off + __popcll(bf & ((1ull << lane) - 1ull))] = q;
+                else if (q < nbd) lam[q] = state[q] == ST_LO ? lo[q] : hi[q];
+                for (int e = 0; e < WG / 64; e++) fbase += s_cnt[0][e];
+                __syncthreads();
+            }
+            nf = fbase;
+        }
+        // W = S[F, F] with the right-hand side b'_F - S_FC lambda_C as its last row
+        for (int a = tid; a <= nf; a += WG) {
+            T *Wa = W + tri(a, 0);
+            if (a == nf) {
+                for (int c = 0; c < nf; c++) {
+                    const int qc = fidx[c];
+                    T r = M[tri(m, nu + qc)];
+                    for (int e = 0; e < nbd; e++)
+                        if (state[e] != ST_FREE && lam[e] != T(0)) r = fma_(-(e >= qc ? M[tri(nu + e, nu + qc)] : M[tri(nu + qc, nu + e)]), lam[e], r);
+                    Wa[c] = r;
+                }
+                Wa[nf] = T(0);
+            } else {
+                const int qa = fidx[a];
+                for (int c = 0; c <= a; c++) Wa[c] = M[tri(nu + qa, nu + fidx[c])];
+            }
+        }
+        __syncthreads();
+        ldlt_steps<T, WG>(W, nf, 0, nf, rd, tol, tid);
+        T *x = rd + nbd;          // (z has room for max(nu, 2 nbd))
+        for (int a = tid; a < nf; a += WG) x[a] = W[tri(nf, a)] * rd[a];
+        __syncthreads();
+        ldlt_backsub<T, WG>(W, nf, rd, x, tid);
+        for (int a = tid; a < nf; a += WG) lam[fidx[a]] = x[a];
+        __syncthreads();
+        // w_B = S lambda_B - b', verdicts
+        if (tid == 0) { s_nv = 0; s_top = -1; }
+        __syncthreads();
+        for (int q = tid; q < nbd; q += WG) {
+            T sacc = -M[tri(m, nu + q)];
+            for (int e = 0; e < nbd; e++) sacc = fma_(e <= q ? M[tri(nu + q, nu + e)] : M[tri(nu + e, nu + q)], lam[e], sacc);
+            wv[q] = sacc;
+            const int st = state[q];
+            int vi = 0;
+            if (st == ST_FREE) vi = (lam[q] < lo[q] - tol) ? 1 : (lam[q] > hi[q] + tol) ? 2 : 0;
+            else if (st == ST_LO) vi = sacc < -tol ? 3 : 0;
+            else vi = sacc > tol ? 3 : 0;
+            viol[q] = vi;
+            if (vi) { atomicAdd(&s_nv, 1); atomicMax(&s_top, q); }
+        }
+        __syncthreads();
+        const int nviol = s_nv, top = s_top;
+        if (nviol == 0 || round >= max_rounds) break;
+        bool all = true;
+        if (nviol < best) { best = nviol; if (!murty_only) patience = 3; }
+        else if (patience > 0) patience--;
+        else all = false;
+        if (murty_only) all = false;
+        for (int q = tid; q < nbd; q += WG) {
+            const int vi = viol[q];
+            if (!vi || (!all && q != top)) continue;
+            state[q] = vi == 1 ? ST_LO : vi == 2 ? ST_HI : ST_FREE;
+        }
+        __syncthreads();
+    }
+    // ---- lambda_U: L_UU^T x = D^-1 y_U - L_BU^T lambda_B
+    for (int k = tid; k < nu; k += WG) {
+        T acc = M[tri(m, k)];
+        for (int e = 0; e < nbd; e++) acc = fma_(-M[tri(nu + e, k)], lam[e], acc);
+        z[k] = acc * dinv[k];
+    }
+    __syncthreads();
+    ldlt_backsub<T, WG>(M, nu, dinv, z, tid);
+    // lambda into the rows (free rows clamped to their bounds as the oracle does), residual, forces, integration
+    double resid = 0.0;
+    for (int p = tid; p < m; p += WG) {
+        const int i = perm[p];
+        T l;
+        if (p < nu) l = z[p];
+        else {
+            const int q = p - nu;
+            l = lam[q];
+            const T w = wv[q];
+            if (state[q] == ST_FREE) { if (l < lo[q]) l = lo[q]; if (l > hi[q]) l = hi[q]; resid += (double)tabs(w); }
+            else resid += (double)(state[q] == ST_LO ? (w < T(0) ? -w : T(0)) : (w > T(0) ? w : T(0)));
+        }
+        rows[(size_t)i * RW_COUNT + RW_LAM] = l;
+    }
+    __syncthreads();
     for (int k = tid; k < nb; k += WG) {
         T f[6] = { T(0), T(0), T(0), T(0), T(0), T(0) };
         for (int i = 0; i < m; i++) {
-            const int2 bb = jbs[i];
+            const int2 bb = *reinterpret_cast<const int2 *>(jb + 2 * (size_t)i);
             if (bb.x != k && bb.y != k) continue;
             const T *ip = rows + (size_t)i * RW_COUNT + RW_IMJ;
-            const T lam = rows[(size_t)i * RW_COUNT + RW_LAM];
-            if (bb.x == k) { for (int q = 0; q < 6; q++) f[q] = fma_(lam, ip[q], f[q]); }
-            if (bb.y == k) { for (int q = 0; q < 6; q++) f[q] = fma_(lam, ip[6 + q], f[q]); }
+            const T l = rows[(size_t)i * RW_COUNT + RW_LAM];
+            if (bb.x == k) { for (int q = 0; q < 6; q++) f[q] = fma_(l, ip[q], f[q]); }
+            if (bb.y == k) { for (int q = 0; q < 6; q++) f[q] = fma_(l, ip[6 + q], f[q]); }
         }
         T *b = bs + (size_t)k * BW_COUNT;
         for (int q = 0; q < 6; q++) b[BW_FC + q] = f[q];
-        finish_body(S, bflags, stride, b, I.bodies[b0 + k], m > 0, P.h);
+        finish_body(S, bflags, stride, b, I.bodies[b0 + k], m > 0, h);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) resid += __shfl_xor(resid, o, 64);
-    if ((tid & 63) == 0 && resid != 0.0) atomicAdd(&diag->residual, resid);
+    if (lane == 0 && resid != 0.0) atomicAdd(&diag->residual, resid);
     if (tid == 0) atomicAdd(&diag->contacts, (unsigned long long)nc);
 }
 
@@ -518,7 +864,9 @@ struct LcpGrid {
     std::unordered_map<uint64_t, uint8_t> warm_prev, warm_next;
     std::vector<int> perm, state;
     int64_t stats[8] = { 0 };
+    double flops = 0;            // algorithmic: the partial factorisation (nu^3/3 + nu^2 nb + nu nb^2) and nf^3/3 per pivoting round
     bool warm = true, murty_only = false;
+    int w_mode = -1;             // DMX_LCP_W: 0 = w from the Schur complement (one product per round), 1 = from the rows through lambda_U; -1: by precision
     double tol_rel = 0;          // DMX_LCP_TOL: the complementarity tolerance relative to 1 + max |rhs| (0: the oracle's, 1e-5 f32 / 1e-11 f64)
 };
 
@@ -530,6 +878,8 @@ LcpGrid *grid_of(dmxBatch *b)
         g->warm = !(e && atoi(e) == 0);
         e = getenv("DMX_LCP_MURTY");
         g->murty_only = e && atoi(e) != 0;
+        e = getenv("DMX_LCP_W");
+        if (e) g->w_mode = atoi(e) != 0 ? 1 : 0;
         e = getenv("DMX_LCP_TOL");
         if (e) g->tol_rel = atof(e);
         b->lcp_grid = g;
@@ -553,7 +903,7 @@ hipError_t factor_panels(T *A, int ld, int nt, int np, T *Ldiag, const T *tol, h
     return hipGetLastError();
 }
 
-template <class T> size_t backsolve_lds(int nt) { return ((size_t)nt * NB + NB * (NB + 1) + NB) * sizeof(T); }
+template <class T> size_t backsolve_lds(int nt) { return ((size_t)nt * NB + 2 * NB * (NB + 1) + NB) * sizeof(T); }
 
 }  // namespace
 
@@ -575,9 +925,9 @@ void lcp_grid_free(dmxBatch *b)
     if (!b->lcp_grid) return;
     LcpGrid *g = (LcpGrid *)b->lcp_grid;
     if (getenv("DMX_LCP_REPORT"))
-        fprintf(stderr, "libode_mi355 lcp grid: solves=%lld rounds=%lld max_rounds=%lld last_m=%lld last_nu=%lld last_nbd=%lld single=%lld fallback=%lld\n",
+        fprintf(stderr, "libode_mi355 lcp grid: solves=%lld rounds=%lld max_rounds=%lld last_m=%lld last_nu=%lld last_nbd=%lld single=%lld fallback=%lld gflop=%.4f\n",
                 (long long)g->stats[0], (long long)g->stats[1], (long long)g->stats[2], (long long)g->stats[3], (long long)g->stats[4],
-                (long long)g->stats[5], (long long)g->stats[6], (long long)g->stats[7]);
+                (long long)g->stats[5], (long long)g->stats[6], (long long)g->stats[7], g->flops * 1e-9);
     for (dmxBatch::DevBuf *d : { &g->A, &g->Ldiag, &g->Sd, &g->Mw, &g->Mdiag, &g->vec, &g->ints })
         if (d->p) (void)hipFree(d->p);
     if (g->pin) (void)hipHostFree(g->pin);
@@ -614,8 +964,9 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
     // vectors: tol[4] bprime lo hi lamB wB rr (nbdP each) z xU (nuP each)
     const size_t nv = 4 + (size_t)6 * (nbdP + NB) + (size_t)2 * (nuP + NB);
     if ((rc = dmx_ensure_dev(g->vec, nv * sizeof(T))) != DMX_OK) return rc;
-    // ints: perm[mP] state[nbdP] fidx[nbdP] viol[nbdP]
-    const size_t ni = (size_t)mP + (size_t)3 * (nbdP + NB);
+    // ints: perm[mP] state[nbdP] fidx[nbdP] viol[nbdP] boff[nb + 1] bodyrows[2 m]
+    const size_t n_csr = R.boff.size() + R.bodyrows.size();
+    const size_t ni = (size_t)mP + (size_t)3 * (nbdP + NB) + n_csr + 8;
     if ((rc = dmx_ensure_dev(g->ints, ni * sizeof(int))) != DMX_OK) return rc;
     if (g->pin_bytes < ni * sizeof(int)) {
         if (g->pin) HIP_TRY(hipHostFree(g->pin));
@@ -629,11 +980,17 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
       *wB = lamB + (nbdP + NB), *rr = wB + (nbdP + NB), *z = rr + (nbdP + NB), *xU = z + (nuP + NB);
     int *d_perm = (int *)g->ints.p, *d_state = d_perm + mP, *d_fidx = d_state + (nbdP + NB), *d_viol = d_fidx + (nbdP + NB);
     int *h_perm = (int *)g->pin, *h_state = h_perm + mP, *h_fidx = h_state + (nbdP + NB), *h_viol = h_fidx + (nbdP + NB);
+    int *d_boff = d_viol + (nbdP + NB), *d_bodyrows = d_boff + R.boff.size();
+    int *h_boff = h_viol + (nbdP + NB), *h_bodyrows = h_boff + R.boff.size();
+    const bool sparse_w = g->w_mode >= 0 ? g->w_mode != 0 : sizeof(T) == 8;
 
     // (the pinned staging is reused by the next island / tick: every copy below is followed by a synchronisation before the
     //  host writes it again -- the rounds' read-back)
     memcpy(h_perm, perm.data(), (size_t)mP * sizeof(int));
     HIP_TRY(hipMemcpyAsync(d_perm, h_perm, (size_t)mP * sizeof(int), hipMemcpyHostToDevice, st));
+    memcpy(h_boff, R.boff.data(), R.boff.size() * sizeof(int));
+    memcpy(h_bodyrows, R.bodyrows.data(), R.bodyrows.size() * sizeof(int));
+    HIP_TRY(hipMemcpyAsync(d_boff, h_boff, n_csr * sizeof(int), hipMemcpyHostToDevice, st));
 
     // rows of this island inside the flat arrays: row_off is a device array, but by construction row_off[isl] = 3 * con_off[isl],
     // which the caller passes as R.row_base
@@ -649,6 +1006,7 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
         if (ea != hipSuccess) HIP_TRY(ea);
     }
     HIP_TRY(factor_panels<T>(A, ld, nt, nuT, Ldiag, tol, st));
+    g->flops += (double)nu * nu * nu / 3.0 + (double)nu * nu * nbd + (double)nu * nbd * nbd;
 
     // ---- the reduced problem in B's rows
     std::vector<int> &state = g->state;
@@ -698,10 +1056,20 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
             if (nf > 0) {
                 hipLaunchKernelGGL((lcp_gather<T>), dim3((unsigned)(nfT + 1), (unsigned)nfT), dim3(256), 0, st, Sd, lds, d_fidx, nfT, rhs, Mw, ldw);
                 HIP_TRY(factor_panels<T>(Mw, ldw, nfT, nfT, Mdiag, tol, st));
+                g->flops += (double)nf * nf * nf / 3.0;
                 hipLaunchKernelGGL((lcp_backsolve<T>), dim3(1), dim3(1024), backsolve_lds<T>(nfT), st, Mw, ldw, Mdiag, nfT,
                                    Mw + nfP, (size_t)ldw, d_fidx, lamB);
             }
-            hipLaunchKernelGGL((lcp_gemv<T, true>), dim3((unsigned)nbT), dim3(256), 0, st, Sd, lds, nbd, lamB, bprime, wB, d_state, lo, hi, tol, d_viol);
+            if (sparse_w) {
+                if (nuT > 0) {
+                    hipLaunchKernelGGL((lcp_zvec<T>), dim3((unsigned)nuP), dim3(64), 0, st, A, ld, nuP, mP, nbd, lamB, z);
+                    hipLaunchKernelGGL((lcp_backsolve<T>), dim3(1), dim3(1024), backsolve_lds<T>(nuT), st, A, ld, Ldiag, nuT, z, (size_t)1,
+                                       (const int *)nullptr, xU);
+                }
+                hipLaunchKernelGGL((lcp_forces<T, false>), dim3(1), dim3(1024), 0, st, (T *)b->slab, b->bflags, b->stride, I, P, isl, d_perm, nuP, mP,
+                                   nbd, xU, lamB, wB, d_state, d_boff, d_bodyrows, tol, d_viol, b->diag_isl);
+            } else
+                hipLaunchKernelGGL((lcp_gemv<T, true>), dim3((unsigned)nbT), dim3(256), 0, st, Sd, lds, nbd, lamB, bprime, wB, d_state, lo, hi, tol, d_viol);
             HIP_TRY(hipMemcpyAsync(h_viol, d_viol, (size_t)nbd * sizeof(int), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             int nviol = 0, top = -1;
@@ -729,18 +1097,13 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
         if (ea != hipSuccess) HIP_TRY(ea);
     }
     // ---- lambda_U, forces, integration
-    if (nuT > 0) {
+    if (nuT > 0 && !(sparse_w && nbd > 0)) {        // (the last round of the accurate form has left lambda_U behind)
         hipLaunchKernelGGL((lcp_zvec<T>), dim3((unsigned)nuP), dim3(64), 0, st, A, ld, nuP, mP, nbd, lamB, z);
         hipLaunchKernelGGL((lcp_backsolve<T>), dim3(1), dim3(1024), backsolve_lds<T>(nuT), st, A, ld, Ldiag, nuT, z, (size_t)1,
                            (const int *)nullptr, xU);
     }
-    if ((size_t)m * sizeof(int2) > (size_t)64 * 1024) {
-        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcp_finish<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)((size_t)m * sizeof(int2)));
-        if (ea != hipSuccess) HIP_TRY(ea);
-    }
-    hipLaunchKernelGGL((lcp_finish<T>), dim3(1), dim3(1024), (size_t)m * sizeof(int2), st, (T *)b->slab, b->bflags, b->stride, I, P, isl, d_perm, nuP, mP, xU, lamB, wB,
-                       d_state, b->diag_isl);
+    hipLaunchKernelGGL((lcp_forces<T, true>), dim3(1), dim3(1024), 0, st, (T *)b->slab, b->bflags, b->stride, I, P, isl, d_perm, nuP, mP, nbd, xU,
+                       lamB, wB, d_state, d_boff, d_bodyrows, tol, d_viol, b->diag_isl);
     HIP_TRY(hipGetLastError());
     g->stats[0] += 1; g->stats[1] += rounds + 1; if (rounds + 1 > g->stats[2]) g->stats[2] = rounds + 1;
     g->stats[3] = m; g->stats[4] = nu; g->stats[5] = nbd; g->stats[6] += single_rounds;
@@ -749,6 +1112,30 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
 
 template int lcp_grid_solve<float>(dmxBatch *, const IslandSet<float> &, const StepParams<float> &, const LcpIslandRows &);
 template int lcp_grid_solve<double>(dmxBatch *, const IslandSet<double> &, const StepParams<double> &, const LcpIslandRows &);
+
+// can island (m rows, nbd of them bounded) be solved by one workgroup in LDS?
+bool lcp_lds_fits(int real_bytes, int m, int nbd)
+{
+    static const int lim = [] { const char *e = getenv("DMX_LCP_LDS_BYTES"); return e ? atoi(e) : 156 * 1024; }();
+    const size_t need = real_bytes == 4 ? lcp_lds_bytes<float>(m, nbd) : lcp_lds_bytes<double>(m, nbd);
+    return need <= (size_t)lim;
+}
+template <class T>
+hipError_t launch_lcp_lds(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P, StepDiag *diag,
+                          size_t lds_bytes, hipStream_t st)
+{
+    if (I.n_big <= 0) return hipSuccess;
+    static const int murty = [] { const char *e = getenv("DMX_LCP_MURTY"); return e && atoi(e) != 0 ? 1 : 0; }();
+    static const double tol_env = [] { const char *e = getenv("DMX_LCP_TOL"); return e ? atof(e) : 0.0; }();
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcp_island_lds<T, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (ea != hipSuccess) return ea;
+    hipLaunchKernelGGL((lcp_island_lds<T, 256>), dim3((unsigned)I.n_big), dim3(256), lds_bytes, st, S, bflags, stride, I, P, diag, murty,
+                       (T)(tol_env > 0 ? tol_env : (sizeof(T) == 4 ? 1e-5 : 1e-11)));
+    return hipGetLastError();
+}
+template hipError_t launch_lcp_lds<float>(float *, const uint8_t *, int64_t, const IslandSet<float> &, const StepParams<float> &, StepDiag *, size_t, hipStream_t);
+template hipError_t launch_lcp_lds<double>(double *, const uint8_t *, int64_t, const IslandSet<double> &, const StepParams<double> &, StepDiag *, size_t, hipStream_t);
+size_t lcp_lds_need(int real_bytes, int m, int nbd) { return real_bytes == 4 ? lcp_lds_bytes<float>(m, nbd) : lcp_lds_bytes<double>(m, nbd); }
 
 void lcp_grid_stats(dmxBatch *b, int64_t out[8])
 {

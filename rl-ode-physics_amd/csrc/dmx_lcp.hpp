@@ -24,6 +24,9 @@ struct LcpIslandRows {
     int row_base = 0;                 // the island's first row in the set's flat row arrays (3 x its first contact)
     std::vector<uint8_t> unbounded;
     std::vector<uint64_t> key;
+    // the rows of every body of the island, ascending: body k's (k = its index within the island) are bodyrows[boff[k] .. boff[k+1]),
+    // each entry 2 * row + side (0: the body is the row's first, 1: its second)
+    std::vector<int> boff, bodyrows;
 };
 
 // Solve island `R.isl` of the set exactly and step its bodies (the launch sequence is enqueued on b->stream; the host waits for
@@ -40,5 +43,12 @@ void lcp_grid_free(dmxBatch *b);
 void lcp_grid_stats(dmxBatch *b, int64_t out[8]);
 void lcp_grid_count_fallback(dmxBatch *b);
 hipError_t dmx_touch_lcp(int real_bytes);
+// dWorldStep's small and medium islands: one workgroup per island of I.big_list, the whole solve in LDS (lcp_island_lds).
+// lcp_lds_fits: does an island of m rows, nbd of them bounded, fit?  (Islands that do not go to the grid solve.)
+bool lcp_lds_fits(int real_bytes, int m, int nbd);
+size_t lcp_lds_need(int real_bytes, int m, int nbd);
+template <class T>
+hipError_t launch_lcp_lds(T *S, const uint8_t *bflags, int64_t stride, const IslandSet<T> &I, const StepParams<T> &P, StepDiag *diag,
+                          size_t lds_bytes, hipStream_t st);
 
 }  // namespace dmx
