@@ -28,6 +28,7 @@
 // Cost per tick at m rows, |B| = m/3: one partial factorisation (m^3/3 less B's own block) + rounds x (|free B|^3/3).
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <algorithm>
 #include <unordered_map>
 
 #include "dmx_lcp.hpp"
@@ -37,7 +38,7 @@ namespace dmx {
 
 int lcp_grid_threshold()
 {
-    static const int v = [] { const char *e = getenv("DMX_LCP_GRID_ROWS"); const int t = e ? atoi(e) : 192; return t < 1 ? 1 : t; }();
+    static const int v = [] { const char *e = getenv("DMX_LCP_GRID_ROWS"); const int t = e ? atoi(e) : 1 << 30; return t < 1 ? 1 : t; }();
     return v;
 }
 int lcp_max_exact_rows()
@@ -337,6 +338,18 @@ __global__ __launch_bounds__(256) void lcp_clamped(const int *__restrict__ state
     const int s = state[i];
     lam[i] = s == ST_LO ? lo[i] : s == ST_HI ? hi[i] : T(0);
 }
+// the same with the rows listed in `except` (the volatile set: the LDS solve accounts for those itself) left at zero
+template <class T>
+__global__ __launch_bounds__(256) void lcp_clamped_except(const int *__restrict__ state, const T *__restrict__ lo, const T *__restrict__ hi, int n,
+                                                          const int *__restrict__ except, int n_except, T *__restrict__ lam)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int s = state[i];
+    T l = s == ST_LO ? lo[i] : s == ST_HI ? hi[i] : T(0);
+    for (int e = 0; e < n_except; e++) if (except[e] == i) l = T(0);
+    lam[i] = l;
+}
 // out = bvec - Sd v   (CLASSIFY = false: a round's right-hand side),   or
 // out = Sd v - bvec = w and every row's verdict (CLASSIFY = true): 0 fine, 1 free row below lo, 2 free row above hi, 3 clamped
 // row whose w has the wrong sign -- the oracle's tests and tolerance.  64 rows a workgroup, the columns in four fixed segments.
@@ -610,6 +623,98 @@ __device__ __forceinline__ void ldlt_backsub(const T *M, int n, const T *dinv, T
     }
 }
 
+// Block principal pivoting on the bounded rows' problem held in LDS: S = rows / columns nu .. nu + nbd - 1 of the packed matrix M,
+// b' = its row m from column nu.  state: in = where the active set starts, out = where it ended; lam / wv: the solution and
+// w = S lam - b'.  W: room for a packed (nbd + 1)-row matrix; rd: 2 nbd reals.  The oracle's rule: every violating row flips;
+// when the count of violations has failed to shrink three times, only the highest violating row does (Murty).  Returns the
+// number of rounds.  Ends after a barrier.
+template <class T, int WG>
+__device__ __forceinline__ int lds_pivot_rounds(const T *M, int m, int nu, int nbd, T *W, T *lam, T *wv, const T *lo, const T *hi, int *state,
+                                                int *fidx, int *viol, T *rd, T tol, int murty_only, int max_rounds, int tid)
+{
+    __shared__ int s_cnt[2][WG / 64 + 1];
+    __shared__ int s_nv, s_top;
+    const int lane = tid & 63, wave = tid >> 6;
+    int round = 0;
+    int best = m + 1, patience = murty_only ? 0 : 3;
+    if (nbd <= 0) return 0;
+    for (;; round++) {
+        // the free rows in order
+        int nf = 0;
+        {
+            int fbase = 0;
+            for (int base = 0; base < nbd; base += WG) {
+                const int q = base + tid;
+                const bool f = q < nbd && state[q] == ST_FREE;
+                const unsigned long long bf = __ballot(f);
+                if (lane == 0) s_cnt[0][wave] = __popcll(bf);
+                __syncthreads();
+                int off = fbase;
+                for (int e = 0; e < wave; e++) off += s_cnt[0][e];
+                if (f) fidx[off + __popcll(bf & ((1ull << lane) - 1ull))] = q;
+                else if (q < nbd) lam[q] = state[q] == ST_LO ? lo[q] : hi[q];
+                for (int e = 0; e < WG / 64; e++) fbase += s_cnt[0][e];
+                __syncthreads();
+            }
+            nf = fbase;
+        }
+        // W = S[F, F] with the right-hand side b'_F - S_FC lambda_C as its last row
+        for (int a = tid; a < nf; a += WG) {
+            T *Wa = W + tri(a, 0);
+            const int qa = fidx[a];
+            for (int c = 0; c <= a; c++) Wa[c] = M[tri(nu + qa, nu + fidx[c])];
+        }
+        for (int c = tid; c <= nf; c += WG) {
+            T r = T(0);
+            if (c < nf) {
+                const int qc = fidx[c];
+                r = M[tri(m, nu + qc)];
+                for (int e = 0; e < nbd; e++)
+                    if (state[e] != ST_FREE && lam[e] != T(0)) r = fma_(-(e >= qc ? M[tri(nu + e, nu + qc)] : M[tri(nu + qc, nu + e)]), lam[e], r);
+            }
+            W[tri(nf, c)] = r;
+        }
+        __syncthreads();
+        ldlt_steps<T, WG>(W, nf, 0, nf, rd, tol, tid);
+        T *x = rd + nbd;          // (z has room for max(nu, 2 nbd))
+        for (int a = tid; a < nf; a += WG) x[a] = W[tri(nf, a)] * rd[a];
+        __syncthreads();
+        ldlt_backsub<T, WG>(W, nf, rd, x, tid);
+        for (int a = tid; a < nf; a += WG) lam[fidx[a]] = x[a];
+        __syncthreads();
+        // w_B = S lambda_B - b', verdicts
+        if (tid == 0) { s_nv = 0; s_top = -1; }
+        __syncthreads();
+        for (int q = tid; q < nbd; q += WG) {
+            T sacc = -M[tri(m, nu + q)];
+            for (int e = 0; e < nbd; e++) sacc = fma_(e <= q ? M[tri(nu + q, nu + e)] : M[tri(nu + e, nu + q)], lam[e], sacc);
+            wv[q] = sacc;
+            const int st = state[q];
+            int vi = 0;
+            if (st == ST_FREE) vi = (lam[q] < lo[q] - tol) ? 1 : (lam[q] > hi[q] + tol) ? 2 : 0;
+            else if (st == ST_LO) vi = sacc < -tol ? 3 : 0;
+            else vi = sacc > tol ? 3 : 0;
+            viol[q] = vi;
+            if (vi) { atomicAdd(&s_nv, 1); atomicMax(&s_top, q); }
+        }
+        __syncthreads();
+        const int nviol = s_nv, top = s_top;
+        if (nviol == 0 || round >= max_rounds) break;
+        bool all = true;
+        if (nviol < best) { best = nviol; if (!murty_only) patience = 3; }
+        else if (patience > 0) patience--;
+        else all = false;
+        if (murty_only) all = false;
+        for (int q = tid; q < nbd; q += WG) {
+            const int vi = viol[q];
+            if (!vi || (!all && q != top)) continue;
+            state[q] = vi == 1 ? ST_LO : vi == 2 ? ST_HI : ST_FREE;
+        }
+        __syncthreads();
+    }
+    return round + 1;
+}
+
 // LDS of lcp_island_lds: M (m + 1 packed rows), W (nbd + 1), lam / w / lo / hi [nbd], dinv [nu], z [max(nu, 2 nbd)]; then the ints
 __host__ __device__ inline size_t lcp_lds_reals(int m, int nbd)
 {
@@ -642,7 +747,6 @@ __global__ __launch_bounds__(WG) void lcp_island_lds(T *__restrict__ S, const ui
     for (int k = tid; k < nb; k += WG) body_tmp(S, stride, bs + (size_t)k * BW_COUNT, I.bodies[b0 + k], hinv);
     __syncthreads();
     __shared__ int s_cnt[2][WG / 64 + 1];
-    __shared__ int s_nv, s_top;
     __shared__ T s_red[WG / 64];
     // rows: setup, the largest |rhs| (the tolerance's scale), and who can never clamp
     T bmax = T(0);
@@ -733,86 +837,8 @@ __global__ __launch_bounds__(WG) void lcp_island_lds(T *__restrict__ S, const ui
     __syncthreads();
     // ---- U eliminated: what is left in rows / columns nu.. is the Schur complement and the reduced right-hand side
     ldlt_steps<T, WG>(M, m, 0, nu, dinv, tol, tid);
-    // dinv[0 .. nu) belongs to U from here on; the rounds use their own (rd)
-    T *rd = z;            // (z is free until the end)
-    int best = m + 1, patience = murty_only ? 0 : 3;
     const int max_rounds = 20 * m + 100;
-    if (nbd > 0)
-    for (int round = 0;; round++) {
-        // the free rows in order
-        int nf = 0;
-        {
-            int fbase = 0;
-            for (int base = 0; base < nbd; base += WG) {
-                const int q = base + tid;
-                const bool f = q < nbd && state[q] == ST_FREE;
-                const unsigned long long bf = __ballot(f);
-                if (lane == 0) s_cnt[0][wave] = __popcll(bf);
-                __syncthreads();
-                int off = fbase;
-                for (int e = 0; e < wave; e++) off += s_cnt[0][e];
-                if (f) fidx[off + __popcll(bf & ((1ull << lane) - 1ull))] = q;
-                else if (q < nbd) lam[q] = state[q] == ST_LO ? lo[q] : hi[q];
-                for (int e = 0; e < WG / 64; e++) fbase += s_cnt[0][e];
-                __syncthreads();
-            }
-            nf = fbase;
-        }
-        // W = S[F, F] with the right-hand side b'_F - S_FC lambda_C as its last row
-        for (int a = tid; a <= nf; a += WG) {
-            T *Wa = W + tri(a, 0);
-            if (a == nf) {
-                for (int c = 0; c < nf; c++) {
-                    const int qc = fidx[c];
-                    T r = M[tri(m, nu + qc)];
-                    for (int e = 0; e < nbd; e++)
-                        if (state[e] != ST_FREE && lam[e] != T(0)) r = fma_(-(e >= qc ? M[tri(nu + e, nu + qc)] : M[tri(nu + qc, nu + e)]), lam[e], r);
-                    Wa[c] = r;
-                }
-                Wa[nf] = T(0);
-            } else {
-                const int qa = fidx[a];
-                for (int c = 0; c <= a; c++) Wa[c] = M[tri(nu + qa, nu + fidx[c])];
-            }
-        }
-        __syncthreads();
-        ldlt_steps<T, WG>(W, nf, 0, nf, rd, tol, tid);
-        T *x = rd + nbd;          // (z has room for max(nu, 2 nbd))
-        for (int a = tid; a < nf; a += WG) x[a] = W[tri(nf, a)] * rd[a];
-        __syncthreads();
-        ldlt_backsub<T, WG>(W, nf, rd, x, tid);
-        for (int a = tid; a < nf; a += WG) lam[fidx[a]] = x[a];
-        __syncthreads();
-        // w_B = S lambda_B - b', verdicts
-        if (tid == 0) { s_nv = 0; s_top = -1; }
-        __syncthreads();
-        for (int q = tid; q < nbd; q += WG) {
-            T sacc = -M[tri(m, nu + q)];
-            for (int e = 0; e < nbd; e++) sacc = fma_(e <= q ? M[tri(nu + q, nu + e)] : M[tri(nu + e, nu + q)], lam[e], sacc);
-            wv[q] = sacc;
-            const int st = state[q];
-            int vi = 0;
-            if (st == ST_FREE) vi = (lam[q] < lo[q] - tol) ? 1 : (lam[q] > hi[q] + tol) ? 2 : 0;
-            else if (st == ST_LO) vi = sacc < -tol ? 3 : 0;
-            else vi = sacc > tol ? 3 : 0;
-            viol[q] = vi;
-            if (vi) { atomicAdd(&s_nv, 1); atomicMax(&s_top, q); }
-        }
-        __syncthreads();
-        const int nviol = s_nv, top = s_top;
-        if (nviol == 0 || round >= max_rounds) break;
-        bool all = true;
-        if (nviol < best) { best = nviol; if (!murty_only) patience = 3; }
-        else if (patience > 0) patience--;
-        else all = false;
-        if (murty_only) all = false;
-        for (int q = tid; q < nbd; q += WG) {
-            const int vi = viol[q];
-            if (!vi || (!all && q != top)) continue;
-            state[q] = vi == 1 ? ST_LO : vi == 2 ? ST_HI : ST_FREE;
-        }
-        __syncthreads();
-    }
+    (void)lds_pivot_rounds<T, WG>(M, m, nu, nbd, W, lam, wv, lo, hi, state, fidx, viol, z, tol, murty_only, max_rounds, tid);
     // ---- lambda_U: L_UU^T x = D^-1 y_U - L_BU^T lambda_B
     for (int k = tid; k < nu; k += WG) {
         T acc = M[tri(m, k)];
@@ -857,13 +883,88 @@ __global__ __launch_bounds__(WG) void lcp_island_lds(T *__restrict__ S, const ui
     if (tid == 0) atomicAdd(&diag->contacts, (unsigned long long)nc);
 }
 
+// =========================================================================================================== the volatile rows' problem
+// Second level of the same idea.  After a pivoting round on the bounded rows B most of them are settled -- free with lambda well
+// inside its bounds, or clamped with w well on its side -- and a few are not (the violators, and rows close to changing sides).
+// The settled FREE rows Fs are eliminated from S like U was from A (gather [Fs | V], panels over Fs: the same kernels), which
+// leaves the LCP in the volatile rows V alone, a hundred or two: small enough for ONE workgroup to pivot to the end in LDS
+// (lds_pivot_rounds), however many rounds -- Murty's single flips included -- that takes.  lambda_Fs follows by
+// back-substitution, and a product with S checks EVERY bounded row: if a settled row turns out to violate, the host flips and
+// goes round again.
+template <class T, int WG>
+__global__ __launch_bounds__(WG) void lcp_reduced_lds(const T *__restrict__ Sv, int ldv, const T *__restrict__ bv, int nv, const T *__restrict__ lo_g,
+                                                      const T *__restrict__ hi_g, int *__restrict__ state_g, T *__restrict__ lam_g,
+                                                      const T *__restrict__ tolp, int murty_only, int *__restrict__ rounds_out)
+{
+    extern __shared__ __align__(16) unsigned char lcp_red_raw[];
+    const int tid = threadIdx.x;
+    const size_t tsz = (size_t)(nv + 1) * (nv + 2) / 2;
+    T *M = reinterpret_cast<T *>(lcp_red_raw), *W = M + tsz;
+    T *lam = W + tsz, *wv = lam + nv, *lo = wv + nv, *hi = lo + nv, *rd = hi + nv;
+    int *state = reinterpret_cast<int *>(lcp_red_raw + (((2 * tsz + (size_t)6 * nv + 8) * sizeof(T) + 15) / 16) * 16);
+    int *fidx = state + nv, *viol = fidx + nv;
+    for (int p = tid; p <= nv; p += WG) {
+        T *Mp = M + tri(p, 0);
+        if (p == nv) { for (int q = 0; q < nv; q++) Mp[q] = bv[q]; Mp[nv] = T(0); }
+        else for (int q = 0; q <= p; q++) Mp[q] = Sv[(size_t)q * ldv + p];
+    }
+    for (int q = tid; q < nv; q += WG) { lo[q] = lo_g[q]; hi[q] = hi_g[q]; state[q] = state_g[q]; lam[q] = T(0); }
+    __syncthreads();
+    const int rounds = lds_pivot_rounds<T, WG>(M, nv, 0, nv, W, lam, wv, lo, hi, state, fidx, viol, rd, tolp[0], murty_only, 20 * nv + 100, tid);
+    for (int q = tid; q < nv; q += WG) { lam_g[q] = lam[q]; state_g[q] = state[q]; }
+    if (tid == 0) rounds_out[0] = rounds;
+}
+template <class T> size_t reduced_lds_bytes(int nv)
+{
+    const size_t tsz = (size_t)(nv + 1) * (nv + 2) / 2;
+    return (((2 * tsz + (size_t)6 * nv + 8) * sizeof(T) + 15) / 16) * 16 + ((size_t)3 * nv + 8) * sizeof(int);
+}
+template <class T> int reduced_lds_cap()
+{
+    static const int cap = [] { int n = 16; while (reduced_lds_bytes<T>(n + 8) <= (size_t)150 * 1024) n += 8; return n; }();
+    return cap;
+}
+// the volatile rows' data out of the level-2 matrix: b'' = its right-hand-side row behind Fs's columns; bounds and states by row
+// (vidx[i] = the bounded row at position i of V, -1 = padding)
+template <class T>
+__global__ __launch_bounds__(256) void lcp_l2_setup(const T *__restrict__ Mw, int ldw, int fsP, int rhs_row, const int *__restrict__ vidx, int nvP,
+                                                    const T *__restrict__ lo, const T *__restrict__ hi, const int *__restrict__ state,
+                                                    T *__restrict__ b2, T *__restrict__ lo2, T *__restrict__ hi2, int *__restrict__ state2, T *__restrict__ lam2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvP) return;
+    const int q = vidx[i];
+    b2[i] = Mw[(size_t)(fsP + i) * ldw + rhs_row];
+    lo2[i] = q >= 0 ? lo[q] : -Limits<T>::inf();
+    hi2[i] = q >= 0 ? hi[q] : Limits<T>::inf();
+    state2[i] = q >= 0 ? state[q] : (int)ST_FREE;
+    lam2[i] = T(0);
+}
+template <class T>
+__global__ __launch_bounds__(256) void lcp_l2_scatter(const int *__restrict__ vidx, int nv, const T *__restrict__ lam2, const int *__restrict__ state2,
+                                                      T *__restrict__ lamB, int *__restrict__ state)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nv) return;
+    const int q = vidx[i];
+    if (q < 0) return;
+    lamB[q] = lam2[i];
+    state[q] = state2[i];
+}
+
 // =========================================================================================================== host side
 struct LcpGrid {
     dmxBatch::DevBuf A, Ldiag, Sd, Mw, Mdiag, vec, ints;
     void *pin = nullptr; size_t pin_bytes = 0;
+    void *pin_real = nullptr; size_t pin_real_bytes = 0;
+    dmxBatch::DevBuf Sv, vec2, ints2;
+    int level2 = -1;             // DMX_LCP_LEVEL2: 1 = the volatile rows' problem is pivoted in LDS between checks of all rows, 0 = every pivoting
+                                 // round refactors the whole free block; -1: by precision (see lcp_grid_solve)
+    std::vector<int> rank_f, rank_c, in_v, state0;
     std::unordered_map<uint64_t, uint8_t> warm_prev, warm_next;
     std::vector<int> perm, state;
     int64_t stats[8] = { 0 };
+    int64_t l2_solves = 0;       // volatile-row problems solved in LDS (level 2)
     double flops = 0;            // algorithmic: the partial factorisation (nu^3/3 + nu^2 nb + nu nb^2) and nf^3/3 per pivoting round
     bool warm = true, murty_only = false;
     int w_mode = -1;             // DMX_LCP_W: 0 = w from the Schur complement (one product per round), 1 = from the rows through lambda_U; -1: by precision
@@ -878,6 +979,8 @@ LcpGrid *grid_of(dmxBatch *b)
         g->warm = !(e && atoi(e) == 0);
         e = getenv("DMX_LCP_MURTY");
         g->murty_only = e && atoi(e) != 0;
+        e = getenv("DMX_LCP_LEVEL2");
+        if (e) g->level2 = atoi(e) != 0 ? 1 : 0;
         e = getenv("DMX_LCP_W");
         if (e) g->w_mode = atoi(e) != 0 ? 1 : 0;
         e = getenv("DMX_LCP_TOL");
@@ -885,6 +988,23 @@ LcpGrid *grid_of(dmxBatch *b)
         b->lcp_grid = g;
     }
     return (LcpGrid *)b->lcp_grid;
+}
+
+// the bounded rows outside `skip`, by how close they are to changing sides: free rows by lambda - lo (a normal row's lo is 0; a
+// bounded friction row's bounds are not known on the host: it counts as closest), clamped rows by |w|
+template <class T>
+void rank_margins(int nbd, const std::vector<int> &state, const std::vector<int> &skip, const T *h_lam, const T *h_w, const LcpIslandRows &R,
+                  const std::vector<int> &perm, int nuP, std::vector<int> &rf, std::vector<int> &rc)
+{
+    rf.clear(); rc.clear();
+    for (int q = 0; q < nbd; q++) {
+        if (skip[(size_t)q]) continue;
+        if (state[(size_t)q] == ST_FREE) rf.push_back(q); else rc.push_back(q);
+    }
+    auto margin_f = [&](int q) { return (R.key[(size_t)perm[(size_t)(nuP + q)]] & 3u) != 0u ? (T)0 : h_lam[q]; };
+    std::sort(rf.begin(), rf.end(), [&](int a, int c) { const T ma = margin_f(a), mc = margin_f(c); return ma < mc || (ma == mc && a < c); });
+    std::sort(rc.begin(), rc.end(), [&](int a, int c) { const T wa = h_w[a] < 0 ? -h_w[a] : h_w[a], wc = h_w[c] < 0 ? -h_w[c] : h_w[c];
+                                                        return wa < wc || (wa == wc && a < c); });
 }
 
 template <class T> size_t panel_lds() { return (size_t)(2 * NB * NB + NB) * sizeof(T); }
@@ -925,12 +1045,13 @@ void lcp_grid_free(dmxBatch *b)
     if (!b->lcp_grid) return;
     LcpGrid *g = (LcpGrid *)b->lcp_grid;
     if (getenv("DMX_LCP_REPORT"))
-        fprintf(stderr, "libode_mi355 lcp grid: solves=%lld rounds=%lld max_rounds=%lld last_m=%lld last_nu=%lld last_nbd=%lld single=%lld fallback=%lld gflop=%.4f\n",
+        fprintf(stderr, "libode_mi355 lcp grid: solves=%lld rounds=%lld max_rounds=%lld last_m=%lld last_nu=%lld last_nbd=%lld single=%lld fallback=%lld gflop=%.4f level2=%lld\n",
                 (long long)g->stats[0], (long long)g->stats[1], (long long)g->stats[2], (long long)g->stats[3], (long long)g->stats[4],
-                (long long)g->stats[5], (long long)g->stats[6], (long long)g->stats[7], g->flops * 1e-9);
-    for (dmxBatch::DevBuf *d : { &g->A, &g->Ldiag, &g->Sd, &g->Mw, &g->Mdiag, &g->vec, &g->ints })
+                (long long)g->stats[5], (long long)g->stats[6], (long long)g->stats[7], g->flops * 1e-9, (long long)g->l2_solves);
+    for (dmxBatch::DevBuf *d : { &g->A, &g->Ldiag, &g->Sd, &g->Mw, &g->Mdiag, &g->vec, &g->ints, &g->Sv, &g->vec2, &g->ints2 })
         if (d->p) (void)hipFree(d->p);
     if (g->pin) (void)hipHostFree(g->pin);
+    if (g->pin_real) (void)hipHostFree(g->pin_real);
     delete g;
     b->lcp_grid = nullptr;
 }
@@ -947,7 +1068,7 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
     const int nbd = m - nu;
     const int nuT = (nu + NB - 1) / NB, nbT = (nbd + NB - 1) / NB;
     const int nuP = nuT * NB, nbdP = nbT * NB, mP = nuP + nbdP, nt = nuT + nbT;
-    const int ld = mP + NB, lds = nbdP > 0 ? nbdP : NB, ldw = nbdP + NB;
+    const int ld = mP + NB, lds = nbdP > 0 ? nbdP : NB, ldw = nbdP + 3 * NB;      // (the level-2 matrix pads Fs and V separately)
     std::vector<int> &perm = g->perm;
     perm.assign((size_t)mP, -1);
     {
@@ -959,8 +1080,21 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
     if ((rc = dmx_ensure_dev(g->A, (size_t)mP * ld * sizeof(T))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(g->Ldiag, (size_t)nt * NB * NB * sizeof(T))) != DMX_OK) return rc;
     if ((rc = dmx_ensure_dev(g->Sd, (size_t)lds * lds * sizeof(T))) != DMX_OK) return rc;
-    if ((rc = dmx_ensure_dev(g->Mw, (size_t)(nbdP + NB) * ldw * sizeof(T))) != DMX_OK) return rc;
-    if ((rc = dmx_ensure_dev(g->Mdiag, (size_t)(nbT + 1) * NB * NB * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(g->Mw, (size_t)(nbdP + 2 * NB) * ldw * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(g->Mdiag, (size_t)(nbT + 2) * NB * NB * sizeof(T))) != DMX_OK) return rc;
+    const int vcap = reduced_lds_cap<T>(), vcapP = ((vcap + NB - 1) / NB) * NB;
+    if ((rc = dmx_ensure_dev(g->Sv, (size_t)vcapP * vcapP * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(g->vec2, (size_t)4 * (vcapP + NB) * sizeof(T))) != DMX_OK) return rc;
+    if ((rc = dmx_ensure_dev(g->ints2, ((size_t)nbdP + 3 * NB + 2 * (vcapP + NB) + 16) * sizeof(int))) != DMX_OK) return rc;
+    {
+        const size_t want = ((size_t)2 * (nbdP + NB) * sizeof(T) + ((size_t)nbdP + 3 * NB + vcapP + 64) * sizeof(int)) + 256;
+        if (g->pin_real_bytes < want) {
+            if (g->pin_real) HIP_TRY(hipHostFree(g->pin_real));
+            g->pin_real = nullptr; g->pin_real_bytes = 0;
+            HIP_TRY(hipHostMalloc(&g->pin_real, want * 2));
+            g->pin_real_bytes = want * 2;
+        }
+    }
     // vectors: tol[4] bprime lo hi lamB wB rr (nbdP each) z xU (nuP each)
     const size_t nv = 4 + (size_t)6 * (nbdP + NB) + (size_t)2 * (nuP + NB);
     if ((rc = dmx_ensure_dev(g->vec, nv * sizeof(T))) != DMX_OK) return rc;
@@ -982,7 +1116,11 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
     int *h_perm = (int *)g->pin, *h_state = h_perm + mP, *h_fidx = h_state + (nbdP + NB), *h_viol = h_fidx + (nbdP + NB);
     int *d_boff = d_viol + (nbdP + NB), *d_bodyrows = d_boff + R.boff.size();
     int *h_boff = h_viol + (nbdP + NB), *h_bodyrows = h_boff + R.boff.size();
-    const bool sparse_w = g->w_mode >= 0 ? g->w_mode != 0 : sizeof(T) == 8;
+    const bool sparse_w = g->w_mode > 0;
+    T *Sv = (T *)g->Sv.p, *b2 = (T *)g->vec2.p, *lo2 = b2 + (vcapP + NB), *hi2 = lo2 + (vcapP + NB), *lam2 = hi2 + (vcapP + NB);
+    int *d_fidx2 = (int *)g->ints2.p, *d_state2 = d_fidx2 + (nbdP + 3 * NB), *d_rounds2 = d_state2 + (vcapP + NB);
+    T *h_lam = (T *)g->pin_real, *h_w = h_lam + (nbdP + NB);
+    int *h_fidx2 = (int *)(h_w + (nbdP + NB)), *h_state2 = h_fidx2 + (nbdP + 3 * NB), *h_rounds2 = h_state2 + vcapP + 8;
 
     // (the pinned staging is reused by the next island / tick: every copy below is followed by a synchronisation before the
     //  host writes it again -- the rounds' read-back)
@@ -1011,54 +1149,98 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
     // ---- the reduced problem in B's rows
     std::vector<int> &state = g->state;
     state.assign((size_t)nbd, ST_FREE);
-    int rounds = 0, single_rounds = 0;
+    int rounds = 0, single_rounds = 0, l2_solves = 0;
     if (nbd > 0) {
         hipLaunchKernelGGL((lcp_extract<T>), dim3((unsigned)nbT, (unsigned)nbT), dim3(256), 0, st, A, ld, nuP, Sd, lds);
         hipLaunchKernelGGL((lcp_bvec<T>), dim3((unsigned)((nbdP + 255) / 256)), dim3(256), 0, st, A, ld, nuP, mP, d_perm, rows, nbdP, bprime, lo, hi);
-        // where the rows' active set starts: what the same contact's row ended the previous tick with
+        // where the rows' active set starts: what the same contact's row ended the previous tick with; and which rows are
+        // expected to move (they were close to changing sides then, or are new): the first pass's volatile set
         bool any_bounded_friction = false;
+        std::vector<int> &in_v = g->in_v, &rf = g->rank_f, &rc2 = g->rank_c, &state0 = g->state0;
+        in_v.assign((size_t)nbd, 0);
+        // (f64, ODE's cfm = 1e-10: the bounded rows' problem is close to degenerate and plain block pivoting cycles -- 40 to 70 rounds in
+        //  the pen, the oracle's own count -- until Murty's single flips end it; pivoting the volatile rows in LDS ends that: 5.9 -> 4.5
+        //  ms per tick at 512 bodies.  f32, cfm = 1e-5: five plain rounds or so, and a pass costs more than a round: 3.1 vs 4.3 ms.)
+        const bool use_l2 = g->level2 >= 0 ? g->level2 != 0 : sizeof(T) == 8;
+        bool classical = !use_l2 || g->murty_only;
+        int nv_pred = 0;
         for (int q = 0; q < nbd; q++) {
             const int i = perm[(size_t)(nuP + q)];
             const uint64_t key = R.key[(size_t)i];
             if ((key & 3u) != 0u) any_bounded_friction = true;
+            bool known = false;
             if (g->warm && key != 0) {
                 auto it = g->warm_prev.find(key);
-                if (it != g->warm_prev.end()) state[(size_t)q] = it->second;
+                if (it != g->warm_prev.end()) { state[(size_t)q] = it->second & 3; known = true; if (it->second & 4) { in_v[(size_t)q] = 1; nv_pred++; } }
             }
+            if (!known && g->warm && !g->warm_prev.empty()) { in_v[(size_t)q] = 1; nv_pred++; }      // a new contact
         }
-        int best = m + 1, patience = g->murty_only ? 0 : 3;
+        if (classical || nv_pred > vcap) { in_v.assign((size_t)nbd, 0); nv_pred = 0; }
+        state0 = state;
+        int best = m + 1, patience = g->murty_only ? 0 : 3, passes = 0;
         const int max_rounds = 20 * m + 100;
         {
             const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcp_backsolve<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      (int)backsolve_lds<T>(nuT > nbT ? nuT : nbT));
+                                                      (int)backsolve_lds<T>((nuT > nbT ? nuT : nbT) + 1));
             if (ea != hipSuccess) HIP_TRY(ea);
+            const hipError_t eb = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcp_reduced_lds<T, 256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)reduced_lds_bytes<T>(vcap));
+            if (eb != hipSuccess) HIP_TRY(eb);
         }
+        // One pass: the settled free rows Fs (free and not in V) are eliminated from S (gather [Fs | V], panels over Fs), V's own LCP is
+        // pivoted to the end by one workgroup in LDS, lambda_Fs follows by back-substitution, and EVERY bounded row is checked.  With V
+        // empty a pass is a plain pivoting round.  Violators join V (with the rows closest to changing sides) and the pass is
+        // repeated; should V outgrow a workgroup's LDS, the violators are flipped on the host instead (the classical block-pivoting
+        // round, with Murty's single flip once the violation count has stalled three times) and V starts empty again.
         for (;; rounds++) {
-            // the free rows in order; a clamped row's value is non-zero only for bounded friction rows (a normal row clamps at 0)
-            int nf = 0;
-            bool clamped_nonzero = false;
+            int nfs = 0, nv2 = 0;
             for (int q = 0; q < nbd; q++) {
                 h_state[q] = state[(size_t)q];
-                if (state[(size_t)q] == ST_FREE) h_fidx[nf++] = q;
-                else if (any_bounded_friction && (R.key[(size_t)perm[(size_t)(nuP + q)]] & 3u) != 0u) clamped_nonzero = true;
+                if (!in_v[(size_t)q] && state[(size_t)q] == ST_FREE) h_fidx2[nfs++] = q;
             }
-            const int nfT = (nf + NB - 1) / NB, nfP = nfT * NB;
-            for (int a = nf; a < nfP; a++) h_fidx[a] = -1;
+            const int fsT = (nfs + NB - 1) / NB, fsP = fsT * NB;
+            for (int a = nfs; a < fsP; a++) h_fidx2[a] = -1;
+            for (int q = 0; q < nbd; q++) if (in_v[(size_t)q]) h_fidx2[fsP + nv2++] = q;
+            const int vT = (nv2 + NB - 1) / NB, vP = vT * NB, nt2 = fsT + vT;
+            for (int a = nv2; a < vP; a++) h_fidx2[fsP + a] = -1;
             HIP_TRY(hipMemcpyAsync(d_state, h_state, (size_t)nbd * sizeof(int), hipMemcpyHostToDevice, st));
-            if (nfP > 0) HIP_TRY(hipMemcpyAsync(d_fidx, h_fidx, (size_t)nfP * sizeof(int), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL((lcp_clamped<T>), dim3((unsigned)((nbd + 255) / 256)), dim3(256), 0, st, d_state, lo, hi, nbd, lamB);
-            const T *rhs = bprime;
-            if (clamped_nonzero) {
-                hipLaunchKernelGGL((lcp_gemv<T, false>), dim3((unsigned)nbT), dim3(256), 0, st, Sd, lds, nbd, lamB, bprime, rr,
-                                   (const int *)nullptr, (const T *)nullptr, (const T *)nullptr, (const T *)nullptr, (int *)nullptr);
-                rhs = rr;
+            if (nt2 > 0) HIP_TRY(hipMemcpyAsync(d_fidx2, h_fidx2, (size_t)(fsP + vP) * sizeof(int), hipMemcpyHostToDevice, st));
+            // right-hand side: b' less the settled clamped rows' part (non-zero only for bounded friction rows at a bound)
+            const T *rhs2 = bprime;
+            if (any_bounded_friction) {
+                bool nz = false;
+                for (int q = 0; q < nbd; q++)
+                    if (!in_v[(size_t)q] && state[(size_t)q] != ST_FREE && (R.key[(size_t)perm[(size_t)(nuP + q)]] & 3u) != 0u) nz = true;
+                if (nz) {
+                    // (V's rows count as free here: their part is the LDS solve's own business)
+                    hipLaunchKernelGGL((lcp_clamped_except<T>), dim3((unsigned)((nbd + 255) / 256)), dim3(256), 0, st, d_state, lo, hi, nbd, d_fidx2 + fsP, nv2, lamB);
+                    hipLaunchKernelGGL((lcp_gemv<T, false>), dim3((unsigned)nbT), dim3(256), 0, st, Sd, lds, nbd, lamB, bprime, rr,
+                                       (const int *)nullptr, (const T *)nullptr, (const T *)nullptr, (const T *)nullptr, (int *)nullptr);
+                    rhs2 = rr;
+                }
             }
-            if (nf > 0) {
-                hipLaunchKernelGGL((lcp_gather<T>), dim3((unsigned)(nfT + 1), (unsigned)nfT), dim3(256), 0, st, Sd, lds, d_fidx, nfT, rhs, Mw, ldw);
-                HIP_TRY(factor_panels<T>(Mw, ldw, nfT, nfT, Mdiag, tol, st));
-                g->flops += (double)nf * nf * nf / 3.0;
-                hipLaunchKernelGGL((lcp_backsolve<T>), dim3(1), dim3(1024), backsolve_lds<T>(nfT), st, Mw, ldw, Mdiag, nfT,
-                                   Mw + nfP, (size_t)ldw, d_fidx, lamB);
+            if (nt2 > 0) {
+                hipLaunchKernelGGL((lcp_gather<T>), dim3((unsigned)(nt2 + 1), (unsigned)nt2), dim3(256), 0, st, Sd, lds, d_fidx2, nt2, rhs2, Mw, ldw);
+                HIP_TRY(factor_panels<T>(Mw, ldw, nt2, fsT, Mdiag, tol, st));
+                g->flops += (double)nfs * nfs * nfs / 3.0 + (double)nfs * nfs * nv2 + (double)nfs * nv2 * nv2;
+            }
+            if (nv2 > 0) {
+                hipLaunchKernelGGL((lcp_extract<T>), dim3((unsigned)vT, (unsigned)vT), dim3(256), 0, st, Mw, ldw, fsP, Sv, vP);
+                hipLaunchKernelGGL((lcp_l2_setup<T>), dim3((unsigned)((vP + 255) / 256)), dim3(256), 0, st, Mw, ldw, fsP, nt2 * NB, d_fidx2 + fsP, vP, lo, hi,
+                                   d_state, b2, lo2, hi2, d_state2, lam2);
+                hipLaunchKernelGGL((lcp_reduced_lds<T, 256>), dim3(1), dim3(256), reduced_lds_bytes<T>(nv2), st, Sv, vP, b2, nv2, lo2, hi2, d_state2, lam2, tol, 0,
+                                   d_rounds2);
+                hipLaunchKernelGGL((lcp_l2_scatter<T>), dim3((unsigned)((nv2 + 255) / 256)), dim3(256), 0, st, d_fidx2 + fsP, nv2, lam2, d_state2, lamB, d_state);
+                l2_solves++;
+            }
+            // lambda_B: clamped rows at their bounds, V from the LDS solve, Fs by back-substitution
+            hipLaunchKernelGGL((lcp_clamped<T>), dim3((unsigned)((nbd + 255) / 256)), dim3(256), 0, st, d_state, lo, hi, nbd, lamB);
+            if (nv2 > 0)
+                hipLaunchKernelGGL((lcp_l2_scatter<T>), dim3((unsigned)((nv2 + 255) / 256)), dim3(256), 0, st, d_fidx2 + fsP, nv2, lam2, d_state2, lamB, d_state);
+            if (fsT > 0) {
+                // (rr is free again: the gather has consumed it)
+                hipLaunchKernelGGL((lcp_zvec<T>), dim3((unsigned)fsP), dim3(64), 0, st, Mw, ldw, fsP, nt2 * NB, vP, lam2, rr);
+                hipLaunchKernelGGL((lcp_backsolve<T>), dim3(1), dim3(1024), backsolve_lds<T>(fsT), st, Mw, ldw, Mdiag, fsT, rr, (size_t)1, d_fidx2, lamB);
             }
             if (sparse_w) {
                 if (nuT > 0) {
@@ -1071,10 +1253,36 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
             } else
                 hipLaunchKernelGGL((lcp_gemv<T, true>), dim3((unsigned)nbT), dim3(256), 0, st, Sd, lds, nbd, lamB, bprime, wB, d_state, lo, hi, tol, d_viol);
             HIP_TRY(hipMemcpyAsync(h_viol, d_viol, (size_t)nbd * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_lam, lamB, (size_t)nbd * sizeof(T), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_w, wB, (size_t)nbd * sizeof(T), hipMemcpyDeviceToHost, st));
+            if (nv2 > 0) {
+                HIP_TRY(hipMemcpyAsync(h_state, d_state, (size_t)nbd * sizeof(int), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(h_rounds2, d_rounds2, sizeof(int), hipMemcpyDeviceToHost, st));
+            }
             HIP_TRY(hipStreamSynchronize(st));
+            passes++;
+            if (nv2 > 0) {
+                for (int q = 0; q < nbd; q++) state[(size_t)q] = h_state[q];
+                g->stats[1] += h_rounds2[0];
+            }
             int nviol = 0, top = -1;
             for (int q = 0; q < nbd; q++) if (h_viol[q]) { nviol++; top = q; }
             if (nviol == 0 || rounds >= max_rounds) break;
+            if (!classical && passes < 40) {
+                // the violators join V, and so do the rows closest to changing sides, while a workgroup's LDS has room
+                int nvv = 0;
+                for (int q = 0; q < nbd; q++) { if (h_viol[q]) in_v[(size_t)q] = 1; nvv += in_v[(size_t)q]; }
+                if (nvv <= vcap) {
+                    rank_margins<T>(nbd, state, in_v, h_lam, h_w, R, perm, nuP, rf, rc2);
+                    const int want = std::min(std::min(vcap, nbd), std::max(nvv + 2 * nviol + 16, 64));
+                    for (size_t a = 0, c = 0; nvv < want && (a < rf.size() || c < rc2.size());) {
+                        if (a < rf.size()) { in_v[(size_t)rf[a++]] = 1; nvv++; }
+                        if (nvv < want && c < rc2.size()) { in_v[(size_t)rc2[c++]] = 1; nvv++; }
+                    }
+                    continue;
+                }
+                in_v.assign((size_t)nbd, 0);           // too many for one workgroup: a classical round on all of them, V starts again
+            }
             bool all = true;
             if (nviol < best) { best = nviol; if (!g->murty_only) patience = 3; }
             else if (patience > 0) patience--;
@@ -1086,10 +1294,25 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
                 state[(size_t)q] = h_viol[q] == 1 ? ST_LO : h_viol[q] == 2 ? ST_HI : ST_FREE;
             }
         }
-        // remember the active set
-        for (int q = 0; q < nbd; q++) {
-            const uint64_t key = R.key[(size_t)perm[(size_t)(nuP + q)]];
-            if (key != 0) g->warm_next[key] = (uint8_t)state[(size_t)q];
+        // remember the active set, and who is likely to move next tick: the rows that changed sides in this solve and the ones
+        // closest to doing so
+        {
+            std::vector<int> &vol = g->in_v;
+            int changed = 0;
+            for (int q = 0; q < nbd; q++) { vol[(size_t)q] = state[(size_t)q] != state0[(size_t)q] ? 1 : 0; changed += vol[(size_t)q]; }
+            if (!classical) {
+                rank_margins<T>(nbd, state, vol, h_lam, h_w, R, perm, nuP, rf, rc2);
+                int nvv = changed;
+                const int want = std::min(std::min(3 * vcap / 4, nbd), std::max(3 * changed + 16, 48));
+                for (size_t a = 0, c = 0; nvv < want && (a < rf.size() || c < rc2.size());) {
+                    if (a < rf.size()) { vol[(size_t)rf[a++]] = 1; nvv++; }
+                    if (nvv < want && c < rc2.size()) { vol[(size_t)rc2[c++]] = 1; nvv++; }
+                }
+            }
+            for (int q = 0; q < nbd; q++) {
+                const uint64_t key = R.key[(size_t)perm[(size_t)(nuP + q)]];
+                if (key != 0) g->warm_next[key] = (uint8_t)(state[(size_t)q] | (vol[(size_t)q] ? 4 : 0));
+            }
         }
     } else {
         const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcp_backsolve<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1106,7 +1329,7 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
                        lamB, wB, d_state, d_boff, d_bodyrows, tol, d_viol, b->diag_isl);
     HIP_TRY(hipGetLastError());
     g->stats[0] += 1; g->stats[1] += rounds + 1; if (rounds + 1 > g->stats[2]) g->stats[2] = rounds + 1;
-    g->stats[3] = m; g->stats[4] = nu; g->stats[5] = nbd; g->stats[6] += single_rounds;
+    g->stats[3] = m; g->stats[4] = nu; g->stats[5] = nbd; g->stats[6] += single_rounds; g->l2_solves += l2_solves;
     return DMX_OK;
 }
 

@@ -82,10 +82,12 @@ def test_pen_of_400_bodies_settled_then_dworldstep(tmp_path, single):
     assert ow.n_contacts() > 300
     assert _rel(got.astype(ref.dtype), ref) <= 1e-5
     if not single:
-        # the active set carried from tick to tick saves pivoting rounds, and changes nothing else (the solution is unique)
-        cold, err_cold = _run(exe, text, env={"HARNESS_EXACT_AFTER": str(settle), "DMX_LCP_WARM": "0"})
-        assert _stats(err_cold)["rounds"] >= st["rounds"]
+        # the active set carried from tick to tick changes the route, not the destination (the solution is unique); nor does
+        # switching the volatile-row solve in LDS off (every pivoting round then refactors the whole free block)
+        cold, _ = _run(exe, text, env={"HARNESS_EXACT_AFTER": str(settle), "DMX_LCP_WARM": "0"})
         assert _rel(cold, ref) <= 1e-5
+        plain, _ = _run(exe, text, env={"HARNESS_EXACT_AFTER": str(settle), "DMX_LCP_LEVEL2": "0"})
+        assert _rel(plain, ref) <= 1e-5
 
 
 def test_every_island_through_the_grid_solve_in_the_small_pen(tmp_path):
