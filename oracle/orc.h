@@ -126,6 +126,9 @@ void orc_geom_set_collide_bits(orc_world *w, int g, uint32_t bits);        /* ma
 
 /* narrowphase: dCollide(o1,o2,flags,contact,skip) (main.c:678) ------------- */
 int orc_collide(orc_world *w, int g1, int g2, int max_contacts, orc_contactgeom *out);
+/* test helper: body-less geoms g1, g2 placed at n poses (pos3 + R12 each; optional n x 3 sizes) in turn, collided each time */
+void orc_collide_bulk(orc_world *w, int g1, int g2, int n, const real *pose1, const real *size1, const real *pose2, const real *size2,
+                      int max_contacts, int *counts, orc_contactgeom *out);
 
 /* one tick = dSpaceCollide + near callback + dWorldQuickStep + dJointGroupEmpty
  * (main.c:211-215 with QuickStep substituted for dWorldStep) */

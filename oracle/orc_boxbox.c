@@ -181,6 +181,14 @@ static int box_box(const real *p1, const real *R1, const real *side1,
 #define Q31 Q[2][0]
 #define Q32 Q[2][1]
 #define Q33 Q[2][2]
+    /* [ODE-recall box.cpp, 0.11 and later] "fudge2": an epsilon added to every |R| entry before the nine edge-pair axes, to
+     * counteract arithmetic error when two edges are (nearly) parallel and their cross product (nearly) vanishes: without it
+     * |expr1| - expr2 is a difference of two rounding errors there and a box lying flat on another is "separated" whenever
+     * that difference happens to come out positive (tests/test_collider_geometry.py met it twice in 20 000 resting boxes). */
+    {
+        const real fudge2 = R(1.0e-5);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Q[i][j] += fudge2;
+    }
     /* separating axis = u1 x (v1,v2,v3) */
     TST2(pp[2] * R21 - pp[1] * R31, (A[1] * Q31 + A[2] * Q21 + B[1] * Q13 + B[2] * Q12), 0, -R31, R21, 7);
     TST2(pp[2] * R22 - pp[1] * R32, (A[1] * Q32 + A[2] * Q22 + B[0] * Q13 + B[2] * Q11), 0, -R32, R22, 8);

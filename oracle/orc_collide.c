@@ -405,6 +405,23 @@ int orc_collide(orc_world *w, int g1, int g2, int maxc, orc_contactgeom *out)
     return n;
 }
 
+/* test helper (tests/test_collider_geometry.py): the two BODY-LESS geoms g1, g2 are given n poses (and, when sizes are passed,
+ * n sets of side lengths / a radius in [0]) in turn and collided each time -- the narrowphase alone, thousands of random pairs
+ * per second without a Python call per pair.  pose = position (3) + rotation (3x4 row-major, 12).  out holds maxc slots per pair. */
+void orc_collide_bulk(orc_world *w, int g1, int g2, int n, const real *pose1, const real *size1, const real *pose2, const real *size2,
+                      int maxc, int *counts, orc_contactgeom *out)
+{
+    orc_geom *a = &w->geoms[g1], *b = &w->geoms[g2];
+    for (int k = 0; k < n; k++) {
+        const real *pa = pose1 + 15 * (size_t)k, *pb = pose2 + 15 * (size_t)k;
+        for (int i = 0; i < 3; i++) { a->pos[i] = pa[i]; b->pos[i] = pb[i]; }
+        for (int i = 0; i < 12; i++) { a->R[i] = pa[3 + i]; b->R[i] = pb[3 + i]; }
+        if (size1) for (int i = 0; i < 3; i++) a->side[i] = size1[3 * (size_t)k + i];
+        if (size2) for (int i = 0; i < 3; i++) b->side[i] = size2[3 * (size_t)k + i];
+        counts[k] = orc_collide(w, g1, g2, maxc, out + (size_t)maxc * k);
+    }
+}
+
 /* ---- NearCallback (main.c:674-693) ---------------------------------------- */
 static void joint_push(orc_world *w, const orc_contactgeom *cg, int b1, int b2)
 {

@@ -89,6 +89,7 @@ class Oracle:
         sig("orc_geom_set_category_bits", None, P, C.c_int, C.c_uint32)
         sig("orc_geom_set_collide_bits", None, P, C.c_int, C.c_uint32)
         sig("orc_collide", C.c_int, P, C.c_int, C.c_int, C.c_int, C.POINTER(self.ContactGeom))
+        sig("orc_collide_bulk", None, P, C.c_int, C.c_int, C.c_int, P, P, P, P, C.c_int, P, P)
         sig("orc_world_tick", None, P, real)
         sig("orc_world_last_contact_count", C.c_int, P)
         sig("orc_world_last_body_pairs", C.c_int, P)

@@ -389,6 +389,13 @@ DMX_HD int box_box(const V3<T> &p1, const M3<T> &R1, const T side1[3], const V3<
             invert_normal = (e < 0); code = (cc);                                        \
         }                                                                                \
     }
+    // ODE's "fudge2" (box.cpp, 0.11 and later): an epsilon on every |R| entry before the nine edge-pair axes -- with two edges
+    // (nearly) parallel |expr1| - expr2 is otherwise a difference of rounding errors, and a box lying flat on another is
+    // "separated" whenever it happens to come out positive
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Q[i][j] += T(1.0e-5);
     // edge axes u_i x v_j
     DMX_TST2(pp[2] * Rr[1][0] - pp[1] * Rr[2][0], (A[1] * Q[2][0] + A[2] * Q[1][0] + B[1] * Q[0][2] + B[2] * Q[0][1]), T(0), -Rr[2][0], Rr[1][0], 7);
     DMX_TST2(pp[2] * Rr[1][1] - pp[1] * Rr[2][1], (A[1] * Q[2][1] + A[2] * Q[1][1] + B[0] * Q[0][2] + B[2] * Q[0][0]), T(0), -Rr[2][1], Rr[1][1], 8);

@@ -398,7 +398,9 @@ def test_kat6_box_box_edge_edge(orc64):
     c = _pair_contacts(orc64, w, 0, 1)
     assert len(c) == 1
     p, n, d = c[0]
-    assert np.allclose(np.abs(n), [0, 1, 0], atol=1e-12) and abs(d - 0.05) < 1e-12
+    # depth: the ridges' overlap, plus dBoxBox's guard against parallel edges [ODE-recall "fudge2"]: 1e-5 on every |R| entry, i.e.
+    # 1e-5 x the four half-sides that enter the edge-pair axis (4 x 0.5) / |u x v| (= 1 here)
+    assert np.allclose(np.abs(n), [0, 1, 0], atol=1e-12) and abs(d - (0.05 + 2.0e-5)) < 1e-12
     assert abs(p[0]) < 1e-12 and abs(p[2]) < 1e-12                   # where the two ridges cross
 
 
