@@ -714,7 +714,9 @@ def rank_main(a):
     }
     if head.get("c_loop_error"):
         out["config"]["c_loop_error"] = ("the rank loop behind the C ABI could not bring up its own RCCL communicator; this run used the same loop "
-                                         "in Python over torch.distributed instead: " + str(head["c_loop_error"]))
+                                         "in Python over torch.distributed instead (that loop has no migration: it is valid for scenes without contacts across "
+                                         "rank boundaries, which configs[3]'s disjoint slabs are -- an island reaching across two ranks raises there): "
+                                         + str(head["c_loop_error"]))
     out["timing"]["ms_per_step_mean"] = head["mean_dt"] * 1e3 / head["steps"]
     out["timing"]["note"] += ("; ms_per_step_mean = (all blocks + the close of the last open chunk) / all timed ticks: every chunk close "
                               "(zone test, flag read) is in it, which a median of short blocks leaves out")

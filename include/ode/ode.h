@@ -25,9 +25,15 @@
 extern "C" {
 #endif
 
-/* ---- contact structures (main.c:676-687) --------------------------------- */
+/* ---- contact structures (main.c:676-687) ---------------------------------
+ * Layout and flag values are those of the ODE 0.13 - 0.16 line's ode/contact.h [ODE-recall; SURVEY.md cites 0.16.x]: rolling
+ * friction (rho, rho2, rhoN; dContactRolling, dContactApprox1_N) sits between mu2 and bounce, so an object compiled against
+ * stock 0.16 headers writes `bounce` where this library reads it (tests/test_ode_compat.py checks every offset).  ODE <= 0.12
+ * had no rho fields: objects built against those headers must be recompiled against these.  The rolling-friction fields are
+ * accepted and ignored (the reference never sets them, main.c:684-687). */
 enum {
     dContactMu2      = 0x001,
+    dContactAxisDep  = 0x001,
     dContactFDir1    = 0x002,
     dContactBounce   = 0x004,   /* main.c:684 */
     dContactSoftERP  = 0x008,
@@ -37,16 +43,19 @@ enum {
     dContactMotionN  = 0x080,
     dContactSlip1    = 0x100,
     dContactSlip2    = 0x200,
+    dContactRolling  = 0x400,
     dContactApprox0  = 0x0000,
     dContactApprox1_1 = 0x1000,
     dContactApprox1_2 = 0x2000,
-    dContactApprox1  = 0x3000
+    dContactApprox1_N = 0x4000,
+    dContactApprox1  = 0x7000
 };
 
 typedef struct dSurfaceParameters {
     int mode;                 /* main.c:684 */
     dReal mu;                 /* main.c:687 */
     dReal mu2;
+    dReal rho, rho2, rhoN;    /* rolling / spinning friction (0.13+): not used by the reference, ignored here */
     dReal bounce;             /* main.c:685 */
     dReal bounce_vel;         /* main.c:686 */
     dReal soft_erp;

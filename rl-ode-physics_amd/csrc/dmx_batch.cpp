@@ -298,12 +298,18 @@ extern "C" int dmxBatchUploadGeomType(dmxBatchID b, const uint8_t *types, int64_
     if (count == 0) return DMX_OK;
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemcpyAsync(b->gtype + first, types, (size_t)count, hipMemcpyHostToDevice, b->stream));
+    // the count of box / sphere slots, kept up to date by what this range loses and gains (not by a pass over all n slots: the
+    // sharded loop's migrate() calls this two or three times per adopted body inside the tick loop, on batches of up to 16 Mi slots)
+    for (int64_t i = 0; i < count; i++) {
+        const uint8_t was = b->h_gtype[(size_t)(first + i)], is = types[i];
+        b->n_simple -= (was == GEOM_BOX || was == GEOM_SPHERE) ? 1 : 0;
+        b->n_simple += (is == GEOM_BOX || is == GEOM_SPHERE) ? 1 : 0;
+    }
     memcpy(b->h_gtype.data() + first, types, (size_t)count);
     if (b->scount.p)        // a slot that changes class must not keep its old class's contact count (np_static / np_convex_static
                             // write the counts of the slots they serve; nobody serves a slot of no class in a hulls-only batch)
         HIP_TRY(hipMemsetAsync((int *)b->scount.p + first, 0, (size_t)count * sizeof(int), b->stream));
-    b->has_simple = false;
-    for (int64_t i = 0; i < b->n && !b->has_simple; i++) b->has_simple = b->h_gtype[(size_t)i] == GEOM_BOX || b->h_gtype[(size_t)i] == GEOM_SPHERE;
+    b->has_simple = b->n_simple > 0;
     b->bp_rmax = 0; b->bp_valid = false;
     HIP_TRY(hipStreamSynchronize(b->stream));
     return DMX_OK;

@@ -145,6 +145,7 @@ struct dmxBatch {
     DevBuf sbuf, scount;
     uint32_t class_pairs = CLASS_PAIRS_ALL;     // dmxBatchSetClassPairs: which geometry classes collide with which
     bool has_simple = true;                    // some slot is a box or a sphere (kept by dmxBatchUploadGeomType)
+    int64_t n_simple = 0;                      // ... how many (h_gtype starts all GEOM_NONE)
     bool static_fast = true;                   // DMX_STATIC_FAST=0: every body at a static box goes through the exact tick (round 2's way)
     bool static_need8 = false;                 // a body with 5..8 static contacts has been met: the second step_contacts launch rides along
     int nofast_hold = 0, nofast_level = 0;     // chunks to go the exact way after a body overflowed the contact buffer (backs off)

@@ -319,7 +319,11 @@ int await_host_record(dmxBatch *b, uint32_t seq)
         const auto t0 = std::chrono::steady_clock::now();
         for (int it = 0;; it++) {
             if (*word == seq) { std::atomic_thread_fence(std::memory_order_acquire); return DMX_OK; }
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#else
+            std::this_thread::yield();
+#endif
             if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
         }
     }
@@ -518,7 +522,10 @@ template <class T> int careful_tick(dmxBatch *b, double h)
             { DmxPhase pw(b, 1); if ((rc = await_host_record(b, seq)) != DMX_OK) return rc; }
             if (exs_timing_enabled()) {
                 uint64_t st[64];
-                HIP_TRY(hipMemcpy(st, B.stamps, sizeof(st), hipMemcpyDeviceToHost));
+                // (on the batch's own stream, and drained: the record's arrival does not mean the stream's later kernels have
+                //  written their stamps, and the null stream is not ordered with a non-blocking stream)
+                HIP_TRY(hipMemcpyAsync(st, B.stamps, sizeof(st), hipMemcpyDeviceToHost, b->stream));
+                HIP_TRY(hipStreamSynchronize(b->stream));
                 for (int k = 1; k < 9; k++) { b->exs_acc[k] += (double)(st[k] - st[k - 1]); b->exs_acc[32 + k] += (double)(st[32 + k] - st[32 + k - 1]); }
                 b->exs_ticks++;
             }

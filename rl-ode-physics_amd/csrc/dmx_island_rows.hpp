@@ -221,6 +221,9 @@ __device__ __forceinline__ T row_sor(T *rows, const int *jb, T *bs, int i)
 // ---- the same row update with the row in registers and the bodies' constraint-force accumulators in LDS
 //      (solve_island_wg): identical arithmetic, identical bits ---------------------------------------------------
 // workgroup barrier that orders LDS traffic only (see solve_island_wg's level loop)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "lds_barrier() spells gfx9's s_waitcnt lgkmcnt(0) + s_barrier: this library is written for gfx950 (csrc/Makefile ARCH)"
+#endif
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <class T> struct RowRegs { T J[12], iMJ[12], rhs, ad, lo, hi, lam; int l1, l2, row; };

@@ -591,17 +591,46 @@ class CShardedStepper:
         self.h = C.c_void_p()
         self._keep = None
         if collectives == "rccl":
+            # Every rank first proves, on its own, what can fail locally -- librccl loads, the device answers, an id can be made
+            # (dmxShardRcclUniqueId does all three; only rank 0's id is used) -- and the ranks AGREE on the outcome over the
+            # torch.distributed group that is already up, BEFORE anybody enters an RCCL call: a rank that cannot load the library
+            # must not leave its peers waiting in a broadcast or in ncclCommInitRank.  Either every rank goes on, or every rank
+            # raises here together (bench.py then falls back on the Python loop on all of them).  What this does not cover: a
+            # failure INSIDE ncclCommInitRank or inside the priming exchange on one rank only (RCCL's own bring-up; never seen,
+            # never run on more than one GPU by the builder) -- the other ranks would wait there.
             ident = (C.c_char * 128)()
-            if rank == 0:
-                _check_rc(self.lib.dmxShardRcclUniqueId(ident), "dmxShardRcclUniqueId")
+            rc_local = self.lib.dmxShardRcclUniqueId(ident)
             if world_size > 1:
+                on_gpu = dist.get_backend(group) == "nccl"
+                flag = torch.tensor([1 if rc_local != 0 else 0], dtype=torch.int32)
+                if on_gpu:
+                    flag = flag.cuda()
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+                if int(flag.item()) != 0:
+                    from .batch import DmxError
+                    raise DmxError("RCCL is not usable on " + ("this rank" if rc_local != 0 else "another rank") +
+                                   f" (dmxShardRcclUniqueId code {rc_local}); every rank stops here together", rc_local or 1)
                 t = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8).clone()
-                if dist.get_backend(group) == "nccl":
+                if on_gpu:
                     t = t.cuda()
                 dist.broadcast(t, src=0, group=group)
                 ident = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
-            _check_rc(self.lib.dmxShardCreateRccl(C.byref(self.h), world_batch.h, layout.side, layout.rows, layout.spare, rank, world_size,
-                                                  ident), "dmxShardCreateRccl")
+            else:
+                _check_rc(rc_local, "dmxShardRcclUniqueId")
+            rc_create = self.lib.dmxShardCreateRccl(C.byref(self.h), world_batch.h, layout.side, layout.rows, layout.spare, rank, world_size, ident)
+            if world_size > 1:
+                # ... and on whether the communicator and the priming exchange came up everywhere (a rank whose create returned an
+                # error AFTER the collectives it shares with its peers -- allocation failures -- is met here, not in the tick loop)
+                flag = torch.tensor([1 if rc_create != 0 else 0], dtype=torch.int32)
+                if dist.get_backend(group) == "nccl":
+                    flag = flag.cuda()
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+                if int(flag.item()) != 0 and rc_create == 0:
+                    self.lib.dmxShardDestroy(self.h)
+                    self.h = C.c_void_p()
+                    from .batch import DmxError
+                    raise DmxError("dmxShardCreateRccl failed on another rank; every rank stops here together", 1)
+            _check_rc(rc_create, "dmxShardCreateRccl")
         else:
             self._keep = self._staged_collectives()
             _check_rc(self.lib.dmxShardCreate(C.byref(self.h), world_batch.h, layout.side, layout.rows, layout.spare, rank, world_size,

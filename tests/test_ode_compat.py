@@ -136,6 +136,50 @@ def test_reference_call_sequence_compiles_and_links(tmp_path, single):
     assert ("libode_mi355_single.so" if single else "libode_mi355.so") in out
 
 
+@pytest.mark.parametrize("single", [False, True])
+def test_contact_structs_have_the_ode_0_16_layout(tmp_path, single):
+    """include/ode/ode.h claims the ODE 0.13 - 0.16 line's dSurfaceParameters / dContactGeom / dContact [ODE-recall contact.h]:
+    int mode, then dReal mu, mu2, rho, rho2, rhoN, bounce, bounce_vel, soft_erp, soft_cfm, motion1, motion2, motionN, slip1,
+    slip2; dContactGeom = pos[4], normal[4], depth, g1, g2, side1, side2; dContact = surface, geom, fdir1[4].  An object
+    compiled against stock headers of that line passes `bounce` where this library reads it."""
+    src = tmp_path / "layout.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <stddef.h>
+#include <ode/ode.h>
+#define P(T, f) printf(#T "." #f " %zu\n", offsetof(T, f))
+int main(void) {
+    P(dSurfaceParameters, mode); P(dSurfaceParameters, mu); P(dSurfaceParameters, mu2); P(dSurfaceParameters, rho);
+    P(dSurfaceParameters, rho2); P(dSurfaceParameters, rhoN); P(dSurfaceParameters, bounce); P(dSurfaceParameters, bounce_vel);
+    P(dSurfaceParameters, soft_erp); P(dSurfaceParameters, soft_cfm); P(dSurfaceParameters, motion1); P(dSurfaceParameters, motion2);
+    P(dSurfaceParameters, motionN); P(dSurfaceParameters, slip1); P(dSurfaceParameters, slip2);
+    printf("sizeof.dSurfaceParameters %zu\n", sizeof(dSurfaceParameters));
+    P(dContactGeom, pos); P(dContactGeom, normal); P(dContactGeom, depth); P(dContactGeom, g1); P(dContactGeom, g2);
+    P(dContactGeom, side1); P(dContactGeom, side2);
+    P(dContact, surface); P(dContact, geom); P(dContact, fdir1);
+    printf("flags %d %d %d %d %d\n", dContactBounce, dContactRolling, dContactApprox1_N, dContactApprox1, dContactSoftCFM);
+    return 0;
+}
+""")
+    exe = str(tmp_path / "layout")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror"] + (["-DdSINGLE"] if single else []) +
+                   ["-I" + os.path.join(ROOT, "include"), str(src), "-o", exe], check=True)
+    got = dict(line.rsplit(" ", 1) for line in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+               if not line.startswith("flags"))
+    r = 4 if single else 8
+    first = r                                        # `int mode` is padded up to dReal's alignment
+    names = ["mu", "mu2", "rho", "rho2", "rhoN", "bounce", "bounce_vel", "soft_erp", "soft_cfm", "motion1", "motion2", "motionN", "slip1", "slip2"]
+    assert got["dSurfaceParameters.mode"] == "0"
+    for k, nm in enumerate(names):
+        assert int(got[f"dSurfaceParameters.{nm}"]) == first + k * r, nm
+    assert int(got["sizeof.dSurfaceParameters"]) == first + len(names) * r
+    assert [int(got[f"dContactGeom.{f}"]) for f in ("pos", "normal", "depth", "g1", "g2")] == [0, 4 * r, 8 * r, 8 * r + 8, 8 * r + 16] if not single \
+        else [int(got[f"dContactGeom.{f}"]) for f in ("pos", "normal", "depth")] == [0, 16, 32]
+    assert int(got["dContact.surface"]) == 0 and int(got["dContact.geom"]) >= first + len(names) * r
+    out = subprocess.run([exe], capture_output=True, text=True).stdout
+    assert "flags 4 1024 16384 28672 16" in out
+
+
 def test_reference_spawner_draws():
     b = pkg.scenes.reference_spawn(200, seed=1)
     kinds = [k for k, _, _ in b]
