@@ -407,6 +407,19 @@ def measure(cx, a, scene, layout, kind, dtype, *, exchanging, every_tick=False, 
                     st = None
                 c_loop = False
                 cx.c_loop_error = err or "another rank's communicator did not come up"
+        rccl_info = None
+        if exchanging and cx.world > 1:
+            # what produced this run's collectives, rank by rank, in the log and in the JSON line: the library's own librccl (path,
+            # communicator up) or the fallback
+            mine = {"rank": cx.rank, "c_loop": bool(c_loop), "collectives": "staged (rehearsal)" if cx.rehearse else "rccl"}
+            if c_loop and not cx.rehearse:
+                try:
+                    mine.update(st.rccl_info())
+                except Exception as e:      # noqa: BLE001
+                    mine["error"] = f"{type(e).__name__}: {e}"
+            print(f"[bench rank {cx.rank}] shard loop: {mine}", file=sys.stderr, flush=True)
+            rccl_info = [None] * cx.world
+            dist.all_gather_object(rccl_info, mine)
         if not c_loop:
             ops = None
             if exchanging and cx.rehearse:
@@ -472,7 +485,7 @@ def measure(cx, a, scene, layout, kind, dtype, *, exchanging, every_tick=False, 
                 "dev_s": statistics.median(dev), "blocks": nblocks, "wall_min": min(wall), "wall_max": max(wall),
                 "steps": steps, "n_exchanges": n_ex, "ticks_timed": nblocks * steps, "graphed": graphed, "stats": stats,
                 "exchanging": c_loop or st.exchange is not None, "tpl": ticks_per_launch if kind == "free" else 1,
-                "bodies": scene.n, "c_loop": c_loop, "c_loop_error": getattr(cx, "c_loop_error", None)}
+                "bodies": scene.n, "c_loop": c_loop, "c_loop_error": getattr(cx, "c_loop_error", None), "rccl_per_rank": rccl_info}
     finally:
         if st is not None and getattr(st, "exchange", None) is not None and st.exchange.fused:
             st.exchange.ops.disarm_pack()       # the send buffers die with the stepper: the batch must not keep aiming at them
@@ -712,6 +725,8 @@ def rank_main(a):
                                  + ("; box-plane and box-box contacts, 20 SOR sweeps" if kind == "small" else "")},
         "roofline": roofline_of(head, kind, rsize, profile_evidence(kind, a.dtype, scene.n), hull_points),
     }
+    if head.get("rccl_per_rank"):
+        out["config"]["shard_loop_per_rank"] = head["rccl_per_rank"]
     if head.get("c_loop_error"):
         out["config"]["c_loop_error"] = ("the rank loop behind the C ABI could not bring up its own RCCL communicator; this run used the same loop "
                                          "in Python over torch.distributed instead (that loop has no migration: it is valid for scenes without contacts across "

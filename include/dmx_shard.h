@@ -56,6 +56,9 @@ typedef struct dmxCollectives {
 #define DMX_RCCL_ID_BYTES 128
 /* rank 0: a fresh RCCL unique id (ncclGetUniqueId) for the other ranks' dmxShardCreateRccl */
 int dmxShardRcclUniqueId(void *id_out);
+/* diagnostics: the path of the librccl this process loaded (up to cap - 1 characters; empty if none) and whether `s` (may be
+ * NULL) holds a communicator brought up by ncclCommInitRank.  Returns DMX_ENODEVICE when no librccl could be loaded. */
+int dmxShardRcclInfo(dmxShardID s, char *path_out, int cap, int *comm_up);
 int dmxShardCreateRccl(dmxShardID *out, dmxBatchID batch, int64_t side, int64_t rows, int64_t spare, int rank, int world,
                        const void *rccl_unique_id);
 int dmxShardCreate(dmxShardID *out, dmxBatchID batch, int64_t side, int64_t rows, int64_t spare, int rank, int world,

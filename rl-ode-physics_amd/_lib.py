@@ -26,7 +26,7 @@ BATCH_SYMBOLS = [
     "dmxBatchSetSnapshotMode", "dmxBatchSetStaticBoxes", "dmxBatchSetStepper", "dmxBatchSetConvexHullFaces",
     "dmxBatchCollisionStatsEx", "dmxBatchFindPairs", "dmxBatchCrossPairs", "dmxBatchSetRowOrder", "dmxBatchLcpStats", "dmxBatchSetExactPipeline", "dmxBatchSetStaticPath", "dmxBatchSetClassPairs",
 ]
-SHARD_SYMBOLS = ["dmxShardRcclUniqueId", "dmxShardCreateRccl", "dmxShardCreate", "dmxShardRun", "dmxShardSettle", "dmxShardStats", "dmxShardDestroy"]
+SHARD_SYMBOLS = ["dmxShardRcclUniqueId", "dmxShardRcclInfo", "dmxShardCreateRccl", "dmxShardCreate", "dmxShardRun", "dmxShardSettle", "dmxShardStats", "dmxShardDestroy"]
 
 _lib = None
 
@@ -111,6 +111,7 @@ def load():
     sig("dmxShardRcclUniqueId", I, P)
     sig("dmxShardCreateRccl", I, C.POINTER(P), P, L, L, L, I, I, P)
     sig("dmxShardCreate", I, C.POINTER(P), P, L, L, L, I, I, P)
+    sig("dmxShardRcclInfo", I, P, P, I, C.POINTER(I))
     sig("dmxShardRun", I, P, D, I)
     sig("dmxShardSettle", I, P)
     sig("dmxShardStats", I, P, C.POINTER(L))

@@ -581,6 +581,20 @@ extern "C" int dmxShardCreateRccl(dmxShardID *out, dmxBatchID batch, int64_t sid
     return rc;
 }
 
+// which librccl this process's shard loop is bound to (the path dladdr reports for ncclCommInitRank), and whether `s` holds a
+// communicator that ncclCommInitRank brought up: what a log of a multi-GPU run should say about its collectives
+extern "C" int dmxShardRcclInfo(dmxShardID s, char *path_out, int cap, int *comm_up)
+{
+    if (comm_up) *comm_up = (s && s->own && ((RcclCtx *)s->own)->comm) ? 1 : 0;
+    if (path_out && cap > 0) {
+        path_out[0] = 0;
+        RcclApi *r = rccl();
+        Dl_info info;
+        if (r && dladdr((void *)r->CommInitRank, &info) && info.dli_fname) { strncpy(path_out, info.dli_fname, (size_t)cap - 1); path_out[cap - 1] = 0; }
+    }
+    return rccl() ? DMX_OK : DMX_ENODEVICE;
+}
+
 extern "C" int dmxShardRun(dmxShardID s, double h, int nticks)
 {
     if (!s || !(h > 0) || nticks < 0) return DMX_EINVAL;

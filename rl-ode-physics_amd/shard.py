@@ -676,6 +676,14 @@ class CShardedStepper:
         ag, ar = AG(all_gather), AR(all_reduce_max)
         return Coll(None, ag, ar), ag, ar
 
+    def rccl_info(self):
+        """{"librccl": path the library's own binding loaded ("" if none), "comm_up": ncclCommInitRank brought a communicator up}"""
+        import ctypes as C
+        path = C.create_string_buffer(512)
+        up = C.c_int(0)
+        self.lib.dmxShardRcclInfo(self.h, path, 512, C.byref(up))
+        return {"librccl": path.value.decode(errors="replace"), "comm_up": bool(up.value)}
+
     def run(self, h, nsteps):
         _check_rc(self.lib.dmxShardRun(self.h, float(h), int(nsteps)), "dmxShardRun")
 
