@@ -191,8 +191,8 @@ __device__ __forceinline__ void subpanel_left(T *own, const T *Lb, int b, int w,
 // One workgroup of 16 wavefronts per tile row below panel k.  Every workgroup factors the panel's 64 x 64 diagonal block for
 // itself, in LDS, lane r = row r: sixteen columns at a time -- first each wavefront brings ONE of the sixteen columns up to date
 // against the columns already factored (left-looking: a broadcast read and a multiply-add per earlier column), then wavefront 0
-// factors the sixteen in registers, pivots handed round by v_readlane -- and then solves ITS tile of the panel's rows (tile
-// k + 1 + blockIdx.x; lane r = a row of that tile) against the factor the same way:  X <- X L_kk^-T.  Workgroup 0 also leaves the
+// factors the sixteen in registers, pivots handed round by v_readlane -- and solves ITS tile of the panel's rows (tile
+// k + 1 + blockIdx.x; lane r = a row of that tile) against the factor the same way, one sub-panel behind:  X <- X L_kk^-T.  Workgroup 0 also leaves the
 // factored block in Ldiag[k] (the block of A itself stays as it was: late workgroups are still reading it).
 template <class T>
 __global__ __launch_bounds__(64 * PANEL_WAVES) void lcp_panel(T *__restrict__ A, int ld, int k, T *__restrict__ Ldiag, const T *__restrict__ tolp)
@@ -207,51 +207,50 @@ __global__ __launch_bounds__(64 * PANEL_WAVES) void lcp_panel(T *__restrict__ A,
 #pragma unroll
     for (int c = w; c < NB; c += PANEL_WAVES) { Lb[c * NB + r] = D[(size_t)c * ld + r]; Xb[c * NB + r] = Xg[(size_t)c * ld + r]; }
     __syncthreads();
-    for (int b = 0; b < 4; b++) {
-        if (b > 0) {
-            subpanel_left(Lb, Lb, b, w, r);
-            __syncthreads();
+    // sixteen factored columns of the diagonal block, in registers (wavefront 0)
+    auto factor16 = [&](int b) {
+        T p[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) p[c] = Lb[(16 * b + c) * NB + r];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int gj = 16 * b + j;
+            T ajj = bcast(p[j], gj);
+            ajj = ajj > T(0) ? ajj : tol;               // (the oracle's guard: a pivot that rounding pushed below zero)
+            const T inv = fast_rsqrt(ajj);
+            p[j] = (r == gj) ? ajj * inv : p[j] * inv;
+            if (r == gj) invd[gj] = inv;
+#pragma unroll
+            for (int c = j + 1; c < 16; c++) p[c] = fma_(-p[j], bcast(p[j], 16 * b + c), p[c]);
         }
-        if (w == 0) {
-            T p[16];
 #pragma unroll
-            for (int c = 0; c < 16; c++) p[c] = Lb[(16 * b + c) * NB + r];
+        for (int c = 0; c < 16; c++) Lb[(16 * b + c) * NB + r] = (r >= 16 * b + c) ? p[c] : T(0);
+    };
+    // sixteen solved columns of this workgroup's tile of the panel (wavefront 1): forward substitution against factored columns
+    auto solve16 = [&](int b) {
+        T p[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int gj = 16 * b + j;
-                T ajj = bcast(p[j], gj);
-                ajj = ajj > T(0) ? ajj : tol;               // (the oracle's guard: a pivot that rounding pushed below zero)
-                const T inv = fast_rsqrt(ajj);
-                p[j] = (r == gj) ? ajj * inv : p[j] * inv;
-                if (r == gj) invd[gj] = inv;
+        for (int c = 0; c < 16; c++) p[c] = Xb[(16 * b + c) * NB + r];
 #pragma unroll
-                for (int c = j + 1; c < 16; c++) p[c] = fma_(-p[j], bcast(p[j], 16 * b + c), p[c]);
-            }
+        for (int j = 0; j < 16; j++) {
+            const int gj = 16 * b + j;
+            p[j] *= invd[gj];
+            const T *lr = Lb + gj * NB + 16 * b;
 #pragma unroll
-            for (int c = 0; c < 16; c++) Lb[(16 * b + c) * NB + r] = (r >= 16 * b + c) ? p[c] : T(0);
+            for (int c = j + 1; c < 16; c++) p[c] = fma_(-p[j], lr[c], p[c]);
         }
-        __syncthreads();
-    }
-    for (int b = 0; b < 4; b++) {
-        if (b > 0) {
-            subpanel_left(Xb, Lb, b, w, r);
-            __syncthreads();
-        }
-        if (w == 0) {
-            T p[16];
 #pragma unroll
-            for (int c = 0; c < 16; c++) p[c] = Xb[(16 * b + c) * NB + r];
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int gj = 16 * b + j;
-                p[j] *= invd[gj];
-                const T *lr = Lb + gj * NB + 16 * b;
-#pragma unroll
-                for (int c = j + 1; c < 16; c++) p[c] = fma_(-p[j], lr[c], p[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < 16; c++) Xb[(16 * b + c) * NB + r] = p[c];
-        }
+        for (int c = 0; c < 16; c++) Xb[(16 * b + c) * NB + r] = p[c];
+    };
+    // The tile's solve runs one sub-panel behind the factorisation, beside it: while wavefront 0 factors columns 16 b .. 16 b + 15 of the
+    // diagonal block, wavefront 1 solves the tile's columns 16 (b - 1) .., and the left-looking updates of both (every wavefront a column)
+    // share the phase before.  Ten barriers a panel; the 64 serial pivots of wavefront 0 are what is left on the chain.
+    for (int b = 0; b <= 4; b++) {
+        if (b >= 1 && b < 4) subpanel_left(Lb, Lb, b, w, r);
+        if (b >= 2) subpanel_left(Xb, Lb, b - 1, w, r);
+        if (b >= 1) __syncthreads();
+        if (w == 0 && b < 4) factor16(b);
+        if (w == 1 && b >= 1) solve16(b - 1);
         __syncthreads();
     }
 #pragma unroll
