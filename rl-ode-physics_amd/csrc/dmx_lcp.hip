@@ -957,6 +957,7 @@ struct LcpGrid {
     void *pin = nullptr; size_t pin_bytes = 0;
     void *pin_real = nullptr; size_t pin_real_bytes = 0;
     dmxBatch::DevBuf Sv, vec2, ints2;
+    int l2_at = 0;               // DMX_LCP_L2_AT (0: 16 rows in f32, 32 in f64)
     int level2 = -1;             // DMX_LCP_LEVEL2: 1 = the volatile rows' problem is pivoted in LDS between checks of all rows, 0 = every pivoting
                                  // round refactors the whole free block; -1: by precision (see lcp_grid_solve)
     std::vector<int> rank_f, rank_c, in_v, state0;
@@ -979,7 +980,9 @@ LcpGrid *grid_of(dmxBatch *b)
         e = getenv("DMX_LCP_MURTY");
         g->murty_only = e && atoi(e) != 0;
         e = getenv("DMX_LCP_LEVEL2");
-        if (e) g->level2 = atoi(e) != 0 ? 1 : 0;
+        if (e) g->level2 = atoi(e);
+        e = getenv("DMX_LCP_L2_AT");
+        if (e) g->l2_at = atoi(e);
         e = getenv("DMX_LCP_W");
         if (e) g->w_mode = atoi(e) != 0 ? 1 : 0;
         e = getenv("DMX_LCP_TOL");
@@ -1158,10 +1161,18 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
         std::vector<int> &in_v = g->in_v, &rf = g->rank_f, &rc2 = g->rank_c, &state0 = g->state0;
         in_v.assign((size_t)nbd, 0);
         // (f64, ODE's cfm = 1e-10: the bounded rows' problem is close to degenerate and plain block pivoting cycles -- 40 to 70 rounds in
-        //  the pen, the oracle's own count -- until Murty's single flips end it; pivoting the volatile rows in LDS ends that: 5.9 -> 4.5
-        //  ms per tick at 512 bodies.  f32, cfm = 1e-5: five plain rounds or so, and a pass costs more than a round: 3.1 vs 4.3 ms.)
-        const bool use_l2 = g->level2 >= 0 ? g->level2 != 0 : sizeof(T) == 8;
-        bool classical = !use_l2 || g->murty_only;
+        //  the pen, the oracle's own count -- until Murty's single flips end it; pivoting the volatile rows in LDS ends that.  f32,
+        //  cfm = 1e-5: five plain rounds or so.)
+        // DMX_LCP_LEVEL2 = 2 (f32's default): plain rounds first -- each cuts the violators severalfold -- and the volatile rows' solve
+        // once no more than DMX_LCP_L2_AT (32) rows violate: the last two or three plain rounds, which chase a handful of rows through
+        // a full refactorisation each, become one pass.
+        // (measured, 400 / 512 bodies in the pen, ms per tick -- f32: plain rounds 2.46 / 3.12, this 2.36 / 3.05 at 16 rows, 3.26 / 3.45 at 64;
+        //  f64: the volatile rows' solve from the first pass on 3.84 / 4.06, this 3.41 / 3.61 at 32 rows, plain rounds 5.5 / 5.9)
+        const int l2_mode = g->level2 >= 0 ? g->level2 : 2;
+        const int l2_at = g->l2_at > 0 ? g->l2_at : (sizeof(T) == 8 ? 32 : 16);
+        const bool use_l2 = l2_mode != 0;
+        bool classical = !use_l2 || g->murty_only || l2_mode == 2;
+        const bool hybrid = use_l2 && !g->murty_only && l2_mode == 2;
         int nv_pred = 0;
         for (int q = 0; q < nbd; q++) {
             const int i = perm[(size_t)(nuP + q)];
@@ -1267,6 +1278,7 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
             int nviol = 0, top = -1;
             for (int q = 0; q < nbd; q++) if (h_viol[q]) { nviol++; top = q; }
             if (nviol == 0 || rounds >= max_rounds) break;
+            if (hybrid && classical && nviol <= l2_at && passes < 40) { classical = false; in_v.assign((size_t)nbd, 0); }
             if (!classical && passes < 40) {
                 // the violators join V, and so do the rows closest to changing sides, while a workgroup's LDS has room
                 int nvv = 0;
@@ -1299,7 +1311,7 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
             std::vector<int> &vol = g->in_v;
             int changed = 0;
             for (int q = 0; q < nbd; q++) { vol[(size_t)q] = state[(size_t)q] != state0[(size_t)q] ? 1 : 0; changed += vol[(size_t)q]; }
-            if (!classical) {
+            if (!classical && !hybrid) {
                 rank_margins<T>(nbd, state, vol, h_lam, h_w, R, perm, nuP, rf, rc2);
                 int nvv = changed;
                 const int want = std::min(std::min(3 * vcap / 4, nbd), std::max(3 * changed + 16, 48));
