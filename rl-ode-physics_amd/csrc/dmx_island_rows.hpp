@@ -49,7 +49,7 @@ __device__ __forceinline__ void stage_body(const T *S, const uint8_t *bflags, in
         const M3<T> R = quat_to_R(q);
         const V3<T> invIb = { T(1) / Ib.x, T(1) / Ib.y, T(1) / Ib.z };
         invIw = rotate_diag(R, invIb);
-        if (P.gyro != 0 && !(fl & BF_NOGYRO)) {
+        if (P.gyro != 0 && !(fl & BF_NOGYRO) && !isotropic(Ib)) {
             const M3<T> Iw = rotate_diag(R, Ib);
             add_gyro_torque(tacc, Iw, w, P.h, P.gyro);
         }

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, MINW) void step_contacts(T *S, T *So, int64_t 
         const V3<T> invIb = { T(1) / Ib.x, T(1) / Ib.y, T(1) / Ib.z };
         facc.x = fma_(mass, P.g.x, facc.x); facc.y = fma_(mass, P.g.y, facc.y); facc.z = fma_(mass, P.g.z, facc.z);
         const M3<T> invIw = rotate_diag(R, invIb);
-        if (P.gyro != 0) {
+        if (P.gyro != 0 && !isotropic(Ib)) {
             const M3<T> Iw = rotate_diag(R, Ib);
             add_gyro_torque(tacc, Iw, w, h, P.gyro);
         }

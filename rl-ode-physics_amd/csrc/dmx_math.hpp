@@ -158,6 +158,10 @@ template <class T> DMX_HD bool invert3(M3<T> &d, const M3<T> &a)
 // Adds the gyroscopic torque for angular velocity w, world inertia Iw, step h to tacc.
 //   explicit:  tacc -= w x (Iw w)
 //   implicit (Lacoursiere 2006): Itild = Iw - h [L]x, tacc += (Iw Itild^-1 - 1) L / h, L = Iw w
+// An isotropic inertia tensor has no gyroscopic torque (w x (I w) = I (w x w) = 0): the callers skip add_gyro_torque for it -- the
+// reference's every body (m = 1, I = identity: AddBody leaves ODE's default mass, main.c:695-733), for which the formulas below
+// would only add the rounding of R I R^T and of the 3 x 3 solve.  The oracle has the same early-out.
+template <class T> DMX_HD bool isotropic(const V3<T> &Ib) { return Ib.x == Ib.y && Ib.y == Ib.z; }
 template <class T> DMX_HD void add_gyro_torque(V3<T> &tacc, const M3<T> &Iw, const V3<T> &w, T h, int mode)
 {
     V3<T> L = mulv(Iw, w);

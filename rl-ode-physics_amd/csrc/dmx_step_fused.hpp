@@ -70,7 +70,7 @@ __device__ __forceinline__ void free_body_step(V3<T> &x, Q4<T> &q, V3<T> &v, V3<
     const V3<T> invIb = { T(1) / Ib.x, T(1) / Ib.y, T(1) / Ib.z };
     facc.x = fma_(mass, g.x, facc.x); facc.y = fma_(mass, g.y, facc.y); facc.z = fma_(mass, g.z, facc.z);
     const M3<T> invIw = rotate_diag(R, invIb);
-    if (gyro != 0) {
+    if (gyro != 0 && !isotropic(Ib)) {
         const M3<T> Iw = rotate_diag(R, Ib);
         add_gyro_torque(tacc, Iw, w, h, gyro);
     }
@@ -136,7 +136,7 @@ __device__ __forceinline__ void step_plane_body(T *S, T *So, const uint8_t *__re
         const V3<T> invIb = { T(1) / Ib.x, T(1) / Ib.y, T(1) / Ib.z };
         facc.x = fma_(mass, P.g.x, facc.x); facc.y = fma_(mass, P.g.y, facc.y); facc.z = fma_(mass, P.g.z, facc.z);
         const M3<T> invIw = rotate_diag(R, invIb);
-        if (P.gyro != 0) {
+        if (P.gyro != 0 && !isotropic(Ib)) {
             const M3<T> Iw = rotate_diag(R, Ib);
             add_gyro_torque(tacc, Iw, w, h, P.gyro);
         }
