@@ -2,7 +2,8 @@
 // geom pair: lane l tests hull point / face 64 j + l, ballots give every hit its rank in array order, so the contacts kept
 // are the ones a sequential walk keeps (the CPU restatement the tests compare with).  Shared by the exact tick's narrowphase (dmx_exact.hip)
 // and the fused path of bodies at static geometry (dmx_narrow.hip).  The caller says where a contact goes:
-// emit(rank, pos, normal, depth) runs on the one lane that holds contact `rank` of this geom pair.
+// emit(rank, pos, normal, depth) runs on the one lane that holds contact `rank` of this geom pair.  The hull's points (3 reals a
+// point) are read through `pts`: StepParams::hull itself, or a workgroup's copy of it in LDS.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -11,37 +12,66 @@
 
 namespace dmx {
 
+// The filters below compute a point's coordinate q = c . (R p + x - x') as (R^T c) . p + c . (x - x') and compare it with a bound;
+// the exact tests compute it the first way.  With u = eps / 2 the unit roundoff, r >= |p|, |c|_2 = 1 (so |c|_1 <= sqrt 3):
+//   exact:  R p three fused steps (3 sqrt3 u r), + x (u (|x| + r)), - x' (u |d|), c . d three fused steps (3 sqrt3 u |d|), the
+//           errors of d carried through c (x sqrt 3):                                      <= 1.8 u |x| + 11 u r + 7 u |d|
+//   filter: R^T c (3 sqrt3 u a component, times |p|: 9 u r), the dot with p and the offset (4 u (r + |off|)), the offset itself
+//           (7 u |x - x'|):                                                                <= 13 u r + 14 u |x - x'|
+// with |d| <= |x - x'| + r the two differ by less than 1.8 u |x| + 31 u r + 21 u |x - x'| <= 32 u (|x|_1 + |x'|_1 + r): the slack
+// is 16 eps of that sum (+ 1, + the bound itself for the rounding of the comparison's right-hand side).
+template <class T> __device__ __forceinline__ T hull_filter_slack();
+template <> __device__ __forceinline__ float  hull_filter_slack<float>()  { return 16.0f * 1.1920929e-7f; }
+template <> __device__ __forceinline__ double hull_filter_slack<double>() { return 16.0 * 2.220446049250313e-16; }
+
 // ---- convex hull against the ground plane (dCollideConvexPlane [ODE-recall]) ----------------------------------------
 // ODE walks the hull's points in array order: a point on or below the plane becomes a contact (position = the point,
 // depth = distance below) until max_contacts are taken, and the result counts only if the hull has points on both
 // sides of the plane (or on it).  ODE's early exit (max_contacts reached and both signs seen) only skips points that can
 // change neither the contact set nor the both-sides test, so the wave may stop at the same condition.
 template <class T, class Emit>
-__device__ __forceinline__ int wave_convex_plane(const V3<T> &x, const M3<T> &R, const StepParams<T> &P, int maxc, int lane, Emit emit)
+__device__ __forceinline__ int wave_convex_plane(const V3<T> &x, const M3<T> &R, T hull_radius, const StepParams<T> &P, int maxc, int lane, Emit emit, const T *pts)
 {
     int contacts = 0;
     bool any_le = false, any_ge = false;
+    // A pass of 64 points is all arithmetic (the wavefront issues ~50 instructions for it) and nearly every point is far above the
+    // plane.  So first the point's height by ONE composite dot product in the hull's frame, (R^T n) . p + (n . x - d): rounded
+    // differently from the walk's own n . (R p + x) - d, but within `slack` of it; a point more than `slack` above the plane is
+    // above it for the walk too (it sets any_ge and nothing else), and a pass with no other point is over.  The rest are evaluated
+    // exactly as before, in array order: same contacts, same bits.
+    const V3<T> u = { fma_(R.m[2][0], P.pn.z, fma_(R.m[1][0], P.pn.y, R.m[0][0] * P.pn.x)),
+                      fma_(R.m[2][1], P.pn.z, fma_(R.m[1][1], P.pn.y, R.m[0][1] * P.pn.x)),
+                      fma_(R.m[2][2], P.pn.z, fma_(R.m[1][2], P.pn.y, R.m[0][2] * P.pn.x)) };
+    const T off = dot(P.pn, x) - P.pd;
+    const T slack = hull_filter_slack<T>() * (tabs(x.x) + tabs(x.y) + tabs(x.z) + tabs(P.pd) + hull_radius + T(1));
     for (int base = 0; base < P.hull_n; base += 64) {
         const int k = base + lane;
-        bool below = false, le = false, ge = false;
-        V3<T> v2 = { T(0), T(0), T(0) };
+        bool below = false, le = false, ge = false, near = false;
+        V3<T> v2 = { T(0), T(0), T(0) }, p = { T(0), T(0), T(0) };
         T distance2 = T(0);
         if (k < P.hull_n) {
-            v2 = mulv(R, V3<T>{ P.hull[3 * k], P.hull[3 * k + 1], P.hull[3 * k + 2] });
-            v2.x += x.x; v2.y += x.y; v2.z += x.z;
-            distance2 = dot(P.pn, v2) - P.pd;
-            le = distance2 <= T(0);
-            ge = distance2 >= T(0);
-            below = le;
+            p = { pts[3 * k], pts[3 * k + 1], pts[3 * k + 2] };
+            near = !(fma_(u.z, p.z, fma_(u.y, p.y, fma_(u.x, p.x, off))) > slack);
+            ge = !near;
         }
-        const unsigned long long mb = __ballot(below);
-        any_le = any_le || (__ballot(le) != 0ull);
+        if (__ballot(near) != 0ull) {
+            if (near) {
+                v2 = mulv(R, p);
+                v2.x += x.x; v2.y += x.y; v2.z += x.z;
+                distance2 = dot(P.pn, v2) - P.pd;
+                le = distance2 <= T(0);
+                ge = distance2 >= T(0);
+                below = le;
+            }
+            const unsigned long long mb = __ballot(below);
+            any_le = any_le || mb != 0ull;
+            if (below) {
+                const int rank = contacts + __popcll(mb & ((1ull << lane) - 1ull));
+                if (rank < maxc) emit(rank, v2, P.pn, -distance2);
+            }
+            contacts += __popcll(mb);
+        }
         any_ge = any_ge || (__ballot(ge) != 0ull);
-        if (below) {
-            const int rank = contacts + __popcll(mb & ((1ull << lane) - 1ull));
-            if (rank < maxc) emit(rank, v2, P.pn, -distance2);
-        }
-        contacts += __popcll(mb);
         if (contacts >= maxc && any_le && any_ge) break;
     }
     return (any_le && any_ge) ? (contacts < maxc ? contacts : maxc) : 0;
@@ -51,19 +81,61 @@ __device__ __forceinline__ int wave_convex_plane(const V3<T> &x, const M3<T> &R,
 // dmxBatchSetConvexHullFaces): (1) hull vertices inside the box, in array order, each along the box face it is nearest to;
 // (2) box corners inside the hull (corner order = bits), each along the hull face it is nearest to.  The normal points
 // into the box; `negate` flips it (hull first in dCollide's order, or a reversed joint).
-template <class T, class Emit>
-__device__ __forceinline__ int wave_box_convex(const V3<T> &xb, const M3<T> &Rb, const T *side, const V3<T> &xh, const M3<T> &Rh,
-                                               T hull_radius, const StepParams<T> &P, int maxc, bool negate, int lane, Emit emit)
+// The walk's filter for one (box, hull) pair: plain per-lane arithmetic, so a caller with several pairs at hand can set them up
+// one pair a lane (np_convex_static_tile) and hand each to the wavefront in turn.
+// Along the box's THINNEST axis a (a floor's, a wall's, a plank's normal): the point's coordinate on it by one composite dot product,
+// (Rh^T b_a) . p + b_a . (xh - xb); a point farther out than half_a + slack is outside the box for the exact test too, and a pass
+// of 64 such points is over after five instructions instead of fifty.
+template <class T> struct BoxFilter { V3<T> u; T off, bound; };
+template <class T>
+__device__ __forceinline__ BoxFilter<T> box_filter(const V3<T> &xb, const M3<T> &Rb, const T (&half)[3], const V3<T> &xh, const M3<T> &Rh, T hull_radius)
 {
-    const T half[3] = { T(0.5) * side[0], T(0.5) * side[1], T(0.5) * side[2] };
+    const int ax = half[0] <= half[1] ? (half[0] <= half[2] ? 0 : 2) : (half[1] <= half[2] ? 1 : 2);
+    const V3<T> ba = { ax == 0 ? Rb.m[0][0] : (ax == 1 ? Rb.m[0][1] : Rb.m[0][2]),
+                       ax == 0 ? Rb.m[1][0] : (ax == 1 ? Rb.m[1][1] : Rb.m[1][2]),
+                       ax == 0 ? Rb.m[2][0] : (ax == 1 ? Rb.m[2][1] : Rb.m[2][2]) };
+    const T ha = ax == 0 ? half[0] : (ax == 1 ? half[1] : half[2]);
+    BoxFilter<T> F;
+    F.u = { fma_(Rh.m[2][0], ba.z, fma_(Rh.m[1][0], ba.y, Rh.m[0][0] * ba.x)),
+            fma_(Rh.m[2][1], ba.z, fma_(Rh.m[1][1], ba.y, Rh.m[0][1] * ba.x)),
+            fma_(Rh.m[2][2], ba.z, fma_(Rh.m[1][2], ba.y, Rh.m[0][2] * ba.x)) };
+    F.off = fma_(ba.z, xh.z - xb.z, fma_(ba.y, xh.y - xb.y, ba.x * (xh.x - xb.x)));
+    F.bound = ha + hull_filter_slack<T>() * (tabs(xh.x) + tabs(xh.y) + tabs(xh.z) + tabs(xb.x) + tabs(xb.y) + tabs(xb.z) + hull_radius + ha + T(1));
+    return F;
+}
+// a corner inside the hull is inside the hull's bounding sphere (slack for rounding): most corners of a floor-sized box are nowhere
+// near it and skip the walk over the hull's faces.  Per-lane arithmetic again: corner cn of the box against one hull.
+template <class T>
+__device__ __forceinline__ bool box_corner_near(const V3<T> &xb, const M3<T> &Rb, const T (&half)[3], const V3<T> &xh, T hull_radius, int cn)
+{
+    const V3<T> l = { (cn & 1) ? half[0] : -half[0], (cn & 2) ? half[1] : -half[1], (cn & 4) ? half[2] : -half[2] };
+    V3<T> cw = mulv(Rb, l);
+    cw.x += xb.x; cw.y += xb.y; cw.z += xb.z;
+    const V3<T> d = { cw.x - xh.x, cw.y - xh.y, cw.z - xh.z };
+    return !(d.x * d.x + d.y * d.y + d.z * d.z > hull_radius * hull_radius * T(1.0001));
+}
+
+// the walk proper, for a pair whose filter F and near corners (bit cn) are at hand
+template <class T, class Emit>
+__device__ __forceinline__ int wave_box_convex_walk(const V3<T> &xb, const M3<T> &Rb, const T (&half)[3], const V3<T> &xh, const M3<T> &Rh,
+                                                    const BoxFilter<T> &F, unsigned near_corners, const StepParams<T> &P, int maxc, bool negate,
+                                                    int lane, Emit emit, const T *pts)
+{
     int contacts = 0;
+    const V3<T> u = F.u;
+    const T off = F.off, bound = F.bound;
     for (int base = 0; base < P.hull_n && contacts < maxc; base += 64) {
         const int k = base + lane;
-        bool inside = false;
-        V3<T> v = { T(0), T(0), T(0) }, n = { T(0), T(0), T(0) };
+        bool inside = false, near = false;
+        V3<T> v = { T(0), T(0), T(0) }, n = { T(0), T(0), T(0) }, p = { T(0), T(0), T(0) };
         T dep = T(0);
         if (k < P.hull_n) {
-            v = mulv(Rh, V3<T>{ P.hull[3 * k], P.hull[3 * k + 1], P.hull[3 * k + 2] });
+            p = { pts[3 * k], pts[3 * k + 1], pts[3 * k + 2] };
+            near = !(tabs(fma_(u.z, p.z, fma_(u.y, p.y, fma_(u.x, p.x, off)))) > bound);
+        }
+        if (__ballot(near) == 0ull) continue;
+        if (near) {
+            v = mulv(Rh, p);
             v.x += xh.x; v.y += xh.y; v.z += xh.z;
             const V3<T> d = { v.x - xb.x, v.y - xb.y, v.z - xb.z };
             T q[3];
@@ -91,14 +163,13 @@ __device__ __forceinline__ int wave_box_convex(const V3<T> &xb, const M3<T> &Rb,
         contacts += __popcll(mb);
     }
     if (contacts > maxc) contacts = maxc;
-    for (int cn = 0; cn < 8 && contacts < maxc && P.hull_nf > 0; cn++) {
+    if (contacts >= maxc || P.hull_nf <= 0) return contacts;
+    for (int cn = 0; cn < 8 && contacts < maxc; cn++) {
+        if (!((near_corners >> cn) & 1u)) continue;
         const V3<T> l = { (cn & 1) ? half[0] : -half[0], (cn & 2) ? half[1] : -half[1], (cn & 4) ? half[2] : -half[2] };
         V3<T> cw = mulv(Rb, l);
         cw.x += xb.x; cw.y += xb.y; cw.z += xb.z;
         const V3<T> d = { cw.x - xh.x, cw.y - xh.y, cw.z - xh.z };
-        // a corner inside the hull is inside the hull's bounding sphere (slack for rounding): most corners of a floor-sized
-        // box are nowhere near it and skip the walk over the faces
-        if (d.x * d.x + d.y * d.y + d.z * d.z > hull_radius * hull_radius * T(1.0001)) continue;
         V3<T> r;
         r.x = fma_(Rh.m[2][0], d.z, fma_(Rh.m[1][0], d.y, Rh.m[0][0] * d.x));
         r.y = fma_(Rh.m[2][1], d.z, fma_(Rh.m[1][1], d.y, Rh.m[0][1] * d.x));
@@ -128,6 +199,17 @@ __device__ __forceinline__ int wave_box_convex(const V3<T> &xb, const M3<T> &Rb,
         contacts++;
     }
     return contacts;
+}
+
+// one pair, set up here: every lane computes the same filter, lane cn asks for corner cn
+template <class T, class Emit>
+__device__ __forceinline__ int wave_box_convex(const V3<T> &xb, const M3<T> &Rb, const T *side, const V3<T> &xh, const M3<T> &Rh,
+                                               T hull_radius, const StepParams<T> &P, int maxc, bool negate, int lane, Emit emit, const T *pts)
+{
+    const T half[3] = { T(0.5) * side[0], T(0.5) * side[1], T(0.5) * side[2] };
+    const BoxFilter<T> F = box_filter<T>(xb, Rb, half, xh, Rh, hull_radius);
+    const unsigned near_corners = (unsigned)(__ballot(box_corner_near<T>(xb, Rb, half, xh, hull_radius, lane & 7)) & 0xffull);
+    return wave_box_convex_walk<T>(xb, Rb, half, xh, Rh, F, near_corners, P, maxc, negate, lane, emit, pts);
 }
 
 // ---- a point of the world in a hull's frame: R^T (v - x), the oracle's to_hull_frame ------------------------------------------

@@ -521,8 +521,8 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
             if (e < cap.inv) {
                 // ---- hull against the ground plane
                 if (P.plane_on && P.hull_n > 0)
-                    nc = wave_convex_plane<T>(H.x, H.R, P, maxc, lane, [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) {
-                        put_c(gpos, gnormal, gdepth, (size_t)8 * e + rank, p, nn, dep); });
+                    nc = wave_convex_plane<T>(H.x, H.R, H.side[0], P, maxc, lane, [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) {
+                        put_c(gpos, gnormal, gdepth, (size_t)8 * e + rank, p, nn, dep); }, P.hull);
             } else {
                 // ---- hull against static box s: dCollide(static box, hull); the joint is attached (0, body): reversed
                 const uint32_t s = (e - cap.inv) / cap.inv;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
                     const T sside[3] = { sb[SBOX_SIDE], sb[SBOX_SIDE + 1], sb[SBOX_SIDE + 2] };
                     const size_t slot0 = cap.static_slot0() + (size_t)8 * (e - cap.inv);
                     nc = wave_box_convex<T>(sx, sR, sside, H.x, H.R, H.side[0], P, maxc, true, lane,
-                                            [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) { put_c(gpos, gnormal, gdepth, slot0 + rank, p, nn, dep); });
+                                            [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) { put_c(gpos, gnormal, gdepth, slot0 + rank, p, nn, dep); }, P.hull);
                 }
             }
         } else {
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void ex_narrow_convex(const T *__restrict__ S,
                 const size_t slot0 = cap.pair_slot0() + (size_t)8 * p;
                 if (P.hull_n > 0)
                     nc = wave_box_convex<T>(Bx.x, Bx.R, Bx.side, H.x, H.R, H.side[0], P, maxc, gi != GEOM_BOX, lane,
-                                            [&](int rank, const V3<T> &pp, const V3<T> &nn, T dep) { put_c(gpos, gnormal, gdepth, slot0 + rank, pp, nn, dep); });
+                                            [&](int rank, const V3<T> &pp, const V3<T> &nn, T dep) { put_c(gpos, gnormal, gdepth, slot0 + rank, pp, nn, dep); }, P.hull);
             } else if (gi == GEOM_CONVEX && gj == GEOM_CONVEX) {
                 if (hull_pairs_elsewhere) continue;
                 // hull i (geom 1, created first) against hull j: vertices of each inside the other, normals into i

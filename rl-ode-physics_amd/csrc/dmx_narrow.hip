@@ -27,8 +27,8 @@ __global__ __launch_bounds__(256) void np_convex_plane(const T *__restrict__ S, 
                                      S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] });
     const int maxc = P.max_contacts < CONVEX_MAXC ? P.max_contacts : CONVEX_MAXC;
     T *out = P.cbuf + (size_t)i * CONVEX_MAXC * 4;
-    const int nc = wave_convex_plane<T>(x, R, P, maxc, lane, [&](int rank, const V3<T> &p, const V3<T> &, T dep) {
-        out[4 * rank + 0] = p.x; out[4 * rank + 1] = p.y; out[4 * rank + 2] = p.z; out[4 * rank + 3] = dep; });
+    const int nc = wave_convex_plane<T>(x, R, S[slab_ix(C_SIDES + 0, i)], P, maxc, lane, [&](int rank, const V3<T> &p, const V3<T> &, T dep) {
+        out[4 * rank + 0] = p.x; out[4 * rank + 1] = p.y; out[4 * rank + 2] = p.z; out[4 * rank + 3] = dep; }, P.hull);
     if (lane == 0) P.ccount[i] = nc;
 }
 
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void np_convex_static(const T *__restrict__ S,
     int nc = 0;
     if (P.hull_n > 0) {
         if (P.plane_on)
-            nc = wave_convex_plane<T>(x, R, P, maxc, lane, [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) { put_sc(P.sbuf, i, rank, p, nn, dep); });
+            nc = wave_convex_plane<T>(x, R, radius, P, maxc, lane, [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) { put_sc(P.sbuf, i, rank, p, nn, dep); }, P.hull);
         for (int s = 0; s < P.n_static; s++) {
             const T *sb = P.sbox + s * SBOX_REALS;
             if (!aabb_meets_static(lo, hi, sb)) continue;
@@ -146,10 +146,111 @@ __global__ __launch_bounds__(256) void np_convex_static(const T *__restrict__ S,
             const T sside[3] = { sb[SBOX_SIDE], sb[SBOX_SIDE + 1], sb[SBOX_SIDE + 2] };
             const int base = nc;
             nc += wave_box_convex<T>(sx, sR, sside, x, R, radius, P, maxc, true, lane, [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) {
-                if (base + rank < SC_MAXC) put_sc(P.sbuf, i, base + rank, p, nn, dep); });
+                if (base + rank < SC_MAXC) put_sc(P.sbuf, i, base + rank, p, nn, dep); }, P.hull);
         }
     }
     if (lane == 0) P.scount[i] = nc > SC_MAXC ? SC_MAXC + 1 : nc;
+}
+
+// convex hulls, a 64-body tile per workgroup (round 4).  The wavefront-per-body form above is a launch of n wavefronts, each alive
+// ~12 us and waiting for two thirds of it (profiles/r04_np_convex_static_experiments.txt): its pose, then the static box, then one
+// pass of 64 hull points after another -- every pass a round trip to L2, and the next one not begun before this one's ballot says
+// that room is left.  Here sixteen wavefronts share one copy of the hull's points in LDS (15 KB in f32 for the teapot), filled once
+// for the 64 bodies of the tile; a wavefront takes four bodies in turn, their poses fetched together by the lanes before the
+// first, so a pass costs an LDS read.  The walk itself -- wave_box_convex, wave_convex_plane -- is the same code on the same
+// values in the same order: identical contacts.
+constexpr int NPC_TILE = 64, NPC_WAVES = 16, NPC_PER_WAVE = NPC_TILE / NPC_WAVES;
+constexpr int NPC_SBOX = 64;         // static boxes staged in LDS beside the hull (the rest are read where they lie)
+template <class T>
+__global__ __launch_bounds__(NPC_WAVES * 64) void np_convex_static_tile(const T *__restrict__ S, const uint8_t *__restrict__ gtype, int64_t n, StepParams<T> P)
+{
+    extern __shared__ __align__(16) unsigned char npc_raw[];
+    T *pts = reinterpret_cast<T *>(npc_raw);                          // [3 hull_n]
+    T *sbl = pts + 3 * (size_t)P.hull_n;                              // [min(n_static, NPC_SBOX)][SBOX_REALS]
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // Everything the tile needs from memory is asked for at once -- what the wavefront form reads one after another, each a round
+    // trip: the refusal flags, the bodies' classes, their poses (lanes 8 j .. 8 j + 7 fetch position, quaternion and bounding
+    // radius of the wavefront's j-th body), then -- behind one barrier, and only in a tile that holds a hull -- the hull's points
+    // and the static boxes into LDS.
+    const int64_t i0 = (int64_t)blockIdx.x * NPC_TILE + w * NPC_PER_WAVE;
+    T pose = T(0);
+    bool live = false;
+    {
+        const int j = lane >> 3, c = lane & 7;
+        const int64_t ib = i0 + j;
+        if (j < NPC_PER_WAVE && ib < n) {
+            live = gtype[ib] == GEOM_CONVEX && !(P.skip != nullptr && P.skip[ib]);
+            const int comp = c < 3 ? C_POS + c : (c < 7 ? C_QUAT + (c - 3) : C_SIDES);
+            pose = S[slab_ix(comp, ib)];
+        }
+    }
+    // a chunk in which a body has left its zone is rolled back whole, and a speculative launch the device's record refuses does
+    // nothing: the step kernel behind this one returns at once in both cases (step_plane / step_contacts), so its contacts need not be made
+    const bool refused = (P.bp_check && P.bp_flags[BPF_VIOLATION] != 0u) || (P.gate != nullptr && *P.gate == 0u);
+    const unsigned long long live_mask = __ballot(live);
+    const int ns_lds = P.n_static < NPC_SBOX ? P.n_static : NPC_SBOX;
+    if (!__syncthreads_or(live_mask != 0ull && !refused) || P.hull_n <= 0) return;      // (block-uniform)
+    for (int e = threadIdx.x; e < 3 * P.hull_n; e += NPC_WAVES * 64) pts[e] = P.hull[e];
+    for (int e = threadIdx.x; e < ns_lds * SBOX_REALS; e += NPC_WAVES * 64) sbl[e] = P.sbox[e];
+    __syncthreads();
+    const int maxc = P.max_contacts < CONVEX_MAXC ? P.max_contacts : CONVEX_MAXC;
+    // What a pair (body, static box) needs before its walk -- the body's rotation matrix, its box against the static box's, the
+    // walk's filter, which of the box's corners are near the hull -- is a few hundred instructions of plain arithmetic, the same for
+    // all 64 lanes.  So the wavefront does it for its four bodies at once, a body a lane (lane l: body l & 3; the corners: lanes
+    // 8 j + c, body j, corner c), and each body's walk fetches its values from its lane.
+    const int jl = lane & 3, jc = (lane >> 3) & 3;
+    const V3<T> xl = { __shfl(pose, 8 * jl + 0, 64), __shfl(pose, 8 * jl + 1, 64), __shfl(pose, 8 * jl + 2, 64) };
+    const M3<T> Rl = quat_to_R(Q4<T>{ __shfl(pose, 8 * jl + 3, 64), __shfl(pose, 8 * jl + 4, 64), __shfl(pose, 8 * jl + 5, 64), __shfl(pose, 8 * jl + 6, 64) });
+    const T radius_l = __shfl(pose, 8 * jl + 7, 64);      // the hull's bounding radius; its AABB is that sphere's box (body_aabb)
+    const T lo[3] = { xl.x - radius_l, xl.y - radius_l, xl.z - radius_l }, hi[3] = { xl.x + radius_l, xl.y + radius_l, xl.z + radius_l };
+    const V3<T> xc = { __shfl(pose, 8 * jc + 0, 64), __shfl(pose, 8 * jc + 1, 64), __shfl(pose, 8 * jc + 2, 64) };
+    const T radius_c = __shfl(pose, 8 * jc + 7, 64);
+    const bool live_l = (live_mask >> (8 * jl)) & 1ull;
+    int nc_l = 0;                                                    // lane j: the contacts of body j so far
+    auto fetch_R = [&](int j) {
+        M3<T> R;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c2 = 0; c2 < 3; c2++) R.m[a][c2] = __shfl(Rl.m[a][c2], j, 64);
+        return R;
+    };
+    if (P.plane_on) {
+        for (int j = 0; j < NPC_PER_WAVE; j++) {
+            if (!((live_mask >> (8 * j)) & 1ull)) continue;          // wave-uniform
+            const int64_t i = i0 + j;
+            const V3<T> x = { __shfl(pose, 8 * j + 0, 64), __shfl(pose, 8 * j + 1, 64), __shfl(pose, 8 * j + 2, 64) };
+            const int k = wave_convex_plane<T>(x, fetch_R(j), __shfl(pose, 8 * j + 7, 64), P, maxc, lane,
+                                               [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) { put_sc(P.sbuf, i, rank, p, nn, dep); }, pts);
+            if (lane == j) nc_l = k;
+        }
+    }
+    auto boxes = [&](const T *sbase, int count) {                    // (twice below: the boxes in LDS, the boxes in memory)
+        for (int s = 0; s < count; s++) {
+            const T *sb = sbase + s * SBOX_REALS;
+            const unsigned meet = (unsigned)(__ballot(live_l && aabb_meets_static(lo, hi, sb)) & 0xfull);
+            if (meet == 0u) continue;
+            const V3<T> sx = { sb[SBOX_POS], sb[SBOX_POS + 1], sb[SBOX_POS + 2] };
+            M3<T> sR;
+            for (int a = 0; a < 3; a++) for (int c2 = 0; c2 < 3; c2++) sR.m[a][c2] = sb[SBOX_R + 3 * a + c2];
+            const T half[3] = { T(0.5) * sb[SBOX_SIDE], T(0.5) * sb[SBOX_SIDE + 1], T(0.5) * sb[SBOX_SIDE + 2] };
+            const BoxFilter<T> Fl = box_filter<T>(sx, sR, half, xl, Rl, radius_l);
+            const unsigned long long corners = __ballot(box_corner_near<T>(sx, sR, half, xc, radius_c, lane & 7));
+            for (int j = 0; j < NPC_PER_WAVE; j++) {
+                if (!((meet >> j) & 1u)) continue;                   // wave-uniform
+                const int64_t i = i0 + j;
+                const V3<T> x = { __shfl(pose, 8 * j + 0, 64), __shfl(pose, 8 * j + 1, 64), __shfl(pose, 8 * j + 2, 64) };
+                const BoxFilter<T> F = { { __shfl(Fl.u.x, j, 64), __shfl(Fl.u.y, j, 64), __shfl(Fl.u.z, j, 64) }, __shfl(Fl.off, j, 64), __shfl(Fl.bound, j, 64) };
+                const int base = __shfl(nc_l, j, 64);
+                const int k = wave_box_convex_walk<T>(sx, sR, half, x, fetch_R(j), F, (unsigned)((corners >> (8 * j)) & 0xffull), P, maxc, true, lane,
+                    [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) { if (base + rank < SC_MAXC) put_sc(P.sbuf, i, base + rank, p, nn, dep); }, pts);
+                if (lane == j) nc_l += k;
+            }
+        }
+    };
+    boxes(sbl, ns_lds);
+    boxes(P.sbox + (size_t)ns_lds * SBOX_REALS, P.n_static - ns_lds);
+    if (lane < NPC_PER_WAVE && live_l) P.scount[i0 + lane] = nc_l > SC_MAXC ? SC_MAXC + 1 : nc_l;
 }
 
 template <class T>
@@ -167,7 +268,15 @@ hipError_t launch_np_static(const T *S, const uint8_t *gtype, int64_t n, const S
     // (np_static serves boxes and spheres and writes a zero count for slots of no class; a batch of hulls only does not need the
     //  launch: slots of no class keep the zero count dmxBatchSetStaticBoxes / dmxBatchUploadGeomType left there)
     if (P.has_simple || P.hull_n <= 0) hipLaunchKernelGGL((np_static<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, gtype, n, P);
-    if (P.hull_n > 0) hipLaunchKernelGGL((np_convex_static<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, S, gtype, n, P);
+    if (P.hull_n > 0) {
+        // the tile form while the hull's points fit the LDS a launch may ask for without more ado (64 KB: some 5 000 points in f32)
+        static const bool per_body = getenv("DMX_HULL_WAVE_PER_BODY") != nullptr;
+        const size_t lds = ((size_t)3 * P.hull_n + (size_t)(P.n_static < NPC_SBOX ? P.n_static : NPC_SBOX) * SBOX_REALS) * sizeof(T);
+        if (!per_body && lds <= 64 * 1024)
+            hipLaunchKernelGGL((np_convex_static_tile<T>), dim3((unsigned)((n + NPC_TILE - 1) / NPC_TILE)), dim3(NPC_WAVES * 64), lds, st, S, gtype, n, P);
+        else
+            hipLaunchKernelGGL((np_convex_static<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, S, gtype, n, P);
+    }
     return hipGetLastError();
 }
 

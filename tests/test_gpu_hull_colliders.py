@@ -175,3 +175,41 @@ def test_hulls_whose_collide_bits_name_the_map_only():
     st = w.collision_stats()
     assert st["careful_ticks"] == 0 and st["fast_ticks"] == steps, st
     w.close()
+
+
+@pytest.mark.parametrize("dtype,plane", [("float64", False), ("float32", False), ("float32", True)])
+def test_teapots_on_a_floor_strewn_with_small_blocks(dtype, plane):
+    """The hull-against-map collider with a 64-body tile per workgroup (np_convex_static_tile): 9 x 8 = 72 tilted, spinning teapots (two
+    wavefronts, the second one part empty) fall on a floor -- a static box, or the ground plane -- strewn with turned blocks
+    0.3 m across: the hull's points inside the floor and inside the blocks (array order, the first max_contacts kept), and block
+    corners inside the hull (the wavefront's walk over the hull's faces, entered from single lanes).  Collisions between the
+    teapots are off so that every contact is the map's.  Bit-identical to the oracle."""
+    hull = _teapot()
+    scene = pkg.scenes.hull_grid(hull, 9, 8, seed=23, y_range=(0.9, 1.6), spin=True, tilt=0.5, floor_box=not plane, plane=plane).astype(dtype)
+    rng = np.random.default_rng(12)
+    statics = list(scene.static_boxes or [])
+    for k in range(scene.n):
+        if k % 3 == 2:
+            continue
+        yaw = rng.uniform(0, np.pi)
+        c, s = np.cos(yaw), np.sin(yaw)
+        R12 = np.array([c, 0.0, s, 0.0, 0.0, 1.0, 0.0, 0.0, -s, 0.0, c, 0.0])
+        statics.append(((0.3, 0.3, 0.3), (scene.pos[k, 0] + rng.uniform(-0.5, 0.5), 0.15, scene.pos[k, 2] + rng.uniform(-0.5, 0.5)), R12))
+    scene.static_boxes = statics
+    steps = 240
+    ow = _oracle_for(dtype, scene, scene.n)
+    n_static = len(statics)
+    first = n_static + (1 if plane else 0)                  # geoms in creation order: the plane, the statics, one per body
+    for g in range(first, first + scene.n):
+        ow.lib.orc_geom_set_collide_bits(ow.w, g, 1)
+    most = 0
+    for _ in range(steps):
+        ow.tick(H)
+        most = max(most, ow.n_contacts())
+    assert most > 3 * scene.n, most
+    w = pkg.BatchWorld(scene.n, dtype=dtype)
+    w.load_scene(scene)
+    w.set_class_pairs(pkg.scenes.GEOM_CONVEX, pkg.scenes.GEOM_CONVEX, False)
+    w.step(H, steps)
+    _same(w, ow)
+    w.close()
