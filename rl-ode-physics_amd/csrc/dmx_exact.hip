@@ -838,12 +838,12 @@ __device__ __forceinline__ void publish_counts(const ExactCounts *C, const uint3
 // ---- 10b. the level schedule of ONE large island, by a whole workgroup of EXS_WG threads.  Same schedule as st_levels' (a row's
 // level is one more than the latest level of any earlier row on either of its bodies; a group's rows -- consecutive contacts
 // between the same two bodies -- take consecutive levels), built differently: groups found by a scan, the bodies' slots mapped to
-// island-local numbers through `last` (all -1 on entry and on return), the one sequential part -- the walk over the GROUPS, two
-// LDS reads and two writes each -- done by one lane in LDS, then every row's level, the per-level counts, offsets and row lists
-// in parallel.  Rows of one level touch disjoint bodies, so their order inside a level list is free (atomic cursors).
+// island-local numbers through `last` (all -1 on entry and on return), the one sequential part -- the walk over the GROUPS --
+// replaced by a relaxation over the groups' predecessors (below; round 3 had one lane walk them in LDS), then every row's level,
+// the per-level counts, offsets and row lists in parallel.  Rows of one level touch disjoint bodies, so their order inside a level list is free (atomic cursors).
 // lds: at least levels_coop_bytes(nb, groups) bytes; returns false (nothing written) when the island does not fit -- the caller
 // falls back on the one-lane walk.
-__host__ __device__ inline size_t levels_coop_bytes(size_t nb, size_t groups) { return 4 * nb + 12 * groups + 16; }
+__host__ __device__ inline size_t levels_coop_bytes(size_t nb, size_t groups) { return 8 * nb + 24 * groups + 32; }
 
 __device__ __forceinline__ bool levels_coop(int isl, int k, const int *con_off, const int *body_off, const int *bodies, const int *cb1,
                                             const int *cb2, int rpc, const int *big, int *lev_count, int *lev_off, int *lev_rows,
@@ -859,39 +859,81 @@ __device__ __forceinline__ bool levels_coop(int isl, int k, const int *con_off, 
     __syncthreads();
     block_scan_inclusive<uint32_t>(gidx, gidx, (uint32_t)nc, wt);
     const int G = (int)gidx[nc - 1];
-    if (levels_coop_bytes((size_t)nb, (size_t)G) > lds_bytes || nb > 65535) { __syncthreads(); return false; }
-    int32_t *lastL = reinterpret_cast<int32_t *>(lds);             // [nb] latest level per island-local body
-    int32_t *ghead = lastL + nb;                                    // [G + 1] a group's first contact (island-relative)
+    if (levels_coop_bytes((size_t)nb, (size_t)G) > lds_bytes || nb > 65535 || G > 65535) { __syncthreads(); return false; }
+    int32_t *bcur = reinterpret_cast<int32_t *>(lds);              // [nb + 1] per island-local body: its groups' count, then the run's start / cursor
+    int32_t *bend = bcur + nb + 1;                                  // [nb] the run's end
+    int32_t *ghead = bend + nb;                                     // [G + 1] a group's first contact (island-relative)
     int32_t *glev = ghead + G + 1;                                  // [G] the level below the group's first row
-    uint16_t *gl1 = reinterpret_cast<uint16_t *>(glev + G), *gl2 = gl1 + G;     // [G] its bodies, island-local (0xffff: none)
+    int32_t *gend = glev + G;                                       // [G] the level of its last row
+    uint16_t *gl1 = reinterpret_cast<uint16_t *>(gend + G), *gl2 = gl1 + G;     // [G] its bodies, island-local (0xffff: none)
+    uint16_t *gp1 = gl2 + G, *gp2 = gp1 + G;                        // [G] the group before it on each of its bodies (0xffff: none)
+    uint16_t *blist = gp2 + G;                                      // [2 G] every body's groups, ascending
     __shared__ int nlev_s;
-    for (int t = tid; t < nb; t += EXS_WG) { last[bodies[b0 + t]] = t; lastL[t] = -1; }
-    if (tid == 0) ghead[G] = nc;
+    for (int t = tid; t < nb; t += EXS_WG) { last[bodies[b0 + t]] = t; bcur[t] = 0; }
+    if (tid == 0) { ghead[G] = nc; bcur[nb] = 0; nlev_s = 0; }
     __syncthreads();
     for (int d = tid; d < nc; d += EXS_WG) {
         const int g = (int)gidx[d] - 1;
         if (d == 0 || (int)gidx[d - 1] - 1 != g) {
             ghead[g] = d;
-            gl1[g] = (uint16_t)last[cb1[c0 + d]];
-            gl2[g] = cb2[c0 + d] >= 0 ? (uint16_t)last[cb2[c0 + d]] : (uint16_t)0xffffu;
+            const int l1 = last[cb1[c0 + d]], l2 = cb2[c0 + d] >= 0 ? last[cb2[c0 + d]] : 0xffff;
+            gl1[g] = (uint16_t)l1; gl2[g] = (uint16_t)l2;
+            atomicAdd(&bcur[l1], 1);
+            if (l2 != 0xffff) atomicAdd(&bcur[l2], 1);
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        int nlev = 0;
-        for (int g = 0; g < G; g++) {
-            const int l1 = gl1[g], l2 = gl2[g], rows = (ghead[g + 1] - ghead[g]) * rpc;
-            int lv = lastL[l1];
-            if (l2 != 0xffff && lastL[l2] > lv) lv = lastL[l2];
-            glev[g] = lv;
-            const int nl = lv + rows;
-            lastL[l1] = nl;
-            if (l2 != 0xffff) lastL[l2] = nl;
-            if (nl + 1 > nlev) nlev = nl + 1;
-        }
-        nlev_s = nlev;
-        lev_count[k] = nlev;
+    // The one sequential part of the schedule is a walk over the groups in creation order: a group starts one level above the latest
+    // row on either of its bodies.  That is a longest-path recurrence over "the group before this one on body 1 / on body 2" -- so
+    // find those two predecessors for every group (a counting sort of the groups by body, each body's short run sorted by a lane),
+    // and let every group take max(end of predecessor 1, end of predecessor 2) until nothing changes: as many rounds as the longest
+    // chain of groups has links (a pile of 512 bodies: ~20), each one pass of the workgroup over LDS, instead of one lane's 580
+    // dependent steps (70 us of the pen's tick).  The recurrence has one solution: the same levels.
+    block_scan_inclusive<uint32_t>(reinterpret_cast<uint32_t *>(bcur), reinterpret_cast<uint32_t *>(bcur), (uint32_t)nb, wt);
+    for (int t = tid; t < nb; t += EXS_WG) bend[t] = bcur[t];      // (inclusive sums: the runs' ends; a run's cursor counts down from its end)
+    __syncthreads();
+    for (int g = tid; g < G; g += EXS_WG) {
+        const int l1 = gl1[g], l2 = gl2[g];
+        blist[atomicSub(&bcur[l1], 1) - 1] = (uint16_t)g;
+        if (l2 != 0xffff) blist[atomicSub(&bcur[l2], 1) - 1] = (uint16_t)g;
+        gp1[g] = gp2[g] = (uint16_t)0xffffu;
     }
+    __syncthreads();
+    for (int t = tid; t < nb; t += EXS_WG) {                        // (bcur[t] is the run's start now)
+        const int lo = bcur[t], hi = bend[t];
+        for (int a = lo + 1; a < hi; a++) {                         // insertion sort: a body touches a handful of others
+            const uint16_t v = blist[a];
+            int c = a - 1;
+            while (c >= lo && blist[c] > v) { blist[c + 1] = blist[c]; c--; }
+            blist[c + 1] = v;
+        }
+        for (int a = lo + 1; a < hi; a++) {
+            const int g = blist[a];
+            if (gl1[g] == t) gp1[g] = blist[a - 1]; else gp2[g] = blist[a - 1];
+        }
+    }
+    __syncthreads();
+    for (int g = tid; g < G; g += EXS_WG) { glev[g] = -1; gend[g] = -1 + (ghead[g + 1] - ghead[g]) * rpc; }
+    __syncthreads();
+    for (;;) {
+        bool changed = false;
+        for (int g = tid; g < G; g += EXS_WG) {
+            const int p1 = gp1[g], p2 = gp2[g];
+            int lv = p1 != 0xffff ? gend[p1] : -1;
+            if (p2 != 0xffff && gend[p2] > lv) lv = gend[p2];
+            if (lv != glev[g]) { glev[g] = lv; changed = true; }
+        }
+        if (!__syncthreads_or(changed)) break;
+        for (int g = tid; g < G; g += EXS_WG) gend[g] = glev[g] + (ghead[g + 1] - ghead[g]) * rpc;
+        __syncthreads();
+    }
+    {
+        int mx = 0;
+        for (int g = tid; g < G; g += EXS_WG) mx = gend[g] + 1 > mx ? gend[g] + 1 : mx;
+        if (mx > 0) atomicMax(&nlev_s, mx);
+    }
+    __syncthreads();
+    if (tid == 0) lev_count[k] = nlev_s;
     for (int t = tid; t < nb; t += EXS_WG) last[bodies[b0 + t]] = -1;      // back to the idle state
     __syncthreads();
     const int nlev = nlev_s;
