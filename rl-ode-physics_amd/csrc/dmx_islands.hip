@@ -648,6 +648,56 @@ __device__ __forceinline__ double wg_island_sweeps(T *rows, const int *jb, const
     return resid;
 }
 
+// The same with CONTACTS as units (three rows per contact throughout): the u-th contact in level order belongs to thread u mod WG,
+// CPL contacts a thread.  A contact's normal and two friction rows sit on consecutive levels on the same two bodies, so a lane that
+// holds all three fetches the bodies' accumulators once, carries them through the three row updates in registers and writes them
+// back once: one LDS round trip and one barrier per CONTACT level where the row form pays three (the pen's pile: 150 row levels x
+// 20 sweeps, each ~260 cycles of which ~130 are the round trip and the barrier).  The arithmetic per row is row_sor_lds's, in the
+// same order: same bits.  cfirst: nc ints of LDS scratch.
+template <class T, int CPL, int WG>
+__device__ __forceinline__ double wg_island_contact_sweeps(T *rows, const int *jb, const int *row_level, const int *lev_rows, const int *lev_off,
+                                                           int m, int nlev, int iters, int tid, T *fc_lds, int *cfirst)
+{
+    const int nc = m / 3, n_clev = nlev / 3;
+    // contacts in level order: the rows of level 3 cl are the first rows of contact level cl's contacts, and the levels below hold
+    // exactly three rows of every earlier contact
+    for (int p = tid; p < m; p += WG) {
+        const int r = lev_rows[p], lv = row_level[r];
+        if (lv % 3 == 0) { const int a = lev_off[lv] - lev_off[0]; cfirst[a / 3 + (p - a)] = r; }
+    }
+    __syncthreads();
+    ContactRegs<T> mine[CPL];
+    int my_cl[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; j++) {
+        const int u = tid + WG * j;
+        my_cl[j] = -1;
+        if (u < nc) { const int r0 = cfirst[u]; contact_load(rows, jb, r0, mine[j]); my_cl[j] = row_level[r0] / 3; }
+    }
+    double resid = 0.0;
+    for (int it = 0; it + 1 < iters; it++)
+        for (int cl = 0; cl < n_clev; cl++) {
+#pragma unroll
+            for (int j = 0; j < CPL; j++)
+                if (my_cl[j] == cl) contact_sor_lds<T, false>(mine[j], fc_lds, true, resid);
+            lds_barrier();
+        }
+    if (iters > 0)
+        for (int cl = 0; cl < n_clev; cl++) {
+#pragma unroll
+            for (int j = 0; j < CPL; j++)
+                if (my_cl[j] == cl) contact_sor_lds<T, true>(mine[j], fc_lds, true, resid);
+            lds_barrier();
+        }
+#pragma unroll
+    for (int j = 0; j < CPL; j++)
+        if (my_cl[j] >= 0) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) rows[(size_t)(mine[j].row0 + d) * RW_COUNT + RW_LAM] = mine[j].lam[d];
+        }
+    return resid;
+}
+
 // ================================================================================ one workgroup per large island
 constexpr int FC_LDS_BYTES = 48 * 1024;     // islands of up to 2048 (f32) / 1024 (f64) bodies keep their accumulators in LDS
 // (WAVE_ISLAND_ROWS, dmx_internal.hpp: islands of up to that many rows are solved by one wavefront with the rows in registers;
@@ -731,13 +781,25 @@ __device__ __forceinline__ void solve_island_wg_body(T *__restrict__ S, const ui
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) bs[(size_t)k * BW_COUNT + BW_FC + j] = fc_lds[6 * k + j];
     } else if (REGS && use_lds && m <= REGS_ROWS<T>) {
+        const int contact_scratch_ints = sched_ints;          // (REGS launches: room behind the accumulators for one int per contact)
         for (int k = tid; k < nb; k += WG)
             for (int j = 0; j < 6; j++) fc_lds[6 * k + j] = bs[(size_t)k * BW_COUNT + BW_FC + j];
         __syncthreads();
         const int *row_level = I.row_level + lev_off[0], *lev_rows = I.lev_rows + lev_off[0];
         // (rows per thread as a template parameter: 32 registers a row in f32, 64 in f64 -- of a lane's 512 at one wave per SIMD)
         constexpr int RMAX = REGS_ROWS_PER_THREAD<T, WG>;          // 6 (f32) / 3 (f64) at 512 threads, 12 / 6 at 256
-        if (m <= 2 * WG) resid = wg_island_sweeps<T, 2, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
+        // three rows per contact throughout (the batch's surface with friction, or per-contact surfaces that all have it) and at
+        // most two contacts a thread (a contact is 90 registers in f32): contacts as units
+        bool all3 = sizeof(T) == 4 && m == 3 * nc && nlev % 3 == 0 && nc <= 2 * WG && contact_scratch_ints >= nc && (I.cmu != nullptr || P.mu > 0);
+        if (all3 && I.cmu != nullptr) {
+            int a3 = 1;
+            for (int c = tid; c < nc; c += WG) a3 &= I.cmu[c0 + c] > 0 ? 1 : 0;
+            all3 = __syncthreads_and(a3) != 0;
+        }
+        int *cfirst = reinterpret_cast<int *>(fc_lds + (size_t)6 * lds_bodies);
+        if (all3 && nc <= WG) resid = wg_island_contact_sweeps<T, 1, WG>(rows, jb, row_level, lev_rows, lev_off, m, nlev, P.iters, tid, fc_lds, cfirst);
+        else if (all3) resid = wg_island_contact_sweeps<T, sizeof(T) == 4 ? 2 : 1, WG>(rows, jb, row_level, lev_rows, lev_off, m, nlev, P.iters, tid, fc_lds, cfirst);
+        else if (m <= 2 * WG) resid = wg_island_sweeps<T, 2, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
         else if (m <= 3 * WG || RMAX <= 3) resid = wg_island_sweeps<T, RMAX < 3 ? RMAX : 3, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
         else if (m <= 4 * WG || RMAX <= 4) resid = wg_island_sweeps<T, RMAX < 4 ? RMAX : 4, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
         else if (m <= 6 * WG || RMAX <= 6) resid = wg_island_sweeps<T, RMAX < 6 ? RMAX : 6, WG>(rows, jb, row_level, lev_rows, m, nlev, P.iters, tid, fc_lds);
@@ -1102,12 +1164,16 @@ hipError_t launch_islands(T *S, const uint8_t *bflags, int64_t stride, const Isl
             // (f64 rows are 64 registers: three a thread at 512 threads spill; 256 threads, six a thread, do not.  Up to 1 024 rows
             //  256 threads hold them in four slots a thread without the accumulator half, and a level step has four waves to
             //  bring to the barrier, not eight: the pen 96 bodies 264 vs 270 us, 400 bodies 645 vs 583, 512 bodies 961 vs 793)
+            // (+ one int per contact behind the accumulators: the contact form's list of contacts in level order)
+            static const bool by_contact = [] { const char *e = getenv("DMX_REGS_BY_CONTACT"); return !(e && atoi(e) == 0); }();
+            const int scratch = by_contact && sizeof(T) == 4 ? REGS_ROWS<T> / 3 : 0;
+            lds += (size_t)scratch * sizeof(int);
             if (regs_wg == 512 && sizeof(T) == 4 && I.big_max_rows > 1024)
                 hipLaunchKernelGGL((solve_island_wg<T, 512, true>), dim3((unsigned)I.n_big), dim3(512), lds, st, S, bflags, stride, I, P, diag, lds_bodies,
-                                   (const ExactCounts *)nullptr, 0);
+                                   (const ExactCounts *)nullptr, scratch);
             else
                 hipLaunchKernelGGL((solve_island_wg<T, 256, true>), dim3((unsigned)I.n_big), dim3(256), lds, st, S, bflags, stride, I, P, diag, lds_bodies,
-                                   (const ExactCounts *)nullptr, 0);
+                                   (const ExactCounts *)nullptr, scratch);
         } else {
             // room for an island's level schedule behind the accumulators (offsets + row lists; big_rows_total bounds any one island's):
             // taken when it is modest -- a few large islands (a pile in the pen) -- not when thousands of small ones share the launch
