@@ -144,7 +144,7 @@ def profile_evidence(kind, dtype, n):
         o = json.load(open(path))
     except (OSError, ValueError):
         # no counter pass for this workload: name the committed kernel-trace summary of the same command, if there is one
-        trace = {"convex": "r03_c5_f32_kernel_stats.csv", "small": "r03_config1_trace.txt", "plane": "r03_c3_f32_kernel_stats.csv"}.get(kind)
+        trace = {"convex": "r04_c5_f32_kernel_stats.csv", "small": "r03_config1_trace.txt", "plane": "r04_c3_f32_kernel_stats.csv"}.get(kind)
         if trace and dtype == "f32" and os.path.exists(os.path.join(ROOT, "profiles", trace)):
             return None, None, f"profiles/{trace} (kernel trace; no PMC pass committed for this workload)"
         return None, None, "no PMC pass committed for this workload"
