@@ -90,6 +90,22 @@ def test_pen_of_400_bodies_settled_then_dworldstep(tmp_path, single):
         assert _rel(plain, ref) <= 1e-5
 
 
+@pytest.mark.parametrize("single,seed,n", [(False, 3, 250), (True, 11, 250), (False, 29, 320), (True, 5, 180)])
+def test_other_piles_other_seeds(tmp_path, single, seed, n):
+    """the same sequence on other draws of the spawner (other shapes, sizes and piles: other active sets, other islands at the
+    boundary between the workgroup and the grid solve): settle with QuickStep, then five ticks of dWorldStep against the oracle"""
+    dtype = "float32" if single else "float64"
+    statics = pkg.scenes.reference_map()
+    bodies = pkg.scenes.reference_spawn(n, seed=seed, y_range=(1.2, 10.0))
+    dt, settle, steps = 1.0 / 120.0, 360, 365
+    exe = _build_harness(str(tmp_path), single)
+    text = _scene_text(dt, steps, False, statics, bodies)
+    got, err = _run(exe, text, env={"HARNESS_EXACT_AFTER": str(settle)})
+    ref, ow = _oracle_poses(dtype, dt, steps, False, statics, bodies, exact_after=settle)
+    assert ow.n_contacts() > n // 2
+    assert _rel(got.astype(ref.dtype), ref) <= 1e-5
+
+
 def test_every_island_through_the_grid_solve_in_the_small_pen(tmp_path):
     """DMX_LCP_GRID_ROWS=1: islands of 3 rows and up all take the grid path (one unbounded tile, one bounded tile, padding
     everywhere) -- 24 bodies dropping into the pen, 120 ticks of dWorldStep"""
