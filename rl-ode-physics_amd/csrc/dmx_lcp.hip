@@ -1187,7 +1187,7 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
         }
         if (classical || nv_pred > vcap) { in_v.assign((size_t)nbd, 0); nv_pred = 0; }
         state0 = state;
-        int best = m + 1, patience = g->murty_only ? 0 : 3, passes = 0;
+        int best = m + 1, patience = g->murty_only ? 0 : 3, passes = 0, l2_passes = 0;
         const int max_rounds = 20 * m + 100;
         {
             const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcp_backsolve<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1271,15 +1271,24 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
             }
             HIP_TRY(hipStreamSynchronize(st));
             passes++;
+            if (nv2 > 0) l2_passes++;
             if (nv2 > 0) {
                 for (int q = 0; q < nbd; q++) state[(size_t)q] = h_state[q];
                 g->stats[1] += h_rounds2[0];
             }
             int nviol = 0, top = -1;
             for (int q = 0; q < nbd; q++) if (h_viol[q]) { nviol++; top = q; }
+            static const int trace = [] { const char *e = getenv("DMX_LCP_TRACE"); return e ? atoi(e) : 0; }();
+            if (trace > 0 && rounds >= trace)
+                fprintf(stderr, "lcp trace: solve %lld round %d pass %d nviol %d nv %d nfs %d %s\n", (long long)g->stats[0], rounds, passes, nviol, nv2, nfs,
+                        classical ? "classical" : "level2");
             if (nviol == 0 || rounds >= max_rounds) break;
-            if (hybrid && classical && nviol <= l2_at && passes < 40) { classical = false; in_v.assign((size_t)nbd, 0); }
-            if (!classical && passes < 40) {
+            // ... or once block pivoting has stalled (the violation count has failed to shrink three times: what would follow is Murty's
+            // single flips, a full refactorisation per flipped row -- 500 rounds in one f64 tick of a 1 500-tick run, 0.2 s) and the
+            // violators with their neighbourhood fit a workgroup's LDS: there a flip costs microseconds.
+            const bool stalled = !g->murty_only && nviol >= best && patience == 0;
+            if (hybrid && classical && (nviol <= l2_at || (stalled && 2 * nviol <= vcap)) && l2_passes < 40) { classical = false; in_v.assign((size_t)nbd, 0); }
+            if (!classical && l2_passes < 40) {
                 // the violators join V, and so do the rows closest to changing sides, while a workgroup's LDS has room
                 int nvv = 0;
                 for (int q = 0; q < nbd; q++) { if (h_viol[q]) in_v[(size_t)q] = 1; nvv += in_v[(size_t)q]; }
@@ -1304,6 +1313,10 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
                 if (!h_viol[q] || (!all && q != top)) continue;
                 state[(size_t)q] = h_viol[q] == 1 ? ST_LO : h_viol[q] == 2 ? ST_HI : ST_FREE;
             }
+        }
+        {
+            static const int trace = [] { const char *e = getenv("DMX_LCP_TRACE"); return e ? atoi(e) : 0; }();
+            if (trace < 0) fprintf(stderr, "lcp solve: %lld m %d nbd %d passes %d l2_passes %d single %d\n", (long long)g->stats[0], m, nbd, passes, l2_passes, single_rounds);
         }
         // remember the active set, and who is likely to move next tick: the rows that changed sides in this solve and the ones
         // closest to doing so

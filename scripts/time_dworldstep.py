@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--single", action="store_true")
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--env", nargs="*", default=[])
+    ap.add_argument("--stderr-to", default="", help="append the harness's stderr (the library's DMX_LCP_TRACE / REPORT lines) to this file")
     a = ap.parse_args()
     tmp = tempfile.mkdtemp()
     exe = _build_harness(tmp, a.single)
@@ -32,6 +33,8 @@ def main():
         env = {**os.environ, "HARNESS_STEPPER": "exact", "HARNESS_EXACT_AFTER": str(a.settle), "HARNESS_TIME_FROM": str(a.settle + 4),
                "DMX_LCP_REPORT": "1", **extra}
         p = subprocess.run([exe], input=_scene_text(1.0 / 120.0, steps, False, statics, bodies), capture_output=True, text=True, env=env)
+        if a.stderr_to:
+            open(a.stderr_to, "a").write(p.stderr)
         if p.returncode != 0:
             print(n, "FAILED", p.stderr[-800:])
             continue
