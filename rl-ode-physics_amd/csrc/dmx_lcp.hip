@@ -1188,6 +1188,7 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
         if (classical || nv_pred > vcap) { in_v.assign((size_t)nbd, 0); nv_pred = 0; }
         state0 = state;
         int best = m + 1, patience = g->murty_only ? 0 : 3, passes = 0, l2_passes = 0;
+        bool subset_mode = false;
         const int max_rounds = 20 * m + 100;
         {
             const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&lcp_backsolve<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1287,11 +1288,23 @@ int lcp_grid_solve(dmxBatch *b, const IslandSet<T> &I, const StepParams<T> &P, c
             // single flips, a full refactorisation per flipped row -- 500 rounds in one f64 tick of a 1 500-tick run, 0.2 s) and the
             // violators with their neighbourhood fit a workgroup's LDS: there a flip costs microseconds.
             const bool stalled = !g->murty_only && nviol >= best && patience == 0;
-            if (hybrid && classical && (nviol <= l2_at || (stalled && 2 * nviol <= vcap)) && l2_passes < 40) { classical = false; in_v.assign((size_t)nbd, 0); }
+            // (More violators than the LDS level holds -- 176 of 679 rows in the worst tick of that run: the level takes them a
+            //  workgroup-full at a time, the highest rows first as Murty's rule takes its one; each pass settles its share exactly
+            //  against the rest as it stands.  No proof of termination comes with that: forty passes, then the single flips.)
+            if (hybrid && classical && (nviol <= l2_at || stalled) && l2_passes < 40) {
+                classical = false; in_v.assign((size_t)nbd, 0);
+                subset_mode = stalled && 2 * nviol > vcap;
+            }
             if (!classical && l2_passes < 40) {
                 // the violators join V, and so do the rows closest to changing sides, while a workgroup's LDS has room
                 int nvv = 0;
                 for (int q = 0; q < nbd; q++) { if (h_viol[q]) in_v[(size_t)q] = 1; nvv += in_v[(size_t)q]; }
+                if (subset_mode && nvv > 3 * vcap / 4) {
+                    int seen = 0;
+                    for (int q = nbd - 1; q >= 0; q--)
+                        if (in_v[(size_t)q]) { if (seen >= 3 * vcap / 4 || !h_viol[q]) in_v[(size_t)q] = 0; else seen++; }
+                    nvv = seen;
+                }
                 if (nvv <= vcap) {
                     rank_margins<T>(nbd, state, in_v, h_lam, h_w, R, perm, nuP, rf, rc2);
                     const int want = std::min(std::min(vcap, nbd), std::max(nvv + 2 * nviol + 16, 64));
