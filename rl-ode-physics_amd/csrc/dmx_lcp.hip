@@ -594,30 +594,109 @@ __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
 // steps [k0, k1) of the LDL^T of the packed matrix M whose rows 0 .. last are stored (row `last` = the right-hand side; the
 // unknowns are rows / columns 0 .. last - 1); dinv[k] = 1 / pivot.  Ends with a barrier.
+// FOUR pivots a pass (round 4; one a pass before: a 93-row solve was 93 passes of a few hundred cycles' work between two barriers,
+// 0.2 us each whatever the work, and the volatile rows' solve refactors ten times a call).  A pass: (A) every thread eliminates the
+// 4 x 4 pivot block for itself (ten values, read before anybody writes them), and the thread that owns a row below the block brings
+// the row's four panel entries up to date -- entry q by the pivots before q, exactly the products the one-pivot passes made, in
+// their order -- leaves them in the matrix and in a small buffer; barrier; (B) the trailing triangle takes the four updates of
+// every element in one read-modify-write; barrier.  Same operands, same order per element: same bits.
+template <class T> constexpr int LDLT_MAXN = sizeof(T) == 8 ? 192 : 288;       // rows (the right-hand side's included) an LDS solve holds at most
 template <class T, int WG>
 __device__ __forceinline__ void ldlt_steps(T *M, int last, int k0, int k1, T *dinv, T tol, int tid)
 {
+    constexpr int NBK = 4;
+    __shared__ T pn[LDLT_MAXN<T>][NBK];
     const int ty = tid >> 4, tx = tid & 15;
-    for (int k = k0; k < k1; k++) {
-        T d = M[tri(k, k)];
-        d = d > T(0) ? d : tol;               // (the oracle's guard: a pivot that rounding pushed below zero)
-        const T inv = T(1) / d;
-        if (tid == 0) dinv[k] = inv;
-        for (int i = k + 1 + ty; i <= last; i += WG / 16) {
-            const T cik = M[tri(i, k)] * inv;
+    for (int k = k0; k < k1; k += NBK) {
+        const int nb = k1 - k < NBK ? k1 - k : NBK;
+        // ---- (A) the pivot block, by everybody
+        T A[NBK][NBK], inv[NBK];
+#pragma unroll
+        for (int p = 0; p < NBK; p++)
+#pragma unroll
+            for (int q = 0; q <= p; q++) A[p][q] = p < nb ? M[tri(k + p, k + q)] : T(0);
+#pragma unroll
+        for (int q = 0; q < NBK; q++) {
+            T d = A[q][q];
+            d = d > T(0) ? d : tol;               // (the oracle's guard: a pivot that rounding pushed below zero)
+            inv[q] = T(1) / d;
+#pragma unroll
+            for (int p = q + 1; p < NBK; p++) {
+                const T c = A[p][q] * inv[q];
+#pragma unroll
+                for (int j = q + 1; j <= p; j++) A[p][j] = fma_(-c, A[j][q], A[p][j]);
+            }
+        }
+        if (tid < nb) dinv[k + tid] = tid == 0 ? inv[0] : tid == 1 ? inv[1] : tid == 2 ? inv[2] : inv[3];
+        // the rows below the block: their panel entries
+        for (int i = k + nb + tid; i <= last; i += WG) {
+            T *Mi = M + tri(i, k);
+            T r[NBK];
+#pragma unroll
+            for (int q = 0; q < NBK; q++) r[q] = q < nb ? Mi[q] : T(0);
+#pragma unroll
+            for (int q = 0; q < NBK; q++) {
+                const T c = r[q] * inv[q];
+#pragma unroll
+                for (int j = q + 1; j < NBK; j++) r[j] = fma_(-c, A[j][q], r[j]);
+            }
+#pragma unroll
+            for (int q = 0; q < NBK; q++) { pn[i][q] = r[q]; if (q >= 1 && q < nb) Mi[q] = r[q]; }
+        }
+        __syncthreads();
+        // ---- (B) the block's own rows keep their final values; the trailing triangle
+        if (tid >= 1 && tid < nb) {
+            T *Mp = M + tri(k + tid, k);
+#pragma unroll
+            for (int p = 1; p < NBK; p++)
+                if (tid == p) {
+#pragma unroll
+                    for (int q = 1; q <= p; q++) Mp[q] = A[p][q];
+                }
+        }
+        for (int i = k + nb + ty; i <= last; i += WG / 16) {
+            T c[NBK];
+#pragma unroll
+            for (int q = 0; q < NBK; q++) c[q] = pn[i][q] * inv[q];
+            T *Mi = M + tri(i, 0);
             const int jmax = i < last ? i : last - 1;
-            for (int j = k + 1 + tx; j <= jmax; j += 16) M[tri(i, j)] = fma_(-cik, M[tri(j, k)], M[tri(i, j)]);
+            for (int j = k + nb + tx; j <= jmax; j += 16) {
+                T v = Mi[j];
+#pragma unroll
+                for (int q = 0; q < NBK; q++)
+                    if (q < nb) v = fma_(-c[q], pn[j][q], v);
+                Mi[j] = v;
+            }
         }
         __syncthreads();
     }
 }
 // L^T x = z in place over unknowns [0, n) of a packed LDL^T (L(i,k) = M(i,k) dinv[k]); z in LDS.  Ends with a barrier.
+// Every z[k] takes its updates in descending i, one product each: 64 unknowns at a time, their own triangle by one wavefront
+// (a lane an unknown, the solved value handed round by a shuffle: no barrier per unknown), then everybody below takes the 64.
 template <class T, int WG>
 __device__ __forceinline__ void ldlt_backsub(const T *M, int n, const T *dinv, T *z, int tid)
 {
-    for (int i = n - 1; i >= 1; i--) {
-        const T xi = z[i];
-        for (int k = tid; k < i; k += WG) z[k] = fma_(-M[tri(i, k)] * dinv[k], xi, z[k]);
+    const int lane = tid & 63;
+    for (int e = n; e > 0; e -= 64) {
+        const int s = e > 64 ? e - 64 : 0;
+        if (tid < 64) {
+            const int k = s + lane;
+            T zk = k < e ? z[k] : T(0);
+            const T dk = k < e ? dinv[k] : T(0);
+            for (int i = e - 1; i > s; i--) {
+                const T xi = __shfl(zk, i - s, 64);
+                if (k < i) zk = fma_(-M[tri(i, k)] * dk, xi, zk);
+            }
+            if (k < e) z[k] = zk;
+        }
+        __syncthreads();
+        for (int k = tid; k < s; k += WG) {
+            T zk = z[k];
+            const T dk = dinv[k];
+            for (int i = e - 1; i >= s; i--) zk = fma_(-M[tri(i, k)] * dk, z[i], zk);
+            z[k] = zk;
+        }
         __syncthreads();
     }
 }
@@ -920,7 +999,7 @@ template <class T> size_t reduced_lds_bytes(int nv)
 }
 template <class T> int reduced_lds_cap()
 {
-    static const int cap = [] { int n = 16; while (reduced_lds_bytes<T>(n + 8) <= (size_t)150 * 1024) n += 8; return n; }();
+    static const int cap = [] { int n = 16; while (reduced_lds_bytes<T>(n + 8) <= (size_t)144 * 1024 && n + 9 <= LDLT_MAXN<T>) n += 8; return n; }();
     return cap;
 }
 // the volatile rows' data out of the level-2 matrix: b'' = its right-hand-side row behind Fs's columns; bounds and states by row
@@ -1376,7 +1455,8 @@ template int lcp_grid_solve<double>(dmxBatch *, const IslandSet<double> &, const
 // can island (m rows, nbd of them bounded) be solved by one workgroup in LDS?
 bool lcp_lds_fits(int real_bytes, int m, int nbd)
 {
-    static const int lim = [] { const char *e = getenv("DMX_LCP_LDS_BYTES"); return e ? atoi(e) : 156 * 1024; }();
+    static const int lim = [] { const char *e = getenv("DMX_LCP_LDS_BYTES"); return e ? atoi(e) : 150 * 1024; }();
+    if (m + 1 > (real_bytes == 4 ? LDLT_MAXN<float> : LDLT_MAXN<double>)) return false;
     const size_t need = real_bytes == 4 ? lcp_lds_bytes<float>(m, nbd) : lcp_lds_bytes<double>(m, nbd);
     return need <= (size_t)lim;
 }
