@@ -497,7 +497,9 @@ __device__ __forceinline__ void contact_build(const T *S, int64_t stride, const 
     contact_load(lrows, ljb, 0, c);
 }
 
-template <class T, bool LAST>
+// FAST: the friction rows are unbounded (mu = inf, the reference's surface, main.c:687): their clamp -- two comparisons that are
+// false and the selects behind them -- is left out; the normal row keeps its own.  Same values either way.
+template <class T, bool LAST, bool FAST = false>
 __device__ __forceinline__ void contact_sor_lds(ContactRegs<T> &c, T *fc, bool eager, double &resid)
 {
     T *fc1 = fc + 6 * c.l1;
@@ -522,7 +524,8 @@ __device__ __forceinline__ void contact_sor_lds(ContactRegs<T> &c, T *fc, bool e
         if (two)
             delta -= fma_(b[5], J[11], fma_(b[4], J[10], fma_(b[3], J[9], fma_(b[2], J[8], fma_(b[1], J[7], b[0] * J[6])))));
         const T nl = old + delta;
-        if (nl < c.lo[d]) { delta = c.lo[d] - old; c.lam[d] = c.lo[d]; }
+        if (FAST && d > 0) c.lam[d] = nl;
+        else if (nl < c.lo[d]) { delta = c.lo[d] - old; c.lam[d] = c.lo[d]; }
         else if (nl > c.hi[d]) { delta = c.hi[d] - old; c.lam[d] = c.hi[d]; }
         else c.lam[d] = nl;
 #pragma unroll
@@ -675,20 +678,32 @@ __device__ __forceinline__ double wg_island_contact_sweeps(T *rows, const int *j
         if (u < nc) { const int r0 = cfirst[u]; contact_load(rows, jb, r0, mine[j]); my_cl[j] = row_level[r0] / 3; }
     }
     double resid = 0.0;
-    for (int it = 0; it + 1 < iters; it++)
-        for (int cl = 0; cl < n_clev; cl++) {
+    // (do this island's friction rows ever clamp?  Asked of the rows themselves: the bounds sit in the registers just loaded)
+    int unbounded = 1;
 #pragma unroll
-            for (int j = 0; j < CPL; j++)
-                if (my_cl[j] == cl) contact_sor_lds<T, false>(mine[j], fc_lds, true, resid);
-            lds_barrier();
-        }
-    if (iters > 0)
-        for (int cl = 0; cl < n_clev; cl++) {
+    for (int j = 0; j < CPL; j++)
+        if (my_cl[j] >= 0)
+            unbounded &= (mine[j].lo[1] == -Limits<T>::inf() && mine[j].hi[1] == Limits<T>::inf() && mine[j].lo[2] == -Limits<T>::inf() &&
+                          mine[j].hi[2] == Limits<T>::inf()) ? 1 : 0;
+    const bool fast = __syncthreads_and(unbounded) != 0;
+    auto sweeps = [&](auto FASTT) {
+        constexpr bool F = decltype(FASTT)::value;
+        for (int it = 0; it + 1 < iters; it++)
+            for (int cl = 0; cl < n_clev; cl++) {
 #pragma unroll
-            for (int j = 0; j < CPL; j++)
-                if (my_cl[j] == cl) contact_sor_lds<T, true>(mine[j], fc_lds, true, resid);
-            lds_barrier();
-        }
+                for (int j = 0; j < CPL; j++)
+                    if (my_cl[j] == cl) contact_sor_lds<T, false, F>(mine[j], fc_lds, true, resid);
+                lds_barrier();
+            }
+        if (iters > 0)
+            for (int cl = 0; cl < n_clev; cl++) {
+#pragma unroll
+                for (int j = 0; j < CPL; j++)
+                    if (my_cl[j] == cl) contact_sor_lds<T, true, F>(mine[j], fc_lds, true, resid);
+                lds_barrier();
+            }
+    };
+    if (fast) sweeps(std::true_type{}); else sweeps(std::false_type{});
 #pragma unroll
     for (int j = 0; j < CPL; j++)
         if (my_cl[j] >= 0) {
