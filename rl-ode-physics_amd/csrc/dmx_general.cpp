@@ -296,7 +296,9 @@ bool use_hybrid_exact(const dmxBatch *b, const ExactCaps &cap)
 {
     static const bool on = [] { const char *e = getenv("DMX_HYBRID_EXACT"); return !(e && atoi(e) == 0); }();
     const int mode = b->exact_pipeline != DMX_EXACT_AUTO ? b->exact_pipeline : default_exact_pipeline();
-    static const long long maxp = [] { const char *e = getenv("DMX_HYBRID_PAIRS"); return e ? atoll(e) : (long long)kSmallExactPairs; }();
+    // (up to 4 096 pairs while the entries fit the one-workgroup kernel: the reference's pen with 400 / 512 bodies is 1 250 / 1 700 pairs,
+    //  and its nine small rocPRIM launches and their neighbours cost more than that kernel: 388 -> 362 / 428 -> 404 us per tick)
+    static const long long maxp = [] { const char *e = getenv("DMX_HYBRID_PAIRS"); return e ? atoll(e) : 4096ll; }();
     return on && mode != DMX_EXACT_STAGED && exact_back_fits(cap) && (long long)b->last_pairs <= maxp;
 }
 
