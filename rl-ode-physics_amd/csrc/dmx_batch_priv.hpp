@@ -235,6 +235,7 @@ template <class T> inline StepParams<T> dmx_make_params(dmxBatch *b, double h)
     P.vec = b->vec;
     P.min_waves = b->min_waves;
     P.nt = b->nt;
+    { static const int nf = [] { const char *e = getenv("DMX_HULL_FILTER"); return !e ? 0 : atoi(e) == 0 ? 1 : atoi(e) == 2 ? 2 : 0; }(); P.hull_nofilter = nf; }
     P.bp_check = 0;          // set by the collision-aware tick (dmx_general.cpp)
     P.ticks = 1;
     P.bp_flags = nullptr;

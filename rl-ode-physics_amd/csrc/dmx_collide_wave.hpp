@@ -12,6 +12,10 @@
 
 namespace dmx {
 
+template <class T> struct RealEps;
+template <> struct RealEps<float>  { static __device__ __forceinline__ float  v() { return 1.1920929e-7f; } };
+template <> struct RealEps<double> { static __device__ __forceinline__ double v() { return 2.220446049250313e-16; } };
+
 // The filters below compute a point's coordinate q = c . (R p + x - x') as (R^T c) . p + c . (x - x') and compare it with a bound;
 // the exact tests compute it the first way.  With u = eps / 2 the unit roundoff, r >= |p|, |c|_2 = 1 (so |c|_1 <= sqrt 3):
 //   exact:  R p three fused steps (3 sqrt3 u r), + x (u (|x| + r)), - x' (u |d|), c . d three fused steps (3 sqrt3 u |d|), the
@@ -43,7 +47,7 @@ __device__ __forceinline__ int wave_convex_plane(const V3<T> &x, const M3<T> &R,
                       fma_(R.m[2][1], P.pn.z, fma_(R.m[1][1], P.pn.y, R.m[0][1] * P.pn.x)),
                       fma_(R.m[2][2], P.pn.z, fma_(R.m[1][2], P.pn.y, R.m[0][2] * P.pn.x)) };
     const T off = dot(P.pn, x) - P.pd;
-    const T slack = hull_filter_slack<T>() * (tabs(x.x) + tabs(x.y) + tabs(x.z) + tabs(P.pd) + hull_radius + T(1));
+    const T slack = (P.hull_nofilter & 1) ? Limits<T>::inf() : hull_filter_slack<T>() * (tabs(x.x) + tabs(x.y) + tabs(x.z) + tabs(P.pd) + hull_radius + T(1));
     for (int base = 0; base < P.hull_n; base += 64) {
         const int k = base + lane;
         bool below = false, le = false, ge = false, near = false;
@@ -86,7 +90,7 @@ __device__ __forceinline__ int wave_convex_plane(const V3<T> &x, const M3<T> &R,
 // Along the box's THINNEST axis a (a floor's, a wall's, a plank's normal): the point's coordinate on it by one composite dot product,
 // (Rh^T b_a) . p + b_a . (xh - xb); a point farther out than half_a + slack is outside the box for the exact test too, and a pass
 // of 64 such points is over after five instructions instead of fifty.
-template <class T> struct BoxFilter { V3<T> u; T off, bound; };
+template <class T> struct BoxFilter { V3<T> u; T off, bound, slack; };
 template <class T>
 __device__ __forceinline__ BoxFilter<T> box_filter(const V3<T> &xb, const M3<T> &Rb, const T (&half)[3], const V3<T> &xh, const M3<T> &Rh, T hull_radius)
 {
@@ -100,7 +104,8 @@ __device__ __forceinline__ BoxFilter<T> box_filter(const V3<T> &xb, const M3<T> 
             fma_(Rh.m[2][1], ba.z, fma_(Rh.m[1][1], ba.y, Rh.m[0][1] * ba.x)),
             fma_(Rh.m[2][2], ba.z, fma_(Rh.m[1][2], ba.y, Rh.m[0][2] * ba.x)) };
     F.off = fma_(ba.z, xh.z - xb.z, fma_(ba.y, xh.y - xb.y, ba.x * (xh.x - xb.x)));
-    F.bound = ha + hull_filter_slack<T>() * (tabs(xh.x) + tabs(xh.y) + tabs(xh.z) + tabs(xb.x) + tabs(xb.y) + tabs(xb.z) + hull_radius + ha + T(1));
+    F.slack = hull_filter_slack<T>() * (tabs(xh.x) + tabs(xh.y) + tabs(xh.z) + tabs(xb.x) + tabs(xb.y) + tabs(xb.z) + hull_radius + half[0] + half[1] + half[2] + T(1));
+    F.bound = ha + F.slack;
     return F;
 }
 // a corner inside the hull is inside the hull's bounding sphere (slack for rounding): most corners of a floor-sized box are nowhere
@@ -119,8 +124,15 @@ __device__ __forceinline__ bool box_corner_near(const V3<T> &xb, const M3<T> &Rb
 template <class T, class Emit>
 __device__ __forceinline__ int wave_box_convex_walk(const V3<T> &xb, const M3<T> &Rb, const T (&half)[3], const V3<T> &xh, const M3<T> &Rh,
                                                     const BoxFilter<T> &F, unsigned near_corners, const StepParams<T> &P, int maxc, bool negate,
-                                                    int lane, Emit emit, const T *pts)
+                                                    int lane, Emit emit, const T *pts, const T *box_aabb = nullptr, bool *aabbs_meet = nullptr)
 {
+    // box_aabb (lo[3], hi[3]; may be null): the box's world AABB as dSpaceCollide tests it.  *aabbs_meet comes back true when some
+    // hull vertex that became a contact lies inside it -- the hull's exact AABB, the bounds of these very vertex positions, then
+    // overlaps it for certain; false says nothing (the caller that has not made dSpaceCollide's test yet makes it then).
+    // (A margin on the depth instead of the comparison with the stored box -- one comparison on values the walk has anyway -- is
+    //  too weak: a resting teapot's contacts are shallower than the rounding of positions 300 m from the origin.)
+    bool wit = false;
+    V3<T> wv = { T(0), T(0), T(0) };
     int contacts = 0;
     const V3<T> u = F.u;
     const T off = F.off, bound = F.bound;
@@ -160,8 +172,14 @@ __device__ __forceinline__ int wave_box_convex_walk(const V3<T> &xb, const M3<T>
             const int rank = contacts + __popcll(mb & ((1ull << lane) - 1ull));
             if (rank < maxc) emit(rank, v, negate ? V3<T>{ -n.x, -n.y, -n.z } : n, dep);
         }
+        // (a lane's first vertex inside the box is kept for the AABB question below: selects, nothing the loop branches on)
+        wv.x = (inside && !wit) ? v.x : wv.x; wv.y = (inside && !wit) ? v.y : wv.y; wv.z = (inside && !wit) ? v.z : wv.z;
+        wit = wit || inside;
         contacts += __popcll(mb);
     }
+    if (aabbs_meet != nullptr && box_aabb != nullptr)
+        *aabbs_meet = __ballot(wit && wv.x >= box_aabb[0] && wv.x <= box_aabb[3] && wv.y >= box_aabb[1] && wv.y <= box_aabb[4] && wv.z >= box_aabb[2] &&
+                               wv.z <= box_aabb[5]) != 0ull;
     if (contacts > maxc) contacts = maxc;
     if (contacts >= maxc || P.hull_nf <= 0) return contacts;
     for (int cn = 0; cn < 8 && contacts < maxc; cn++) {
@@ -204,12 +222,14 @@ __device__ __forceinline__ int wave_box_convex_walk(const V3<T> &xb, const M3<T>
 // one pair, set up here: every lane computes the same filter, lane cn asks for corner cn
 template <class T, class Emit>
 __device__ __forceinline__ int wave_box_convex(const V3<T> &xb, const M3<T> &Rb, const T *side, const V3<T> &xh, const M3<T> &Rh,
-                                               T hull_radius, const StepParams<T> &P, int maxc, bool negate, int lane, Emit emit, const T *pts)
+                                               T hull_radius, const StepParams<T> &P, int maxc, bool negate, int lane, Emit emit, const T *pts,
+                                               const T *box_aabb = nullptr, bool *aabbs_meet = nullptr)
 {
     const T half[3] = { T(0.5) * side[0], T(0.5) * side[1], T(0.5) * side[2] };
-    const BoxFilter<T> F = box_filter<T>(xb, Rb, half, xh, Rh, hull_radius);
+    BoxFilter<T> F = box_filter<T>(xb, Rb, half, xh, Rh, hull_radius);
+    if (P.hull_nofilter & 1) F.bound = Limits<T>::inf();
     const unsigned near_corners = (unsigned)(__ballot(box_corner_near<T>(xb, Rb, half, xh, hull_radius, lane & 7)) & 0xffull);
-    return wave_box_convex_walk<T>(xb, Rb, half, xh, Rh, F, near_corners, P, maxc, negate, lane, emit, pts);
+    return wave_box_convex_walk<T>(xb, Rb, half, xh, Rh, F, near_corners, P, maxc, negate, lane, emit, pts, box_aabb, aabbs_meet);
 }
 
 // ---- a point of the world in a hull's frame: R^T (v - x), the oracle's to_hull_frame ------------------------------------------

@@ -103,6 +103,7 @@ template <class T> struct StepParams {
     int vec;            // launch tuning (env DMX_VEC): bodies per lane in integrate_free (0 = default, one)
     int min_waves;      // launch tuning (env DMX_MIN_WAVES): waves per SIMD the register allocator must leave room for, 0 = default
     int nt;             // launch tuning (env DMX_NT): bit 0 = non-temporal state stores, bit 1 = non-temporal loads (integrate_free)
+    int hull_nofilter;  // DMX_HULL_FILTER=0: the hull colliders' conservative filter lets every point through (A/B, diagnosis)
     int bp_check;       // safe-zone test of every body's pre-step position (BPC_* bits; any bit = "this tick" for one-tick kernels)
     int ticks;          // integrate_free: ticks taken by one launch with the state held in registers (>= 1)
     uint32_t *bp_flags; // device flags (BPF_*), written when a body has left its safe zone

@@ -54,6 +54,21 @@ template <class T> __device__ __forceinline__ bool aabb_meets_static(const T lo[
              lo[2] > b[SBOX_HI + 2] || b[SBOX_LO + 2] > hi[2]);
 }
 
+// dSpaceCollide's AABB test between a hull and a static box as the oracle (and the exact tick) makes it: on the hull's EXACT world box,
+// the bounds of its transformed points.  The fused path tests the bounding sphere's box first -- conservative, and free -- and for
+// colliders that are exact geometry that changes nothing IN REAL ARITHMETIC: a vertex inside the box means the true boxes overlap.
+// In floating point a vertex within rounding of a face can be inside by the collider's arithmetic while the two AABBs, rounded
+// their own way, miss each other by an ulp -- one contact in 10^5 a metre from the origin, one scene in a hundred at 7 km in f32
+// (scripts/fuzz_hulls_r04.py found it).  So a pair that made contacts is confirmed: at once when a contact vertex lies inside the
+// box's AABB (wave_box_convex_walk), by the exact box otherwise (a wavefront's pass over the hull, once in a long while).
+template <class T>
+__device__ __forceinline__ bool hull_aabb_meets_static(const V3<T> &x, const M3<T> &R, const T *pts, int hull_n, int lane, const T *sb)
+{
+    T lo[3], hi[3];
+    wave_hull_aabb<T>(x, R, pts, hull_n, lane, lo, hi);
+    return aabb_meets_static(lo, hi, sb);
+}
+
 // boxes and spheres: one lane per body
 template <class T>
 __global__ __launch_bounds__(256) void np_static(const T *__restrict__ S, const uint8_t *__restrict__ gtype, int64_t n, StepParams<T> P)
@@ -131,7 +146,8 @@ __global__ __launch_bounds__(256) void np_convex_static(const T *__restrict__ S,
     const M3<T> R = quat_to_R(Q4<T>{ S[slab_ix(C_QUAT + 0, i)], S[slab_ix(C_QUAT + 1, i)],
                                      S[slab_ix(C_QUAT + 2, i)], S[slab_ix(C_QUAT + 3, i)] });
     const T radius = S[slab_ix(C_SIDES + 0, i)];          // the hull's bounding radius; its AABB is that sphere's box (body_aabb)
-    const T lo[3] = { x.x - radius, x.y - radius, x.z - radius }, hi[3] = { x.x + radius, x.y + radius, x.z + radius };
+    const T wide = radius * T(1.0001) + T(8) * RealEps<T>::v() * (tabs(x.x) + tabs(x.y) + tabs(x.z));      // (as in np_convex_static_tile)
+    const T lo[3] = { x.x - wide, x.y - wide, x.z - wide }, hi[3] = { x.x + wide, x.y + wide, x.z + wide };
     const int maxc = P.max_contacts < CONVEX_MAXC ? P.max_contacts : CONVEX_MAXC;
     int nc = 0;
     if (P.hull_n > 0) {
@@ -145,8 +161,11 @@ __global__ __launch_bounds__(256) void np_convex_static(const T *__restrict__ S,
             for (int a = 0; a < 3; a++) for (int c2 = 0; c2 < 3; c2++) sR.m[a][c2] = sb[SBOX_R + 3 * a + c2];
             const T sside[3] = { sb[SBOX_SIDE], sb[SBOX_SIDE + 1], sb[SBOX_SIDE + 2] };
             const int base = nc;
-            nc += wave_box_convex<T>(sx, sR, sside, x, R, radius, P, maxc, true, lane, [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) {
-                if (base + rank < SC_MAXC) put_sc(P.sbuf, i, base + rank, p, nn, dep); }, P.hull);
+            bool meet_exact = false;
+            int k = wave_box_convex<T>(sx, sR, sside, x, R, radius, P, maxc, true, lane, [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) {
+                if (base + rank < SC_MAXC) put_sc(P.sbuf, i, base + rank, p, nn, dep); }, P.hull, sb + SBOX_LO, &meet_exact);
+            if (k > 0 && !meet_exact && !hull_aabb_meets_static<T>(x, R, P.hull, P.hull_n, lane, sb)) k = 0;
+            nc += k;
         }
     }
     if (lane == 0) P.scount[i] = nc > SC_MAXC ? SC_MAXC + 1 : nc;
@@ -202,7 +221,10 @@ __global__ __launch_bounds__(NPC_WAVES * 64) void np_convex_static_tile(const T 
     const V3<T> xl = { __shfl(pose, 8 * jl + 0, 64), __shfl(pose, 8 * jl + 1, 64), __shfl(pose, 8 * jl + 2, 64) };
     const M3<T> Rl = quat_to_R(Q4<T>{ __shfl(pose, 8 * jl + 3, 64), __shfl(pose, 8 * jl + 4, 64), __shfl(pose, 8 * jl + 5, 64), __shfl(pose, 8 * jl + 6, 64) });
     const T radius_l = __shfl(pose, 8 * jl + 7, 64);      // the hull's bounding radius; its AABB is that sphere's box (body_aabb)
-    const T lo[3] = { xl.x - radius_l, xl.y - radius_l, xl.z - radius_l }, hi[3] = { xl.x + radius_l, xl.y + radius_l, xl.z + radius_l };
+    // (the bounding sphere's box, a rounding's worth wider: it only has to CONTAIN the exact box -- pairs that make contacts are
+    //  confirmed against that one, hull_aabb_meets_static)
+    const T wide = radius_l * T(1.0001) + T(8) * RealEps<T>::v() * (tabs(xl.x) + tabs(xl.y) + tabs(xl.z));
+    const T lo[3] = { xl.x - wide, xl.y - wide, xl.z - wide }, hi[3] = { xl.x + wide, xl.y + wide, xl.z + wide };
     const V3<T> xc = { __shfl(pose, 8 * jc + 0, 64), __shfl(pose, 8 * jc + 1, 64), __shfl(pose, 8 * jc + 2, 64) };
     const T radius_c = __shfl(pose, 8 * jc + 7, 64);
     const bool live_l = (live_mask >> (8 * jl)) & 1ull;
@@ -234,16 +256,22 @@ __global__ __launch_bounds__(NPC_WAVES * 64) void np_convex_static_tile(const T 
             M3<T> sR;
             for (int a = 0; a < 3; a++) for (int c2 = 0; c2 < 3; c2++) sR.m[a][c2] = sb[SBOX_R + 3 * a + c2];
             const T half[3] = { T(0.5) * sb[SBOX_SIDE], T(0.5) * sb[SBOX_SIDE + 1], T(0.5) * sb[SBOX_SIDE + 2] };
-            const BoxFilter<T> Fl = box_filter<T>(sx, sR, half, xl, Rl, radius_l);
+            const T baabb[6] = { sb[SBOX_LO], sb[SBOX_LO + 1], sb[SBOX_LO + 2], sb[SBOX_HI], sb[SBOX_HI + 1], sb[SBOX_HI + 2] };      // (once a box, not once a body)
+            BoxFilter<T> Fl = box_filter<T>(sx, sR, half, xl, Rl, radius_l);
+            if (P.hull_nofilter & 1) Fl.bound = Limits<T>::inf();
             const unsigned long long corners = __ballot(box_corner_near<T>(sx, sR, half, xc, radius_c, lane & 7));
             for (int j = 0; j < NPC_PER_WAVE; j++) {
                 if (!((meet >> j) & 1u)) continue;                   // wave-uniform
                 const int64_t i = i0 + j;
                 const V3<T> x = { __shfl(pose, 8 * j + 0, 64), __shfl(pose, 8 * j + 1, 64), __shfl(pose, 8 * j + 2, 64) };
-                const BoxFilter<T> F = { { __shfl(Fl.u.x, j, 64), __shfl(Fl.u.y, j, 64), __shfl(Fl.u.z, j, 64) }, __shfl(Fl.off, j, 64), __shfl(Fl.bound, j, 64) };
+                const BoxFilter<T> F = { { __shfl(Fl.u.x, j, 64), __shfl(Fl.u.y, j, 64), __shfl(Fl.u.z, j, 64) }, __shfl(Fl.off, j, 64), __shfl(Fl.bound, j, 64), __shfl(Fl.slack, j, 64) };
                 const int base = __shfl(nc_l, j, 64);
-                const int k = wave_box_convex_walk<T>(sx, sR, half, x, fetch_R(j), F, (unsigned)((corners >> (8 * j)) & 0xffull), P, maxc, true, lane,
-                    [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) { if (base + rank < SC_MAXC) put_sc(P.sbuf, i, base + rank, p, nn, dep); }, pts);
+                const M3<T> R = fetch_R(j);
+                bool meet_exact = false;
+                int k = wave_box_convex_walk<T>(sx, sR, half, x, R, F, (unsigned)((corners >> (8 * j)) & 0xffull), P, maxc, true, lane,
+                    [&](int rank, const V3<T> &p, const V3<T> &nn, T dep) { if (base + rank < SC_MAXC) put_sc(P.sbuf, i, base + rank, p, nn, dep); }, pts,
+                    baabb, &meet_exact);
+                if (k > 0 && !meet_exact && !(P.hull_nofilter & 2) && !hull_aabb_meets_static<T>(x, R, pts, P.hull_n, lane, sb)) k = 0;
                 if (lane == j) nc_l += k;
             }
         }

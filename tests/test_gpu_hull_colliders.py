@@ -213,3 +213,17 @@ def test_teapots_on_a_floor_strewn_with_small_blocks(dtype, plane):
     w.step(H, steps)
     _same(w, ow)
     w.close()
+
+
+@pytest.mark.parametrize("seed", [1179, 1235, 1527, 1581, 2091])
+def test_hulls_on_blocks_kilometres_from_the_origin(seed):
+    """Scenes of scripts/fuzz_hulls_r04.py that failed before the fused hull path confirmed its pairs by dSpaceCollide's test on
+    the hull's EXACT box: f32, the whole scene 2.5-8 km from the origin, where positions round to 0.2-0.5 mm -- a hull vertex within
+    rounding of a block's face is inside the block by the collider's arithmetic while the two AABBs, rounded their own way, miss
+    each other by an ulp; the oracle (ODE's order: AABBs first) then makes no contact, and neither may the device."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_hulls_r04", os.path.join(ROOT, "scripts", "fuzz_hulls_r04.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    ok, most, n = fz.one(seed, _teapot())
+    assert ok and most > 0
