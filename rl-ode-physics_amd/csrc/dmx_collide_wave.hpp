@@ -131,8 +131,9 @@ __device__ __forceinline__ int wave_box_convex_walk(const V3<T> &xb, const M3<T>
     // overlaps it for certain; false says nothing (the caller that has not made dSpaceCollide's test yet makes it then).
     // (A margin on the depth instead of the comparison with the stored box -- one comparison on values the walk has anyway -- is
     //  too weak: a resting teapot's contacts are shallower than the rounding of positions 300 m from the origin.)
-    bool wit = false;
-    V3<T> wv = { T(0), T(0), T(0) };
+    // (no flag beside it: a per-lane bool carried through the loop is a lane mask that has to be merged on every pass, three scalar
+    //  instructions in a pass of twenty-one; "not yet" is a NaN in the vertex itself, which also fails every comparison at the end)
+    V3<T> wv = { Limits<T>::nan(), T(0), T(0) };
     int contacts = 0;
     const V3<T> u = F.u;
     const T off = F.off, bound = F.bound;
@@ -173,12 +174,14 @@ __device__ __forceinline__ int wave_box_convex_walk(const V3<T> &xb, const M3<T>
             if (rank < maxc) emit(rank, v, negate ? V3<T>{ -n.x, -n.y, -n.z } : n, dep);
         }
         // (a lane's first vertex inside the box is kept for the AABB question below: selects, nothing the loop branches on)
-        wv.x = (inside && !wit) ? v.x : wv.x; wv.y = (inside && !wit) ? v.y : wv.y; wv.z = (inside && !wit) ? v.z : wv.z;
-        wit = wit || inside;
+        {
+            const bool first = inside && wv.x != wv.x;
+            wv.y = first ? v.y : wv.y; wv.z = first ? v.z : wv.z; wv.x = first ? v.x : wv.x;
+        }
         contacts += __popcll(mb);
     }
     if (aabbs_meet != nullptr && box_aabb != nullptr)
-        *aabbs_meet = __ballot(wit && wv.x >= box_aabb[0] && wv.x <= box_aabb[3] && wv.y >= box_aabb[1] && wv.y <= box_aabb[4] && wv.z >= box_aabb[2] &&
+        *aabbs_meet = __ballot(wv.x >= box_aabb[0] && wv.x <= box_aabb[3] && wv.y >= box_aabb[1] && wv.y <= box_aabb[4] && wv.z >= box_aabb[2] &&
                                wv.z <= box_aabb[5]) != 0ull;
     if (contacts > maxc) contacts = maxc;
     if (contacts >= maxc || P.hull_nf <= 0) return contacts;

@@ -13,8 +13,8 @@
 namespace dmx {
 
 template <class T> struct Limits;
-template <> struct Limits<float>  { static DMX_HD float  inf() { return __builtin_huge_valf(); } };
-template <> struct Limits<double> { static DMX_HD double inf() { return __builtin_huge_val(); } };
+template <> struct Limits<float>  { static DMX_HD float  inf() { return __builtin_huge_valf(); } static DMX_HD float  nan() { return __builtin_nanf(""); } };
+template <> struct Limits<double> { static DMX_HD double inf() { return __builtin_huge_val(); } static DMX_HD double nan() { return __builtin_nan(""); } };
 
 template <class T> DMX_HD T tsqrt(T x);
 template <> DMX_HD float  tsqrt<float>(float x)   { return __builtin_sqrtf(x); }
