@@ -49,15 +49,13 @@ __device__ __forceinline__ int wave_convex_plane(const V3<T> &x, const M3<T> &R,
     const T off = dot(P.pn, x) - P.pd;
     const T slack = (P.hull_nofilter & 1) ? Limits<T>::inf() : hull_filter_slack<T>() * (tabs(x.x) + tabs(x.y) + tabs(x.z) + tabs(P.pd) + hull_radius + T(1));
     for (int base = 0; base < P.hull_n; base += 64) {
-        const int k = base + lane;
-        bool below = false, le = false, ge = false, near = false;
-        V3<T> v2 = { T(0), T(0), T(0) }, p = { T(0), T(0), T(0) };
+        const int k = base + lane, kc = k < P.hull_n ? k : P.hull_n - 1;
+        bool below = false, le = false;
+        V3<T> v2 = { T(0), T(0), T(0) };
         T distance2 = T(0);
-        if (k < P.hull_n) {
-            p = { pts[3 * k], pts[3 * k + 1], pts[3 * k + 2] };
-            near = !(fma_(u.z, p.z, fma_(u.y, p.y, fma_(u.x, p.x, off))) > slack);
-            ge = !near;
-        }
+        const V3<T> p = { pts[3 * kc], pts[3 * kc + 1], pts[3 * kc + 2] };       // (spare lanes of the last pass: the last point again, told apart below)
+        const bool near = k < P.hull_n && !(fma_(u.z, p.z, fma_(u.y, p.y, fma_(u.x, p.x, off))) > slack);
+        bool ge = k < P.hull_n && !near;
         if (__ballot(near) != 0ull) {
             if (near) {
                 v2 = mulv(R, p);
@@ -138,14 +136,14 @@ __device__ __forceinline__ int wave_box_convex_walk(const V3<T> &xb, const M3<T>
     const V3<T> u = F.u;
     const T off = F.off, bound = F.bound;
     for (int base = 0; base < P.hull_n && contacts < maxc; base += 64) {
-        const int k = base + lane;
-        bool inside = false, near = false;
-        V3<T> v = { T(0), T(0), T(0) }, n = { T(0), T(0), T(0) }, p = { T(0), T(0), T(0) };
+        const int k = base + lane, kc = k < P.hull_n ? k : P.hull_n - 1;
+        bool inside = false;
+        V3<T> v = { T(0), T(0), T(0) }, n = { T(0), T(0), T(0) };
         T dep = T(0);
-        if (k < P.hull_n) {
-            p = { pts[3 * k], pts[3 * k + 1], pts[3 * k + 2] };
-            near = !(tabs(fma_(u.z, p.z, fma_(u.y, p.y, fma_(u.x, p.x, off)))) > bound);
-        }
+        // (the last pass's spare lanes fetch the last point again and are told apart afterwards: no branch around the fetch, no
+        //  registers to clear for it -- six of a pass's twenty-one instructions)
+        const V3<T> p = { pts[3 * kc], pts[3 * kc + 1], pts[3 * kc + 2] };
+        const bool near = k < P.hull_n && !(tabs(fma_(u.z, p.z, fma_(u.y, p.y, fma_(u.x, p.x, off)))) > bound);
         if (__ballot(near) == 0ull) continue;
         if (near) {
             v = mulv(Rh, p);
