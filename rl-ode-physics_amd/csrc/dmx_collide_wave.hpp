@@ -135,7 +135,9 @@ __device__ __forceinline__ int wave_box_convex_walk(const V3<T> &xb, const M3<T>
     int contacts = 0;
     const V3<T> u = F.u;
     const T off = F.off, bound = F.bound;
-    for (int base = 0; base < P.hull_n && contacts < maxc; base += 64) {
+    // (one loop condition: the walk's end moves to 0 once the contacts are full -- decided after a pass that found something)
+    int limit = maxc > 0 ? P.hull_n : 0;
+    for (int base = 0; base < limit; base += 64) {
         const int k = base + lane, kc = k < P.hull_n ? k : P.hull_n - 1;
         bool inside = false;
         V3<T> v = { T(0), T(0), T(0) }, n = { T(0), T(0), T(0) };
@@ -177,6 +179,7 @@ __device__ __forceinline__ int wave_box_convex_walk(const V3<T> &xb, const M3<T>
             wv.y = first ? v.y : wv.y; wv.z = first ? v.z : wv.z; wv.x = first ? v.x : wv.x;
         }
         contacts += __popcll(mb);
+        limit = contacts < maxc ? limit : 0;
     }
     if (aabbs_meet != nullptr && box_aabb != nullptr)
         *aabbs_meet = __ballot(wv.x >= box_aabb[0] && wv.x <= box_aabb[3] && wv.y >= box_aabb[1] && wv.y <= box_aabb[4] && wv.z >= box_aabb[2] &&
